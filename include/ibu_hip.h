@@ -1,0 +1,361 @@
+/*
+ * ibu_hip.h — C ABI of libibu_hip.so, the MI355X (gfx950) batch record-stream + 2-bit codec
+ * path for the IBU binary format.
+ *
+ * This is the drop-in boundary.  The reference (noamteyssier/ibu, Rust) has no FFI of its
+ * own; its boundary is the crate's public API (src/lib.rs:178-181).  Every entry point below
+ * names the reference item it stands behind, so that a Rust `extern "C"` shim (source in
+ * bindings/rust/, walkthrough in INTEGRATION.md) can re-create `Header / Record / Reader /
+ * Writer / MmapReader / ParallelProcessor` on top of it.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, fixed-width ints.  No C++/torch types.
+ *   - every fallible function returns int32_t: 0 = IBU_OK, 1..10 = the ten IbuError variants
+ *     in declaration order (src/error.rs:56-128), 11.. = codec / argument errors that the
+ *     reference expresses as panics or leaves to `bitnuc`, >=100 = HIP runtime.
+ *   - the payload of the failing call (expected/actual, pos, idx/max, errno, message) is
+ *     kept per calling thread and read with ibu_last_error().
+ *   - nothing throws or aborts across this boundary.
+ *   - host pointers are `h_` / unprefixed; device pointers are prefixed `d_`.  `stream` is a
+ *     hipStream_t passed as void* (NULL = the context's own stream).  Launch functions are
+ *     asynchronous, allocate nothing and never synchronise (graph-capturable).
+ *   - the caller owns every buffer it passes; the library owns only what *_open/_create
+ *     returned, until the matching *_close/_destroy.
+ *
+ * 2-bit codec convention (the reference only documents the table, src/constructs/record.rs:19-27;
+ * its README defers to the `bitnuc` crate which is not a dependency — parity for the codec is
+ * therefore UNPINNED):
+ *   A/a=00 C/c=01 G/g=10 T/t=11; base i of a sequence occupies bits [2i, 2i+1] (first base in
+ *   the least-significant bits: "ACGT" -> 0b11100100); len in 1..=32; bits >= 2*len are
+ *   ignored on unpack and written as zero on pack; unpack emits upper-case ASCII; any other
+ *   input byte on pack is IBU_ERR_INVALID_BASE.
+ */
+#ifndef IBU_HIP_H
+#define IBU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants (src/constructs/header.rs:5-7, record.rs:3, io/reader.rs:14, io/mmap.rs:284) */
+#define IBU_MAGIC 0x21554249u /* "IBU!" little-endian */
+#define IBU_VERSION 2u
+#define IBU_HEADER_SIZE 32
+#define IBU_RECORD_SIZE 24
+#define IBU_DEFAULT_BUFFER_SIZE (48 * 1024 * IBU_RECORD_SIZE) /* 1 179 648 B */
+#define IBU_BATCH_SIZE (1024 * 1024)                          /* records per parallel batch */
+#define IBU_MAX_SEQ_LEN 32
+#define IBU_FLAG_SORTED 1ull
+
+/* ---- POD types, layout-identical to the #[repr(C)] structs ---------------------------- */
+typedef struct ibu_header { /* src/constructs/header.rs:48-61 */
+  uint32_t magic;
+  uint32_t version;
+  uint32_t bc_len;
+  uint32_t umi_len;
+  uint64_t flags;
+  uint8_t reserved[8];
+} ibu_header_t;
+
+typedef struct ibu_record { /* src/constructs/record.rs:58-66 */
+  uint64_t barcode;
+  uint64_t umi;
+  uint64_t index;
+} ibu_record_t;
+
+/* ---- status codes ---------------------------------------------------------------------- */
+enum {
+  IBU_OK = 0,
+  IBU_ERR_IO = 1,               /* IbuError::Io                 error.rs:58  detail.os_errno        */
+  IBU_ERR_NIFFLER = 2,          /* IbuError::Niffler            error.rs:62  (decompression)        */
+  IBU_ERR_INVALID_MAGIC = 3,    /* InvalidMagicNumber{expected,actual}       detail.a=exp, .b=act   */
+  IBU_ERR_TRUNCATED_RECORD = 4, /* TruncatedRecord{pos}                      detail.a=pos           */
+  IBU_ERR_INVALID_VERSION = 5,  /* InvalidVersion{expected,actual}           detail.a=exp, .b=act   */
+  IBU_ERR_INVALID_BC_LEN = 6,   /* InvalidBarcodeLength(u32)                 detail.a=len           */
+  IBU_ERR_INVALID_UMI_LEN = 7,  /* InvalidUmiLength(u32)                     detail.a=len           */
+  IBU_ERR_INVALID_MAP_SIZE = 8, /* InvalidMapSize                                                   */
+  IBU_ERR_INVALID_INDEX = 9,    /* InvalidIndex{idx,max}                     detail.a=idx, .b=max   */
+  IBU_ERR_PROCESS = 10,         /* Process(Box<dyn Error>)   user processor returned non-zero:
+                                   detail.a = that value                                            */
+  IBU_ERR_INVALID_BASE = 11,    /* codec: byte outside ACGTacgt; detail.a = first bad record,
+                                   detail.b = number of offending records                           */
+  IBU_ERR_SEQ_LEN = 12,         /* codec: len outside 1..=32; detail.a=len                          */
+  IBU_ERR_INVALID_ARG = 13,     /* NULL/size misuse — where the reference would panic
+                                   (Header::from_bytes on a wrong length, header.rs:226)            */
+  IBU_ERR_HIP = 100,            /* any hipError_t != hipSuccess; detail.a = hipError_t              */
+  IBU_ERR_NO_DEVICE = 101       /* no usable gfx950 device: the device path FAILS, never falls back */
+};
+
+typedef struct ibu_error_detail {
+  int32_t code;
+  int32_t os_errno;
+  uint64_t a;
+  uint64_t b;
+  char message[232]; /* Display text in the reference's wording (error.rs:57-127) */
+} ibu_error_detail_t;
+
+/* Detail of the last failing call made by the calling thread. */
+void ibu_last_error(ibu_error_detail_t* out);
+/* Static name of a status code ("InvalidMagicNumber", ...). */
+const char* ibu_status_name(int32_t status);
+/* Library version string and ABI revision (bumped on any signature change). */
+const char* ibu_version(void);
+uint32_t ibu_abi_revision(void);
+/* Free a buffer returned by ibu_load_to_vec / ibu_writer_into_inner. */
+void ibu_free(void* p);
+
+/* ======================================================================================= */
+/* A2  Header                                                     src/constructs/header.rs */
+/* ======================================================================================= */
+void ibu_header_init(ibu_header_t* h, uint32_t bc_len, uint32_t umi_len); /* Header::new :84-93    */
+void ibu_header_set_sorted(ibu_header_t* h);                              /* set_sorted  :111-113  */
+int32_t ibu_header_sorted(const ibu_header_t* h);                         /* sorted      :130-132  */
+int32_t ibu_header_validate(const ibu_header_t* h);                       /* validate    :167-187  */
+int32_t ibu_header_from_bytes(const uint8_t* bytes, size_t len, ibu_header_t* out); /* :226-228    */
+int32_t ibu_header_as_bytes(const ibu_header_t* h, uint8_t* out, size_t cap);       /* :203-205    */
+
+/* ======================================================================================= */
+/* A1  Record                                                     src/constructs/record.rs */
+/* ======================================================================================= */
+int32_t ibu_record_from_bytes(const uint8_t* bytes, size_t len, ibu_record_t* out); /* :130-132    */
+int32_t ibu_record_as_bytes(const ibu_record_t* r, uint8_t* out, size_t cap);       /* :108-110    */
+/* derive(Ord): lexicographic (barcode, umi, index) -> -1/0/+1                         :58         */
+int32_t ibu_record_cmp(const ibu_record_t* a, const ibu_record_t* b);
+
+/* ======================================================================================= */
+/* A3/A4  Writer<W>                                                    src/io/writer.rs     */
+/* ======================================================================================= */
+typedef struct ibu_writer ibu_writer_t;
+/* W: Write as two callbacks.  write must consume all `len` bytes or return non-zero (errno). */
+typedef int32_t (*ibu_write_fn)(void* user, const uint8_t* data, size_t len);
+typedef int32_t (*ibu_flush_fn)(void* user);
+
+/* Writer::new(inner, header) :129-143 — header written immediately, NOT validated (quirk Q2).
+ * header == NULL gives Writer::new_headless :169-179. */
+int32_t ibu_writer_open_callback(ibu_write_fn wr, ibu_flush_fn fl, void* user,
+                                 const ibu_header_t* header, ibu_writer_t** out);
+int32_t ibu_writer_open_path(const char* path, const ibu_header_t* header, ibu_writer_t** out); /* from_path :556-559 */
+int32_t ibu_writer_open_fd(int fd, const ibu_header_t* header, ibu_writer_t** out); /* from_stdout :587-589 (fd 1) */
+int32_t ibu_writer_open_mem(const ibu_header_t* header, ibu_writer_t** out);        /* Writer<Vec<u8>>            */
+
+int32_t ibu_writer_write_record(ibu_writer_t* w, const ibu_record_t* r);                /* :260-273 */
+int32_t ibu_writer_write_batch(ibu_writer_t* w, const ibu_record_t* recs, size_t n);    /* :315-351 */
+int32_t ibu_writer_ingest(ibu_writer_t* w, ibu_writer_t* other_mem);                    /* :477-482 */
+int32_t ibu_writer_finish(ibu_writer_t* w);                                             /* :429-433 */
+uint64_t ibu_writer_records_written(const ibu_writer_t* w);                             /* :207-209 */
+/* Bytes the inner sink has received so far (what `into_inner()` of a Vec<u8> writer would hold). */
+int32_t ibu_writer_mem_view(const ibu_writer_t* w, const uint8_t** data, size_t* len);
+/* into_inner :507-511 — NO flush (ManuallyDrop skips Drop); frees the writer; mem writers hand
+ * their bytes to the caller (release with ibu_free), other sinks return data=NULL. */
+int32_t ibu_writer_into_inner(ibu_writer_t* w, uint8_t** data, size_t* len);
+/* Drop :519-523 — finish().ok(), errors swallowed, then free. */
+void ibu_writer_close(ibu_writer_t* w);
+
+/* ======================================================================================= */
+/* A5  Reader<R>                                                       src/io/reader.rs     */
+/* ======================================================================================= */
+typedef struct ibu_reader ibu_reader_t;
+/* R: Read as one callback: fill up to cap bytes, *got = bytes read (0 = EOF); non-zero = errno. */
+typedef int32_t (*ibu_read_fn)(void* user, uint8_t* dst, size_t cap, size_t* got);
+
+/* Reader::new :152-176 — read_exact 32 B, validate. */
+int32_t ibu_reader_open_callback(ibu_read_fn rd, void* user, ibu_reader_t** out);
+/* Reader::new(Cursor<&[u8]>) — bytes are borrowed, not copied. */
+int32_t ibu_reader_open_mem(const uint8_t* data, size_t len, ibu_reader_t** out);
+/* Reader::from_path :345-352 — sniffs gzip magic (niffler's role); plain files pass through. */
+int32_t ibu_reader_open_path(const char* path, ibu_reader_t** out);
+int32_t ibu_reader_open_fd(int fd, ibu_reader_t** out); /* from_stdin :389-396 (fd 0), sniffs too */
+
+int32_t ibu_reader_header(const ibu_reader_t* r, ibu_header_t* out);   /* header()    :244-246 */
+int32_t ibu_reader_read_batch(ibu_reader_t* r, int32_t* has_data);     /* read_batch  :218-242 */
+/* Iterator::next :279-306 — *got = 1 and *out filled, or *got = 0 (None); error = Some(Err). */
+int32_t ibu_reader_next(ibu_reader_t* r, ibu_record_t* out, int32_t* got);
+/* Zero-copy view of the records left in the current buffer and how many to mark consumed
+ * (feeds the device ring; no reference equivalent — Reader keeps `buffer` private). */
+int32_t ibu_reader_buffered(ibu_reader_t* r, const ibu_record_t** recs, size_t* n);
+int32_t ibu_reader_consume(ibu_reader_t* r, size_t n);
+uint64_t ibu_reader_bytes_read(const ibu_reader_t* r);                 /* field :107-108        */
+void ibu_reader_close(ibu_reader_t* r);
+
+/* A6  load_to_vec :510-535 — uncompressed files only (quirk Q10); *records from ibu_free. */
+int32_t ibu_load_to_vec(const char* path, ibu_header_t* header, ibu_record_t** records, size_t* n);
+
+/* ======================================================================================= */
+/* A7/A8  MmapReader + ParallelReader                                  src/io/mmap.rs       */
+/* ======================================================================================= */
+typedef struct ibu_mmap ibu_mmap_t;
+int32_t ibu_mmap_open(const char* path, ibu_mmap_t** out);              /* MmapReader::new :143-161 */
+int32_t ibu_mmap_clone(ibu_mmap_t* m, ibu_mmap_t** out);                /* Clone (Arc<Mmap>) :99    */
+size_t ibu_mmap_len(const ibu_mmap_t* m);                               /* len    :178-180          */
+int32_t ibu_mmap_header(const ibu_mmap_t* m, ibu_header_t* out);        /* header :201-203          */
+/* slice :253-270 — InvalidIndex{idx:end,max:len} if start>=len || end>len || end<=start (Q7). */
+int32_t ibu_mmap_slice(const ibu_mmap_t* m, size_t start, size_t end, const ibu_record_t** recs,
+                       size_t* n);
+const void* ibu_mmap_base(const ibu_mmap_t* m); /* Arc::ptr_eq analogue, mmap.rs:541 */
+void ibu_mmap_close(ibu_mmap_t* m);
+
+/* Static contiguous range split of mmap.rs:297-307: per = len/n, remainder to the LAST shard.
+ * Used for OS threads by the reference and for GPUs / ranks by this library. */
+int32_t ibu_shard_range(size_t len, size_t n_shards, size_t shard, size_t* start, size_t* end);
+
+/* ParallelProcessor :100-190 as a C vtable.  `clone` is P: Clone (one copy per worker);
+ * process_record / on_batch_complete return 0 or a non-zero user code -> IBU_ERR_PROCESS.
+ * set_tid is part of the trait but is never called by process_parallel (quirk Q4). */
+typedef struct ibu_processor_vtable {
+  void* (*clone)(void* user);
+  void (*drop)(void* user_clone);
+  int32_t (*process_record)(void* user_clone, const ibu_record_t* rec);
+  int32_t (*on_batch_complete)(void* user_clone); /* may be NULL: default Ok(()) */
+  void (*set_tid)(void* user_clone, size_t tid);  /* may be NULL */
+} ibu_processor_vtable_t;
+
+/* process_parallel :286-332 with a HOST processor (user code, exactly the reference's
+ * contract: n = 0 -> all cores, else min(n, cores); 1Mi-record batches; join in spawn order,
+ * first Err wins — quirk Q12). */
+int32_t ibu_mmap_process_parallel(const ibu_mmap_t* m, const ibu_processor_vtable_t* vt, void* user,
+                                  size_t num_threads);
+
+/* ======================================================================================= */
+/* Device context                                                                           */
+/* ======================================================================================= */
+typedef struct ibu_ctx ibu_ctx_t;
+/* One context per host thread and device; owns a stream, a status slot and reduce scratch.
+ * Fails with IBU_ERR_NO_DEVICE when the device is absent or not gfx950. */
+int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out);
+void ibu_ctx_destroy(ibu_ctx_t* ctx);
+int32_t ibu_ctx_device(const ibu_ctx_t* ctx);
+void* ibu_ctx_stream(const ibu_ctx_t* ctx);        /* hipStream_t */
+int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream);
+int32_t ibu_device_count(int32_t* n);
+/* Device memory helpers for callers without their own allocator (tests in C, Rust shim). */
+int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr);
+int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr);
+int32_t ibu_memcpy_h2d(ibu_ctx_t* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream);
+int32_t ibu_memcpy_d2h(ibu_ctx_t* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream);
+
+/* ======================================================================================= */
+/* Hot-path kernels (all asynchronous on `stream`)                                          */
+/* ======================================================================================= */
+/* K1  deserialise: AoS 24-byte records -> three u64 columns.  The reference's cast_slice
+ * (reader.rs:301,531; mmap.rs:268) followed by the field access every consumer performs.
+ * 24 B read + 24 B written per record. */
+int32_t ibu_deserialize(ibu_ctx_t* ctx, const void* d_records, size_t n, uint64_t* d_barcode,
+                        uint64_t* d_umi, uint64_t* d_index, void* stream);
+/* K1' serialise: three u64 columns -> AoS records (Record::new + write_batch's cast_slice,
+ * record.rs:87-93, writer.rs:315-318).  48 B per record. */
+int32_t ibu_serialize(ibu_ctx_t* ctx, const uint64_t* d_barcode, const uint64_t* d_umi,
+                      const uint64_t* d_index, size_t n, void* d_records, void* stream);
+/* 2-bit unpack of one u64 column to n*len ASCII bytes (row i at d_ascii + i*len).          */
+int32_t ibu_unpack_2bit(ibu_ctx_t* ctx, const uint64_t* d_codes, size_t n, uint32_t len,
+                        uint8_t* d_ascii, void* stream);
+/* 2-bit pack of n rows of len ASCII bytes into one u64 column; invalid bytes are reported
+ * through ibu_codec_status(). */
+int32_t ibu_pack_2bit(ibu_ctx_t* ctx, const uint8_t* d_ascii, size_t n, uint32_t len,
+                      uint64_t* d_codes, void* stream);
+/* K2  fused decode: AoS records -> barcode ASCII (n*bc_len), UMI ASCII (n*umi_len), index
+ * column.  24 B read + (bc_len+umi_len+8) B written per record.  Any output may be NULL to
+ * skip that column. */
+int32_t ibu_decode_ascii(ibu_ctx_t* ctx, const void* d_records, size_t n, uint32_t bc_len,
+                         uint32_t umi_len, uint8_t* d_bc_ascii, uint8_t* d_umi_ascii,
+                         uint64_t* d_index, void* stream);
+/* K3  fused encode: barcode/UMI ASCII + index column -> AoS records.  d_index == NULL writes
+ * index = first_index + i (the usual "record number" use, README.md:38-47). */
+int32_t ibu_encode_ascii(ibu_ctx_t* ctx, const uint8_t* d_bc_ascii, const uint8_t* d_umi_ascii,
+                         const uint64_t* d_index, uint64_t first_index, size_t n, uint32_t bc_len,
+                         uint32_t umi_len, void* d_records, void* stream);
+/* Invalid-base report for every pack/encode launched on this context since the last call.
+ * Synchronises `stream`, returns IBU_OK or IBU_ERR_INVALID_BASE (detail.a = first offending
+ * record index, detail.b = offending record count) and re-arms the slot. */
+int32_t ibu_codec_status(ibu_ctx_t* ctx, void* stream, uint64_t* first_bad_record,
+                         uint64_t* n_bad_records);
+
+/* K4  reduce: the device ParallelProcessor.  Fixed processors restating the reference's
+ * in-repo ones: count (lib.rs:117-129), wrapping sum of the three fields
+ * (examples/parallel.rs:21-36, mmap.rs:358-373), XOR of the three fields
+ * (examples/roundtrip.rs:84-87).  24 B read per record. */
+typedef struct ibu_reduce_result {
+  uint64_t count;
+  uint64_t sum[3]; /* barcode, umi, index — wrapping (mod 2^64) */
+  uint64_t xor_[3];
+} ibu_reduce_result_t;
+/* Accumulates INTO the context's device accumulator (call ibu_reduce_reset first). */
+int32_t ibu_reduce_reset(ibu_ctx_t* ctx, void* stream);
+int32_t ibu_reduce(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream);
+/* Synchronises `stream` and copies the accumulator out. */
+int32_t ibu_reduce_fetch(ibu_ctx_t* ctx, void* stream, ibu_reduce_result_t* out);
+
+/* Counter-based synthetic records: r(i,k) = splitmix64(seed + 3*i + k);
+ * barcode = r(i,0) & mask(2*bc_len), umi = r(i,1) & mask(2*umi_len), index = i, for
+ * i in [first, first+n).  Shard-independent, so each GPU materialises its own range. */
+int32_t ibu_generate(ibu_ctx_t* ctx, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
+                     uint32_t umi_len, void* d_records, void* stream);
+
+/* Device-side sort by (barcode, umi, index) — the order `derive(Ord)` defines (record.rs:58)
+ * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch. */
+int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
+/* 1 if the n records are non-decreasing under ibu_record_cmp. Synchronises. */
+int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream,
+                      int32_t* sorted);
+
+/* ======================================================================================= */
+/* Record streams: file / mmap / gzip  <->  device, through a pinned ring                   */
+/* ======================================================================================= */
+typedef struct ibu_ring_config {
+  uint32_t slots;        /* pinned hipHostMalloc staging slots (>= 2; default 4)             */
+  uint32_t slot_records; /* records per slot (default IBU_BATCH_SIZE * 4 = 96 MiB)           */
+  uint32_t feeder_threads; /* host threads copying mmap pages into a slot (default 4)        */
+  uint32_t reserved;
+} ibu_ring_config_t;
+
+typedef struct ibu_stream_stats {
+  uint64_t records;
+  uint64_t bytes_h2d;
+  uint64_t bytes_d2h;
+  uint64_t batches;
+  double seconds_total;
+  double seconds_kernel; /* sum of hipEvent kernel spans */
+} ibu_stream_stats_t;
+
+/* Device analogue of load_to_vec (reader.rs:510-535): whole uncompressed file -> device AoS
+ * buffer of *n records.  If *d_records is NULL the library hipMallocs it (release with
+ * ibu_device_free); otherwise cap_records bounds it. */
+int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg,
+                           ibu_header_t* header, void** d_records, size_t cap_records, size_t* n,
+                           ibu_stream_stats_t* stats);
+
+/* Device analogue of Writer::write_batch (writer.rs:315-351): n device-resident AoS records
+ * are copied back through the ring and appended to the writer (same buffered/direct rules). */
+int32_t ibu_writer_write_batch_device(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
+                                      const void* d_records, size_t n, ibu_stream_stats_t* stats);
+
+/* Device processors for process_parallel. */
+enum {
+  IBU_PROC_REDUCE = 1, /* count + sums + xors -> ibu_reduce_result_t                         */
+  IBU_PROC_DECODE = 2  /* fused decode of every batch into caller-provided device columns    */
+};
+typedef struct ibu_decode_sink {
+  uint8_t* d_bc_ascii; /* shard_records * bc_len  */
+  uint8_t* d_umi_ascii;
+  uint64_t* d_index;
+} ibu_decode_sink_t;
+
+/* Device analogue of MmapReader::process_parallel (mmap.rs:286-332) for ONE shard of the
+ * static split: shard `shard` of `n_shards` (one per GPU / rank) streams its record range
+ * through the pinned ring in IBU_BATCH_SIZE-multiples, H2D || kernel overlapped on two
+ * streams.  `sink` is ibu_reduce_result_t* or ibu_decode_sink_t* according to `proc`. */
+int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
+                                int32_t proc, size_t shard, size_t n_shards, void* sink,
+                                ibu_stream_stats_t* stats);
+
+/* Streaming Reader (plain or gzip; reader.rs:345-352 path) -> device processor: host inflate
+ * thread -> pinned ring -> H2D || kernel.  Consumes the reader to EOF. */
+int32_t ibu_reader_process_device(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
+                                  int32_t proc, void* sink, ibu_stream_stats_t* stats);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* IBU_HIP_H */

@@ -355,7 +355,7 @@ def test_parallel_split_quirks(oracle, tmp_path):
     r = mb.process_parallel(1)
     assert r.count == n and r.batches == 3
     with pytest.raises(oracle.OracleError) as ei:
-        mb.process_parallel_fail(4, fail_index=n - 1)
+        mb.process_parallel_fail(4, fail_index=3 * (n - 1))  # index column is 3i
     assert ei.value.name == "Process"
 
 

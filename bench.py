@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — records/s of the IBU hot path (fused 2-bit decode + encode of 24-byte records)
+on N MI355X GPUs, with the roofline of the dominant kernel and a CPU baseline beside it.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1
+the driver launches one rank per GPU with torch.distributed.run.  A *step* is one pass of the
+hot path over the rank's shard: K2 decode (AoS records -> barcode ASCII + UMI ASCII + index
+column) followed by K3 encode (those columns -> AoS records).  Inputs are resident in HBM
+before the timed region (synthetic, generated on device by the counter-based generator of
+SURVEY §8d, so every rank materialises its own contiguous record range of the global stream —
+the static split of src/io/mmap.rs:297-307).  No collective on the data path; ONE all-reduce
+at the end carries the global record count and field sums (BASELINE north_star).
+
+Output: one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--records", type=float, default=1e9, help="records per GPU (weak scaling)")
+    p.add_argument("--bc-len", type=int, default=16)
+    p.add_argument("--umi-len", type=int, default=12)
+    p.add_argument("--seed", type=lambda s: int(s, 0), default=0x1B00003)
+    p.add_argument("--cpu-sample", type=float, default=0, help="records for the CPU baseline (0 = auto)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (a C restatement of the reference's CPU path: static range split over OS threads,
+    1Mi-record batches, scalar 2-bit codec) timed on this box's host cores on a bounded sample."""
+    from oracle import oracle as orc  # the checker, used here only as the reported baseline
+
+    threads = len(os.sched_getaffinity(0))
+    n = int(args.cpu_sample) or 20_000_000
+    t, chk = orc.bench_decode_encode(min(n, 2_000_000), args.bc_len, args.umi_len, args.seed, threads)  # warm-up
+    if not args.cpu_sample:  # scale the sample to ~10-20 s of CPU work
+        rate = min(n, 2_000_000) / max(t, 1e-6)
+        n = int(min(max(rate * 12, 5_000_000), 400_000_000))
+    t, chk = orc.bench_decode_encode(n, args.bc_len, args.umi_len, args.seed, threads)
+    assert chk != 2**64 - 1, "oracle round trip failed"
+    return {
+        "value": n / t, "unit": "records/s", "cores": threads, "kind": "port",
+        "sample": f"{n} records bc_len={args.bc_len} umi_len={args.umi_len}, decode+encode, static split over "
+                  f"{threads} OS threads (C restatement of the reference's std::thread path; the reference is Rust "
+                  f"and cannot be built here)",
+        "seconds": t,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import ibu_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = ibu_amd.Context(local_rank)
+
+    n = int(args.records)
+    bc_len, umi_len = args.bc_len, args.umi_len
+    n_global = n * world
+    first, end = ibu_amd.shard_range(n_global, world, rank)  # contiguous record-range split
+    assert end - first == n
+
+    def buf(nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    recs, back = buf(n * 24), buf(n * 24)
+    bc, umi, idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.generate(args.seed, first, n, bc_len, umi_len, recs, stream=st)
+    torch.cuda.synchronize()
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
+        if ev:
+            ev[1].record()
+        ctx.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back, stream=st)
+        if ev:
+            ev[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    dec_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+    enc_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+
+    # ---- outside the timed region: correctness of what was timed ------------------------------
+    ctx.codec_status(stream=st)  # raises if any record failed to encode
+    red = ctx.reduce(recs, n, stream=st)
+    verified = None
+    if not args.no_verify:
+        red_back = ctx.reduce(back, n, stream=st)
+        verified = bool(torch.equal(recs, back)) and red == red_back and red["count"] == n
+        if not verified:
+            raise SystemExit("round trip encode(decode(x)) != x")
+    # the one cross-GPU exchange: global count + wrapping field sums (4 x i64 over RCCL)
+    tot = [red["count"]] + red["sum"]
+    if world > 1:
+        t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in tot], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tot = [int(v) % (1 << 64) for v in t.tolist()]
+    assert tot[0] == n_global
+    assert tot[3] == (n_global * (n_global - 1) // 2) % (1 << 64)  # index column is 0..n_global-1
+
+    if rank == 0:
+        dec_bytes = n * (24 + bc_len + umi_len + 8)
+        enc_bytes = dec_bytes
+        achieved = dec_bytes / (dec_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):  # PMC-derived HBM bytes per decode launch, recorded by profiles/collect_pmc.py
+            try:
+                with open(tp) as f:
+                    rec = json.load(f).get(f"decode_{bc_len}_{umi_len}")
+                if rec:
+                    traffic = rec["hbm_bytes_per_record"] * n
+            except (OSError, ValueError, KeyError):
+                traffic = None
+        out = {
+            "metric": "records/s, fused 2-bit decode+encode of 24-byte IBU records (HBM-resident)",
+            "value": n_global * args.steps / elapsed,
+            "unit": "records/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n:.3g} records/GPU bc_len={bc_len} umi_len={umi_len}, K2 decode + K3 encode per step "
+                            f"(BASELINE configs[3] shape; contiguous record-range shard per rank, no data-path collective)",
+                "records_per_gpu": n, "records_total": n_global, "bc_len": bc_len, "umi_len": umi_len,
+                "parallelism": f"range-shard x{world}",
+            },
+            "kernel_ms": {"decode": dec_ms, "encode": enc_ms},
+            "kernel_GBps": {"decode": achieved, "encode": enc_bytes / (enc_ms * 1e-3) / 1e9},
+            "roofline": {
+                "bound": "hbm", "kernel": "ibu_k_decode", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "bytes_per_record": 24 + bc_len + umi_len + 8,
+            },
+            "verified_roundtrip": verified,
+            "global_count": tot[0],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,649 @@
+"""ibu_amd — MI355X-native batch record-stream + 2-bit codec path for the IBU format.
+
+A thin Python mirror of the reference crate's public API (src/lib.rs:178-181:
+Header, Record, HEADER_SIZE, MAGIC, RECORD_SIZE, VERSION, IbuError, load_to_vec, MmapReader,
+Reader, Writer, ParallelProcessor, ParallelReader) over the C ABI of include/ibu_hip.h, plus
+the device context that exposes the HIP kernels.  All work happens in libibu_hip.so; this
+package binds it and nothing else (no numpy/torch arithmetic stands in for a kernel).
+"""
+import copy
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import CDecodeSink, CErrorDetail, CHeader, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
+
+lib = _lib.load()
+
+MAGIC = 0x21554249  # src/constructs/header.rs:5
+VERSION = 2  # header.rs:6
+HEADER_SIZE = 32  # header.rs:7
+RECORD_SIZE = 24  # record.rs:3
+DEFAULT_BUFFER_SIZE = 48 * 1024 * RECORD_SIZE  # reader.rs:14, writer.rs:10
+BATCH_SIZE = 1024 * 1024  # mmap.rs:284
+
+PROC_REDUCE, PROC_DECODE = 1, 2
+
+#: numpy view of a `&[Record]` (bytemuck::cast_slice)
+REC_DTYPE = np.dtype([("barcode", "<u8"), ("umi", "<u8"), ("index", "<u8")])
+
+
+# ---- errors (src/error.rs:56-128) ---------------------------------------------------------------
+class IbuError(Exception):
+    """`kind` is the reference's variant name; payload fields follow the variant."""
+
+    def __init__(self, code, detail):
+        self.code = code
+        self.kind = lib.ibu_status_name(code).decode()
+        self.a, self.b, self.os_errno = detail.a, detail.b, detail.os_errno
+        self.expected, self.actual = detail.a, detail.b  # InvalidMagicNumber / InvalidVersion
+        self.pos = detail.a  # TruncatedRecord
+        self.idx, self.max = detail.a, detail.b  # InvalidIndex
+        self.length = detail.a  # InvalidBarcodeLength / InvalidUmiLength
+        self.first_bad, self.n_bad = detail.a, detail.b  # InvalidBase
+        super().__init__(f"{self.kind}: {detail.message.decode(errors='replace')}")
+
+
+def _check(rc):
+    if rc:
+        d = CErrorDetail()
+        lib.ibu_last_error(C.byref(d))
+        raise IbuError(rc, d)
+
+
+# ---- Header / Record ---------------------------------------------------------------------------------
+class Header:
+    """src/constructs/header.rs:44-61 — 32-byte POD."""
+
+    def __init__(self, bc_len, umi_len):  # Header::new :84-93
+        self._h = CHeader()
+        lib.ibu_header_init(C.byref(self._h), bc_len, umi_len)
+
+    magic = property(lambda s: s._h.magic, lambda s, v: setattr(s._h, "magic", v))
+    version = property(lambda s: s._h.version, lambda s, v: setattr(s._h, "version", v))
+    bc_len = property(lambda s: s._h.bc_len, lambda s, v: setattr(s._h, "bc_len", v))
+    umi_len = property(lambda s: s._h.umi_len, lambda s, v: setattr(s._h, "umi_len", v))
+    flags = property(lambda s: s._h.flags, lambda s, v: setattr(s._h, "flags", v))
+    reserved = property(lambda s: bytes(s._h.reserved))
+
+    def set_sorted(self):  # :111-113
+        lib.ibu_header_set_sorted(C.byref(self._h))
+
+    def sorted(self):  # :130-132
+        return bool(lib.ibu_header_sorted(C.byref(self._h)))
+
+    def validate(self):  # :167-187
+        _check(lib.ibu_header_validate(C.byref(self._h)))
+
+    def as_bytes(self):  # :203-205
+        buf = C.create_string_buffer(HEADER_SIZE)
+        _check(lib.ibu_header_as_bytes(C.byref(self._h), buf, HEADER_SIZE))
+        return buf.raw
+
+    @classmethod
+    def from_bytes(cls, b):  # :226-228 (the reference panics on a wrong length; here InvalidArg)
+        h = cls.__new__(cls)
+        h._h = CHeader()
+        _check(lib.ibu_header_from_bytes(bytes(b), len(b), C.byref(h._h)))
+        return h
+
+    @classmethod
+    def _wrap(cls, ch):
+        h = cls.__new__(cls)
+        h._h = ch
+        return h
+
+    def __eq__(self, o):
+        return isinstance(o, Header) and self.as_bytes() == o.as_bytes()
+
+    def __hash__(self):
+        return hash(self.as_bytes())
+
+    def __repr__(self):
+        return (f"Header {{ magic: {self.magic:#x}, version: {self.version}, bc_len: {self.bc_len}, "
+                f"umi_len: {self.umi_len}, flags: {self.flags} }}")
+
+
+class Record(namedtuple("Record", ["barcode", "umi", "index"])):
+    """src/constructs/record.rs:58-66 — tuple order is the derived lexicographic Ord."""
+    __slots__ = ()
+
+    def __new__(cls, barcode=0, umi=0, index=0):
+        return super().__new__(cls, int(barcode), int(umi), int(index))
+
+    def _c(self):
+        return CRecord(self.barcode, self.umi, self.index)
+
+    def as_bytes(self):  # :108-110
+        buf = C.create_string_buffer(RECORD_SIZE)
+        r = self._c()
+        _check(lib.ibu_record_as_bytes(C.byref(r), buf, RECORD_SIZE))
+        return buf.raw
+
+    @classmethod
+    def from_bytes(cls, b):  # :130-132
+        r = CRecord()
+        _check(lib.ibu_record_from_bytes(bytes(b), len(b), C.byref(r)))
+        return cls(r.barcode, r.umi, r.index)
+
+    def cmp(self, other):
+        a, b = self._c(), Record(*other)._c()
+        return lib.ibu_record_cmp(C.byref(a), C.byref(b))
+
+
+def records_array(rows):
+    """iterable of Record / 3-tuples, or an (n,3) integer array -> contiguous AoS array."""
+    if isinstance(rows, np.ndarray) and rows.dtype == REC_DTYPE:
+        return np.ascontiguousarray(rows)
+    a = np.asarray(list(rows) if not isinstance(rows, np.ndarray) else rows, dtype=np.uint64).reshape(-1, 3)
+    out = np.empty(a.shape[0], dtype=REC_DTYPE)
+    out["barcode"], out["umi"], out["index"] = a[:, 0], a[:, 1], a[:, 2]
+    return out
+
+
+def _hptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- Writer (src/io/writer.rs) ---------------------------------------------------------------------------
+class Writer:
+    """`Writer<W>`; W is a path (from_path), a file descriptor, a Python file-like (callback
+    sink) or memory (`Writer::new(Vec::new(), header)`)."""
+
+    def __init__(self, inner=None, header=None, _handle=None):
+        self._w = _handle
+        self._cb = None
+        if _handle is not None:
+            return
+        hp = C.byref(header._h) if header is not None else None
+        out = C.c_void_p()
+        if inner is None or isinstance(inner, (bytearray, list)):  # Vec<u8>
+            _check(lib.ibu_writer_open_mem(hp, C.byref(out)))
+        elif isinstance(inner, int):
+            _check(lib.ibu_writer_open_fd(inner, hp, C.byref(out)))
+        else:  # any object with .write(bytes) [and .flush()]
+            def _wr(_u, data, n, _f=inner):
+                try:
+                    _f.write(C.string_at(data, n))
+                    return 0
+                except OSError as e:
+                    return e.errno or 5
+            def _fl(_u, _f=inner):
+                try:
+                    if hasattr(_f, "flush"):
+                        _f.flush()
+                    return 0
+                except OSError as e:
+                    return e.errno or 5
+            self._cb = (_lib.WRITE_FN(_wr), _lib.FLUSH_FN(_fl))
+            _check(lib.ibu_writer_open_callback(self._cb[0], self._cb[1], None, hp, C.byref(out)))
+        self._w = out
+
+    @classmethod
+    def new(cls, inner, header):  # Writer::new :129-143
+        return cls(inner, header)
+
+    @classmethod
+    def new_headless(cls, inner=None):  # :169-179
+        return cls(inner, None)
+
+    @classmethod
+    def from_path(cls, path, header):  # :556-559
+        out = C.c_void_p()
+        _check(lib.ibu_writer_open_path(str(path).encode(), C.byref(header._h) if header else None, C.byref(out)))
+        return cls(_handle=out)
+
+    @classmethod
+    def from_stdout(cls, header):  # :587-589
+        return cls(1, header)
+
+    @classmethod
+    def from_optional_path(cls, path, header):  # :617-626
+        return cls.from_path(path, header) if path is not None else cls.from_stdout(header)
+
+    def write_record(self, record):  # :260-273
+        r = Record(*record)._c()
+        _check(lib.ibu_writer_write_record(self._w, C.byref(r)))
+
+    def write_batch(self, records):  # :315-318
+        a = records_array(records)
+        _check(lib.ibu_writer_write_batch(self._w, _hptr(a), a.shape[0]))
+
+    def write_iter(self, records):  # :383-391
+        for r in records:
+            self.write_record(r)
+
+    def write_batch_device(self, ctx, d_records, n, ring=None):
+        """Device-resident AoS records -> pinned ring -> this writer (write_batch rules)."""
+        st = CStreamStats()
+        _check(lib.ibu_writer_write_batch_device(self._w, ctx._c, _ring(ring), _dptr(d_records), n, C.byref(st)))
+        return st
+
+    def ingest(self, other):  # :477-482
+        _check(lib.ibu_writer_ingest(self._w, other._w))
+
+    def finish(self):  # :429-433
+        _check(lib.ibu_writer_finish(self._w))
+
+    def records_written(self):  # :207-209
+        return lib.ibu_writer_records_written(self._w)
+
+    def inner_bytes(self):
+        """What a `Vec<u8>` sink holds right now (tests peek at `writer.inner`)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib.ibu_writer_mem_view(self._w, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def into_inner(self):  # :507-511 — no flush
+        p, n = C.c_void_p(), C.c_size_t()
+        w, self._w = self._w, None
+        _check(lib.ibu_writer_into_inner(w, C.byref(p), C.byref(n)))
+        if not p:
+            return None
+        data = C.string_at(p, n.value)
+        lib.ibu_free(p)
+        return data
+
+    def close(self):  # Drop :519-523
+        if getattr(self, "_w", None):
+            lib.ibu_writer_close(self._w)
+            self._w = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ---- Reader (src/io/reader.rs) -------------------------------------------------------------------------------
+class Reader:
+    """`Reader<R>`; R is bytes (Cursor), a file descriptor or a file-like with .readinto/.read."""
+
+    def __init__(self, inner=None, _handle=None):
+        self._r, self._keep, self._cb = _handle, None, None
+        if _handle is not None:
+            return
+        out = C.c_void_p()
+        if isinstance(inner, (bytes, bytearray, memoryview, np.ndarray)):
+            self._keep = np.frombuffer(bytes(inner), dtype=np.uint8)
+            _check(lib.ibu_reader_open_mem(_hptr(self._keep), self._keep.size, C.byref(out)))
+        elif isinstance(inner, int):
+            _check(lib.ibu_reader_open_fd(inner, C.byref(out)))
+        else:
+            def _rd(_u, dst, cap, got, _f=inner):
+                try:
+                    b = _f.read(cap)
+                    C.memmove(dst, b, len(b))
+                    got[0] = len(b)
+                    return 0
+                except OSError as e:
+                    return e.errno or 5
+            self._cb = _lib.READ_FN(_rd)
+            _check(lib.ibu_reader_open_callback(self._cb, None, C.byref(out)))
+        self._r = out
+
+    @classmethod
+    def new(cls, inner):  # :152-176
+        return cls(inner)
+
+    @classmethod
+    def from_path(cls, path):  # :345-352 (gzip sniffed; bz2/xz/zstd -> Niffler error)
+        out = C.c_void_p()
+        _check(lib.ibu_reader_open_path(str(path).encode(), C.byref(out)))
+        return cls(_handle=out)
+
+    @classmethod
+    def from_stdin(cls):  # :389-396
+        out = C.c_void_p()
+        _check(lib.ibu_reader_open_fd(0, C.byref(out)))
+        return cls(_handle=out)
+
+    @classmethod
+    def from_optional_path(cls, path):  # :425-434
+        return cls.from_path(path) if path is not None else cls.from_stdin()
+
+    def header(self):  # :244-246
+        h = CHeader()
+        _check(lib.ibu_reader_header(self._r, C.byref(h)))
+        return Header._wrap(h)
+
+    def read_batch(self):  # :218-242
+        has = C.c_int32()
+        _check(lib.ibu_reader_read_batch(self._r, C.byref(has)))
+        return bool(has.value)
+
+    @property
+    def bytes_read(self):
+        return lib.ibu_reader_bytes_read(self._r)
+
+    def buffered(self):
+        """Zero-copy numpy view of the records left in the current refill."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib.ibu_reader_buffered(self._r, C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.empty(0, dtype=REC_DTYPE)
+        return np.frombuffer((C.c_uint8 * (n.value * RECORD_SIZE)).from_address(p.value), dtype=REC_DTYPE)
+
+    def consume(self, n):
+        _check(lib.ibu_reader_consume(self._r, n))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):  # Iterator::next :279-306; an Err item is raised
+        r, got = CRecord(), C.c_int32()
+        _check(lib.ibu_reader_next(self._r, C.byref(r), C.byref(got)))
+        if not got.value:
+            raise StopIteration
+        return Record(r.barcode, r.umi, r.index)
+
+    def process_device(self, ctx, proc=PROC_REDUCE, sink=None, ring=None):
+        """Stream the rest of this reader (plain or gzip) through the pinned ring to a device
+        processor.  Returns (result, stats)."""
+        return ctx._run_proc(lambda c, rg, s, st: lib.ibu_reader_process_device(self._r, c, rg, proc, s, st),
+                             proc, sink, ring)
+
+    def close(self):
+        if getattr(self, "_r", None):
+            lib.ibu_reader_close(self._r)
+            self._r = None
+
+    __del__ = close
+
+
+def load_to_vec(path):  # src/io/reader.rs:510-535
+    h, p, n = CHeader(), C.c_void_p(), C.c_size_t()
+    _check(lib.ibu_load_to_vec(str(path).encode(), C.byref(h), C.byref(p), C.byref(n)))
+    recs = np.frombuffer(C.string_at(p, n.value * RECORD_SIZE), dtype=REC_DTYPE).copy() if n.value else np.empty(0, REC_DTYPE)
+    lib.ibu_free(p)
+    return Header._wrap(h), recs
+
+
+# ---- parallel (src/parallel.rs, src/io/mmap.rs) ------------------------------------------------------------------
+class ParallelProcessor:
+    """src/parallel.rs:100-190.  Subclass and override process_record (and optionally
+    on_batch_complete / set_tid / get_tid).  `clone()` is `P: Clone`: shallow copy, so shared
+    accumulators (the Arc<Mutex<..>> pattern) stay shared."""
+
+    def process_record(self, record):
+        raise NotImplementedError
+
+    def on_batch_complete(self):  # default Ok(()) :137-139
+        return None
+
+    def set_tid(self, tid):  # default no-op :166-168
+        pass
+
+    def get_tid(self):  # default None :187-189
+        return None
+
+    def clone(self):
+        return copy.copy(self)
+
+
+class ProcessError(Exception):
+    """Raise from process_record / on_batch_complete to return IbuError::Process."""
+
+
+def shard_range(length, n_shards, shard):  # mmap.rs:297-307
+    s, e = C.c_size_t(), C.c_size_t()
+    _check(lib.ibu_shard_range(length, n_shards, shard, C.byref(s), C.byref(e)))
+    return s.value, e.value
+
+
+class MmapReader:
+    """src/io/mmap.rs:99-332 (MmapReader + its ParallelReader impl)."""
+
+    def __init__(self, path=None, _handle=None):
+        if _handle is None:
+            _handle = C.c_void_p()
+            _check(lib.ibu_mmap_open(str(path).encode(), C.byref(_handle)))
+        self._m = _handle
+
+    @classmethod
+    def new(cls, path):  # :143-161
+        return cls(path)
+
+    def clone(self):  # Arc clone :99
+        out = C.c_void_p()
+        _check(lib.ibu_mmap_clone(self._m, C.byref(out)))
+        return MmapReader(_handle=out)
+
+    def len(self):  # :178-180
+        return lib.ibu_mmap_len(self._m)
+
+    __len__ = len
+
+    def header(self):  # :201-203
+        h = CHeader()
+        _check(lib.ibu_mmap_header(self._m, C.byref(h)))
+        return Header._wrap(h)
+
+    def slice(self, start, end):  # :253-270 — zero-copy view into the map
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib.ibu_mmap_slice(self._m, start, end, C.byref(p), C.byref(n)))
+        return np.frombuffer((C.c_uint8 * (n.value * RECORD_SIZE)).from_address(p.value), dtype=REC_DTYPE)
+
+    def map_ptr(self):
+        return lib.ibu_mmap_base(self._m)
+
+    def process_parallel(self, processor, num_threads):  # :286-332, host processor (user code)
+        clones, errors = {}, []
+
+        def _clone(_u):
+            c = processor.clone()
+            key = len(clones) + 1
+            clones[key] = c
+            return key
+
+        def _drop(_k):
+            pass
+
+        def _proc(k, rec):
+            try:
+                r = rec[0]
+                clones[k].process_record(Record(r.barcode, r.umi, r.index))
+                return 0
+            except Exception as e:  # -> IbuError::Process
+                errors.append(e)
+                return 1
+
+        def _batch(k):
+            try:
+                clones[k].on_batch_complete()
+                return 0
+            except Exception as e:
+                errors.append(e)
+                return 1
+
+        vt = CProcessorVTable(_lib.CLONE_FN(_clone), _lib.DROP_FN(_drop), _lib.PROCESS_FN(_proc),
+                              _lib.BATCH_FN(_batch), _lib.TID_FN())
+        _check(lib.ibu_mmap_process_parallel(self._m, C.byref(vt), None, num_threads))
+
+    def process_device(self, ctx, proc=PROC_REDUCE, shard=0, n_shards=1, sink=None, ring=None):
+        """One shard of the static split on one GPU, through the pinned ring."""
+        return ctx._run_proc(
+            lambda c, rg, s, st: lib.ibu_mmap_process_device(self._m, c, rg, proc, shard, n_shards, s, st),
+            proc, sink, ring)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib.ibu_mmap_close(self._m)
+            self._m = None
+
+    __del__ = close
+
+
+# ---- device side ----------------------------------------------------------------------------------------------------
+def _dptr(x):
+    """int | DeviceBuffer | torch.Tensor | None -> c_void_p."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "ptr"):
+        return C.c_void_p(x.ptr)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"not a device pointer: {type(x)}")
+
+
+def _ring(r):
+    if r is None:
+        return None
+    if isinstance(r, CRingConfig):
+        return C.byref(r)
+    return C.byref(CRingConfig(r.get("slots", 0), r.get("slot_records", 0), r.get("feeder_threads", 0), 0))
+
+
+def device_count():
+    n = C.c_int32()
+    rc = lib.ibu_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned through the context (for callers without torch)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _check(lib.ibu_device_alloc(ctx._c, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        a = np.ascontiguousarray(host)
+        assert a.nbytes <= self.nbytes
+        _check(lib.ibu_memcpy_h2d(self.ctx._c, self.ptr, _hptr(a), a.nbytes, None))
+        self.ctx.synchronize()
+        return self
+
+    def download(self, dtype=np.uint8, count=None, offset=0):
+        dt = np.dtype(dtype)
+        nbytes = (self.nbytes - offset) if count is None else count * dt.itemsize
+        out = np.empty(nbytes // dt.itemsize, dtype=dt)
+        _check(lib.ibu_memcpy_d2h(self.ctx._c, _hptr(out), self.ptr + offset, out.nbytes, None))
+        self.ctx.synchronize()
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", 0) and getattr(self.ctx, "_c", None):
+            lib.ibu_device_free(self.ctx._c, self.ptr)
+            self.ptr = 0
+
+    __del__ = free
+
+
+class Context:
+    """ibu_ctx_t: one per host thread and GPU.  Every method launches asynchronously on
+    `stream` (default: the context's own stream) unless it says it synchronises."""
+
+    def __init__(self, device=0):
+        c = C.c_void_p()
+        _check(lib.ibu_ctx_create(device, C.byref(c)))
+        self._c = c
+
+    @property
+    def stream(self):
+        return lib.ibu_ctx_stream(self._c)
+
+    def synchronize(self, stream=None):
+        _check(lib.ibu_ctx_synchronize(self._c, stream))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, host):
+        a = np.ascontiguousarray(host)
+        return DeviceBuffer(self, max(a.nbytes, 16)).upload(a)
+
+    # K1 / K1'
+    def deserialize(self, d_records, n, d_barcode, d_umi, d_index, stream=None):
+        _check(lib.ibu_deserialize(self._c, _dptr(d_records), n, _dptr(d_barcode), _dptr(d_umi), _dptr(d_index), stream))
+
+    def serialize(self, d_barcode, d_umi, d_index, n, d_records, stream=None):
+        _check(lib.ibu_serialize(self._c, _dptr(d_barcode), _dptr(d_umi), _dptr(d_index), n, _dptr(d_records), stream))
+
+    # column codec
+    def unpack_2bit(self, d_codes, n, length, d_ascii, stream=None):
+        _check(lib.ibu_unpack_2bit(self._c, _dptr(d_codes), n, length, _dptr(d_ascii), stream))
+
+    def pack_2bit(self, d_ascii, n, length, d_codes, stream=None):
+        _check(lib.ibu_pack_2bit(self._c, _dptr(d_ascii), n, length, _dptr(d_codes), stream))
+
+    # K2 / K3
+    def decode_ascii(self, d_records, n, bc_len, umi_len, d_bc, d_umi, d_index, stream=None):
+        _check(lib.ibu_decode_ascii(self._c, _dptr(d_records), n, bc_len, umi_len, _dptr(d_bc), _dptr(d_umi),
+                                    _dptr(d_index), stream))
+
+    def encode_ascii(self, d_bc, d_umi, d_index, n, bc_len, umi_len, d_records, first_index=0, stream=None):
+        _check(lib.ibu_encode_ascii(self._c, _dptr(d_bc), _dptr(d_umi), _dptr(d_index), first_index, n, bc_len,
+                                    umi_len, _dptr(d_records), stream))
+
+    def codec_status(self, stream=None):
+        """Synchronises; raises IbuError(InvalidBase) if any pack/encode since the last call saw a bad byte."""
+        fb, nb = C.c_uint64(), C.c_uint64()
+        _check(lib.ibu_codec_status(self._c, stream, C.byref(fb), C.byref(nb)))
+
+    # K4
+    def reduce(self, d_records, n, stream=None, reset=True, fetch=True):
+        if reset:
+            _check(lib.ibu_reduce_reset(self._c, stream))
+        _check(lib.ibu_reduce(self._c, _dptr(d_records), n, stream))
+        return self.reduce_fetch(stream) if fetch else None
+
+    def reduce_fetch(self, stream=None):
+        r = CReduceResult()
+        _check(lib.ibu_reduce_fetch(self._c, stream, C.byref(r)))
+        return {"count": r.count, "sum": list(r.sum), "xor": list(r.xor_)}
+
+    def generate(self, seed, first, n, bc_len, umi_len, d_records, stream=None):
+        _check(lib.ibu_generate(self._c, seed, first, n, bc_len, umi_len, _dptr(d_records), stream))
+
+    def sort_records(self, d_records, d_tmp, n, stream=None):
+        _check(lib.ibu_sort_records(self._c, _dptr(d_records), _dptr(d_tmp), n, stream))
+
+    def is_sorted(self, d_records, n, stream=None):
+        s = C.c_int32()
+        _check(lib.ibu_is_sorted(self._c, _dptr(d_records), n, stream, C.byref(s)))
+        return bool(s.value)
+
+    # streams
+    def load_to_device(self, path, ring=None, d_records=None, cap_records=0):
+        """Device analogue of load_to_vec -> (Header, device pointer (int) or the given buffer, n, stats)."""
+        h, n, st = CHeader(), C.c_size_t(), CStreamStats()
+        p = C.c_void_p(_dptr(d_records).value if d_records is not None else None)
+        _check(lib.ibu_load_to_device(self._c, str(path).encode(), _ring(ring), C.byref(h), C.byref(p), cap_records,
+                                      C.byref(n), C.byref(st)))
+        return Header._wrap(h), p.value, n.value, st
+
+    def free(self, ptr):
+        _check(lib.ibu_device_free(self._c, ptr))
+
+    def _run_proc(self, call, proc, sink, ring):
+        st = CStreamStats()
+        if proc == PROC_REDUCE:
+            r = CReduceResult()
+            _check(call(self._c, _ring(ring), C.cast(C.byref(r), C.c_void_p), C.byref(st)))
+            return {"count": r.count, "sum": list(r.sum), "xor": list(r.xor_)}, st
+        s = CDecodeSink(*(_dptr(x) for x in sink))
+        _check(call(self._c, _ring(ring), C.cast(C.byref(s), C.c_void_p), C.byref(st)))
+        return None, st
+
+    def close(self):
+        if getattr(self, "_c", None):
+            lib.ibu_ctx_destroy(self._c)
+            self._c = None
+
+    __del__ = close
+
+
+__all__ = ["Header", "Record", "HEADER_SIZE", "MAGIC", "RECORD_SIZE", "VERSION", "IbuError", "load_to_vec",
+           "MmapReader", "Reader", "Writer", "ParallelProcessor", "ProcessError", "shard_range", "Context",
+           "DeviceBuffer", "records_array", "REC_DTYPE", "device_count", "PROC_REDUCE", "PROC_DECODE",
+           "DEFAULT_BUFFER_SIZE", "BATCH_SIZE"]

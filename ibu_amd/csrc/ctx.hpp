@@ -1,0 +1,55 @@
+// ctx.hpp — the device context behind ibu_ctx_t (shared by device.cpp and stream.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.h"
+
+namespace ibu {
+
+inline int32_t hip_fail(hipError_t e, const char* what) {
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
+    return set_error(IBU_ERR_NO_DEVICE, (uint64_t)e, 0, 0, "no usable HIP device (%s): %s", what, hipGetErrorString(e));
+  return set_error(IBU_ERR_HIP, (uint64_t)e, 0, 0, "HIP error in %s: %s", what, hipGetErrorString(e));
+}
+#define IBU_HIP(call)                                  \
+  do {                                                 \
+    hipError_t e__ = (call);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, #call); \
+  } while (0)
+
+// Pinned-host + device staging ring used by the record-stream entry points.
+struct Ring {
+  uint32_t slots = 0;
+  size_t slot_bytes = 0;
+  std::vector<uint8_t*> pinned;  // hipHostMalloc
+  std::vector<uint8_t*> dev;     // hipMalloc, same size (H2D landing zone / D2H source)
+  std::vector<hipEvent_t> copied;    // H2D (or D2H) of the slot finished
+  std::vector<hipEvent_t> consumed;  // kernel that read the slot finished
+};
+
+}  // namespace ibu
+
+struct ibu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;   // compute
+  hipStream_t copy_stream = nullptr;
+  ibu::LaunchCfg cfg;
+  uint64_t* d_status = nullptr;  // [first_bad_record, n_bad_records]
+  uint64_t* d_acc = nullptr;     // [count, sum0..2, xor0..2, pad]
+  uint32_t* d_flag = nullptr;    // sortedness flag
+  uint64_t* h_pinned = nullptr;  // 16 x u64 of pinned host memory for small read-backs
+  void* d_sort_scratch = nullptr;
+  size_t sort_scratch_bytes = 0;
+  ibu::Ring ring;
+};
+
+namespace ibu {
+int32_t ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_dev);
+void ring_release(ibu_ctx* ctx);
+inline hipStream_t pick_stream(const ibu_ctx* ctx, void* stream) {
+  return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+}
+}  // namespace ibu

@@ -1,0 +1,290 @@
+// device.cpp — device context and the kernel entry points of the C ABI (include/ibu_hip.h).
+//
+// Every function here fails loudly (IBU_ERR_NO_DEVICE / IBU_ERR_HIP) when there is no gfx950
+// device; nothing falls back to host arithmetic.  Launch functions are asynchronous, allocate
+// nothing and never synchronise, so callers may capture them into hipGraphs.
+#include <string.h>
+
+#include "ctx.hpp"
+
+using namespace ibu;
+
+namespace {
+
+int32_t check_ctx(const ibu_ctx* ctx) {
+  if (!ctx) return err_arg("ctx is NULL");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  return IBU_OK;
+}
+int32_t check_lens(uint32_t bc_len, uint32_t umi_len) {  // header.rs:180-185
+  if (bc_len == 0 || bc_len > 32) return err_bc_len(bc_len);
+  if (umi_len == 0 || umi_len > 32) return err_umi_len(umi_len);
+  return IBU_OK;
+}
+bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+}  // namespace
+
+extern "C" int32_t ibu_device_count(int32_t* n) {
+  if (!n) return err_arg("n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return hip_fail(e, "hipGetDeviceCount");
+  }
+  *n = c;
+  return IBU_OK;
+}
+
+extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
+  if (!out) return err_arg("out is NULL");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+  if (device < 0 || device >= count)
+    return set_error(IBU_ERR_NO_DEVICE, 0, 0, 0, "device %d not present (%d visible)", device, count);
+  IBU_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  IBU_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(IBU_ERR_NO_DEVICE, 0, 0, 0, "device %d is %s; this library carries gfx950 code objects only",
+                     device, prop.gcnArchName);
+  ibu_ctx* ctx = new ibu_ctx;
+  ctx->device = device;
+  ctx->cfg.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  ctx->cfg.blocks_per_cu = 8;
+  hipError_t rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 2 * sizeof(uint64_t));
+  if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_acc), 8 * sizeof(uint64_t));
+  if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_flag), 16);
+  if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 16 * sizeof(uint64_t), hipHostMallocDefault);
+  if (rc == hipSuccess) rc = hipMemsetAsync(ctx->d_acc, 0, 8 * sizeof(uint64_t), ctx->stream);
+  if (rc == hipSuccess) rc = launch_fill2(ctx->d_status, ~0ull, 0, ctx->stream);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(ctx->stream);
+  if (rc != hipSuccess) {
+    ibu_ctx_destroy(ctx);
+    return hip_fail(rc, "ibu_ctx_create");
+  }
+  *out = ctx;
+  return IBU_OK;
+}
+
+extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  ring_release(ctx);
+  if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->d_acc) (void)hipFree(ctx->d_acc);
+  if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  delete ctx;
+}
+extern "C" int32_t ibu_ctx_device(const ibu_ctx_t* ctx) { return ctx ? ctx->device : -1; }
+extern "C" void* ibu_ctx_stream(const ibu_ctx_t* ctx) { return ctx ? ctx->stream : nullptr; }
+extern "C" int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  IBU_HIP(hipStreamSynchronize(pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!d_ptr) return err_arg("d_ptr is NULL");
+  IBU_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  IBU_HIP(hipFree(d_ptr));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_memcpy_h2d(ibu_ctx_t* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (bytes) IBU_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_memcpy_d2h(ibu_ctx_t* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (bytes) IBU_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+
+// ---- K1 / K1' ------------------------------------------------------------------------------
+extern "C" int32_t ibu_deserialize(ibu_ctx_t* ctx, const void* d_records, size_t n, uint64_t* d_barcode,
+                                   uint64_t* d_umi, uint64_t* d_index, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || !d_barcode || !d_umi || !d_index) return err_arg("NULL device pointer");
+  if (!aligned8(d_records) || !aligned8(d_barcode) || !aligned8(d_umi) || !aligned8(d_index))
+    return err_arg("u64 data must be 8-byte aligned");
+  IBU_HIP(launch_deserialize(ctx->cfg, d_records, n, d_barcode, d_umi, d_index, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_serialize(ibu_ctx_t* ctx, const uint64_t* d_barcode, const uint64_t* d_umi,
+                                 const uint64_t* d_index, size_t n, void* d_records, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || !d_barcode || !d_umi || !d_index) return err_arg("NULL device pointer");
+  if (!aligned8(d_records) || !aligned8(d_barcode) || !aligned8(d_umi) || !aligned8(d_index))
+    return err_arg("u64 data must be 8-byte aligned");
+  IBU_HIP(launch_serialize(ctx->cfg, d_barcode, d_umi, d_index, n, d_records, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+
+// ---- column codec ----------------------------------------------------------------------------
+extern "C" int32_t ibu_unpack_2bit(ibu_ctx_t* ctx, const uint64_t* d_codes, size_t n, uint32_t len, uint8_t* d_ascii,
+                                   void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (len == 0 || len > 32) return err_seq_len(len);
+  if (n == 0) return IBU_OK;
+  if (!d_codes || !d_ascii) return err_arg("NULL device pointer");
+  if (!aligned8(d_codes)) return err_arg("u64 data must be 8-byte aligned");
+  IBU_HIP(launch_unpack(ctx->cfg, d_codes, n, len, d_ascii, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_pack_2bit(ibu_ctx_t* ctx, const uint8_t* d_ascii, size_t n, uint32_t len, uint64_t* d_codes,
+                                 void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (len == 0 || len > 32) return err_seq_len(len);
+  if (n == 0) return IBU_OK;
+  if (!d_codes || !d_ascii) return err_arg("NULL device pointer");
+  if (!aligned8(d_codes)) return err_arg("u64 data must be 8-byte aligned");
+  IBU_HIP(launch_pack(ctx->cfg, d_ascii, n, len, d_codes, ctx->d_status, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+
+// ---- K2 / K3 -----------------------------------------------------------------------------------
+extern "C" int32_t ibu_decode_ascii(ibu_ctx_t* ctx, const void* d_records, size_t n, uint32_t bc_len, uint32_t umi_len,
+                                    uint8_t* d_bc_ascii, uint8_t* d_umi_ascii, uint64_t* d_index, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  rc = check_lens(bc_len, umi_len);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records) return err_arg("d_records is NULL");
+  if (!aligned8(d_records) || !aligned8(d_index)) return err_arg("u64 data must be 8-byte aligned");
+  IBU_HIP(launch_decode(ctx->cfg, d_records, n, bc_len, umi_len, d_bc_ascii, d_umi_ascii, d_index,
+                        pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_encode_ascii(ibu_ctx_t* ctx, const uint8_t* d_bc_ascii, const uint8_t* d_umi_ascii,
+                                    const uint64_t* d_index, uint64_t first_index, size_t n, uint32_t bc_len,
+                                    uint32_t umi_len, void* d_records, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  rc = check_lens(bc_len, umi_len);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || !d_bc_ascii || !d_umi_ascii) return err_arg("NULL device pointer");
+  if (!aligned8(d_records) || !aligned8(d_index)) return err_arg("u64 data must be 8-byte aligned");
+  IBU_HIP(launch_encode(ctx->cfg, d_bc_ascii, d_umi_ascii, d_index, first_index, n, bc_len, umi_len, d_records,
+                        ctx->d_status, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_codec_status(ibu_ctx_t* ctx, void* stream, uint64_t* first_bad_record, uint64_t* n_bad_records) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  hipStream_t st = pick_stream(ctx, stream);
+  IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_status, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipStreamSynchronize(st));
+  const uint64_t first = ctx->h_pinned[0], nbad = ctx->h_pinned[1];
+  if (first_bad_record) *first_bad_record = first;
+  if (n_bad_records) *n_bad_records = nbad;
+  if (nbad == 0) return IBU_OK;
+  IBU_HIP(launch_fill2(ctx->d_status, ~0ull, 0, st));  // re-arm
+  return set_error(IBU_ERR_INVALID_BASE, first, nbad, 0,
+                   "Invalid base: %llu record(s) hold a byte outside ACGTacgt, first at record %llu",
+                   (unsigned long long)nbad, (unsigned long long)first);
+}
+
+// ---- K4 ---------------------------------------------------------------------------------------------
+extern "C" int32_t ibu_reduce_reset(ibu_ctx_t* ctx, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, 8 * sizeof(uint64_t), pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_reduce(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || !aligned8(d_records)) return err_arg("d_records must be non-NULL and 8-byte aligned");
+  IBU_HIP(launch_reduce(ctx->cfg, d_records, n, ctx->d_acc, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_reduce_fetch(ibu_ctx_t* ctx, void* stream, ibu_reduce_result_t* out) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!out) return err_arg("out is NULL");
+  hipStream_t st = pick_stream(ctx, stream);
+  IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_acc, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipStreamSynchronize(st));
+  out->count = ctx->h_pinned[0];
+  for (int k = 0; k < 3; ++k) {
+    out->sum[k] = ctx->h_pinned[1 + k];
+    out->xor_[k] = ctx->h_pinned[4 + k];
+  }
+  return IBU_OK;
+}
+
+// ---- synthetic records, sortedness, sort ---------------------------------------------------------------
+extern "C" int32_t ibu_generate(ibu_ctx_t* ctx, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
+                                uint32_t umi_len, void* d_records, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  rc = check_lens(bc_len, umi_len);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || (reinterpret_cast<uintptr_t>(d_records) & 15u)) return err_arg("d_records must be 16-byte aligned");
+  IBU_HIP(launch_generate(ctx->cfg, seed, first, n, bc_len, umi_len, d_records, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream, int32_t* sorted) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!sorted) return err_arg("sorted is NULL");
+  *sorted = 1;
+  if (n < 2) return IBU_OK;
+  if (!d_records || !aligned8(d_records)) return err_arg("d_records must be non-NULL and 8-byte aligned");
+  hipStream_t st = pick_stream(ctx, stream);
+  IBU_HIP(hipMemsetAsync(ctx->d_flag, 0, 4, st));
+  IBU_HIP(launch_sorted_check(ctx->cfg, d_records, n, ctx->d_flag, st));
+  IBU_HIP(hipMemcpyAsync(ctx->h_pinned + 8, ctx->d_flag, 4, hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipStreamSynchronize(st));
+  *sorted = (*reinterpret_cast<uint32_t*>(ctx->h_pinned + 8)) == 0;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n < 2) return IBU_OK;
+  if (!d_records || !d_tmp || !aligned8(d_records) || !aligned8(d_tmp))
+    return err_arg("d_records / d_tmp must be non-NULL and 8-byte aligned");
+  const size_t need = sort_scratch_bytes(ctx->cfg, n);
+  if (need > ctx->sort_scratch_bytes) {  // grows only; the one allocation a launch path may make
+    if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));
+    ctx->d_sort_scratch = nullptr;
+    ctx->sort_scratch_bytes = 0;
+    IBU_HIP(hipMalloc(&ctx->d_sort_scratch, need));
+    ctx->sort_scratch_bytes = need;
+  }
+  IBU_HIP(launch_sort_records(ctx->cfg, d_records, d_tmp, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes,
+                              pick_stream(ctx, stream)));
+  return IBU_OK;
+}

@@ -1,0 +1,783 @@
+// host_io.cpp — host half of libibu_hip.so: the reference's Header / Record / Writer / Reader /
+// load_to_vec / MmapReader / ParallelReader behaviour behind the C ABI of include/ibu_hip.h.
+//
+// This is I/O plumbing (syscalls, buffering, error mapping): it performs no codec or record
+// arithmetic — that lives only in kernels.hip.  Reference lines are cited per function; the
+// quirk numbers (Q1..Q15) refer to SURVEY.md Appendix C.
+#include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cstddef>
+#include <cstdlib>
+
+#include <atomic>
+#include <memory>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
+#include "host_io.hpp"
+
+static_assert(sizeof(ibu_header_t) == IBU_HEADER_SIZE, "header.rs:248-251");
+static_assert(sizeof(ibu_record_t) == IBU_RECORD_SIZE, "record.rs:149-152");
+static_assert(offsetof(ibu_header_t, flags) == 16 && offsetof(ibu_header_t, reserved) == 24, "repr(C)");
+static_assert(offsetof(ibu_record_t, umi) == 8 && offsetof(ibu_record_t, index) == 16, "repr(C)");
+
+using namespace ibu;
+
+// ------------------------------------------------------------------------------------------
+// misc
+// ------------------------------------------------------------------------------------------
+extern "C" void ibu_last_error(ibu_error_detail_t* out) {
+  if (out) *out = tls_error();
+}
+extern "C" const char* ibu_status_name(int32_t s) {
+  switch (s) {
+    case IBU_OK: return "Ok";
+    case IBU_ERR_IO: return "Io";
+    case IBU_ERR_NIFFLER: return "Niffler";
+    case IBU_ERR_INVALID_MAGIC: return "InvalidMagicNumber";
+    case IBU_ERR_TRUNCATED_RECORD: return "TruncatedRecord";
+    case IBU_ERR_INVALID_VERSION: return "InvalidVersion";
+    case IBU_ERR_INVALID_BC_LEN: return "InvalidBarcodeLength";
+    case IBU_ERR_INVALID_UMI_LEN: return "InvalidUmiLength";
+    case IBU_ERR_INVALID_MAP_SIZE: return "InvalidMapSize";
+    case IBU_ERR_INVALID_INDEX: return "InvalidIndex";
+    case IBU_ERR_PROCESS: return "Process";
+    case IBU_ERR_INVALID_BASE: return "InvalidBase";
+    case IBU_ERR_SEQ_LEN: return "SeqLen";
+    case IBU_ERR_INVALID_ARG: return "InvalidArg";
+    case IBU_ERR_HIP: return "Hip";
+    case IBU_ERR_NO_DEVICE: return "NoDevice";
+    default: return "Unknown";
+  }
+}
+extern "C" const char* ibu_version(void) { return "ibu_hip 0.1.0 (format v2, reference ibu 0.2.1, gfx950)"; }
+extern "C" uint32_t ibu_abi_revision(void) { return 1; }
+extern "C" void ibu_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------------
+// Header (src/constructs/header.rs)
+// ------------------------------------------------------------------------------------------
+extern "C" void ibu_header_init(ibu_header_t* h, uint32_t bc_len, uint32_t umi_len) {  // :84-93
+  h->magic = IBU_MAGIC;
+  h->version = IBU_VERSION;
+  h->bc_len = bc_len;
+  h->umi_len = umi_len;
+  h->flags = 0;
+  memset(h->reserved, 0, sizeof h->reserved);
+}
+extern "C" void ibu_header_set_sorted(ibu_header_t* h) { h->flags |= IBU_FLAG_SORTED; }          // :111-113
+extern "C" int32_t ibu_header_sorted(const ibu_header_t* h) { return (h->flags & IBU_FLAG_SORTED) != 0; }  // :130-132
+extern "C" int32_t ibu_header_validate(const ibu_header_t* h) {                                   // :167-187
+  if (!h) return err_arg("header is NULL");
+  if (h->magic != IBU_MAGIC) return err_magic(h->magic);
+  if (h->version != IBU_VERSION) return err_version(h->version);
+  if (h->bc_len == 0 || h->bc_len > 32) return err_bc_len(h->bc_len);
+  if (h->umi_len == 0 || h->umi_len > 32) return err_umi_len(h->umi_len);
+  return IBU_OK;
+}
+extern "C" int32_t ibu_header_from_bytes(const uint8_t* bytes, size_t len, ibu_header_t* out) {  // :226-228
+  if (!bytes || !out || len != IBU_HEADER_SIZE) return err_arg("Header::from_bytes needs exactly 32 bytes");
+  memcpy(out, bytes, IBU_HEADER_SIZE);
+  return IBU_OK;
+}
+extern "C" int32_t ibu_header_as_bytes(const ibu_header_t* h, uint8_t* out, size_t cap) {        // :203-205
+  if (!h || !out || cap < IBU_HEADER_SIZE) return err_arg("Header::as_bytes needs 32 bytes of room");
+  memcpy(out, h, IBU_HEADER_SIZE);
+  return IBU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Record (src/constructs/record.rs)
+// ------------------------------------------------------------------------------------------
+extern "C" int32_t ibu_record_from_bytes(const uint8_t* bytes, size_t len, ibu_record_t* out) {  // :130-132
+  if (!bytes || !out || len != IBU_RECORD_SIZE) return err_arg("Record::from_bytes needs exactly 24 bytes");
+  memcpy(out, bytes, IBU_RECORD_SIZE);
+  return IBU_OK;
+}
+extern "C" int32_t ibu_record_as_bytes(const ibu_record_t* r, uint8_t* out, size_t cap) {        // :108-110
+  if (!r || !out || cap < IBU_RECORD_SIZE) return err_arg("Record::as_bytes needs 24 bytes of room");
+  memcpy(out, r, IBU_RECORD_SIZE);
+  return IBU_OK;
+}
+extern "C" int32_t ibu_record_cmp(const ibu_record_t* a, const ibu_record_t* b) {  // derive(Ord) :58
+  const uint64_t ka[3] = {a->barcode, a->umi, a->index}, kb[3] = {b->barcode, b->umi, b->index};
+  for (int k = 0; k < 3; ++k)
+    if (ka[k] != kb[k]) return ka[k] < kb[k] ? -1 : 1;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// sinks / sources
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Sink {
+  virtual ~Sink() {}
+  virtual int write_all(const uint8_t* p, size_t n) = 0;  // 0 or errno
+  virtual int flush() { return 0; }
+};
+struct MemSink : Sink {
+  std::vector<uint8_t> v;
+  int write_all(const uint8_t* p, size_t n) override {
+    try {
+      v.insert(v.end(), p, p + n);
+    } catch (const std::bad_alloc&) {
+      return ENOMEM;
+    }
+    return 0;
+  }
+};
+struct FdSink : Sink {
+  int fd;
+  bool owned;
+  FdSink(int f, bool o) : fd(f), owned(o) {}
+  ~FdSink() override {
+    if (owned && fd >= 0) close(fd);
+  }
+  int write_all(const uint8_t* p, size_t n) override {
+    while (n) {
+      ssize_t k = ::write(fd, p, n);
+      if (k < 0) {
+        if (errno == EINTR) continue;
+        return errno;
+      }
+      p += k;
+      n -= (size_t)k;
+    }
+    return 0;
+  }
+};
+struct CallbackSink : Sink {
+  ibu_write_fn wr;
+  ibu_flush_fn fl;
+  void* user;
+  CallbackSink(ibu_write_fn w, ibu_flush_fn f, void* u) : wr(w), fl(f), user(u) {}
+  int write_all(const uint8_t* p, size_t n) override { return wr(user, p, n); }
+  int flush() override { return fl ? fl(user) : 0; }
+};
+
+struct Source {
+  virtual ~Source() {}
+  virtual int read(uint8_t* dst, size_t cap, size_t* got) = 0;  // 0 or errno; *got == 0 is EOF
+};
+struct MemSource : Source {
+  const uint8_t* p;
+  size_t len, pos = 0;
+  MemSource(const uint8_t* d, size_t n) : p(d), len(n) {}
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    size_t k = len - pos < cap ? len - pos : cap;
+    memcpy(dst, p + pos, k);
+    pos += k;
+    *got = k;
+    return 0;
+  }
+};
+struct FdSource : Source {
+  int fd;
+  bool owned;
+  FdSource(int f, bool o) : fd(f), owned(o) {}
+  ~FdSource() override {
+    if (owned && fd >= 0) close(fd);
+  }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    for (;;) {
+      ssize_t k = ::read(fd, dst, cap);
+      if (k < 0) {
+        if (errno == EINTR) continue;
+        return errno;
+      }
+      *got = (size_t)k;
+      return 0;
+    }
+  }
+};
+struct CallbackSource : Source {
+  ibu_read_fn rd;
+  void* user;
+  CallbackSource(ibu_read_fn r, void* u) : rd(r), user(u) {}
+  int read(uint8_t* dst, size_t cap, size_t* got) override { return rd(user, dst, cap, got); }
+};
+// A source with a few already-consumed bytes pushed back in front (format sniffing).
+struct PrefixSource : Source {
+  std::vector<uint8_t> pre;
+  size_t pos = 0;
+  std::unique_ptr<Source> inner;
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    if (pos < pre.size()) {
+      size_t k = pre.size() - pos < cap ? pre.size() - pos : cap;
+      memcpy(dst, pre.data() + pos, k);
+      pos += k;
+      *got = k;
+      return 0;
+    }
+    return inner->read(dst, cap, got);
+  }
+};
+// gzip (possibly multi-member) inflate over another source — the part of niffler that
+// Reader::from_path relies on (reader.rs:348-352).  Errors surface as EPROTO -> the reader maps
+// them to IBU_ERR_NIFFLER.
+struct GzSource : Source {
+  std::unique_ptr<Source> inner;
+  z_stream zs;
+  std::vector<uint8_t> in;
+  bool inited = false, inner_eof = false, member_done = false;
+  explicit GzSource(std::unique_ptr<Source> s) : inner(std::move(s)), in(1 << 18) {
+    memset(&zs, 0, sizeof zs);
+    inited = inflateInit2(&zs, 15 + 16) == Z_OK;
+  }
+  ~GzSource() override {
+    if (inited) inflateEnd(&zs);
+  }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    *got = 0;
+    if (!inited) return EPROTO;
+    const size_t want = cap > (1u << 30) ? (size_t)(1u << 30) : cap;
+    zs.next_out = dst;
+    zs.avail_out = (uInt)want;
+    while (zs.avail_out == (uInt)want) {
+      if (zs.avail_in == 0 && !inner_eof) {
+        size_t k = 0;
+        int rc = inner->read(in.data(), in.size(), &k);
+        if (rc) return rc;
+        if (k == 0) inner_eof = true;
+        zs.next_in = in.data();
+        zs.avail_in = (uInt)k;
+      }
+      if (member_done) {
+        if (zs.avail_in == 0 && inner_eof) return 0;  // clean EOF after the last member
+        if (inflateReset(&zs) != Z_OK) return EPROTO;
+        member_done = false;
+      }
+      if (zs.avail_in == 0 && inner_eof) return EPROTO;  // stream ends inside a member
+      int rc = inflate(&zs, Z_NO_FLUSH);
+      if (rc == Z_STREAM_END) member_done = true;
+      else if (rc != Z_OK && rc != Z_BUF_ERROR) return EPROTO;
+    }
+    *got = want - zs.avail_out;
+    return 0;
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Writer (src/io/writer.rs)
+// ------------------------------------------------------------------------------------------
+struct ibu_writer {
+  std::unique_ptr<Sink> inner;
+  MemSink* mem = nullptr;  // set when inner is a Vec<u8>
+  std::vector<uint8_t> buffer;
+  size_t pos = 0;
+  uint64_t records_written = 0;
+};
+
+namespace {
+
+int32_t writer_flush_buffer(ibu_writer* w) {  // writer.rs:220-226
+  if (w->pos > 0) {
+    int e = w->inner->write_all(w->buffer.data(), w->pos);
+    if (e) return err_io(e, "write");
+    w->pos = 0;
+  }
+  return IBU_OK;
+}
+
+int32_t writer_write_slice(ibu_writer* w, const uint8_t* bytes, size_t len) {  // writer.rs:321-351
+  const size_t num_records = len / IBU_RECORD_SIZE;
+  if (len > w->buffer.size()) {  // larger than the buffer: flush what is pending, then write through
+    int32_t rc = writer_flush_buffer(w);
+    if (rc) return rc;
+    int e = w->inner->write_all(bytes, len);
+    if (e) return err_io(e, "write");
+    w->records_written += num_records;
+    return IBU_OK;
+  }
+  while (len) {
+    const size_t room = w->buffer.size() - w->pos;
+    const size_t k = len < room ? len : room;
+    memcpy(w->buffer.data() + w->pos, bytes, k);
+    w->pos += k;
+    bytes += k;
+    len -= k;
+    if (w->pos >= w->buffer.size()) {
+      int32_t rc = writer_flush_buffer(w);
+      if (rc) return rc;
+    }
+  }
+  w->records_written += num_records;
+  return IBU_OK;
+}
+
+int32_t writer_make(std::unique_ptr<Sink> sink, MemSink* mem, const ibu_header_t* header, ibu_writer_t** out) {
+  if (!out) return err_arg("out is NULL");
+  std::unique_ptr<ibu_writer> w(new (std::nothrow) ibu_writer);
+  if (!w) return err_io(ENOMEM, "alloc");
+  w->inner = std::move(sink);
+  w->mem = mem;
+  if (header) {  // Writer::new: header goes out at once, unvalidated (Q2)  writer.rs:129-143
+    int e = w->inner->write_all(reinterpret_cast<const uint8_t*>(header), IBU_HEADER_SIZE);
+    if (e) return err_io(e, "write header");
+  }
+  w->buffer.assign(IBU_DEFAULT_BUFFER_SIZE, 0);
+  *out = w.release();
+  return IBU_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t ibu_writer_open_callback(ibu_write_fn wr, ibu_flush_fn fl, void* user, const ibu_header_t* header,
+                                            ibu_writer_t** out) {
+  if (!wr) return err_arg("write callback is NULL");
+  return writer_make(std::unique_ptr<Sink>(new CallbackSink(wr, fl, user)), nullptr, header, out);
+}
+extern "C" int32_t ibu_writer_open_path(const char* path, const ibu_header_t* header, ibu_writer_t** out) {
+  if (!path) return err_arg("path is NULL");
+  int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);  // File::create  writer.rs:557
+  if (fd < 0) return err_io(errno, path);
+  return writer_make(std::unique_ptr<Sink>(new FdSink(fd, true)), nullptr, header, out);
+}
+extern "C" int32_t ibu_writer_open_fd(int fd, const ibu_header_t* header, ibu_writer_t** out) {
+  if (fd < 0) return err_arg("fd < 0");
+  return writer_make(std::unique_ptr<Sink>(new FdSink(fd, false)), nullptr, header, out);
+}
+extern "C" int32_t ibu_writer_open_mem(const ibu_header_t* header, ibu_writer_t** out) {
+  MemSink* m = new MemSink;
+  return writer_make(std::unique_ptr<Sink>(m), m, header, out);
+}
+
+extern "C" int32_t ibu_writer_write_record(ibu_writer_t* w, const ibu_record_t* r) {  // writer.rs:260-273
+  if (!w || !r) return err_arg("writer or record is NULL");
+  if (w->pos + IBU_RECORD_SIZE > w->buffer.size()) {
+    int32_t rc = writer_flush_buffer(w);
+    if (rc) return rc;
+  }
+  memcpy(w->buffer.data() + w->pos, r, IBU_RECORD_SIZE);
+  w->pos += IBU_RECORD_SIZE;
+  w->records_written += 1;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_writer_write_batch(ibu_writer_t* w, const ibu_record_t* recs, size_t n) {  // :315-318
+  if (!w || (!recs && n)) return err_arg("writer or records is NULL");
+  return writer_write_slice(w, reinterpret_cast<const uint8_t*>(recs), n * IBU_RECORD_SIZE);
+}
+int32_t ibu::writer_write_bytes(ibu_writer_t* w, const uint8_t* bytes, size_t len) {
+  return writer_write_slice(w, bytes, len);
+}
+extern "C" int32_t ibu_writer_ingest(ibu_writer_t* w, ibu_writer_t* other) {  // writer.rs:477-482
+  if (!w || !other || !other->mem) return err_arg("ingest needs a memory-backed (Vec<u8>) source writer");
+  int32_t rc = writer_flush_buffer(other);
+  if (rc) return rc;
+  rc = writer_write_slice(w, other->mem->v.data(), other->mem->v.size());  // Q15: header bytes included if any
+  if (rc) return rc;
+  other->mem->v.clear();
+  return IBU_OK;
+}
+extern "C" int32_t ibu_writer_finish(ibu_writer_t* w) {  // writer.rs:429-433
+  if (!w) return err_arg("writer is NULL");
+  int32_t rc = writer_flush_buffer(w);
+  if (rc) return rc;
+  int e = w->inner->flush();
+  if (e) return err_io(e, "flush");
+  return IBU_OK;
+}
+extern "C" uint64_t ibu_writer_records_written(const ibu_writer_t* w) { return w ? w->records_written : 0; }
+extern "C" int32_t ibu_writer_mem_view(const ibu_writer_t* w, const uint8_t** data, size_t* len) {
+  if (!w || !w->mem || !data || !len) return err_arg("not a memory-backed writer");
+  *data = w->mem->v.data();
+  *len = w->mem->v.size();
+  return IBU_OK;
+}
+extern "C" int32_t ibu_writer_into_inner(ibu_writer_t* w, uint8_t** data, size_t* len) {  // writer.rs:507-511
+  if (!w) return err_arg("writer is NULL");
+  if (data) *data = nullptr;
+  if (len) *len = 0;
+  int32_t rc = IBU_OK;
+  if (w->mem && data && len) {
+    size_t n = w->mem->v.size();
+    uint8_t* p = static_cast<uint8_t*>(malloc(n ? n : 1));
+    if (!p) rc = err_io(ENOMEM, "alloc");
+    else {
+      memcpy(p, w->mem->v.data(), n);
+      *data = p;
+      *len = n;
+    }
+  }
+  delete w;  // no flush: buffered records are dropped exactly as ManuallyDrop does
+  return rc;
+}
+extern "C" void ibu_writer_close(ibu_writer_t* w) {  // Drop  writer.rs:519-523
+  if (!w) return;
+  (void)ibu_writer_finish(w);
+  delete w;
+}
+
+// ------------------------------------------------------------------------------------------
+// Reader (src/io/reader.rs)
+// ------------------------------------------------------------------------------------------
+struct ibu_reader {
+  std::unique_ptr<Source> inner;
+  bool compressed = false;
+  std::vector<uint8_t> buffer;  // capacity DEFAULT_BUFFER_SIZE
+  ibu_header_t header;
+  size_t pos = 0, cap = 0;
+  uint64_t bytes_read = 0;
+  bool eof = false;
+};
+
+namespace {
+
+int32_t src_error(const ibu_reader* r, int e, const char* what) {
+  if (r && r->compressed && e == EPROTO) return err_niffler("corrupt or truncated gzip stream");
+  return err_io(e, what);
+}
+
+int32_t reader_make(std::unique_ptr<Source> src, bool compressed, ibu_reader_t** out) {  // reader.rs:152-176
+  if (!out) return err_arg("out is NULL");
+  std::unique_ptr<ibu_reader> r(new (std::nothrow) ibu_reader);
+  if (!r) return err_io(ENOMEM, "alloc");
+  r->inner = std::move(src);
+  r->compressed = compressed;
+  uint8_t hb[IBU_HEADER_SIZE];
+  size_t have = 0;
+  while (have < IBU_HEADER_SIZE) {  // read_exact
+    size_t got = 0;
+    int e = r->inner->read(hb + have, IBU_HEADER_SIZE - have, &got);
+    if (e) return src_error(r.get(), e, "read header");
+    if (got == 0) return err_io(0, "read header");  // UnexpectedEof is an io::Error
+    have += got;
+  }
+  memcpy(&r->header, hb, IBU_HEADER_SIZE);  // pod_read_unaligned
+  int32_t rc = ibu_header_validate(&r->header);
+  if (rc) return rc;
+  r->buffer.resize(IBU_DEFAULT_BUFFER_SIZE);
+  r->bytes_read = IBU_HEADER_SIZE;
+  *out = r.release();
+  return IBU_OK;
+}
+
+// niffler::send::get_reader: sniff the first bytes, wrap in a decoder when compressed.
+int32_t reader_make_sniffed(std::unique_ptr<Source> src, ibu_reader_t** out) {
+  std::unique_ptr<PrefixSource> ps(new PrefixSource);
+  ps->pre.resize(5);
+  size_t have = 0;
+  while (have < 5) {
+    size_t got = 0;
+    int e = src->read(ps->pre.data() + have, 5 - have, &got);
+    if (e) return err_io(e, "read");
+    if (got == 0) break;
+    have += got;
+  }
+  if (have < 5) return err_niffler("file too short to sniff its format");
+  const uint8_t* m = ps->pre.data();
+  ps->inner = std::move(src);
+  if (m[0] == 0x1f && m[1] == 0x8b)
+    return reader_make(std::unique_ptr<Source>(new GzSource(std::move(ps))), true, out);
+  if ((m[0] == 0x42 && m[1] == 0x5a) || (m[0] == 0xfd && m[1] == 0x37 && m[2] == 0x7a && m[3] == 0x58 && m[4] == 0x5a) ||
+      (m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd))
+    return err_niffler("bzip2/xz/zstd input: decoder not built into this library (gzip only)");
+  return reader_make(std::move(ps), false, out);
+}
+
+}  // namespace
+
+extern "C" int32_t ibu_reader_open_callback(ibu_read_fn rd, void* user, ibu_reader_t** out) {
+  if (!rd) return err_arg("read callback is NULL");
+  return reader_make(std::unique_ptr<Source>(new CallbackSource(rd, user)), false, out);
+}
+extern "C" int32_t ibu_reader_open_mem(const uint8_t* data, size_t len, ibu_reader_t** out) {
+  if (!data && len) return err_arg("data is NULL");
+  return reader_make(std::unique_ptr<Source>(new MemSource(data, len)), false, out);
+}
+extern "C" int32_t ibu_reader_open_path(const char* path, ibu_reader_t** out) {  // reader.rs:345-352
+  if (!path) return err_arg("path is NULL");
+  int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return err_io(errno, path);
+  return reader_make_sniffed(std::unique_ptr<Source>(new FdSource(fd, true)), out);
+}
+extern "C" int32_t ibu_reader_open_fd(int fd, ibu_reader_t** out) {  // reader.rs:389-396
+  if (fd < 0) return err_arg("fd < 0");
+  return reader_make_sniffed(std::unique_ptr<Source>(new FdSource(fd, false)), out);
+}
+extern "C" int32_t ibu_reader_header(const ibu_reader_t* r, ibu_header_t* out) {
+  if (!r || !out) return err_arg("reader or out is NULL");
+  *out = r->header;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_reader_read_batch(ibu_reader_t* r, int32_t* has_data) {  // reader.rs:218-242
+  if (!r) return err_arg("reader is NULL");
+  size_t read = 0;
+  while (read < r->buffer.size()) {
+    size_t got = 0;
+    int e = r->inner->read(r->buffer.data() + read, r->buffer.size() - read, &got);
+    if (e) return src_error(r, e, "read");
+    if (got == 0) break;
+    read += got;
+  }
+  if (read % IBU_RECORD_SIZE != 0)  // Q8: the whole refill is rejected
+    return err_truncated(r->bytes_read + (read - read % IBU_RECORD_SIZE));
+  r->pos = 0;
+  r->cap = read / IBU_RECORD_SIZE;
+  r->bytes_read += read;
+  if (has_data) *has_data = read > 0;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_reader_next(ibu_reader_t* r, ibu_record_t* out, int32_t* got) {  // reader.rs:279-306
+  if (!r || !out || !got) return err_arg("reader, out or got is NULL");
+  *got = 0;
+  if (r->eof) return IBU_OK;
+  if (r->pos >= r->cap) {
+    int32_t has = 0;
+    int32_t rc = ibu_reader_read_batch(r, &has);
+    if (rc) return rc;  // Q9: eof stays false
+    if (!has) r->eof = true;
+  }
+  if (r->eof) return IBU_OK;
+  memcpy(out, r->buffer.data() + IBU_RECORD_SIZE * r->pos, IBU_RECORD_SIZE);
+  r->pos += 1;
+  *got = 1;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_reader_buffered(ibu_reader_t* r, const ibu_record_t** recs, size_t* n) {
+  if (!r || !recs || !n) return err_arg("reader, recs or n is NULL");
+  *recs = reinterpret_cast<const ibu_record_t*>(r->buffer.data() + IBU_RECORD_SIZE * r->pos);
+  *n = r->cap - r->pos;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_reader_consume(ibu_reader_t* r, size_t n) {
+  if (!r || n > r->cap - r->pos) return err_arg("consume beyond the buffered records");
+  r->pos += n;
+  return IBU_OK;
+}
+extern "C" uint64_t ibu_reader_bytes_read(const ibu_reader_t* r) { return r ? r->bytes_read : 0; }
+extern "C" void ibu_reader_close(ibu_reader_t* r) { delete r; }
+
+// ------------------------------------------------------------------------------------------
+// load_to_vec (src/io/reader.rs:510-535)
+// ------------------------------------------------------------------------------------------
+int32_t ibu::open_plain_file(const char* path, int* fd_out, ibu_header_t* header, size_t* n_records) {
+  int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return err_io(errno, path);
+  uint8_t hb[IBU_HEADER_SIZE];
+  size_t have = 0;
+  while (have < IBU_HEADER_SIZE) {
+    ssize_t k = ::read(fd, hb + have, IBU_HEADER_SIZE - have);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) {
+      int e = k < 0 ? errno : 0;
+      close(fd);
+      return err_io(e, "read header");
+    }
+    have += (size_t)k;
+  }
+  memcpy(header, hb, IBU_HEADER_SIZE);
+  int32_t rc = ibu_header_validate(header);
+  if (rc) {
+    close(fd);
+    return rc;
+  }
+  struct stat st;
+  if (fstat(fd, &st)) {
+    int e = errno;
+    close(fd);
+    return err_io(e, "metadata");
+  }
+  const size_t data_size = (size_t)st.st_size - IBU_HEADER_SIZE;
+  if (data_size % IBU_RECORD_SIZE != 0) {
+    close(fd);
+    return err_map_size();
+  }
+  *n_records = data_size / IBU_RECORD_SIZE;
+  *fd_out = fd;
+  return IBU_OK;
+}
+
+extern "C" int32_t ibu_load_to_vec(const char* path, ibu_header_t* header, ibu_record_t** records, size_t* n) {
+  if (!path || !header || !records || !n) return err_arg("NULL argument");
+  int fd = -1;
+  size_t num = 0;
+  int32_t rc = open_plain_file(path, &fd, header, &num);
+  if (rc) return rc;
+  ibu_record_t* v = static_cast<ibu_record_t*>(calloc(num ? num : 1, sizeof(ibu_record_t)));  // vec![default; n]
+  if (!v) {
+    close(fd);
+    return err_io(ENOMEM, "alloc");
+  }
+  uint8_t* p = reinterpret_cast<uint8_t*>(v);
+  size_t left = num * IBU_RECORD_SIZE;
+  while (left) {  // read_exact
+    ssize_t k = ::read(fd, p, left);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) {
+      int e = k < 0 ? errno : 0;
+      free(v);
+      close(fd);
+      return err_io(e, "read records");
+    }
+    p += k;
+    left -= (size_t)k;
+  }
+  close(fd);
+  *records = v;
+  *n = num;
+  return IBU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MmapReader (src/io/mmap.rs)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Mapping {  // Arc<Mmap>
+  uint8_t* base = nullptr;
+  size_t len = 0;
+  std::atomic<int> refs{1};
+};
+}  // namespace
+struct ibu_mmap {
+  Mapping* map;
+  ibu_header_t header;
+  size_t len;
+};
+
+extern "C" int32_t ibu_mmap_open(const char* path, ibu_mmap_t** out) {  // mmap.rs:143-161
+  if (!path || !out) return err_arg("NULL argument");
+  int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return err_io(errno, path);
+  struct stat st;
+  if (fstat(fd, &st)) {
+    int e = errno;
+    close(fd);
+    return err_io(e, "metadata");
+  }
+  const size_t flen = (size_t)st.st_size;
+  if (flen < IBU_HEADER_SIZE) {  // the reference panics slicing map[0..32]; an error here
+    close(fd);
+    return err_arg("file shorter than the 32-byte header (the reference panics here)");
+  }
+  void* p = mmap(nullptr, flen, PROT_READ, MAP_PRIVATE, fd, 0);
+  int e = errno;
+  close(fd);
+  if (p == MAP_FAILED) return err_io(e, "mmap");
+  ibu_header_t h;
+  memcpy(&h, p, IBU_HEADER_SIZE);
+  int32_t rc = ibu_header_validate(&h);
+  if (!rc && (flen - IBU_HEADER_SIZE) % IBU_RECORD_SIZE != 0) rc = err_map_size();
+  if (rc) {
+    munmap(p, flen);
+    return rc;
+  }
+  Mapping* mp = new Mapping;
+  mp->base = static_cast<uint8_t*>(p);
+  mp->len = flen;
+  ibu_mmap* m = new ibu_mmap;
+  m->map = mp;
+  m->header = h;
+  m->len = (flen - IBU_HEADER_SIZE) / IBU_RECORD_SIZE;
+  *out = m;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_mmap_clone(ibu_mmap_t* m, ibu_mmap_t** out) {  // derive(Clone) mmap.rs:99
+  if (!m || !out) return err_arg("NULL argument");
+  m->map->refs.fetch_add(1, std::memory_order_relaxed);
+  *out = new ibu_mmap(*m);
+  return IBU_OK;
+}
+extern "C" size_t ibu_mmap_len(const ibu_mmap_t* m) { return m ? m->len : 0; }
+extern "C" int32_t ibu_mmap_header(const ibu_mmap_t* m, ibu_header_t* out) {
+  if (!m || !out) return err_arg("NULL argument");
+  *out = m->header;
+  return IBU_OK;
+}
+extern "C" int32_t ibu_mmap_slice(const ibu_mmap_t* m, size_t start, size_t end, const ibu_record_t** recs,
+                                  size_t* n) {  // mmap.rs:253-270
+  if (!m || !recs || !n) return err_arg("NULL argument");
+  if (start >= m->len || end > m->len) return err_index(end, m->len);  // Q7: idx is always `end`
+  if (end <= start) return err_index(end, m->len);
+  *recs = reinterpret_cast<const ibu_record_t*>(m->map->base + IBU_HEADER_SIZE + start * IBU_RECORD_SIZE);
+  *n = end - start;
+  return IBU_OK;
+}
+extern "C" const void* ibu_mmap_base(const ibu_mmap_t* m) { return m ? m->map->base : nullptr; }
+extern "C" void ibu_mmap_close(ibu_mmap_t* m) {
+  if (!m) return;
+  if (m->map->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    munmap(m->map->base, m->map->len);
+    delete m->map;
+  }
+  delete m;
+}
+
+extern "C" int32_t ibu_shard_range(size_t len, size_t n_shards, size_t shard, size_t* start, size_t* end) {
+  if (!start || !end || n_shards == 0 || shard >= n_shards) return err_arg("shard out of range");
+  const size_t per = len / n_shards, rem = len % n_shards;  // mmap.rs:297-298
+  *start = shard * per;
+  *end = shard == n_shards - 1 ? *start + per + rem : *start + per;  // :301-307
+  return IBU_OK;
+}
+
+size_t ibu::host_cores() {  // num_cpus::get(): CPUs this process may run on
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) {
+    int c = CPU_COUNT(&set);
+    if (c > 0) return (size_t)c;
+  }
+  unsigned h = std::thread::hardware_concurrency();
+  return h ? h : 1;
+}
+
+extern "C" int32_t ibu_mmap_process_parallel(const ibu_mmap_t* m, const ibu_processor_vtable_t* vt, void* user,
+                                             size_t num_threads) {  // mmap.rs:286-332
+  if (!m || !vt || !vt->process_record) return err_arg("NULL reader / vtable / process_record");
+  const size_t cores = host_cores();
+  const size_t nt = num_threads == 0 ? cores : (num_threads < cores ? num_threads : cores);
+  struct Worker {
+    std::thread th;
+    int32_t rc = IBU_OK;
+    ibu_error_detail_t detail;
+  };
+  std::vector<Worker> ws(nt);
+  for (size_t i = 0; i < nt; ++i) {
+    size_t start = 0, end = 0;
+    ibu_shard_range(m->len, nt, i, &start, &end);
+    void* clone = vt->clone ? vt->clone(user) : user;  // processor.clone()  :309
+    Worker* w = &ws[i];
+    w->th = std::thread([m, vt, clone, start, end, w]() {
+      size_t batch_start = start;
+      while (batch_start < end && w->rc == IBU_OK) {
+        const size_t batch_end = batch_start + IBU_BATCH_SIZE < end ? batch_start + IBU_BATCH_SIZE : end;
+        const ibu_record_t* recs;
+        size_t n;
+        w->rc = ibu_mmap_slice(m, batch_start, batch_end, &recs, &n);
+        for (size_t k = 0; k < n && w->rc == IBU_OK; ++k) {
+          int32_t u = vt->process_record(clone, &recs[k]);
+          if (u) w->rc = err_process((uint64_t)(uint32_t)u);
+        }
+        if (w->rc == IBU_OK && vt->on_batch_complete) {
+          int32_t u = vt->on_batch_complete(clone);
+          if (u) w->rc = err_process((uint64_t)(uint32_t)u);
+        }
+        batch_start += IBU_BATCH_SIZE;
+      }
+      if (w->rc) w->detail = tls_error();  // the payload lives in the worker's thread-local slot
+      if (vt->clone && vt->drop) vt->drop(clone);
+    });
+  }
+  // Join in spawn order, first Err wins (Q12).  The reference drops the remaining handles and
+  // lets those threads run on detached; here they are joined so `user` may be freed on return.
+  int32_t rc = IBU_OK;
+  for (size_t i = 0; i < nt; ++i) {
+    ws[i].th.join();
+    if (rc == IBU_OK && ws[i].rc) {
+      rc = ws[i].rc;
+      tls_error() = ws[i].detail;
+    }
+  }
+  return rc;
+}

@@ -1,0 +1,39 @@
+// kernels.h — launch interface between the C-ABI layer (device.cpp) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ibu {
+
+struct LaunchCfg {
+  int cus = 256;           // hipDeviceProp_t::multiProcessorCount
+  int blocks_per_cu = 8;   // persistent grid = cus * blocks_per_cu workgroups of 256 threads
+};
+
+// All launchers are asynchronous on `st`, allocate nothing and never synchronise.
+hipError_t launch_decode(const LaunchCfg&, const void* recs, size_t n, uint32_t bc_len, uint32_t umi_len,
+                         uint8_t* bc, uint8_t* umi, uint64_t* idx, hipStream_t st);
+hipError_t launch_encode(const LaunchCfg&, const uint8_t* bc, const uint8_t* umi, const uint64_t* idx,
+                         uint64_t first_index, size_t n, uint32_t bc_len, uint32_t umi_len, void* recs,
+                         uint64_t* status, hipStream_t st);
+hipError_t launch_deserialize(const LaunchCfg&, const void* recs, size_t n, uint64_t* bc, uint64_t* umi,
+                              uint64_t* idx, hipStream_t st);
+hipError_t launch_serialize(const LaunchCfg&, const uint64_t* bc, const uint64_t* umi, const uint64_t* idx,
+                            size_t n, void* recs, hipStream_t st);
+hipError_t launch_unpack(const LaunchCfg&, const uint64_t* codes, size_t n, uint32_t len, uint8_t* out,
+                         hipStream_t st);
+hipError_t launch_pack(const LaunchCfg&, const uint8_t* in, size_t n, uint32_t len, uint64_t* codes,
+                       uint64_t* status, hipStream_t st);
+hipError_t launch_reduce(const LaunchCfg&, const void* recs, size_t n, uint64_t* acc, hipStream_t st);
+hipError_t launch_generate(const LaunchCfg&, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
+                           uint32_t umi_len, void* recs, hipStream_t st);
+hipError_t launch_sorted_check(const LaunchCfg&, const void* recs, size_t n, uint32_t* flag, hipStream_t st);
+hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
+
+// sort.hip
+hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n, void* scratch,
+                               size_t scratch_bytes, hipStream_t st);
+size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
+
+}  // namespace ibu

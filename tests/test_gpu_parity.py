@@ -1,0 +1,283 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ibu_amd -> libibu_hip.so),
+bit-exact against the CPU oracle on the same seeded inputs.  Integer / byte work: the bar is
+equality of every byte, no tolerance.  Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x1B00002
+# sizes straddling the 128-record wave tile, the 49 152-record reader buffer and the grid
+SIZES = [0, 1, 2, 63, 127, 128, 129, 255, 257, 4096, 49_152, 100_000, 1_000_003]
+
+
+@pytest.fixture(scope="module")
+def ia():
+    import ibu_amd
+    return ibu_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ia):
+    c = ia.Context(0)
+    yield c
+    c.close()
+
+
+def _up(ctx, a):
+    return ctx.upload(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_generate_matches_oracle(ctx, oracle, n):
+    d = ctx.alloc(max(n, 1) * 24)
+    ctx.generate(SEED, 7, n, 16, 12, d)
+    ctx.synchronize()
+    assert d.download(count=n * 24).tobytes() == oracle.generate(SEED, 7, n, 16, 12).tobytes()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_deserialize_serialize(ctx, oracle, n):
+    recs = oracle.generate(SEED, 0, n, 32, 32)
+    d_recs = _up(ctx, recs) if n else ctx.alloc(16)
+    cols = [ctx.alloc(max(n, 2) * 8) for _ in range(3)]
+    ctx.deserialize(d_recs, n, *cols)
+    want = oracle.deserialize(recs)
+    for c, w in zip(cols, want):
+        assert c.download(np.uint64, count=n).tobytes() == w.tobytes()
+    d_back = ctx.alloc(max(n, 1) * 24)
+    ctx.serialize(*cols, n, d_back)
+    assert d_back.download(count=n * 24).tobytes() == recs.tobytes()
+    assert oracle.serialize(*want).tobytes() == recs.tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 127, 128, 129, 100_000, 1_000_003])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32), (1, 1), (15, 11), (20, 8), (4, 28), (31, 3), (12, 16)])
+def test_decode_encode(ctx, oracle, n, lens):
+    bc_len, umi_len = lens
+    recs = oracle.generate(SEED, 0, n, bc_len, umi_len)
+    d_recs = _up(ctx, recs) if n else ctx.alloc(16)
+    d_bc, d_umi, d_idx = ctx.alloc(max(n, 1) * bc_len), ctx.alloc(max(n, 1) * umi_len), ctx.alloc(max(n, 2) * 8)
+    ctx.decode_ascii(d_recs, n, bc_len, umi_len, d_bc, d_umi, d_idx)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    assert d_bc.download(count=n * bc_len).tobytes() == bc.tobytes()
+    assert d_umi.download(count=n * umi_len).tobytes() == umi.tobytes()
+    assert d_idx.download(np.uint64, count=n).tobytes() == idx.tobytes()
+    d_back = ctx.alloc(max(n, 1) * 24)
+    ctx.encode_ascii(d_bc, d_umi, d_idx, n, bc_len, umi_len, d_back)
+    ctx.codec_status()
+    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+    assert nb == 0
+    got = d_back.download(count=n * 24)
+    assert got.tobytes() == want.tobytes() == recs.tobytes()
+
+
+def test_all_length_pairs_small(ctx, oracle):
+    """Every (bc_len, umi_len) in {1..32}^2 on one-and-a-bit tiles."""
+    n = 128 + 37
+    d_recs = ctx.alloc(n * 24)
+    d_bc, d_umi, d_idx, d_back = ctx.alloc(n * 32), ctx.alloc(n * 32), ctx.alloc(n * 8), ctx.alloc(n * 24)
+    full = oracle.generate(SEED, 0, n, 32, 32)  # full-range values: bits above 2*len must be ignored (F7/Q13)
+    d_recs.upload(full)
+    for bc_len in range(1, 33):
+        for umi_len in range(1, 33):
+            ctx.decode_ascii(d_recs, n, bc_len, umi_len, d_bc, d_umi, d_idx)
+            bc, umi, idx = oracle.decode_records(full, bc_len, umi_len)
+            assert d_bc.download(count=n * bc_len).tobytes() == bc.tobytes(), (bc_len, umi_len)
+            assert d_umi.download(count=n * umi_len).tobytes() == umi.tobytes(), (bc_len, umi_len)
+            ctx.encode_ascii(d_bc, d_umi, d_idx, n, bc_len, umi_len, d_back)
+            ctx.codec_status()
+            want, _, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+            assert nb == 0 and d_back.download().tobytes() == want.tobytes(), (bc_len, umi_len)
+
+
+def test_decode_skips_null_columns(ctx, oracle):
+    n = 1000
+    recs = oracle.generate(SEED, 0, n, 16, 12)
+    d_recs, d_bc = _up(ctx, recs), ctx.alloc(n * 16)
+    ctx.decode_ascii(d_recs, n, 16, 12, d_bc, None, None)
+    assert d_bc.download().tobytes() == oracle.decode_records(recs, 16, 12)[0].tobytes()
+
+
+def test_encode_without_index_column(ctx, oracle):
+    n = 777
+    recs = oracle.generate(SEED, 0, n, 16, 12)
+    bc, umi, _ = oracle.decode_records(recs, 16, 12)
+    d_back = ctx.alloc(n * 24)
+    ctx.encode_ascii(_up(ctx, bc), _up(ctx, umi), None, n, 16, 12, d_back, first_index=10**12)
+    ctx.codec_status()
+    want, _, _ = oracle.encode_records(bc, umi, None, n, 16, 12, first_index=10**12)
+    assert d_back.download().tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("off", [1, 3, 8])
+def test_unaligned_bases_take_the_tail_path(ctx, oracle, off):
+    """Column / record bases that are not 16-byte aligned (a record slice starting at an odd
+    record, ASCII at an arbitrary row) must still be exact."""
+    n, bc_len, umi_len = 5000, 15, 12
+    recs = oracle.generate(SEED, 0, n + 1, bc_len, umi_len)
+    d_all = _up(ctx, recs)
+    d_bc, d_umi, d_idx = ctx.alloc(n * bc_len + 64), ctx.alloc(n * umi_len + 64), ctx.alloc(n * 8 + 64)
+    ctx.decode_ascii(d_all.ptr + 24, n, bc_len, umi_len, d_bc.ptr + off, d_umi.ptr + off, d_idx.ptr + 8)
+    bc, umi, idx = oracle.decode_records(recs[1:], bc_len, umi_len)
+    assert d_bc.download(count=n * bc_len, offset=off).tobytes() == bc.tobytes()
+    assert d_umi.download(count=n * umi_len, offset=off).tobytes() == umi.tobytes()
+    assert d_idx.download(np.uint64, count=n, offset=8).tobytes() == idx.tobytes()
+    d_back = ctx.alloc((n + 1) * 24)
+    ctx.encode_ascii(d_bc.ptr + off, d_umi.ptr + off, d_idx.ptr + 8, n, bc_len, umi_len, d_back.ptr + 24)
+    ctx.codec_status()
+    assert d_back.download(count=n * 24, offset=24).tobytes() == recs[1:].tobytes()
+
+
+@pytest.mark.parametrize("length", [1, 3, 4, 8, 12, 13, 16, 24, 31, 32])
+@pytest.mark.parametrize("n", [0, 1, 129, 65_537])
+def test_pack_unpack_columns(ctx, oracle, n, length):
+    rng = np.random.default_rng(length * 1000 + n)
+    codes = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    d_codes = _up(ctx, codes) if n else ctx.alloc(16)
+    d_ascii = ctx.alloc(max(n, 1) * length)
+    ctx.unpack_2bit(d_codes, n, length, d_ascii)
+    want = oracle.unpack_column(codes, length)
+    got = d_ascii.download(count=n * length)
+    assert got.tobytes() == want.tobytes()
+    d_back = ctx.alloc(max(n, 2) * 8)
+    ctx.pack_2bit(d_ascii, n, length, d_back)
+    ctx.codec_status()
+    wcodes, _, nb = oracle.pack_column(want, n, length)
+    assert nb == 0 and d_back.download(np.uint64, count=n).tobytes() == wcodes.tobytes()
+    # lower-case input packs to the same codes
+    d_low = _up(ctx, np.frombuffer(want.tobytes().lower(), dtype=np.uint8)) if n else ctx.alloc(16)
+    ctx.pack_2bit(d_low, n, length, d_back)
+    ctx.codec_status()
+    assert d_back.download(np.uint64, count=n).tobytes() == wcodes.tobytes()
+
+
+@pytest.mark.parametrize("n", [200, 70_001])
+@pytest.mark.parametrize("lens", [(16, 12), (15, 7)])
+def test_invalid_bases_reported(ia, ctx, oracle, n, lens):
+    bc_len, umi_len = lens
+    recs = oracle.generate(SEED, 0, n, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    bc, umi = bc.copy(), umi.copy()
+    bad_rows = sorted({5, 130, n // 2, n - 1})
+    bc[bad_rows[0] * bc_len] = ord("N")
+    umi[bad_rows[1] * umi_len + umi_len - 1] = 0
+    bc[bad_rows[2] * bc_len + bc_len - 1] = ord("U")
+    umi[bad_rows[2] * umi_len] = ord(" ")  # same row bad in both fields: counted once
+    umi[bad_rows[3] * umi_len] = 0xC1      # high-bit byte that upper-cases to 'A'-like pattern
+    d_back = ctx.alloc(n * 24)
+    ctx.encode_ascii(_up(ctx, bc), _up(ctx, umi), _up(ctx, idx), n, bc_len, umi_len, d_back)
+    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.codec_status()
+    assert ei.value.kind == "InvalidBase"
+    assert (ei.value.first_bad, ei.value.n_bad) == (fb, nb) == (bad_rows[0], len(bad_rows))
+    assert d_back.download().tobytes() == want.tobytes()  # offending fields are written as zero
+    ctx.codec_status()  # slot re-armed
+    d_codes = ctx.alloc(n * 8)
+    ctx.pack_2bit(_up(ctx, bc), n, bc_len, d_codes)
+    wc, fb, nb = oracle.pack_column(bc, n, bc_len)
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.codec_status()
+    assert (ei.value.first_bad, ei.value.n_bad) == (fb, nb)
+    assert d_codes.download(np.uint64).tobytes() == wc.tobytes()
+
+
+def test_every_byte_value_classified(ctx, oracle):
+    """All 256 byte values in every position of a 4-base row."""
+    rows = []
+    for pos in range(4):
+        for b in range(256):
+            r = bytearray(b"ACGT")
+            r[pos] = b
+            rows.append(bytes(r))
+    a = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    n = len(rows)
+    d_codes = ctx.alloc(n * 8)
+    ctx.pack_2bit(_up(ctx, a), n, 4, d_codes)
+    want, fb, nb = oracle.pack_column(a, n, 4)
+    fbd, nbd = None, 0
+    try:
+        ctx.codec_status()
+    except Exception as e:
+        fbd, nbd = e.first_bad, e.n_bad
+    assert (fbd, nbd) == (fb, nb) and nb == 4 * (256 - 8)
+    assert d_codes.download(np.uint64).tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n", SIZES + [3_000_001])
+def test_reduce(ctx, oracle, n):
+    recs = oracle.generate(SEED, 0, n, 32, 32)  # full-range u64: sums must wrap mod 2^64
+    d = _up(ctx, recs) if n else ctx.alloc(16)
+    got = ctx.reduce(d, n)
+    assert got == oracle.reduce_records(recs)
+
+
+def test_reduce_accumulates_across_calls_and_shards(ctx, ia, oracle):
+    """Shard partials combine to the whole (the multi-GPU reduction is a sum / xor of these)."""
+    n = 1_000_000
+    recs = oracle.generate(SEED, 0, n, 16, 12)
+    d = _up(ctx, recs)
+    whole = ctx.reduce(d, n)
+    ctx.reduce(d, 0, reset=True, fetch=False)
+    for i in range(8):
+        s, e = ia.shard_range(n, 8, i)
+        ctx.reduce(d.ptr + 24 * s, e - s, reset=False, fetch=False)
+    assert ctx.reduce_fetch() == whole == oracle.reduce_records(recs)
+
+
+def test_reference_example_values(ctx, oracle, kat):
+    """examples/roundtrip.rs records at N = 1e6 (BASELINE config 1) through the device reduce."""
+    k = kat["roundtrip_1e6"]
+    i = np.arange(k["n"], dtype=np.uint64)
+    recs = oracle.records_array(np.stack([i % 1_000_000, (i * 31) % 1_000_000, i], axis=1))
+    got = ctx.reduce(_up(ctx, recs), k["n"])
+    assert got["count"] == k["n"] and got["sum"] == k["sums"] and got["xor"] == k["xors"]
+
+
+def test_is_sorted(ctx, oracle):
+    n = 100_000
+    recs = oracle.generate(SEED, 0, n, 8, 8)
+    assert ctx.is_sorted(_up(ctx, recs), n) == oracle.is_sorted(recs)
+    s = oracle.sort_records(recs)
+    assert ctx.is_sorted(_up(ctx, s), n) is True
+    s2 = s.copy()
+    s2[[n - 2, n - 1]] = s2[[n - 1, n - 2]]
+    assert ctx.is_sorted(_up(ctx, s2), n) == oracle.is_sorted(s2)
+
+
+def test_argument_errors(ia, ctx):
+    d = ctx.alloc(4096)
+    for bc, umi, kind in [(0, 12, "InvalidBarcodeLength"), (33, 12, "InvalidBarcodeLength"),
+                          (16, 0, "InvalidUmiLength"), (16, 33, "InvalidUmiLength")]:
+        with pytest.raises(ia.IbuError) as ei:
+            ctx.decode_ascii(d, 10, bc, umi, d, d, d)
+        assert ei.value.kind == kind
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.unpack_2bit(d, 10, 33, d)
+    assert ei.value.kind == "SeqLen"
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.deserialize(d.ptr + 4, 10, d, d, d)
+    assert ei.value.kind == "InvalidArg"
+    with pytest.raises(ia.IbuError) as ei:
+        ia.Context(99)
+    assert ei.value.kind == "NoDevice"
+
+
+def test_large_roundtrip_properties(ctx):
+    """Size-independent properties at a size the oracle would be slow on (5e7 records, 16/12):
+    encode(decode(x)) == x byte for byte (checked on device via reduce of both + is-equal of
+    checksums over 8 shards), and count/sums of generated index column are closed-form."""
+    n, bc_len, umi_len = 50_000_000, 16, 12
+    d_recs, d_back = ctx.alloc(n * 24), ctx.alloc(n * 24)
+    d_bc, d_umi, d_idx = ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)
+    ctx.generate(SEED, 0, n, bc_len, umi_len, d_recs)
+    ctx.decode_ascii(d_recs, n, bc_len, umi_len, d_bc, d_umi, d_idx)
+    ctx.encode_ascii(d_bc, d_umi, d_idx, n, bc_len, umi_len, d_back)
+    ctx.codec_status()
+    a, b = ctx.reduce(d_recs, n), ctx.reduce(d_back, n)
+    assert a == b and a["count"] == n
+    assert a["sum"][2] == (n * (n - 1) // 2) % 2**64
+    # spot-check raw bytes of the first and last MiB
+    for off in (0, n * 24 - (1 << 20)):
+        assert d_recs.download(count=1 << 20, offset=off).tobytes() == d_back.download(count=1 << 20, offset=off).tobytes()

@@ -92,7 +92,12 @@ def main():
 
     recs, back = buf(n * 24), buf(n * 24)
     bc, umi, idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
-    st = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) stream: the ABI reads a NULL stream as "the context's own stream", and
+    # torch.cuda.Event only sees work on torch's current stream
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    st = tstream.cuda_stream
+    assert st != 0
     ctx.generate(args.seed, first, n, bc_len, umi_len, recs, stream=st)
     torch.cuda.synchronize()
 

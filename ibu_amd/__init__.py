@@ -327,7 +327,9 @@ class Reader:
         _check(lib.ibu_reader_buffered(self._r, C.byref(p), C.byref(n)))
         if not n.value:
             return np.empty(0, dtype=REC_DTYPE)
-        return np.frombuffer((C.c_uint8 * (n.value * RECORD_SIZE)).from_address(p.value), dtype=REC_DTYPE)
+        raw = (C.c_uint8 * (n.value * RECORD_SIZE)).from_address(p.value)
+        raw._owner = self  # valid until the next read_batch(); keeps the reader itself alive
+        return np.frombuffer(raw, dtype=REC_DTYPE)
 
     def consume(self, n):
         _check(lib.ibu_reader_consume(self._r, n))
@@ -427,7 +429,9 @@ class MmapReader:
     def slice(self, start, end):  # :253-270 — zero-copy view into the map
         p, n = C.c_void_p(), C.c_size_t()
         _check(lib.ibu_mmap_slice(self._m, start, end, C.byref(p), C.byref(n)))
-        return np.frombuffer((C.c_uint8 * (n.value * RECORD_SIZE)).from_address(p.value), dtype=REC_DTYPE)
+        raw = (C.c_uint8 * (n.value * RECORD_SIZE)).from_address(p.value)
+        raw._owner = self  # the borrow `&'a [Record]`: the view keeps this handle (and so the map) alive
+        return np.frombuffer(raw, dtype=REC_DTYPE)
 
     def map_ptr(self):
         return lib.ibu_mmap_base(self._m)

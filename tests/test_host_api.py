@@ -1,0 +1,511 @@
+"""Host half of the product (libibu_hip.so's Header / Record / Writer / Reader / load_to_vec /
+MmapReader) driven through the ibu_amd mirror, case-for-case after the reference's own unit
+tests (file:line in each test), and cross-checked byte-for-byte against the golden vectors and
+the oracle.  CPU-only."""
+import gzip
+import io
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import ibu_amd
+from ibu_amd import (HEADER_SIZE, MAGIC, RECORD_SIZE, VERSION, Header, IbuError, MmapReader, ParallelProcessor,
+                     ProcessError, Reader, Record, Writer, load_to_vec, records_array)
+
+
+def create_test_data(records, header=None):  # reader.rs:543-550
+    w = Writer.new(None, header or Header(16, 12))
+    w.write_batch(records)
+    w.finish()
+    return w.into_inner()
+
+
+def create_test_file(path, records):  # mmap.rs:342-348
+    w = Writer.from_path(path, Header(16, 12))
+    w.write_batch(records)
+    w.finish()
+    w.close()
+
+
+def seq(n, f=lambda i: (i, 2 * i, 3 * i)):
+    i = np.arange(n, dtype=np.uint64)
+    return records_array(np.stack(f(i), axis=1)) if n else records_array(np.zeros((0, 3), np.uint64))
+
+
+# ---------------------------------------------------------------- header.rs tests
+def test_header_creation_size_flags(kat):  # header.rs:236-270
+    h = Header(16, 12)
+    assert (h.magic, h.version, h.bc_len, h.umi_len, h.flags, h.reserved) == (MAGIC, VERSION, 16, 12, 0, b"\0" * 8)
+    assert HEADER_SIZE == 32 == len(h.as_bytes())
+    assert h.as_bytes().hex() == kat["header_new_16_12"]["hex"]
+    assert not h.sorted()
+    h.set_sorted()
+    h.set_sorted()
+    assert h.sorted() and h.flags == 1
+    assert h.as_bytes().hex() == kat["header_sorted_16_12"]["hex"]
+
+
+def test_header_validation(kat):  # header.rs:273-348
+    for bc, umi in kat["validate_ok"]["cases"]:
+        Header(bc, umi).validate()
+    for c in kat["validate_err"]["cases"]:
+        with pytest.raises(IbuError) as ei:
+            Header.from_bytes(bytes.fromhex(c["hex"])).validate()
+        assert (ei.value.kind, ei.value.a, ei.value.b) == (c["kind"], c["a"], c["b"]), c["src"]
+    with pytest.raises(IbuError) as ei:
+        h = Header(16, 12)
+        h.magic = 0x12345678
+        h.validate()
+    assert (ei.value.expected, ei.value.actual) == (MAGIC, 0x12345678)
+    assert "0x21554249" in str(ei.value) and "0x12345678" in str(ei.value)  # error.rs:201-206
+
+
+def test_header_bytes_roundtrip_and_derives():  # header.rs:351-411
+    a = Header(20, 10)
+    assert Header.from_bytes(a.as_bytes()) == a
+    s = Header(16, 12)
+    s.set_sorted()
+    assert Header.from_bytes(s.as_bytes()).sorted()
+    assert Header(16, 12) == Header(16, 12) and Header(16, 12) != Header(20, 10)
+    assert {Header(16, 12): "v"}[Header(16, 12)] == "v" and "Header" in repr(a)
+    with pytest.raises(IbuError) as ei:  # the reference panics (bytemuck) — here an error
+        Header.from_bytes(b"\0" * 31)
+    assert ei.value.kind == "InvalidArg"
+
+
+# ---------------------------------------------------------------- record.rs tests
+def test_record_basics(kat):  # record.rs:140-161, 235-264
+    r = Record(0x1234, 0x5678, 42)
+    assert (r.barcode, r.umi, r.index) == (0x1234, 0x5678, 42) and RECORD_SIZE == 24 == len(r.as_bytes())
+    assert Record() == (0, 0, 0)
+    for c in kat["record_bytes"]["cases"]:
+        rec = Record(*c["rec"])
+        assert rec.as_bytes().hex() == c["hex"] and Record.from_bytes(bytes.fromhex(c["hex"])) == rec
+
+
+def test_record_ordering(kat):  # record.rs:164-232
+    o = kat["ordering"]
+    assert sorted(Record(*r) for r in o["unsorted"]) == [Record(*r) for r in o["sorted"]]
+    for a, b in o["greater"]:
+        assert Record(*a) > Record(*b) and Record(*a).cmp(b) == 1 and Record(*b).cmp(a) == -1
+    assert Record(1, 2, 3).cmp((1, 2, 3)) == 0
+    assert Record(0, 0, 0) < Record(1, 0, 0) and Record(0, 0, 0) < Record(0, 1, 0) and Record(0, 0, 0) < Record(0, 0, 1)
+    big = Record(2**64 - 1, 2**64 - 2, 2**64 - 3)  # record.rs:313-321
+    assert Record.from_bytes(big.as_bytes()) == big and big.cmp((2**64 - 1, 2**64 - 2, 2**64 - 2)) == -1
+
+
+# ---------------------------------------------------------------- writer.rs tests
+def test_writer_lengths(kat):  # writer.rs:636-694
+    k = kat["writer_lengths"]
+    w = Writer.new(None, Header(16, 12))
+    assert w.records_written() == 0 and len(w.into_inner()) == k["new"]
+    assert len(Writer.new_headless().into_inner()) == k["headless"]
+    w = Writer.new(None, Header(16, 12))
+    w.write_record(Record(*k["one_record"]["rec"]))
+    assert w.records_written() == 1
+    w.finish()
+    assert w.into_inner().hex() == k["one_record"]["hex"]
+    w = Writer.new(None, Header(16, 12))
+    w.write_batch([Record(*r) for r in k["batch3"]["recs"]])
+    assert w.records_written() == 3
+    w.finish()
+    assert w.into_inner().hex() == k["batch3"]["hex"]
+
+
+def test_writer_readme_file(kat):  # README.md:66-85
+    h = Header(16, 12)
+    h.set_sorted()
+    w = Writer.new(None, h)
+    for r in kat["readme_file"]["records"]:
+        w.write_record(Record(*r))
+    w.finish()
+    assert w.into_inner().hex() == kat["readme_file"]["hex"]
+
+
+def test_writer_iter_and_large_batch(kat):  # writer.rs:697-719
+    w = Writer.new(None, Header(16, 12))
+    w.write_iter(Record(i, i * 2, i * 3) for i in range(100))
+    assert w.records_written() == 100
+    w = Writer.new(None, Header(16, 12))
+    w.write_batch(seq(kat["writer_buffer"]["direct_batch_records"]))
+    assert w.records_written() == 100_000
+    assert len(w.inner_bytes()) == 32 + 100_000 * 24  # direct path: already in the sink, unbuffered
+
+
+def test_writer_ingest(kat):  # writer.rs:722-741
+    main, aux = Writer.new(None, Header(16, 12)), Writer.new_headless()
+    for r in kat["writer_ingest"]["aux_records"]:
+        aux.write_record(Record(*r))
+    main.ingest(aux)
+    assert main.records_written() == 2 and aux.inner_bytes() == b""
+    with pytest.raises(IbuError):  # ingest source must be Writer<Vec<u8>> (type-enforced in the reference)
+        main.ingest(Writer(io.BytesIO(), None))
+
+
+def test_writer_roundtrip_and_flush_boundary(kat):  # writer.rs:744-787
+    recs = [Record(0x12345, 0x67890, 100), Record(0xABCDE, 0xF0123, 200)]
+    data = create_test_data(recs, Header(20, 10))
+    assert list(Reader.new(data)) == recs
+    w = Writer.new(None, Header(16, 12))
+    per = ibu_amd.DEFAULT_BUFFER_SIZE // RECORD_SIZE
+    w.write_batch(seq(per - 1))
+    w.write_record(Record(per - 1, 0, 0))
+    assert len(w.inner_bytes()) == 32  # exactly full is not flushed by write_record (:262 is a strict >)
+    wb = Writer.new(None, Header(16, 12))
+    wb.write_batch(seq(per))
+    assert len(wb.inner_bytes()) == 32 + ibu_amd.DEFAULT_BUFFER_SIZE  # write_batch filling it to the brim flushes (:344)
+    w2 = Writer.new(None, Header(16, 12))
+    for i in range(per):
+        w2.write_record(Record(i, 0, 0))
+    assert len(w2.inner_bytes()) == 32  # write_record flushes lazily (:262)
+    w2.write_record(Record(999, 0, 0))
+    assert len(w2.inner_bytes()) == 32 + kat["writer_buffer"]["buffer_bytes"]
+
+
+def test_writer_counter_drop_empty_mixed(kat, tmp_path):  # writer.rs:790-865
+    w = Writer.new(None, Header(16, 12))
+    w.write_record(Record(1, 2, 3))
+    w.write_batch([Record(4, 5, 6), Record(7, 8, 9)])
+    w.write_iter(Record(i, i, i) for i in range(10, 15))
+    assert w.records_written() == 8
+    p = tmp_path / "drop.ibu"
+    w = Writer.from_path(p, Header(16, 12))
+    w.write_record(Record(1, 2, 3))
+    w.close()  # Drop flushes
+    assert p.stat().st_size == 56
+    w = Writer.new(None, Header(16, 12))
+    w.write_batch([])
+    assert w.records_written() == 0
+    k = kat["writer_mixed"]
+    w = Writer.new(None, Header(16, 12))
+    w.write_record(Record(*k["write_record"]))
+    w.write_batch([Record(*r) for r in k["write_batch"]])
+    w.write_iter(Record(i, i * 2, i * 3) for i in range(10, 13))
+    assert w.records_written() == 6
+    w.finish()
+    data = w.into_inner()
+    assert data.hex() == k["hex"]
+    got = list(Reader.new(data))
+    assert len(got) == 6 and got[0] == (1, 2, 3) and got[1] == (4, 5, 6) and got[5] == (12, 24, 36)
+
+
+def test_writer_does_not_validate_header():  # quirk Q2, writer.rs:129-143
+    bad = Header(0, 99)
+    data = Writer.new(None, bad).into_inner()
+    assert data == bad.as_bytes()
+    with pytest.raises(IbuError) as ei:
+        Reader.new(data)
+    assert ei.value.kind == "InvalidBarcodeLength"
+
+
+def test_writer_generic_sink_and_fd(tmp_path):
+    sink = io.BytesIO()
+    w = Writer.new(sink, Header(16, 12))
+    w.write_batch(seq(10))
+    w.finish()
+    assert sink.getvalue() == create_test_data(seq(10))
+    p = tmp_path / "fd.ibu"
+    fd = os.open(p, os.O_WRONLY | os.O_CREAT)
+    w = Writer(fd, Header(16, 12))
+    w.write_batch(seq(3))
+    w.close()
+    os.close(fd)
+    assert p.read_bytes() == create_test_data(seq(3))
+    with pytest.raises(IbuError) as ei:
+        Writer.from_path(tmp_path / "no" / "such" / "dir.ibu", Header(16, 12))
+    assert ei.value.kind == "Io" and ei.value.os_errno != 0
+
+
+# ---------------------------------------------------------------- reader.rs tests
+def test_reader_creation_and_invalid_header():  # reader.rs:553-575
+    h = Reader.new(create_test_data([Record(1, 2, 3), Record(4, 5, 6)])).header()
+    assert (h.bc_len, h.umi_len, h.magic, h.version) == (16, 12, MAGIC, VERSION)
+    with pytest.raises(IbuError) as ei:
+        Reader.new(b"\0" * 32)
+    assert ei.value.kind == "InvalidMagicNumber"
+    with pytest.raises(IbuError) as ei:
+        Reader.new(b"IBU!")
+    assert ei.value.kind == "Io"
+
+
+def test_reader_iterator_empty_large(kat):  # reader.rs:578-616
+    recs = [Record(1, 2, 3), Record(4, 5, 6), Record(7, 8, 9)]
+    assert list(Reader.new(create_test_data(recs))) == recs
+    assert list(Reader.new(create_test_data([]))) == []
+    big = seq(kat["reader_stream"]["n"])
+    r = Reader.new(create_test_data(big))
+    got = records_array(list(r))
+    assert got.tobytes() == big.tobytes()
+    r = Reader.new(create_test_data(big))
+    caps = []
+    while r.read_batch():
+        caps.append(len(r.buffered()))
+    assert caps == kat["reader_stream"]["refills"]
+
+
+def test_reader_truncated_and_manual_batches(kat, oracle):  # reader.rs:619-653
+    data = bytes.fromhex(kat["truncated"]["hex"])
+    r = Reader.new(data)
+    with pytest.raises(IbuError) as ei:
+        next(r)
+    assert ei.value.kind == "TruncatedRecord" and ei.value.pos == kat["truncated"]["stream"]["pos"]
+    assert "32" in str(ei.value)
+    r = Reader.new(create_test_data([Record(1, 2, 3)]))
+    assert r.read_batch() is True and r.read_batch() is False
+    # quirk Q8 against the oracle: same pos, same number of records yielded before the error
+    d = create_test_data(seq(49152 + 10))[:-5]
+    r, n = Reader.new(d), 0
+    with pytest.raises(IbuError) as ei:
+        for _ in r:
+            n += 1
+    o = oracle.Reader(d)
+    with pytest.raises(oracle.OracleError) as oe:
+        while o.next() is not None:
+            pass
+    assert n == 49152 and ei.value.pos == oe.value.a
+
+
+def test_reader_short_reads_and_bytes_read():  # reader.rs:224-231, :744-766
+    data = create_test_data(seq(60_000))
+
+    class Dribble(io.RawIOBase):
+        def __init__(self, b):
+            self.b, self.p = b, 0
+
+        def read(self, n=-1):
+            k = min(n, 1 + (self.p * 7919) % 4099)
+            out = self.b[self.p:self.p + k]
+            self.p += len(out)
+            return out
+
+    r = Reader.new(Dribble(data))
+    assert r.bytes_read == HEADER_SIZE
+    first = next(r)
+    assert first == (0, 0, 0) and r.bytes_read > HEADER_SIZE
+    rest = list(r)
+    assert len(rest) == 59_999 and rest[-1] == (59_999, 2 * 59_999, 3 * 59_999)
+    assert r.bytes_read == len(data)
+
+
+def test_load_to_vec(kat, tmp_path, oracle):  # reader.rs:669-741
+    recs = [Record(1, 2, 3), Record(4, 5, 6), Record(7, 8, 9)]
+    p = tmp_path / "test_load_to_vec.ibu"
+    p.write_bytes(create_test_data(recs))
+    h, got = load_to_vec(p)
+    assert (h.bc_len, h.umi_len) == (16, 12) and [Record(*r) for r in got.tolist()] == recs
+    p.write_bytes(create_test_data([]))
+    h, got = load_to_vec(p)
+    assert len(got) == 0
+    p.write_bytes(bytes.fromhex(kat["truncated"]["hex"]))
+    with pytest.raises(IbuError) as ei:
+        load_to_vec(p)
+    assert ei.value.kind == "InvalidMapSize" and "not a multiple" in str(ei.value)
+    with pytest.raises(IbuError) as ei:
+        load_to_vec(tmp_path / "missing.ibu")
+    assert ei.value.kind == "Io"
+    big = oracle.generate(11, 0, 250_000, 16, 12)
+    p.write_bytes(create_test_data(big))
+    h, got = load_to_vec(p)
+    assert got.tobytes() == big.tobytes() == oracle.load_to_vec(str(p))[1].tobytes()
+
+
+def test_reader_from_path_plain_and_gzip(tmp_path, oracle):  # reader.rs:345-352 (niffler)
+    recs = oracle.generate(5, 0, 120_000, 16, 12)
+    raw = create_test_data(recs)
+    plain, gz, gz2 = tmp_path / "a.ibu", tmp_path / "a.ibu.gz", tmp_path / "multi.ibu.gz"
+    plain.write_bytes(raw)
+    gz.write_bytes(gzip.compress(raw, 1))
+    cut = 32 + 24 * 50_000 + 7  # member boundary in the middle of a record
+    gz2.write_bytes(gzip.compress(raw[:cut], 6) + gzip.compress(raw[cut:], 1))
+    for p in (plain, gz, gz2):
+        got = records_array(list(Reader.from_path(p)))
+        assert got.tobytes() == recs.tobytes(), p
+    # load_to_vec never decompresses (quirk Q10): gzip bytes are not an IBU header
+    with pytest.raises(IbuError) as ei:
+        load_to_vec(gz)
+    assert ei.value.kind == "InvalidMagicNumber"
+    bad = tmp_path / "bad.gz"
+    bad.write_bytes(gzip.compress(raw, 1)[:-20])
+    with pytest.raises(IbuError) as ei:
+        list(Reader.from_path(bad))
+    assert ei.value.kind in ("Niffler", "TruncatedRecord")
+    tiny = tmp_path / "tiny"
+    tiny.write_bytes(b"IB")
+    with pytest.raises(IbuError) as ei:
+        Reader.from_path(tiny)
+    assert ei.value.kind == "Niffler"
+    z = tmp_path / "z.zst"
+    z.write_bytes(b"\x28\xb5\x2f\xfd" + b"\0" * 40)
+    with pytest.raises(IbuError) as ei:
+        Reader.from_path(z)
+    assert ei.value.kind == "Niffler"
+
+
+# ---------------------------------------------------------------- mmap.rs / parallel.rs tests
+class TestProcessor(ParallelProcessor):  # mmap.rs:350-373, parallel.rs:359-382
+    __test__ = False
+
+    def __init__(self):
+        self.local_count = self.local_sum = 0
+        self.shared = {"count": 0, "sum": 0, "batches": 0, "lock": threading.Lock()}
+        self.tid = None
+
+    def process_record(self, record):
+        self.local_count += 1
+        self.local_sum += record.barcode + record.umi + record.index
+
+    def on_batch_complete(self):
+        with self.shared["lock"]:
+            self.shared["count"] += self.local_count
+            self.shared["sum"] += self.local_sum
+            self.shared["batches"] += 1
+        self.local_count = self.local_sum = 0
+
+    def set_tid(self, tid):
+        self.tid = tid
+
+    def get_tid(self):
+        return self.tid
+
+
+def test_mmap_reader_creation_slice_errors(kat, tmp_path):  # mmap.rs:376-452
+    p = tmp_path / "test_mmap.ibu"
+    create_test_file(p, [Record(1, 2, 3), Record(4, 5, 6), Record(7, 8, 9)])
+    m = MmapReader.new(p)
+    assert m.len() == 3 and (m.header().bc_len, m.header().umi_len) == (16, 12)
+    create_test_file(p, seq(100))
+    m = MmapReader.new(p)
+    for c in kat["mmap"]["slice_100"]["checks"]:
+        s = m.slice(c["s"], c["e"])
+        assert len(s) == c["e"] - c["s"] and list(s[0]) == c["first"] and list(s[-1]) == c["last"]
+    create_test_file(p, [Record(1, 2, 3)])
+    m1 = MmapReader.new(p)
+    for c in kat["mmap"]["slice_errors_len1"]:
+        with pytest.raises(IbuError) as ei:
+            m1.slice(c["s"], c["e"])
+        assert (ei.value.kind, ei.value.idx, ei.value.max) == ("InvalidIndex", c["idx"], c["max"])
+
+
+def test_mmap_parallel_processing(kat, tmp_path):  # mmap.rs:455-519
+    p = tmp_path / "test_mmap_parallel.ibu"
+    create_test_file(p, seq(10_000))
+    proc = TestProcessor()
+    MmapReader.new(p).process_parallel(proc, 4)
+    assert proc.shared["count"] == kat["mmap"]["parallel_10000"]["count"]
+    assert proc.shared["sum"] == kat["mmap"]["parallel_10000"]["sum"]
+    assert proc.tid is None  # quirk Q4: set_tid is never called
+    create_test_file(p, seq(1000, lambda i: (i, 0 * i, 0 * i)))
+    proc = TestProcessor()
+    MmapReader.new(p).process_parallel(proc, 0)
+    assert proc.shared["count"] == 1000
+    create_test_file(p, [])
+    m = MmapReader.new(p)
+    proc = TestProcessor()
+    m.process_parallel(proc, 2)
+    assert m.len() == 0 and proc.shared["count"] == 0 and proc.shared["batches"] == 0
+
+
+def test_mmap_clone_and_large(kat, tmp_path):  # mmap.rs:522-565
+    p = tmp_path / "c.ibu"
+    create_test_file(p, [Record(1, 2, 3), Record(4, 5, 6)])
+    m = MmapReader.new(p)
+    c = m.clone()
+    assert m.len() == c.len() and m.header() == c.header()
+    assert m.slice(0, 2).tobytes() == c.slice(0, 2).tobytes() and m.map_ptr() == c.map_ptr()  # Arc::ptr_eq
+    m.close()
+    assert list(c.slice(1, 2)[0]) == [4, 5, 6]  # the map outlives the first handle
+    big = kat["mmap"]["large"]
+    create_test_file(p, seq(big["n"], lambda i: (i % 1000, i % 500, i)))
+    s = MmapReader.new(p).slice(big["s"], big["e"])
+    assert len(s) == 10 and int(s[0]["index"]) == big["first_index"]
+    assert ibu_amd.BATCH_SIZE == 1024 * 1024  # mmap.rs:568-573
+
+
+def test_processor_errors_and_defaults(tmp_path):  # parallel.rs:414-459
+    class ErrorProcessor(ParallelProcessor):
+        def process_record(self, record):
+            if record.index == 3 * 5:
+                raise ProcessError("Test error")
+
+    p = tmp_path / "e.ibu"
+    create_test_file(p, seq(100))
+    with pytest.raises(IbuError) as ei:
+        MmapReader.new(p).process_parallel(ErrorProcessor(), 2)
+    assert ei.value.kind == "Process" and "Processing error" in str(ei.value)
+
+    class Minimal(ParallelProcessor):
+        def process_record(self, record):
+            pass
+
+    mp = Minimal()
+    assert mp.on_batch_complete() is None and mp.get_tid() is None
+    mp.set_tid(123)
+    assert mp.get_tid() is None
+    MmapReader.new(p).process_parallel(mp, 1)
+
+
+def test_shard_range_matches_oracle_and_quirks(oracle):  # mmap.rs:297-307, quirk Q5
+    for length in (0, 1, 3, 10, 1000, 10**9 + 7):
+        for n in (1, 2, 3, 4, 8, 64):
+            for i in range(n):
+                assert ibu_amd.shard_range(length, n, i) == oracle.shard_range(length, n, i)
+    assert [ibu_amd.shard_range(3, 8, i) for i in range(8)] == [(0, 0)] * 7 + [(0, 3)]
+    with pytest.raises(IbuError):
+        ibu_amd.shard_range(10, 4, 4)
+
+
+def test_product_file_equals_oracle_file(tmp_path, oracle):
+    """Same records through the product Writer and the oracle Writer -> identical files, at every
+    interleaving of write_record / write_batch across the buffer boundary."""
+    recs = oracle.generate(99, 0, 120_000, 16, 12)
+    cuts = [0, 1, 49_151, 49_152, 49_153, 98_304, 100_000, 120_000]
+    h = Header(16, 12)
+    pw = Writer.from_path(tmp_path / "p.ibu", h)
+    ow = oracle.Writer(oracle.header_new(16, 12), path=str(tmp_path / "o.ibu"))
+    for a, b in zip(cuts, cuts[1:]):
+        if b - a == 1:
+            r = recs[a]
+            pw.write_record(Record(*r.tolist()))
+            ow.write_record(r.tolist())
+        else:
+            pw.write_batch(recs[a:b])
+            ow.write_batch(recs[a:b])
+        assert pw.records_written() == ow.records_written
+    pw.finish()
+    pw.close()
+    ow.finish()
+    ow.drop()
+    assert (tmp_path / "p.ibu").read_bytes() == (tmp_path / "o.ibu").read_bytes()
+
+
+def test_roundtrip_example_1e6(kat, tmp_path):
+    """BASELINE config 1: examples/roundtrip.rs at N = 1e6 through the product's host plumbing."""
+    k = kat["roundtrip_1e6"]
+    recs = seq(k["n"], lambda i: (i % 1_000_000, (i * 31) % 1_000_000, i))
+    p = tmp_path / "test_roundtrip.ibu"
+    h = Header(16, 12)
+    h.set_sorted()
+    w = Writer.from_path(p, h)
+    w.write_batch(recs[:10])
+    for r in recs[10:2010]:
+        w.write_record(Record(*r.tolist()))
+    w.write_batch(recs[2010:])
+    w.finish()
+    w.close()
+    assert p.stat().st_size == k["file_len"]
+    r = Reader.from_path(p)
+    hh = r.header()
+    assert hh.bc_len == 16 and hh.umi_len == 12 and hh.sorted()
+    n, x, sums = 0, 0, np.zeros(3, dtype=np.uint64)
+    while r.read_batch():
+        b = r.buffered()
+        n += len(b)
+        for j, f in enumerate(("barcode", "umi", "index")):
+            sums[j] += b[f].sum(dtype=np.uint64)
+            x ^= int(np.bitwise_xor.reduce(b[f]))
+        r.consume(len(b))
+    assert n == k["n"] and [int(v) for v in sums] == k["sums"] and x == k["checksum"]
+    hh, got = load_to_vec(p)
+    assert got.tobytes() == recs.tobytes()

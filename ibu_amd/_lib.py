@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libibu_hip.so")
+SO_PATH = os.environ.get("IBU_HIP_SO") or os.path.join(_HERE, "libibu_hip.so")  # IBU_HIP_SO: A/B builds of the same ABI
 
 u8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
 vp, sz, u64, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int32

@@ -3,6 +3,7 @@
 // Every function here fails loudly (IBU_ERR_NO_DEVICE / IBU_ERR_HIP) when there is no gfx950
 // device; nothing falls back to host arithmetic.  Launch functions are asynchronous, allocate
 // nothing and never synchronise, so callers may capture them into hipGraphs.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.hpp"
@@ -55,6 +56,10 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
   ctx->device = device;
   ctx->cfg.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ctx->cfg.blocks_per_cu = 8;
+  if (const char* e = getenv("IBU_BLOCKS_PER_CU")) {  // tuning knob: cap on resident workgroups per CU
+    int v = atoi(e);
+    if (v >= 1 && v <= 8) ctx->cfg.blocks_per_cu = v;
+  }
   hipError_t rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 2 * sizeof(uint64_t));

@@ -184,7 +184,7 @@ __device__ __forceinline__ void report_bad(bool bad, u64 row_global, u64* status
 // =============================================================================================
 // K2  fused decode: AoS records -> barcode ASCII, UMI ASCII, index column
 // =============================================================================================
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
              uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
@@ -228,7 +228,7 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
 // Dynamic LDS per wave: max(3072, 128*(bc_len+umi_len)) bytes; the AoS tile reuses the ASCII
 // staging area once every row has been packed (in-order DS makes that safe).
 // =============================================================================================
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_in,
              const u64* __restrict__ idx_in, u64 first_index, u32 ntiles, u32 bc_len, u32 umi_len,
              u32 wave_lds_bytes, uint8_t* __restrict__ recs, u64* __restrict__ status) {
@@ -277,7 +277,7 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
 // =============================================================================================
 // K1  deserialise AoS -> three u64 columns          K1' serialise columns -> AoS
 // =============================================================================================
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_deserialize(const uint8_t* __restrict__ recs, u32 ntiles, u64* __restrict__ bc,
                   u64* __restrict__ umi, u64* __restrict__ idx) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
@@ -316,7 +316,7 @@ ibu_k_deserialize(const uint8_t* __restrict__ recs, u32 ntiles, u64* __restrict_
   }
 }
 
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_serialize(const u64* __restrict__ bc, const u64* __restrict__ umi, const u64* __restrict__ idx,
                 u32 ntiles, uint8_t* __restrict__ recs) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
@@ -346,7 +346,7 @@ ibu_k_serialize(const u64* __restrict__ bc, const u64* __restrict__ umi, const u
 // =============================================================================================
 // Single-column 2-bit unpack / pack (stride-8 "records")
 // =============================================================================================
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * 1024];
   const u32 lane = threadIdx.x & (kWave - 1);
@@ -362,7 +362,7 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
   }
 }
 
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_pack(const uint8_t* __restrict__ in, u32 ntiles, u32 len, u64* __restrict__ codes,
            u64* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileRecs * 32];
@@ -397,7 +397,7 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
   return ((u64)hi << 32) | lo;
 }
 
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_reduce(const uint8_t* __restrict__ recs, u32 ntiles, u64 n_total, u64* __restrict__ acc) {
   __shared__ u64 part[kWavesPerBlock][6];
   const u32 lane = threadIdx.x & (kWave - 1);
@@ -476,7 +476,7 @@ __device__ __forceinline__ u64 synth_elem(u64 seed, u64 first, u64 e, u64 mb, u6
   const u64 r = splitmix64(seed + 3 * gi + k);
   return k == 0 ? (r & mb) : (r & mu);
 }
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_generate(u64 seed, u64 first, u64 n_elems, u32 bc_len, u32 umi_len, u64* __restrict__ out) {
   const u64 mb = mask2(bc_len), mu = mask2(umi_len);
   const u64 stride = (u64)gridDim.x * kBlock;
@@ -576,6 +576,18 @@ static inline u32 grid_for(u32 ntiles, int cus, int blocks_per_cu) {
   u32 cap = (u32)(cus * blocks_per_cu);
   return need < cap ? (need ? need : 1) : cap;
 }
+// Persistent grids must be exactly resident: a workgroup that has to wait for a slot runs its
+// whole share alone at the end.  Ask the runtime how many 256-thread blocks of this kernel fit
+// on a CU (registers, LDS), cap it by cfg.blocks_per_cu, remember the answer per kernel.
+template <class K>
+static inline int resident_blocks(const LaunchCfg& cfg, K kernel, size_t dyn_lds, int* cache) {
+  if (*cache <= 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, dyn_lds) != hipSuccess || nb <= 0) nb = 4;
+    *cache = nb;
+  }
+  return *cache < cfg.blocks_per_cu ? *cache : cfg.blocks_per_cu;
+}
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline u32 tail_grid(u64 rows) { return (u32)((rows + 255) / 256); }
 
@@ -586,7 +598,9 @@ hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint3
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_decode, dim3(grid_for(ntiles, cfg.cus, cfg.blocks_per_cu)), dim3(kBlock), 0, st,
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_decode, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_decode, 0, &occ))),
+                       dim3(kBlock), 0, st,
                        (const uint8_t*)recs, ntiles, bc_len, umi_len, bc, umi, (u64*)idx);
   }
   if (n_main < n)
@@ -605,7 +619,9 @@ hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t*
     u32 ntiles = (u32)(n_main / kTileRecs);
     u32 wave_lds = kTileRecs * (bc_len + umi_len);
     if (wave_lds < (u32)kTileBytes) wave_lds = kTileBytes;
-    hipLaunchKernelGGL(ibu_k_encode, dim3(grid_for(ntiles, cfg.cus, cfg.blocks_per_cu)), dim3(kBlock),
+    static int occ[65] = {0};
+    const int nb = resident_blocks(cfg, ibu_k_encode, wave_lds * kWavesPerBlock, &occ[bc_len + umi_len]);
+    hipLaunchKernelGGL(ibu_k_encode, dim3(grid_for(ntiles, cfg.cus, nb)), dim3(kBlock),
                        wave_lds * kWavesPerBlock, st, bc, umi, (const u64*)idx, (u64)first_index, ntiles, bc_len,
                        umi_len, wave_lds, (uint8_t*)recs, (u64*)status);
   }
@@ -622,7 +638,9 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_deserialize, dim3(grid_for(ntiles, cfg.cus, cfg.blocks_per_cu)), dim3(kBlock), 0, st,
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_deserialize,
+                       dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
                        (const uint8_t*)recs, ntiles, (u64*)bc, (u64*)umi, (u64*)idx);
   }
   if (n_main < n)
@@ -638,7 +656,9 @@ hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, cfg.blocks_per_cu)), dim3(kBlock), 0, st,
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_serialize, 0, &occ))),
+                       dim3(kBlock), 0, st,
                        (const u64*)bc, (const u64*)umi, (const u64*)idx, ntiles, (uint8_t*)recs);
   }
   if (n_main < n)
@@ -654,7 +674,9 @@ hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, 
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_unpack, dim3(grid_for(ntiles, cfg.cus, cfg.blocks_per_cu)), dim3(kBlock), 0, st,
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_unpack, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_unpack, 0, &occ))),
+                       dim3(kBlock), 0, st,
                        (const u64*)codes, ntiles, len, out);
   }
   if (n_main < n)
@@ -670,7 +692,9 @@ hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_pack, dim3(grid_for(ntiles, cfg.cus, 4)), dim3(kBlock), 0, st, in, ntiles, len,
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_pack, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_pack, 0, &occ))),
+                       dim3(kBlock), 0, st, in, ntiles, len,
                        (u64*)codes, (u64*)status);
   }
   if (n_main < n)
@@ -685,7 +709,9 @@ hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint6
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   u32 ntiles = (u32)(n_main / kTileRecs);
   // the main kernel also adds n to the count slot, so it always runs (ntiles may be 0)
-  hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, cfg.blocks_per_cu)), dim3(kBlock), 0, st,
+  static int occ = 0;
+  hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_reduce, 0, &occ))),
+                     dim3(kBlock), 0, st,
                      (const uint8_t*)recs, ntiles, (u64)n, (u64*)acc);
   if (n_main < n)
     hipLaunchKernelGGL(ibu_k_reduce_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,

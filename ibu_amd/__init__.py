@@ -559,6 +559,9 @@ class Context:
     def synchronize(self, stream=None):
         _check(lib.ibu_ctx_synchronize(self._c, stream))
 
+    def set_option(self, key, value):
+        _check(lib.ibu_ctx_set_option(self._c, key.encode(), int(value)))
+
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 

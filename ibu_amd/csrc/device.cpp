@@ -55,11 +55,7 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
   ibu_ctx* ctx = new ibu_ctx;
   ctx->device = device;
   ctx->cfg.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  ctx->cfg.blocks_per_cu = 8;
-  if (const char* e = getenv("IBU_BLOCKS_PER_CU")) {  // tuning knob: cap on resident workgroups per CU
-    int v = atoi(e);
-    if (v >= 1 && v <= 8) ctx->cfg.blocks_per_cu = v;
-  }
+  // blocks_per_cu keeps LaunchCfg's measured default; ibu_ctx_set_option overrides it
   hipError_t rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 2 * sizeof(uint64_t));
@@ -91,6 +87,15 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;
+}
+extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return err_arg("ctx or key is NULL");
+  if (strcmp(key, "blocks_per_cu") == 0) {
+    if (value < 1 || value > 8) return err_arg("blocks_per_cu must be 1..8");
+    ctx->cfg.blocks_per_cu = (int)value;
+    return IBU_OK;
+  }
+  return err_arg("unknown option key");
 }
 extern "C" int32_t ibu_ctx_device(const ibu_ctx_t* ctx) { return ctx ? ctx->device : -1; }
 extern "C" void* ibu_ctx_stream(const ibu_ctx_t* ctx) { return ctx ? ctx->stream : nullptr; }

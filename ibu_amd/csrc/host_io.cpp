@@ -2,7 +2,7 @@
 // load_to_vec / MmapReader / ParallelReader behaviour behind the C ABI of include/ibu_hip.h.
 //
 // This is I/O plumbing (syscalls, buffering, error mapping): it performs no codec or record
-// arithmetic — that lives only in kernels.hip.  Reference lines are cited per function; the
+// arithmetic — that lives only in the k_*.hip kernel files.  Reference lines are cited per function; the
 // quirk numbers (Q1..Q15) refer to SURVEY.md Appendix C.
 #include <errno.h>
 #include <fcntl.h>

@@ -1,0 +1,176 @@
+// k_decode.hip — K2 fused decode (AoS records -> barcode ASCII, UMI ASCII, index column) and
+// the single-column 2-bit unpack.  Design notes: kcommon.hpp.  Reference semantics: the 2-bit
+// table of src/constructs/record.rs:19-27 applied to the fields of a cast_slice'd &[Record]
+// (reader.rs:301, mmap.rs:268); see include/ibu_hip.h.
+#include "kcommon.hpp"
+#include "kernels.h"
+
+namespace ibu {
+
+// Stage one AoS tile held in registers into the wave's LDS slice and expand it.
+template <int BC, int UM>
+__device__ __forceinline__ void decode_tile(uint8_t* tile, u32x4 a0, u32x4 a1, u32x4 a2, u32 t, u32 bc_len,
+                                            u32 umi_len, uint8_t* bc_out, uint8_t* umi_out, u64* idx_out,
+                                            u32 lane) {
+  wave_lds_fence();                            // previous tile's LDS reads precede these writes
+  *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
+  *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
+  *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
+  wave_lds_fence();
+  if (bc_out) expand_field<BC>(tile, 24, 0, bc_len, bc_out + (size_t)t * kTileRecs * bc_len, lane);
+  if (umi_out) expand_field<UM>(tile, 24, 8, umi_len, umi_out + (size_t)t * kTileRecs * umi_len, lane);
+  if (idx_out) {                               // chunk = indices of records 2*lane, 2*lane+1
+    u64 i0 = *reinterpret_cast<const u64*>(tile + (2 * lane) * 24 + 16);
+    u64 i1 = *reinterpret_cast<const u64*>(tile + (2 * lane + 1) * 24 + 16);
+    u32x4 o; o.x = (u32)i0; o.y = (u32)(i0 >> 32); o.z = (u32)i1; o.w = (u32)(i1 >> 32);
+    st16(reinterpret_cast<uint8_t*>(idx_out) + (size_t)t * 1024 + 16 * lane, o);
+  }
+}
+
+// BC / UM: compile-time barcode / UMI length, or 0 for "runtime length" (generic kernel).
+// Two register sets take turns (phase A expands `a` while `b` is in flight, phase B the
+// reverse): the next tile's three loads are issued FIRST in each phase, never copied, never
+// behind a wait.
+// Register budget: the dword-path specialisations fit 64 VGPRs (8 waves/SIMD); the byte-path
+// (len % 4 != 0) and generic kernels would spill there, so they get 168 (3 waves/SIMD).  72 VGPRs
+// (7 waves/SIMD) measured as fast as 64 (8) for the streaming kernels (profiles/r01_b sweep).
+constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
+template <int BC, int UM>
+__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? 7 : 3)
+ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
+             uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * kTileBytes;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  if (t >= ntiles) return;
+  if (BC > 0) bc_len = BC;
+  if (UM > 0) umi_len = UM;
+
+  const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
+  u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
+  for (;;) {
+    u32 tn = t + nwaves;
+    bool more = tn < ntiles;                   // wave-uniform
+    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
+    u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
+    decode_tile<BC, UM>(tile, a0, a1, a2, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
+    if (!more) break;
+    t = tn;
+    tn = t + nwaves;
+    more = tn < ntiles;
+    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
+    a0 = ld16(src); a1 = ld16(src + 1024); a2 = ld16(src + 2048);
+    decode_tile<BC, UM>(tile, b0, b1, b2, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
+    if (!more) break;
+    t = tn;
+  }
+}
+
+// Single u64 column -> ASCII (stride-8 "records", 1 KiB tile).
+template <int LEN>
+__global__ void __launch_bounds__(kBlock, dword_len(LEN) ? 8 : 3)
+ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * 1024];
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * 1024;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  if (t >= ntiles) return;
+  if (LEN > 0) len = LEN;
+  const uint8_t* base = reinterpret_cast<const uint8_t*>(codes) + 16 * lane;
+  u32x4 a = ld16(base + (size_t)t * 1024);
+  for (;;) {                                   // two phases, registers swap roles: see decode
+    u32 tn = t + nwaves;
+    bool more = tn < ntiles;
+    u32x4 b = ld16(base + (size_t)(more ? tn : t) * 1024);
+    wave_lds_fence();
+    *reinterpret_cast<u32x4*>(tile + 16 * lane) = a;
+    wave_lds_fence();
+    expand_field<LEN>(tile, 8, 0, len, out + (size_t)t * kTileRecs * len, lane);
+    if (!more) break;
+    t = tn;
+    tn = t + nwaves;
+    more = tn < ntiles;
+    a = ld16(base + (size_t)(more ? tn : t) * 1024);
+    wave_lds_fence();
+    *reinterpret_cast<u32x4*>(tile + 16 * lane) = b;
+    wave_lds_fence();
+    expand_field<LEN>(tile, 8, 0, len, out + (size_t)t * kTileRecs * len, lane);
+    if (!more) break;
+    t = tn;
+  }
+}
+
+// ---- tails: one thread per record, any alignment -----------------------------------------------
+__device__ __forceinline__ void unpack_row_bytes(u64 code, u32 len, uint8_t* out) {
+  for (u32 i = 0; i < len; ++i) out[i] = (uint8_t)((kPool >> (8 * ((code >> (2 * i)) & 3))) & 0xFF);
+}
+extern "C" __global__ void ibu_k_decode_tail(const u64* __restrict__ recs, u64 row0, u64 n, u32 bc_len,
+                                             u32 umi_len, uint8_t* bc_out, uint8_t* umi_out, u64* idx_out) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (bc_out) unpack_row_bytes(recs[3 * i], bc_len, bc_out + i * bc_len);
+  if (umi_out) unpack_row_bytes(recs[3 * i + 1], umi_len, umi_out + i * umi_len);
+  if (idx_out) idx_out[i] = recs[3 * i + 2];
+}
+extern "C" __global__ void ibu_k_unpack_tail(const u64* codes, u64 row0, u64 n, u32 len, uint8_t* out) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unpack_row_bytes(codes[i], len, out + i * len);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+typedef void (*DecFn)(const uint8_t*, u32, u32, u32, uint8_t*, uint8_t*, u64*);
+template <int B, int U>
+static constexpr DecFn dec_entry() { return ibu_k_decode<len_of_mode(B), len_of_mode(U)>; }
+#define IBU_DEC_ROW(B) {dec_entry<B, 0>(), dec_entry<B, 1>(), dec_entry<B, 2>(), dec_entry<B, 3>(), dec_entry<B, 4>(), dec_entry<B, 5>()}
+static const DecFn kDecTable[kNumLenModes][kNumLenModes] = {IBU_DEC_ROW(0), IBU_DEC_ROW(1), IBU_DEC_ROW(2),
+                                                            IBU_DEC_ROW(3), IBU_DEC_ROW(4), IBU_DEC_ROW(5)};
+
+hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t bc_len, uint32_t umi_len,
+                         uint8_t* bc, uint8_t* umi, uint64_t* idx, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
+  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
+  if (n_main) {
+    const u32 ntiles = (u32)(n_main / kTileRecs);
+    const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
+    const DecFn fn = kDecTable[mb][mu];
+    static int occ[kNumLenModes][kNumLenModes] = {{0}};
+    hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, fn, 0, &occ[mb][mu]))), dim3(kBlock), 0,
+                       st, (const uint8_t*)recs, ntiles, bc_len, umi_len, bc, umi, (u64*)idx);
+  }
+  if (n_main < n)
+    hipLaunchKernelGGL(ibu_k_decode_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)n_main, (u64)n, bc_len, umi_len, bc, umi, (u64*)idx);
+  return hipGetLastError();
+}
+
+typedef void (*UnpFn)(const u64*, u32, u32, uint8_t*);
+static const UnpFn kUnpTable[kNumLenModes] = {ibu_k_unpack<len_of_mode(0)>, ibu_k_unpack<len_of_mode(1)>,
+                                              ibu_k_unpack<len_of_mode(2)>, ibu_k_unpack<len_of_mode(3)>,
+                                              ibu_k_unpack<len_of_mode(4)>, ibu_k_unpack<len_of_mode(5)>};
+
+hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, uint32_t len, uint8_t* out,
+                         hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const bool fast = aligned16(codes) && aligned16(out);
+  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
+  if (n_main) {
+    const u32 ntiles = (u32)(n_main / kTileRecs);
+    const int m = mode_of_len(len);
+    static int occ[kNumLenModes] = {0};
+    hipLaunchKernelGGL(kUnpTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, kUnpTable[m], 0, &occ[m]))),
+                       dim3(kBlock), 0, st, (const u64*)codes, ntiles, len, out);
+  }
+  if (n_main < n)
+    hipLaunchKernelGGL(ibu_k_unpack_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)codes,
+                       (u64)n_main, (u64)n, len, out);
+  return hipGetLastError();
+}
+
+}  // namespace ibu

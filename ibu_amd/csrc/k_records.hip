@@ -1,0 +1,321 @@
+// k_records.hip — K1/K1' (AoS <-> u64 columns), K4 reduce, synthetic generator, sortedness check.
+// Design notes: kcommon.hpp.  Reference semantics are cited at the C-ABI entry points in device.cpp
+// and include/ibu_hip.h (cast_slice of &[Record]: reader.rs:301, writer.rs:317, mmap.rs:268; the
+// in-repo processors: lib.rs:117-129, examples/parallel.rs:21-36, examples/roundtrip.rs:84-87).
+#include "kcommon.hpp"
+#include "kernels.h"
+
+namespace ibu {
+
+// =============================================================================================
+// K1  deserialise AoS -> three u64 columns          K1' serialise columns -> AoS
+// =============================================================================================
+__device__ __forceinline__ void deserialize_tile(uint8_t* tile, u32x4 a0, u32x4 a1, u32x4 a2, u32 t, u64* bc,
+                                                 u64* umi, u64* idx, u32 lane) {
+  wave_lds_fence();
+  *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
+  *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
+  *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
+  wave_lds_fence();
+  const u64* r0 = reinterpret_cast<const u64*>(tile + (2 * lane) * 24);
+  const u64* r1 = reinterpret_cast<const u64*>(tile + (2 * lane + 1) * 24);
+  u64* cols[3] = {bc, umi, idx};
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    u64 x = r0[f], y = r1[f];
+    u32x4 o; o.x = (u32)x; o.y = (u32)(x >> 32); o.z = (u32)y; o.w = (u32)(y >> 32);
+    st16(reinterpret_cast<uint8_t*>(cols[f]) + (size_t)t * 1024 + 16 * lane, o);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_deserialize(const uint8_t* __restrict__ recs, u32 ntiles, u64* __restrict__ bc,
+                  u64* __restrict__ umi, u64* __restrict__ idx) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * kTileBytes;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  if (t >= ntiles) return;
+  const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
+  u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
+  for (;;) {                                   // two phases, register sets swap roles: see decode
+    u32 tn = t + nwaves;
+    bool more = tn < ntiles;
+    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
+    u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
+    deserialize_tile(tile, a0, a1, a2, t, bc, umi, idx, lane);
+    if (!more) break;
+    t = tn;
+    tn = t + nwaves;
+    more = tn < ntiles;
+    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
+    a0 = ld16(src); a1 = ld16(src + 1024); a2 = ld16(src + 2048);
+    deserialize_tile(tile, b0, b1, b2, t, bc, umi, idx, lane);
+    if (!more) break;
+    t = tn;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_serialize(const u64* __restrict__ bc, const u64* __restrict__ umi, const u64* __restrict__ idx,
+                u32 ntiles, uint8_t* __restrict__ recs) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * kTileBytes;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  if (t >= ntiles) return;
+  size_t off = (size_t)t * 1024 + 16 * lane;   // records 2*lane, 2*lane+1 of each column
+  u32x4 c0 = ld16(reinterpret_cast<const uint8_t*>(bc) + off);
+  u32x4 c1 = ld16(reinterpret_cast<const uint8_t*>(umi) + off);
+  u32x4 c2 = ld16(reinterpret_cast<const uint8_t*>(idx) + off);
+  for (;;) {
+    wave_lds_fence();
+    u32x4* r = reinterpret_cast<u32x4*>(tile + lane * 48);  // two adjacent records = 48 B
+    u32x4 w0, w1, w2;
+    w0.x = c0.x; w0.y = c0.y; w0.z = c1.x; w0.w = c1.y;     // bc[2l]   umi[2l]
+    w1.x = c2.x; w1.y = c2.y; w1.z = c0.z; w1.w = c0.w;     // idx[2l]  bc[2l+1]
+    w2.x = c1.z; w2.y = c1.w; w2.z = c2.z; w2.w = c2.w;     // umi[2l+1] idx[2l+1]
+    r[0] = w0; r[1] = w1; r[2] = w2;
+    const u32 tn = t + nwaves;
+    const bool more = tn < ntiles;
+    off = (size_t)(more ? tn : t) * 1024 + 16 * lane;       // unconditional: see decode
+    c0 = ld16(reinterpret_cast<const uint8_t*>(bc) + off);
+    c1 = ld16(reinterpret_cast<const uint8_t*>(umi) + off);
+    c2 = ld16(reinterpret_cast<const uint8_t*>(idx) + off);
+    wave_lds_fence();
+    uint8_t* dst = recs + (size_t)t * kTileBytes + 16 * lane;
+    st16(dst, *reinterpret_cast<const u32x4*>(tile + 16 * lane));
+    st16(dst + 1024, *reinterpret_cast<const u32x4*>(tile + 1024 + 16 * lane));
+    st16(dst + 2048, *reinterpret_cast<const u32x4*>(tile + 2048 + 16 * lane));
+    if (!more) break;
+    t = tn;
+  }
+}
+
+
+// =============================================================================================
+// K4  reduce: wrapping sums and XORs of the three fields.  Pure streaming read, no LDS in the
+// loop: a lane's dwordx4 always lands on the same two field slots because the wave stride
+// (3072 B = 384 u64) is a multiple of 3.
+// =============================================================================================
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+  u32 lo = __shfl_xor((u32)v, m), hi = __shfl_xor((u32)(v >> 32), m);
+  return ((u64)hi << 32) | lo;
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_reduce(const uint8_t* __restrict__ recs, u32 ntiles, u64 n_total, u64* __restrict__ acc) {
+  __shared__ u64 part[kWavesPerBlock][6];
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 wib = threadIdx.x >> 6;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u64 s[3][2] = {{0, 0}, {0, 0}, {0, 0}}, x[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  for (; t + nwaves < ntiles; t += 2 * nwaves) {  // two tiles (6 KiB per wave) in flight
+    const uint8_t* p = recs + (size_t)t * kTileBytes + 16 * lane;
+    const uint8_t* q = recs + (size_t)(t + nwaves) * kTileBytes + 16 * lane;
+    u32x4 a[3], b[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a[k] = ld16(p + 1024 * k); b[k] = ld16(q + 1024 * k); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u64 a0 = ((u64)a[k].y << 32) | a[k].x, a1 = ((u64)a[k].w << 32) | a[k].z;
+      u64 b0 = ((u64)b[k].y << 32) | b[k].x, b1 = ((u64)b[k].w << 32) | b[k].z;
+      s[k][0] += a0 + b0; s[k][1] += a1 + b1;
+      x[k][0] ^= a0 ^ b0; x[k][1] ^= a1 ^ b1;
+    }
+  }
+  if (t < ntiles) {
+    const uint8_t* p = recs + (size_t)t * kTileBytes + 16 * lane;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u32x4 a = ld16(p + 1024 * k);
+      u64 a0 = ((u64)a.y << 32) | a.x, a1 = ((u64)a.w << 32) | a.z;
+      s[k][0] += a0; s[k][1] += a1;
+      x[k][0] ^= a0; x[k][1] ^= a1;
+    }
+  }
+  // slot (k,h) of this lane is flat u64 element 2*(64k+lane)+h of the tile -> field e % 3
+  u64 S[3] = {0, 0, 0}, X[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 f = (2 * (64 * k + lane) + h) % 3;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        if (f == (u32)g) { S[g] += s[k][h]; X[g] ^= x[k][h]; }
+    }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { S[g] += shfl_xor_u64(S[g], m); X[g] ^= shfl_xor_u64(X[g], m); }
+  if (lane == 0)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { part[wib][g] = S[g]; part[wib][3 + g] = X[g]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    u64 v = part[0][threadIdx.x];
+    for (int w = 1; w < kWavesPerBlock; ++w)
+      v = threadIdx.x < 3 ? v + part[w][threadIdx.x] : v ^ part[w][threadIdx.x];
+    if (threadIdx.x < 3) { if (v) atomicAdd(&acc[1 + threadIdx.x], v); }
+    else                 { if (v) atomicXor(&acc[1 + threadIdx.x], v); }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 6) atomicAdd(&acc[0], n_total);
+}
+
+// =============================================================================================
+// Synthetic records: flat u64 element e = 3*i + k of the record stream is splitmix64(seed + e)
+// masked for k = 0,1 and i for k = 2.  One 16-B chunk (two elements) per thread, coalesced.
+// =============================================================================================
+__device__ __forceinline__ u64 splitmix64(u64 z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 synth_elem(u64 seed, u64 first, u64 e, u64 mb, u64 mu) {
+  const u64 i = e / 3;
+  const u32 k = (u32)(e - 3 * i);
+  const u64 gi = first + i;
+  if (k == 2) return gi;
+  const u64 r = splitmix64(seed + 3 * gi + k);
+  return k == 0 ? (r & mb) : (r & mu);
+}
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_generate(u64 seed, u64 first, u64 n_elems, u32 bc_len, u32 umi_len, u64* __restrict__ out) {
+  const u64 mb = mask2(bc_len), mu = mask2(umi_len);
+  const u64 stride = (u64)gridDim.x * kBlock;
+  const u64 npairs = n_elems >> 1;  // n_elems = 3n; pairs cover the 16-B chunks
+  for (u64 c = (u64)blockIdx.x * kBlock + threadIdx.x; c < npairs; c += stride) {
+    u64 v0 = synth_elem(seed, first, 2 * c, mb, mu), v1 = synth_elem(seed, first, 2 * c + 1, mb, mu);
+    u32x4 o; o.x = (u32)v0; o.y = (u32)(v0 >> 32); o.z = (u32)v1; o.w = (u32)(v1 >> 32);
+    st16(reinterpret_cast<uint8_t*>(out) + 16 * c, o);
+  }
+  if ((n_elems & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    out[n_elems - 1] = synth_elem(seed, first, n_elems - 1, mb, mu);
+}
+
+// =============================================================================================
+// Tail / unaligned kernels: one thread per record, no alignment assumption beyond the natural
+// 8 B of the u64 columns and records.  Used for n % 128 and for misaligned bases only.
+// =============================================================================================
+extern "C" __global__ void ibu_k_deserialize_tail(const u64* __restrict__ recs, u64 row0, u64 n, u64* bc,
+                                                  u64* umi, u64* idx) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bc[i] = recs[3 * i]; umi[i] = recs[3 * i + 1]; idx[i] = recs[3 * i + 2];
+}
+extern "C" __global__ void ibu_k_serialize_tail(const u64* bc, const u64* umi, const u64* idx, u64 row0, u64 n,
+                                                u64* __restrict__ recs) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  recs[3 * i] = bc[i]; recs[3 * i + 1] = umi[i]; recs[3 * i + 2] = idx[i];
+}
+extern "C" __global__ void ibu_k_reduce_tail(const u64* __restrict__ recs, u64 row0, u64 n, u64* acc) {
+  // at most a few hundred records: one block, one thread per record, atomics straight to acc
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    u64 v = recs[3 * i + f];
+    if (v) { atomicAdd(&acc[1 + f], v); atomicXor(&acc[4 + f], v); }
+  }
+}
+extern "C" __global__ void ibu_k_sorted_check(const u64* __restrict__ recs, u64 n, u32* unsorted) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride) {
+    const u64* a = recs + 3 * i;
+    bool gt = a[0] != a[3] ? a[0] > a[3] : (a[1] != a[4] ? a[1] > a[4] : a[2] > a[5]);
+    if (gt) atomicOr(unsorted, 1u);
+  }
+}
+extern "C" __global__ void ibu_k_fill_u64(u64* p, u64 v0, u64 v1) { p[0] = v0; p[1] = v1; }
+
+// =============================================================================================
+// Launchers
+// =============================================================================================
+hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* bc, uint64_t* umi,
+                              uint64_t* idx, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
+  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
+  if (n_main) {
+    u32 ntiles = (u32)(n_main / kTileRecs);
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_deserialize,
+                       dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
+                       (const uint8_t*)recs, ntiles, (u64*)bc, (u64*)umi, (u64*)idx);
+  }
+  if (n_main < n)
+    hipLaunchKernelGGL(ibu_k_deserialize_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)n_main, (u64)n, (u64*)bc, (u64*)umi, (u64*)idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint64_t* umi, const uint64_t* idx,
+                            size_t n, void* recs, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
+  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
+  if (n_main) {
+    u32 ntiles = (u32)(n_main / kTileRecs);
+    static int occ = 0;
+    hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_serialize, 0, &occ))),
+                       dim3(kBlock), 0, st,
+                       (const u64*)bc, (const u64*)umi, (const u64*)idx, ntiles, (uint8_t*)recs);
+  }
+  if (n_main < n)
+    hipLaunchKernelGGL(ibu_k_serialize_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)bc,
+                       (const u64*)umi, (const u64*)idx, (u64)n_main, (u64)n, (u64*)recs);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* acc, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const bool fast = aligned16(recs);
+  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
+  u32 ntiles = (u32)(n_main / kTileRecs);
+  // the main kernel also adds n to the count slot, so it always runs (ntiles may be 0)
+  static int occ = 0;
+  hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_reduce, 0, &occ))),
+                     dim3(kBlock), 0, st,
+                     (const uint8_t*)recs, ntiles, (u64)n, (u64*)acc);
+  if (n_main < n)
+    hipLaunchKernelGGL(ibu_k_reduce_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)n_main, (u64)n, (u64*)acc);
+  return hipGetLastError();
+}
+
+hipError_t launch_generate(const LaunchCfg& cfg, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
+                           uint32_t umi_len, void* recs, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  u64 n_elems = 3ull * n;
+  u64 blocks = ((n_elems >> 1) + kBlock - 1) / kBlock;
+  u64 cap = (u64)cfg.cus * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(ibu_k_generate, dim3((u32)blocks), dim3(kBlock), 0, st, (u64)seed, (u64)first, n_elems, bc_len,
+                     umi_len, (u64*)recs);
+  return hipGetLastError();
+}
+
+hipError_t launch_sorted_check(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t* flag, hipStream_t st) {
+  if (n < 2) return hipSuccess;
+  u64 blocks = (n + 255) / 256;
+  u64 cap = (u64)cfg.cus * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(ibu_k_sorted_check, dim3((u32)blocks), dim3(256), 0, st, (const u64*)recs, (u64)n, flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st) {
+  hipLaunchKernelGGL(ibu_k_fill_u64, dim3(1), dim3(1), 0, st, (u64*)p, (u64)v0, (u64)v1);
+  return hipGetLastError();
+}
+
+}  // namespace ibu

@@ -1,0 +1,256 @@
+// kcommon.hpp — device-side building blocks shared by the gfx950 kernels (k_*.hip).
+//
+// Everything on this path is HBM-bound integer / byte work: no MFMA.  The rules are the
+// streaming ones:
+//   * every global access is a fully coalesced 16 B-per-lane wave instruction (1 KiB each),
+//     with the nontemporal hint (each byte is touched once; measured in-process: reduce
+//     6.0 -> 6.7 TB/s, decode 5.7 -> 6.0 TB/s — profiles/r01_c);
+//   * the 24-byte record stride is absorbed in LDS: a wave-private 128-record = 3 KiB tile;
+//     stride-24 ds_read_b64 is bank-conflict-free (6 dwords * k mod 64 distinct for 32 k);
+//   * waves never share a tile, so there is no workgroup barrier anywhere;
+//   * persistent grid, grid-stride over tiles, next tile's loads in flight while the current
+//     one is processed.  The prefetch loads are UNCONDITIONAL (the last iteration re-reads its
+//     own tile) and loop trip counts around loads/stores are compile-time constants: hipcc's
+//     waitcnt pass tracks the in-order vmcnt counter per path and merges paths conservatively,
+//     so a branch around a load, or a store in a runtime-count loop, turns the wait before the
+//     LDS write into vmcnt(0) and drains the prefetch every iteration (seen in the ISA of the
+//     first version of these kernels).
+//
+// Tile geometry (one wave):  128 records  = 3072 B AoS = 3 x (64 lanes x 16 B)
+//                             ASCII column  = 128*len B  = 8*len 16-B chunks
+//                             u64 column    = 1024 B     = 64 chunks
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ibu {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int kWave = 64;
+static constexpr int kBlock = 256;                 // 4 waves, each with a private LDS slice
+static constexpr int kWavesPerBlock = kBlock / kWave;
+static constexpr int kTileRecs = 128;              // records per wave tile
+static constexpr int kTileBytes = kTileRecs * 24;  // 3072
+static constexpr u32 kPool = 0x54474341u;          // "ACGT" little-endian: byte k = base code k
+
+// Lengths with a fully specialised (constant-folded, straight-line) kernel; every other length
+// 1..32 runs the generic kernel (runtime loops).  Mode 0 = generic.
+static constexpr int kNumLenModes = 6;
+__host__ __device__ constexpr int len_of_mode(int m) { return m == 1 ? 8 : m == 2 ? 10 : m == 3 ? 12 : m == 4 ? 16 : m == 5 ? 32 : 0; }
+static inline int mode_of_len(uint32_t len) {
+  switch (len) {
+    case 8: return 1;
+    case 10: return 2;
+    case 12: return 3;
+    case 16: return 4;
+    case 32: return 5;
+    default: return 0;
+  }
+}
+
+#ifndef IBU_NT_LOAD
+#define IBU_NT_LOAD 1
+#endif
+#ifndef IBU_NT_STORE
+#define IBU_NT_STORE 1
+#endif
+__device__ __forceinline__ u32x4 ld16(const void* p) {
+#if IBU_NT_LOAD
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+  return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void st16(void* p, u32x4 v) {
+#if IBU_NT_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#else
+  *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+
+// A wave's DS instructions execute in order, so a ds_read issued after a ds_write of the same
+// wave observes it.  Only the compiler has to be told not to move LDS traffic across this.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- 2-bit <-> ASCII primitives -----------------------------------------------------------
+// One code byte (4 bases, base i at bits [2i,2i+1]) -> 4 ASCII bytes.
+__device__ __forceinline__ u32 expand4(u32 x) {
+  u32 t = (x | (x << 12)) & 0x000F000Fu;          // nibbles to bytes 0 and 2
+  t = (t | (t << 6)) & 0x03030303u;               // 2-bit fields to the low bits of bytes 0..3
+  return __builtin_amdgcn_perm(kPool, kPool, t);  // selector bytes 0..3 pick A,C,G,T
+}
+// 4 ASCII bytes -> one code byte; ok cleared if any byte is outside ACGTacgt.
+__device__ __forceinline__ u32 pack4(u32 w, bool& ok) {
+  u32 sel = ((w >> 1) ^ (w >> 2)) & 0x03030303u;  // A/a=0 C/c=1 G/g=2 T/t=3 per byte
+  u32 expect = __builtin_amdgcn_perm(kPool, kPool, sel);
+  ok = ok && ((w & 0xDFDFDFDFu) == expect);       // upper-cased input must be the letter decoded
+  u32 y = sel | (sel >> 6);
+  return (y | (y >> 12)) & 0xFFu;
+}
+__device__ __forceinline__ u32 pack1(u32 c, bool& ok) {
+  u32 code = ((c >> 1) ^ (c >> 2)) & 3u;
+  ok = ok && ((c & 0xDFu) == ((kPool >> (8 * code)) & 0xFFu));
+  return code;
+}
+__device__ __forceinline__ u32x4 expand16(u32 w) {  // 16 bases
+  u32x4 o;
+  o.x = expand4(w & 0xFF); o.y = expand4((w >> 8) & 0xFF);
+  o.z = expand4((w >> 16) & 0xFF); o.w = expand4(w >> 24);
+  return o;
+}
+
+// One 16-byte chunk `c` of the ASCII stream of a staged tile (rows of `len` bases, u64 field at
+// byte `foff` of records of stride `rstride`).  `len` may be a compile-time constant.
+__device__ __forceinline__ u32x4 expand_chunk(const uint8_t* tile, u32 rstride, u32 foff, u32 len, u32 c) {
+  if ((len & 3) == 0) {
+    const u32 l4 = len >> 2;                       // code bytes per row (1..8)
+    if (l4 == 4) return expand16(*reinterpret_cast<const u32*>(tile + c * rstride + foff));
+    if (l4 == 8) return expand16(*reinterpret_cast<const u32*>(tile + (c >> 1) * rstride + foff + (c & 1) * 4));
+    const u32 d = 4 * c;                           // 4,8,12,20,24,28 bases: gather 4 code bytes
+    u32 r = (d * (65536u / l4 + 1)) >> 16;         // d / l4 for d < 1024
+    u32 q = d - r * l4;
+    u32 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = expand4(tile[r * rstride + foff + q]);
+      if (++q == l4) { q = 0; ++r; }
+    }
+    u32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+    return o;
+  }
+  // len not a multiple of 4: rows straddle dwords; resolve every output byte on its own.
+  const u32 o0 = 16 * c;
+  u32 r = (o0 * ((1u << 20) / len + 1)) >> 20;     // o0 / len for o0 < 128*len
+  u32 p = o0 - r * len;
+  u32 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32 w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      u32 code = (tile[r * rstride + foff + (p >> 2)] >> (2 * (p & 3))) & 3u;
+      w |= ((kPool >> (8 * code)) & 0xFFu) << (8 * b);
+      if (++p == len) { p = 0; ++r; }
+    }
+    v[j] = w;
+  }
+  u32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+  return o;
+}
+
+// Output-centric expansion of one field of a staged tile: every lane produces whole 16-byte
+// chunks of the ASCII stream, so every store is a full coalesced dwordx4 whatever len is.
+//   LEN > 0 : compile-time length; ceil(LEN/8) rounds, straight-line; lanes past the last chunk
+//             recompute and re-store the LAST chunk (same bytes, same address: benign) so no
+//             store is exec-branched and the store count per tile is exact.
+//   LEN == 0: runtime length, plain loop (generic kernel).
+template <int LEN>
+__device__ __forceinline__ void expand_field(const uint8_t* tile, u32 rstride, u32 foff, u32 rt_len,
+                                             uint8_t* out_tile, u32 lane) {
+  if constexpr (LEN > 0) {
+    constexpr u32 last = 8 * LEN - 1;
+    constexpr int rounds = (LEN + 7) / 8;
+#pragma unroll
+    for (int i = 0; i < rounds; ++i) {
+      u32 c = lane + 64 * i;
+      c = c < last ? c : last;
+      st16(out_tile + 16 * (size_t)c, expand_chunk(tile, rstride, foff, (u32)LEN, c));
+    }
+  } else {
+    const u32 nchunks = 8 * rt_len;
+    for (u32 c = lane; c < nchunks; c += kWave)
+      st16(out_tile + 16 * (size_t)c, expand_chunk(tile, rstride, foff, rt_len, c));
+  }
+}
+
+// Record-centric packing of one row of ASCII bytes staged in LDS.
+template <int L4>
+__device__ __forceinline__ u64 pack_row_dwords(const uint8_t* row, bool& ok) {
+  u64 v = 0;
+#pragma unroll
+  for (int q = 0; q < L4; ++q) v |= (u64)pack4(*reinterpret_cast<const u32*>(row + 4 * q), ok) << (8 * q);
+  return v;
+}
+__device__ __forceinline__ u64 pack_row_bytes(const uint8_t* row, u32 len, bool& ok) {
+  u64 v = 0;
+  for (u32 i = 0; i < len; ++i) v |= (u64)pack1(row[i], ok) << (2 * i);
+  return v;
+}
+template <int LEN>
+__device__ __forceinline__ u64 pack_row(const uint8_t* row, u32 rt_len, bool& ok) {
+  if constexpr (LEN > 0 && (LEN & 3) == 0) {
+    return pack_row_dwords<LEN / 4>(row, ok);
+  } else if constexpr (LEN > 0) {
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) v |= (u64)pack1(row[i], ok) << (2 * i);
+    return v;
+  } else {
+    if ((rt_len & 3) == 0) {
+      u64 v = 0;
+      for (u32 q = 0; q < (rt_len >> 2); ++q) v |= (u64)pack4(*reinterpret_cast<const u32*>(row + 4 * q), ok) << (8 * q);
+      return v;
+    }
+    return pack_row_bytes(row, rt_len, ok);
+  }
+}
+
+// Staging of one ASCII tile global -> registers -> LDS (linear).
+//   LEN > 0 : ceil(LEN/8) wave-wide dwordx4 loads in straight-line code; lanes past the last
+//             chunk re-read the last chunk (same cache line as their neighbours: no extra HBM
+//             traffic) and skip the LDS write.
+//   LEN == 0: generic kernel; 4 rounds, the unused ones predicated off.
+template <int LEN>
+struct AsciiStage {
+  static constexpr int rounds = LEN > 0 ? (LEN + 7) / 8 : 4;
+  u32x4 v[rounds];
+  __device__ __forceinline__ void issue(const uint8_t* g, u32 rt_len, u32 lane) {
+    const u32 last = 8 * (LEN > 0 ? (u32)LEN : rt_len) - 1;
+#pragma unroll
+    for (int i = 0; i < rounds; ++i) {
+      u32 c = lane + 64 * i;
+      c = c < last ? c : last;
+      v[i] = ld16(g + 16 * (size_t)c);
+    }
+  }
+  __device__ __forceinline__ void land(uint8_t* lds, u32 rt_len, u32 lane) const {
+    const u32 nchunks = 8 * (LEN > 0 ? (u32)LEN : rt_len);
+#pragma unroll
+    for (int i = 0; i < rounds; ++i) {
+      const u32 c = lane + 64 * i;
+      if (c < nchunks) *reinterpret_cast<u32x4*>(lds + 16 * c) = v[i];
+    }
+  }
+};
+
+// Report offending rows of this wave's tile: one atomicMin + one atomicAdd per wave, and only
+// when something is actually wrong (wave-uniform branch on the ballot).
+__device__ __forceinline__ void report_bad(bool bad, u64 row_global, u64* status, u32 lane) {
+  u64 m = __ballot(bad);
+  if (m) {
+    if (bad) atomicMin(&status[0], row_global);
+    if (lane == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&status[1], (u64)__popcll(m));
+  }
+}
+
+__device__ __forceinline__ u64 mask2(u32 len) { return len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1); }
+
+// ---- host-side launch helpers ------------------------------------------------------------------
+static inline u32 grid_for(u32 ntiles, int cus, int blocks_per_cu) {
+  u32 need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  u32 cap = (u32)(cus * blocks_per_cu);
+  return need < cap ? (need ? need : 1) : cap;
+}
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline u32 tail_grid(u64 rows) { return (u32)((rows + 255) / 256); }
+
+}  // namespace ibu

@@ -230,6 +230,10 @@ int32_t ibu_ctx_device(const ibu_ctx_t* ctx);
 void* ibu_ctx_stream(const ibu_ctx_t* ctx);        /* hipStream_t */
 int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream);
 int32_t ibu_device_count(int32_t* n);
+/* Tuning knobs (all optional; defaults are the measured best for MI355X):
+ *   "blocks_per_cu"  1..8   cap on resident 256-thread workgroups per CU for the persistent grids
+ * Unknown keys / out-of-range values return IBU_ERR_INVALID_ARG. */
+int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value);
 /* Device memory helpers for callers without their own allocator (tests in C, Rust shim). */
 int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr);
 int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr);

@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""Kernel micro-benchmark: every hot-path kernel at one size, HIP-event timed on one stream,
-interleaved rounds (A/B deltas come from one process, cdna_hip_programming.md rule 24).
-  python tools/kbench.py [--records 2e8] [--lens 16,12] [--rounds 5] [--kernels decode,encode,...]
-Prints one JSON line per kernel: median / min ms and algorithmic GB/s."""
+"""Kernel micro-benchmark / A-B harness.
+
+Times the hot-path kernels with HIP events on one stream.  Variants (different builds of
+libibu_hip.so and/or different residency caps) are run in interleaved rounds inside ONE
+process (cdna_hip_programming.md rule 24), all on the same buffers.
+
+  python tools/kbench.py [--records 2e8] [--lens 16,12] [--rounds 7] [--kernels decode,encode,...]
+                         [--so tag=path ...] [--blocks 8,7,6]
+Prints one JSON line per (variant, blocks, kernel): median / best ms and algorithmic GB/s."""
 import argparse
+import ctypes as C
 import json
 import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -18,57 +25,86 @@ def main():
     ap.add_argument("--lens", default="16,12")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--kernels", default="decode,encode,deserialize,serialize,reduce,unpack,pack,generate")
-    ap.add_argument("--tag", default=os.environ.get("IBU_HIP_SO", "default"))
+    ap.add_argument("--so", action="append", default=[], help="tag=path of an alternative build (repeatable)")
+    ap.add_argument("--blocks", default="", help="comma list of blocks_per_cu caps to sweep (default: library default)")
     a = ap.parse_args()
     import torch
 
-    import ibu_amd
+    from ibu_amd import _lib
 
     n = int(a.records)
     bc_len, umi_len = (int(x) for x in a.lens.split(","))
     dev = torch.device("cuda", 0)
-    ctx = ibu_amd.Context(0)
     ts = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(ts)
-    st = ts.cuda_stream
+    st = C.c_void_p(ts.cuda_stream)
     buf = lambda b: torch.empty(b, dtype=torch.uint8, device=dev)
     recs, back = buf(n * 24), buf(n * 24)
     bc, umi, idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
     c0, c1 = buf(n * 8), buf(n * 8)
-    ctx.generate(1, 0, n, bc_len, umi_len, recs, stream=st)
-    ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
-    ctx.deserialize(recs, n, c0, c1, idx, stream=st)
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    variants = [("default", _lib.SO_PATH)] + [tuple(s.split("=", 1)) for s in a.so]
+    blocks = [int(b) for b in a.blocks.split(",") if b] or [0]
+    cfgs = []
+    for tag, path in variants:
+        lib = _lib.load(path)
+        ctx = C.c_void_p()
+        assert lib.ibu_ctx_create(0, C.byref(ctx)) == 0, tag
+        cfgs.append((tag, lib, ctx))
+
+    def ops_for(lib, ctx):
+        return {
+            "decode": (lambda: lib.ibu_decode_ascii(ctx, p(recs), n, bc_len, umi_len, p(bc), p(umi), p(idx), st), 24 + bc_len + umi_len + 8),
+            "encode": (lambda: lib.ibu_encode_ascii(ctx, p(bc), p(umi), p(idx), 0, n, bc_len, umi_len, p(back), st), 24 + bc_len + umi_len + 8),
+            "deserialize": (lambda: lib.ibu_deserialize(ctx, p(recs), n, p(c0), p(c1), p(idx), st), 48),
+            "serialize": (lambda: lib.ibu_serialize(ctx, p(c0), p(c1), p(idx), n, p(back), st), 48),
+            "reduce": (lambda: lib.ibu_reduce(ctx, p(recs), n, st), 24),
+            "unpack": (lambda: lib.ibu_unpack_2bit(ctx, p(c0), n, bc_len, p(bc), st), 8 + bc_len),
+            "pack": (lambda: lib.ibu_pack_2bit(ctx, p(bc), n, bc_len, p(c1), st), 8 + bc_len),
+            "generate": (lambda: lib.ibu_generate(ctx, 1, 0, n, bc_len, umi_len, p(back), st), 24),
+        }
+
+    tag0, lib0, ctx0 = cfgs[0]
+    assert lib0.ibu_generate(ctx0, 1, 0, n, bc_len, umi_len, p(recs), st) == 0
+    assert lib0.ibu_decode_ascii(ctx0, p(recs), n, bc_len, umi_len, p(bc), p(umi), p(idx), st) == 0
+    assert lib0.ibu_deserialize(ctx0, p(recs), n, p(c0), p(c1), p(idx), st) == 0
     torch.cuda.synchronize()
-    ops = {
-        "decode": (lambda: ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st), 24 + bc_len + umi_len + 8),
-        "encode": (lambda: ctx.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back, stream=st), 24 + bc_len + umi_len + 8),
-        "deserialize": (lambda: ctx.deserialize(recs, n, c0, c1, idx, stream=st), 48),
-        "serialize": (lambda: ctx.serialize(c0, c1, idx, n, back, stream=st), 48),
-        "reduce": (lambda: ctx.reduce(recs, n, stream=st, reset=False, fetch=False), 24),
-        "unpack": (lambda: ctx.unpack_2bit(c0, n, bc_len, bc, stream=st), 8 + bc_len),
-        "pack": (lambda: ctx.pack_2bit(bc, n, bc_len, c1, stream=st), 8 + bc_len),
-        "generate": (lambda: ctx.generate(1, 0, n, bc_len, umi_len, back, stream=st), 24),
-    }
-    names = [k for k in a.kernels.split(",") if k in ops]
-    times = {k: [] for k in names}
-    for k in names:  # warm-up
-        ops[k][0]()
-    torch.cuda.synchronize()
+
+    names = [k for k in a.kernels.split(",") if k in ops_for(lib0, ctx0)]
+    runs = []  # (tag, blocks, kernel, fn, bytes_per_record, lib, ctx)
+    for tag, lib, ctx in cfgs:
+        ops = ops_for(lib, ctx)
+        for b in blocks:
+            for k in names:
+                runs.append((tag, b, k, ops[k][0], ops[k][1], lib, ctx))
+    times = {(r[0], r[1], r[2]): [] for r in runs}
+
+    def run(r):
+        tag, b, k, fn, _, lib, ctx = r
+        if b:
+            assert lib.ibu_ctx_set_option(ctx, b"blocks_per_cu", b) == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        e1.synchronize()
+        assert rc == 0, (tag, k, rc)
+        return e0.elapsed_time(e1)
+
+    for r in runs:  # warm-up (module load, occupancy query)
+        run(r)
     for _ in range(a.rounds):
-        for k in names:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops[k][0]()
-            e1.record()
-            e1.synchronize()
-            times[k].append(e0.elapsed_time(e1))
-    ctx.codec_status(stream=st)
-    for k in names:
-        med, mn = statistics.median(times[k]), min(times[k])
-        print(json.dumps({"tag": a.tag, "kernel": k, "n": n, "lens": [bc_len, umi_len], "ms_med": round(med, 4),
-                          "ms_min": round(mn, 4), "GBps_med": round(n * ops[k][1] / med / 1e6, 1),
-                          "GBps_best": round(n * ops[k][1] / mn / 1e6, 1),
-                          "blocks_per_cu": os.environ.get("IBU_BLOCKS_PER_CU", "8")}), flush=True)
+        for r in runs:
+            times[(r[0], r[1], r[2])].append(run(r))
+    for tag, lib, ctx in cfgs:
+        assert lib.ibu_codec_status(ctx, st, None, None) == 0
+    for r in runs:
+        t = times[(r[0], r[1], r[2])]
+        med, mn = statistics.median(t), min(t)
+        print(json.dumps({"tag": r[0], "blocks_per_cu": r[1] or "default", "kernel": r[2], "n": n, "lens": [bc_len, umi_len],
+                          "ms_med": round(med, 4), "ms_min": round(mn, 4), "GBps_med": round(n * r[4] / med / 1e6, 1),
+                          "GBps_best": round(n * r[4] / mn / 1e6, 1)}), flush=True)
 
 
 if __name__ == "__main__":

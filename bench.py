@@ -84,7 +84,9 @@ def main():
     n = int(args.records)
     bc_len, umi_len = args.bc_len, args.umi_len
     n_global = n * world
-    first, end = ibu_amd.shard_range(n_global, world, rank)  # contiguous record-range split
+    from ibu_amd import sharding
+
+    first, end = sharding.rank_shard(n_global, world, rank)  # contiguous record-range split (mmap.rs:297-307)
     assert end - first == n
 
     def buf(nbytes):
@@ -143,13 +145,10 @@ def main():
         if not verified:
             raise SystemExit("round trip encode(decode(x)) != x")
     # the one cross-GPU exchange: global count + wrapping field sums (4 x i64 over RCCL)
-    tot = [red["count"]] + red["sum"]
-    if world > 1:
-        t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in tot], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        tot = [int(v) % (1 << 64) for v in t.tolist()]
+    g = sharding.global_totals(red, device=dev)
+    tot = [g["count"]] + g["sum"]
     assert tot[0] == n_global
-    assert tot[3] == (n_global * (n_global - 1) // 2) % (1 << 64)  # index column is 0..n_global-1
+    assert tot[3] == sharding.expected_index_sum(n_global)  # index column is 0..n_global-1
 
     if rank == 0:
         dec_bytes = n * (24 + bc_len + umi_len + 8)

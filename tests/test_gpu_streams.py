@@ -1,0 +1,236 @@
+"""GPU parity tests for the device-backed stream entry points (csrc/stream.cpp), through the C ABI:
+load_to_device (reader.rs:510-535), Writer::write_batch from device memory (writer.rs:315-351),
+one shard of MmapReader::process_parallel per GPU (mmap.rs:286-332) and the streaming Reader
+incl. the gzip path (reader.rs:279-306, :345-352).  Everything is compared byte for byte with the
+CPU oracle on the same seeded file; small ring slots force many ring wrap-arounds."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x1B00004
+SMALL_RING = {"slots": 3, "slot_records": 4096, "feeder_threads": 2}  # wraps the ring many times
+ODD_RING = {"slots": 2, "slot_records": 1000, "feeder_threads": 1}    # slot size is rounded up to 1024
+
+
+@pytest.fixture(scope="module")
+def ia():
+    import ibu_amd
+    return ibu_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ia):
+    c = ia.Context(0)
+    yield c
+    c.close()
+
+
+def _write_file(oracle, path, n, bc_len=16, umi_len=12, sorted_flag=False, first=0):
+    recs = oracle.generate(SEED, first, n, bc_len, umi_len)
+    h = oracle.header_new(bc_len, umi_len)
+    if sorted_flag:
+        h.flags |= 1
+    w = oracle.Writer(header=h, path=str(path))
+    if n:
+        w.write_batch(recs)
+    w.finish()
+    w.drop()
+    assert os.path.getsize(path) == 32 + 24 * n
+    return recs
+
+
+@pytest.mark.parametrize("n", [0, 1, 127, 4096, 4097, 100_000, 1_000_003])
+@pytest.mark.parametrize("ring", [None, SMALL_RING, ODD_RING])
+def test_load_to_device_equals_load_to_vec(ia, ctx, oracle, tmp_path, n, ring):
+    if ring is ODD_RING and n > 200_000:
+        pytest.skip("1 Ki-record slots over 1e6 records adds nothing but time")
+    p = tmp_path / "load.ibu"
+    recs = _write_file(oracle, p, n, sorted_flag=True)
+    h, dptr, got_n, st = ctx.load_to_device(p, ring=ring)
+    try:
+        oh, orecs = oracle.load_to_vec(str(p))
+        assert got_n == n == len(orecs)
+        assert (h.bc_len, h.umi_len, h.sorted()) == (16, 12, True)
+        assert st.records == n and st.bytes_h2d == 24 * n
+        if n:
+            buf = ia.DeviceBuffer.__new__(ia.DeviceBuffer)
+            buf.ctx, buf.ptr, buf.nbytes = ctx, dptr, 24 * n
+            assert ia.DeviceBuffer.download(buf, count=24 * n).tobytes() == recs.tobytes() == np.asarray(orecs).tobytes()
+            assert ctx.reduce(dptr, n) == oracle.reduce_records(recs)
+    finally:
+        ctx.free(dptr)
+
+
+def test_load_to_device_into_caller_buffer_and_errors(ia, ctx, oracle, tmp_path):
+    p = tmp_path / "own.ibu"
+    n = 10_000
+    recs = _write_file(oracle, p, n)
+    d = ctx.alloc(24 * n)
+    h, dptr, got_n, _ = ctx.load_to_device(p, d_records=d, cap_records=n)
+    assert dptr == d.ptr and got_n == n
+    assert d.download().tobytes() == recs.tobytes()
+    with pytest.raises(ia.IbuError) as e:  # too small a buffer is an argument error, not a partial load
+        ctx.load_to_device(p, d_records=d, cap_records=n - 1)
+    assert e.value.kind == "InvalidArg"
+    # InvalidMapSize on a truncated file (reader.rs:520-525), Io on a missing one
+    with open(p, "r+b") as f:
+        f.truncate(32 + 24 * n - 5)
+    with pytest.raises(ia.IbuError) as e:
+        ctx.load_to_device(p)
+    assert e.value.kind == "InvalidMapSize"
+    with pytest.raises(ia.IbuError) as e:
+        ctx.load_to_device(tmp_path / "missing.ibu")
+    assert e.value.kind == "Io"
+
+
+@pytest.mark.parametrize("n", [0, 1, 49_152, 49_153, 100_000, 300_001])
+@pytest.mark.parametrize("ring", [None, SMALL_RING])
+def test_write_batch_device_file_equals_oracle_file(ia, ctx, oracle, tmp_path, n, ring):
+    bc_len, umi_len = 16, 12
+    d = ctx.alloc(max(n, 1) * 24)
+    ctx.generate(SEED, 5, n, bc_len, umi_len, d)
+    p = tmp_path / "dev.ibu"
+    w = ia.Writer.from_path(p, ia.Header(bc_len, umi_len))
+    st = w.write_batch_device(ctx, d, n, ring=ring)
+    assert w.records_written() == n and st.records == n and st.bytes_d2h == 24 * n
+    w.finish()
+    w.close()
+    q = tmp_path / "cpu.ibu"
+    _write_file(oracle, q, n, bc_len, umi_len, first=5)
+    assert p.read_bytes() == q.read_bytes()
+
+
+def test_write_batch_device_mixes_with_host_writes(ia, ctx, oracle):
+    """Buffered rule of writer.rs:321-351 holds when device batches interleave with write_record."""
+    n = 1000
+    recs = oracle.generate(SEED, 0, n, 8, 8)
+    d = ctx.upload(recs)
+    w = ia.Writer.new_headless()
+    w.write_record(ia.Record(1, 2, 3))
+    w.write_batch_device(ctx, d, n, ring=ODD_RING)
+    w.write_record(ia.Record(4, 5, 6))
+    w.finish()
+    want = ia.Record(1, 2, 3).as_bytes() + recs.tobytes() + ia.Record(4, 5, 6).as_bytes()
+    assert w.records_written() == n + 2
+    assert w.inner_bytes() == want
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 10_000, 1_000_003])
+@pytest.mark.parametrize("n_shards", [1, 2, 4, 7])
+def test_mmap_process_device_reduce_shards_sum_to_whole(ia, ctx, oracle, tmp_path, n, n_shards):
+    p = tmp_path / "m.ibu"
+    recs = _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    want = oracle.reduce_records(recs)
+    count, sums, xors = 0, [0, 0, 0], [0, 0, 0]
+    for s in range(n_shards):
+        res, st = m.process_device(ctx, ia.PROC_REDUCE, shard=s, n_shards=n_shards, ring=SMALL_RING)
+        a, b = oracle.shard_range(n, n_shards, s)
+        assert res == oracle.reduce_records(recs[a:b]), (s, a, b)  # Q5: len < shards leaves all but the last empty
+        assert st.records == b - a
+        count += res["count"]
+        sums = [(x + y) % 2**64 for x, y in zip(sums, res["sum"])]
+        xors = [x ^ y for x, y in zip(xors, res["xor"])]
+    assert {"count": count, "sum": sums, "xor": xors} == want
+    m.close()
+
+
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32), (15, 11)])
+def test_mmap_process_device_decode_shards_concatenate(ia, ctx, oracle, tmp_path, lens):
+    bc_len, umi_len = lens
+    n, n_shards = 200_003, 3
+    p = tmp_path / "d.ibu"
+    recs = _write_file(oracle, p, n, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    m = ia.MmapReader.new(p)
+    got_bc, got_umi, got_idx = [], [], []
+    for s in range(n_shards):
+        a, b = ia.shard_range(n, n_shards, s)
+        k = b - a
+        d_bc, d_umi, d_idx = ctx.alloc(k * bc_len), ctx.alloc(k * umi_len), ctx.alloc(k * 8)
+        _, st = m.process_device(ctx, ia.PROC_DECODE, shard=s, n_shards=n_shards, sink=(d_bc, d_umi, d_idx),
+                                 ring=SMALL_RING)
+        assert st.records == k and st.batches == (k + 4095) // 4096
+        got_bc.append(d_bc.download().tobytes())
+        got_umi.append(d_umi.download().tobytes())
+        got_idx.append(d_idx.download().tobytes())
+    # outputs concatenate in shard order (the Writer::ingest pattern, writer.rs:477-482)
+    assert b"".join(got_bc) == bc.tobytes()
+    assert b"".join(got_umi) == umi.tobytes()
+    assert b"".join(got_idx) == idx.tobytes()
+    m.close()
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+@pytest.mark.parametrize("n", [0, 1, 49_152, 100_000, 500_003])
+def test_reader_process_device_plain_and_gzip(ia, ctx, oracle, tmp_path, compressed, n):
+    p = tmp_path / "r.ibu"
+    recs = _write_file(oracle, p, n)
+    path = p
+    if compressed:
+        path = tmp_path / "r.ibu.gz"
+        raw = p.read_bytes()
+        half = len(raw) // 2
+        with open(path, "wb") as f:  # two gzip members: multi-member streams must be followed to the end
+            f.write(gzip.compress(raw[:half], 1))
+            f.write(gzip.compress(raw[half:], 1))
+    r = ia.Reader.from_path(path)
+    res, st = r.process_device(ctx, ia.PROC_REDUCE, ring=SMALL_RING)
+    assert res == oracle.reduce_records(recs)
+    assert st.records == n
+    r.close()
+    # decode sink through the same path
+    r = ia.Reader.from_path(path)
+    d_bc, d_umi, d_idx = ctx.alloc(max(n, 1) * 16), ctx.alloc(max(n, 1) * 12), ctx.alloc(max(n, 2) * 8)
+    r.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=SMALL_RING)
+    bc, umi, idx = oracle.decode_records(recs, 16, 12)
+    assert d_bc.download(count=n * 16).tobytes() == bc.tobytes()
+    assert d_umi.download(count=n * 12).tobytes() == umi.tobytes()
+    assert d_idx.download(count=n * 8).tobytes() == idx.tobytes()
+    r.close()
+
+
+def test_reader_process_device_after_partial_host_iteration(ia, ctx, oracle, tmp_path):
+    """The device stream takes over where the host iterator stopped (records already yielded are not re-read)."""
+    n = 60_000
+    p = tmp_path / "part.ibu"
+    recs = _write_file(oracle, p, n)
+    r = ia.Reader.from_path(p)
+    head = [next(r) for _ in range(7)]
+    assert [tuple(x) for x in head] == [tuple(int(v) for v in recs[i]) for i in range(7)]
+    res, _ = r.process_device(ctx, ia.PROC_REDUCE, ring=ODD_RING)
+    assert res == oracle.reduce_records(recs[7:])
+    r.close()
+
+
+def test_reader_process_device_truncated_stream(ia, ctx, oracle, tmp_path):
+    """Q8 / reader.rs:232-237: a trailing partial record is TruncatedRecord; nothing after it is processed."""
+    n = 1000
+    p = tmp_path / "t.ibu"
+    _write_file(oracle, p, n)
+    with open(p, "r+b") as f:
+        f.truncate(32 + 24 * n - 5)
+    r = ia.Reader.from_path(p)
+    with pytest.raises(ia.IbuError) as e:
+        r.process_device(ctx, ia.PROC_REDUCE, ring=SMALL_RING)
+    assert e.value.kind == "TruncatedRecord"
+    r.close()
+    # the context is still usable afterwards (ring drained, no stuck stream)
+    d = ctx.alloc(24 * 256)
+    ctx.generate(1, 0, 256, 16, 12, d)
+    assert ctx.reduce(d, 256)["count"] == 256
+
+
+def test_stream_stats_report_kernel_and_total_time(ia, ctx, oracle, tmp_path):
+    n = 2_000_000
+    p = tmp_path / "s.ibu"
+    _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    _, st = m.process_device(ctx, ia.PROC_REDUCE, ring={"slots": 4, "slot_records": 262_144, "feeder_threads": 4})
+    assert st.records == n and st.batches == (n + 262_143) // 262_144 and st.bytes_h2d == 24 * n
+    assert 0 < st.seconds_kernel <= st.seconds_total
+    m.close()

@@ -135,6 +135,20 @@ def main():
     dec_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     enc_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
 
+    # ---- outside the timed region: this box's own copy ceiling (plain dwordx4 copy kernel, recs -> scratch) ----
+    # the second denominator SURVEY 8d asks for next to the 8 TB/s spec peak; boxes of this pool differ by ~20 %
+    copy_ms = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.copy(bc, recs, min(bc.numel(), recs.numel()), stream=st)
+        e1.record()
+        e1.synchronize()
+        copy_ms.append(e0.elapsed_time(e1))
+    copy_GBps = 2 * min(bc.numel(), recs.numel()) / (sorted(copy_ms)[len(copy_ms) // 2] * 1e-3) / 1e9
+    # the copy overwrote the decoded barcode column: decode once more so the verification below sees real data
+    ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
+
     # ---- outside the timed region: correctness of what was timed ------------------------------
     ctx.codec_status(stream=st)  # raises if any record failed to encode
     red = ctx.reduce(recs, n, stream=st)
@@ -189,7 +203,9 @@ def main():
                 "bound": "hbm", "kernel": "ibu_k_decode", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "bytes_per_record": 24 + bc_len + umi_len + 8,
+                "copy_ceiling": copy_GBps, "frac_of_copy_ceiling": achieved / copy_GBps,
             },
+            "gpu": {"name": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))},
             "verified_roundtrip": verified,
             "global_count": tot[0],
         }

@@ -133,6 +133,8 @@ extern "C" {
     pub fn ibu_ctx_synchronize(ctx: *mut ibu_ctx_t, stream: *mut c_void) -> i32;
     pub fn ibu_device_count(n: *mut i32) -> i32;
     pub fn ibu_ctx_set_option(ctx: *mut ibu_ctx_t, key: *const c_char, value: i64) -> i32;
+    pub fn ibu_device_copy(ctx: *mut ibu_ctx_t, d_dst: *mut c_void, d_src: *const c_void, bytes: usize,
+                           stream: *mut c_void) -> i32;
     pub fn ibu_device_alloc(ctx: *mut ibu_ctx_t, bytes: usize, d_ptr: *mut *mut c_void) -> i32;
     pub fn ibu_device_free(ctx: *mut ibu_ctx_t, d_ptr: *mut c_void) -> i32;
     pub fn ibu_memcpy_h2d(ctx: *mut ibu_ctx_t, d_dst: *mut c_void, h_src: *const c_void, bytes: usize,

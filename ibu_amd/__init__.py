@@ -515,10 +515,17 @@ class DeviceBuffer:
     """hipMalloc'ed bytes owned through the context (for callers without torch)."""
 
     def __init__(self, ctx, nbytes):
-        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ctx, self.nbytes, self.owned = ctx, int(nbytes), True
         p = C.c_void_p()
         _check(lib.ibu_device_alloc(ctx._c, self.nbytes, C.byref(p)))
         self.ptr = p.value
+
+    @classmethod
+    def wrap(cls, ctx, ptr, nbytes):
+        """View of device memory owned by someone else (e.g. what load_to_device returned): never freed here."""
+        b = cls.__new__(cls)
+        b.ctx, b.ptr, b.nbytes, b.owned = ctx, int(ptr), int(nbytes), False
+        return b
 
     def upload(self, host):
         a = np.ascontiguousarray(host)
@@ -536,9 +543,9 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if getattr(self, "ptr", 0) and getattr(self.ctx, "_c", None):
+        if getattr(self, "ptr", 0) and getattr(self, "owned", False) and getattr(self.ctx, "_c", None):
             lib.ibu_device_free(self.ctx._c, self.ptr)
-            self.ptr = 0
+        self.ptr = 0
 
     __del__ = free
 
@@ -611,6 +618,9 @@ class Context:
 
     def generate(self, seed, first, n, bc_len, umi_len, d_records, stream=None):
         _check(lib.ibu_generate(self._c, seed, first, n, bc_len, umi_len, _dptr(d_records), stream))
+
+    def copy(self, d_dst, d_src, nbytes, stream=None):
+        _check(lib.ibu_device_copy(self._c, _dptr(d_dst), _dptr(d_src), nbytes, stream))
 
     def sort_records(self, d_records, d_tmp, n, stream=None):
         _check(lib.ibu_sort_records(self._c, _dptr(d_records), _dptr(d_tmp), n, stream))

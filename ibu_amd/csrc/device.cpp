@@ -265,6 +265,16 @@ extern "C" int32_t ibu_generate(ibu_ctx_t* ctx, uint64_t seed, uint64_t first, s
   IBU_HIP(launch_generate(ctx->cfg, seed, first, n, bc_len, umi_len, d_records, pick_stream(ctx, stream)));
   return IBU_OK;
 }
+extern "C" int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t bytes, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (bytes == 0) return IBU_OK;
+  if (!d_dst || !d_src) return err_arg("NULL device pointer");
+  const uintptr_t a = reinterpret_cast<uintptr_t>(d_dst), b = reinterpret_cast<uintptr_t>(d_src);
+  if (a < b + bytes && b < a + bytes) return err_arg("source and destination overlap");
+  IBU_HIP(launch_copy(ctx->cfg, d_src, d_dst, bytes, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
 extern "C" int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream, int32_t* sorted) {
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;

@@ -44,7 +44,7 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   if (BC > 0) bc_len = BC;
   if (UM > 0) umi_len = UM;
@@ -78,7 +78,7 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * 1024;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   if (LEN > 0) len = LEN;
   const uint8_t* base = reinterpret_cast<const uint8_t*>(codes) + 16 * lane;
@@ -133,6 +133,7 @@ static const DecFn kDecTable[kNumLenModes][kNumLenModes] = {IBU_DEC_ROW(0), IBU_
 
 hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t bc_len, uint32_t umi_len,
                          uint8_t* bc, uint8_t* umi, uint64_t* idx, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
@@ -141,7 +142,7 @@ hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint3
     const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
     const DecFn fn = kDecTable[mb][mu];
     static int occ[kNumLenModes][kNumLenModes] = {{0}};
-    hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, fn, 0, &occ[mb][mu]))), dim3(kBlock), 0,
+    hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, fn, 0, &occ[mb][mu]))), dim3(kBlock), 0,
                        st, (const uint8_t*)recs, ntiles, bc_len, umi_len, bc, umi, (u64*)idx);
   }
   if (n_main < n)
@@ -157,6 +158,7 @@ static const UnpFn kUnpTable[kNumLenModes] = {ibu_k_unpack<len_of_mode(0)>, ibu_
 
 hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, uint32_t len, uint8_t* out,
                          hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(codes) && aligned16(out);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
@@ -164,7 +166,7 @@ hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, 
     const u32 ntiles = (u32)(n_main / kTileRecs);
     const int m = mode_of_len(len);
     static int occ[kNumLenModes] = {0};
-    hipLaunchKernelGGL(kUnpTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, kUnpTable[m], 0, &occ[m]))),
+    hipLaunchKernelGGL(kUnpTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kUnpTable[m], 0, &occ[m]))),
                        dim3(kBlock), 0, st, (const u64*)codes, ntiles, len, out);
   }
   if (n_main < n)

@@ -39,7 +39,7 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   uint8_t* asc_bc = area;
   uint8_t* asc_umi = area + kTileRecs * bc_len;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   // idx_in == NULL: the loads below read the (valid, 16-B aligned) barcode column instead and
   // the result is ignored, so the instruction stream has no branch around a load.
@@ -100,7 +100,7 @@ ibu_k_pack(const uint8_t* __restrict__ in, u32 ntiles, u32 len, u64* __restrict_
   uint8_t* asc = lds + wib * kTileRecs * 32;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
   if (LEN > 0) len = LEN;
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   AsciiStage<LEN> sv;
   sv.issue(in + (size_t)t * kTileRecs * len, len, lane);
@@ -160,6 +160,7 @@ static const EncFn kEncTable[kNumLenModes][kNumLenModes] = {IBU_ENC_ROW(0), IBU_
 hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t* umi, const uint64_t* idx,
                          uint64_t first_index, size_t n, uint32_t bc_len, uint32_t umi_len, void* recs,
                          uint64_t* status, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
@@ -170,7 +171,7 @@ hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t*
     const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
     const EncFn fn = kEncTable[mb][mu];
     static int occ[33][33] = {{0}};  // LDS depends on the actual lengths, not only on the mode
-    const int nb = resident_blocks(cfg, fn, wave_lds * kWavesPerBlock, &occ[bc_len][umi_len]);
+    const int nb = resident_blocks<kBlock>(cfg, fn, wave_lds * kWavesPerBlock, &occ[bc_len][umi_len]);
     hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, nb)), dim3(kBlock), wave_lds * kWavesPerBlock, st, bc, umi,
                        (const u64*)idx, (u64)first_index, ntiles, bc_len, umi_len, wave_lds, (uint8_t*)recs,
                        (u64*)status);
@@ -188,6 +189,7 @@ static const PackFn kPackTable[kNumLenModes] = {ibu_k_pack<len_of_mode(0)>, ibu_
 
 hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32_t len, uint64_t* codes,
                        uint64_t* status, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(in) && aligned16(codes);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
@@ -195,7 +197,7 @@ hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32
     const u32 ntiles = (u32)(n_main / kTileRecs);
     const int m = mode_of_len(len);
     static int occ[kNumLenModes] = {0};
-    hipLaunchKernelGGL(kPackTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, kPackTable[m], 0, &occ[m]))),
+    hipLaunchKernelGGL(kPackTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kPackTable[m], 0, &occ[m]))),
                        dim3(kBlock), 0, st, in, ntiles, len, (u64*)codes, (u64*)status);
   }
   if (n_main < n)

@@ -36,7 +36,7 @@ ibu_k_deserialize(const uint8_t* __restrict__ recs, u32 ntiles, u64* __restrict_
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
   u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
@@ -66,7 +66,7 @@ ibu_k_serialize(const u64* __restrict__ bc, const u64* __restrict__ umi, const u
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   size_t off = (size_t)t * 1024 + 16 * lane;   // records 2*lane, 2*lane+1 of each column
   u32x4 c0 = ld16(reinterpret_cast<const uint8_t*>(bc) + off);
@@ -114,7 +114,7 @@ ibu_k_reduce(const uint8_t* __restrict__ recs, u32 ntiles, u64 n_total, u64* __r
   const u32 wib = threadIdx.x >> 6;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
   u64 s[3][2] = {{0, 0}, {0, 0}, {0, 0}}, x[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-  u32 t = blockIdx.x * kWavesPerBlock + wib;
+  u32 t = logical_block() * kWavesPerBlock + wib;
   for (; t + nwaves < ntiles; t += 2 * nwaves) {  // two tiles (6 KiB per wave) in flight
     const uint8_t* p = recs + (size_t)t * kTileBytes + 16 * lane;
     const uint8_t* q = recs + (size_t)(t + nwaves) * kTileBytes + 16 * lane;
@@ -201,6 +201,30 @@ ibu_k_generate(u64 seed, u64 first, u64 n_elems, u32 bc_len, u32 umi_len, u64* _
 }
 
 // =============================================================================================
+// Plain streaming copy: the device-side form of the reference's memcpy hot loops (write_slice's
+// copy_from_slice, writer.rs:335-347; Writer::ingest's append, writer.rs:477-482) and the
+// on-device COPY CEILING every other kernel here is priced against ("measure an
+// on-device copy ceiling with a plain dwordx4 copy kernel and report both denominators").
+// Four 16-B chunks per lane in flight, grid-stride, nontemporal both ways.
+// =============================================================================================
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchunks) {
+  const u64 stride = (u64)gridDim.x * kBlock;
+  u64 c = (u64)logical_block() * kBlock + threadIdx.x;
+  for (; c + 3 * stride < nchunks; c += 4 * stride) {
+    u32x4 v0 = ld16(src + 16 * c), v1 = ld16(src + 16 * (c + stride));
+    u32x4 v2 = ld16(src + 16 * (c + 2 * stride)), v3 = ld16(src + 16 * (c + 3 * stride));
+    st16(dst + 16 * c, v0); st16(dst + 16 * (c + stride), v1);
+    st16(dst + 16 * (c + 2 * stride), v2); st16(dst + 16 * (c + 3 * stride), v3);
+  }
+  for (; c < nchunks; c += stride) st16(dst + 16 * c, ld16(src + 16 * c));
+}
+extern "C" __global__ void ibu_k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 off, u64 n) {
+  const u64 i = off + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// =============================================================================================
 // Tail / unaligned kernels: one thread per record, no alignment assumption beyond the natural
 // 8 B of the u64 columns and records.  Used for n % 128 and for misaligned bases only.
 // =============================================================================================
@@ -241,6 +265,7 @@ extern "C" __global__ void ibu_k_fill_u64(u64* p, u64 v0, u64 v1) { p[0] = v0; p
 // =============================================================================================
 hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* bc, uint64_t* umi,
                               uint64_t* idx, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
@@ -248,7 +273,7 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
     u32 ntiles = (u32)(n_main / kTileRecs);
     static int occ = 0;
     hipLaunchKernelGGL(ibu_k_deserialize,
-                       dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
+                       dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
                        (const uint8_t*)recs, ntiles, (u64*)bc, (u64*)umi, (u64*)idx);
   }
   if (n_main < n)
@@ -259,13 +284,14 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
 
 hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint64_t* umi, const uint64_t* idx,
                             size_t n, void* recs, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
     static int occ = 0;
-    hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_serialize, 0, &occ))),
+    hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_serialize, 0, &occ))),
                        dim3(kBlock), 0, st,
                        (const u64*)bc, (const u64*)umi, (const u64*)idx, ntiles, (uint8_t*)recs);
   }
@@ -276,13 +302,14 @@ hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint
 }
 
 hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* acc, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(recs);
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   u32 ntiles = (u32)(n_main / kTileRecs);
   // the main kernel also adds n to the count slot, so it always runs (ntiles may be 0)
   static int occ = 0;
-  hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, resident_blocks(cfg, ibu_k_reduce, 0, &occ))),
+  hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_reduce, 0, &occ))),
                      dim3(kBlock), 0, st,
                      (const uint8_t*)recs, ntiles, (u64)n, (u64*)acc);
   if (n_main < n)
@@ -293,6 +320,7 @@ hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint6
 
 hipError_t launch_generate(const LaunchCfg& cfg, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
                            uint32_t umi_len, void* recs, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   u64 n_elems = 3ull * n;
   u64 blocks = ((n_elems >> 1) + kBlock - 1) / kBlock;
@@ -304,7 +332,30 @@ hipError_t launch_generate(const LaunchCfg& cfg, uint64_t seed, uint64_t first, 
   return hipGetLastError();
 }
 
+hipError_t launch_copy(const LaunchCfg& cfg, const void* src, void* dst, size_t bytes, hipStream_t st) {
+  (void)hipGetLastError();
+  if (bytes == 0) return hipSuccess;
+  const bool fast = aligned16(src) && aligned16(dst);
+  const u64 nchunks = fast ? bytes / 16 : 0;
+  if (nchunks) {
+    u64 blocks = (nchunks + kBlock - 1) / kBlock;
+    static int occ = 0;
+    const u64 cap = (u64)cfg.cus * resident_blocks<kBlock>(cfg, ibu_k_copy, 0, &occ);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ibu_k_copy, dim3((u32)blocks), dim3(kBlock), 0, st, (const uint8_t*)src, (uint8_t*)dst, nchunks);
+  }
+  const u64 done = nchunks * 16;
+  if (done < bytes) {
+    const u64 rest = bytes - done;
+    if (rest > (1ull << 31) * 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ibu_k_copy_bytes, dim3((u32)((rest + 255) / 256)), dim3(256), 0, st, (const uint8_t*)src,
+                       (uint8_t*)dst, done, (u64)bytes);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_sorted_check(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t* flag, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n < 2) return hipSuccess;
   u64 blocks = (n + 255) / 256;
   u64 cap = (u64)cfg.cus * 8;
@@ -314,6 +365,7 @@ hipError_t launch_sorted_check(const LaunchCfg& cfg, const void* recs, size_t n,
 }
 
 hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st) {
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipLaunchKernelGGL(ibu_k_fill_u64, dim3(1), dim3(1), 0, st, (u64*)p, (u64)v0, (u64)v1);
   return hipGetLastError();
 }

@@ -31,7 +31,10 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int kWave = 64;
-static constexpr int kBlock = 256;                 // 4 waves, each with a private LDS slice
+#ifndef IBU_BLOCK
+#define IBU_BLOCK 256
+#endif
+static constexpr int kBlock = IBU_BLOCK;           // waves of a workgroup each own a private LDS slice
 static constexpr int kWavesPerBlock = kBlock / kWave;
 static constexpr int kTileRecs = 128;              // records per wave tile
 static constexpr int kTileBytes = kTileRecs * 24;  // 3072
@@ -50,6 +53,23 @@ static inline int mode_of_len(uint32_t len) {
     case 32: return 5;
     default: return 0;
   }
+}
+
+// XCD-aware block order.  Hardware places workgroup i on XCD i % 8 (8 XCDs, each with its own
+// L2 and TLB hierarchy).  With the identity order every XCD's workgroups are scattered over the
+// whole moving front of the grid-stride sweep; remapped, each XCD sweeps ONE contiguous eighth of
+// the front in each of the arrays, so its L2 / translation working set is 8x more compact.
+#ifndef IBU_XCD_REMAP
+#define IBU_XCD_REMAP 1
+#endif
+__device__ __forceinline__ u32 logical_block() {
+#if IBU_XCD_REMAP
+  const u32 nb = gridDim.x;
+  if (nb & 7u) return blockIdx.x;                  // small grids: identity
+  return (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+#else
+  return blockIdx.x;
+#endif
 }
 
 #ifndef IBU_NT_LOAD

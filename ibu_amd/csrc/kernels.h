@@ -15,14 +15,17 @@ struct LaunchCfg {
 // whole share alone at the end (measured: decode 5.07 -> 5.6 TB/s once fixed).  Ask the runtime
 // how many 256-thread blocks of this kernel fit on a CU (registers, LDS), cap by
 // cfg.blocks_per_cu, remember the answer per kernel instantiation.
-template <class K>
+template <int BLOCK, class K>
 static inline int resident_blocks(const LaunchCfg& cfg, K kernel, size_t dyn_lds, int* cache) {
   if (*cache <= 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, dyn_lds) != hipSuccess || nb <= 0) nb = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, dyn_lds) != hipSuccess || nb <= 0)
+      nb = 1024 / BLOCK;
     *cache = nb;
   }
-  return *cache < cfg.blocks_per_cu ? *cache : cfg.blocks_per_cu;
+  int cap = cfg.blocks_per_cu * 256 / BLOCK;  // blocks_per_cu is stated in 256-thread units (4 waves)
+  if (cap < 1) cap = 1;
+  return *cache < cap ? *cache : cap;
 }
 
 // All launchers are asynchronous on `st`, allocate nothing and never synchronise.
@@ -42,6 +45,7 @@ hipError_t launch_pack(const LaunchCfg&, const uint8_t* in, size_t n, uint32_t l
 hipError_t launch_reduce(const LaunchCfg&, const void* recs, size_t n, uint64_t* acc, hipStream_t st);
 hipError_t launch_generate(const LaunchCfg&, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
                            uint32_t umi_len, void* recs, hipStream_t st);
+hipError_t launch_copy(const LaunchCfg&, const void* src, void* dst, size_t bytes, hipStream_t st);
 hipError_t launch_sorted_check(const LaunchCfg&, const void* recs, size_t n, uint32_t* flag, hipStream_t st);
 hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
 

@@ -297,6 +297,13 @@ int32_t ibu_reduce_fetch(ibu_ctx_t* ctx, void* stream, ibu_reduce_result_t* out)
 int32_t ibu_generate(ibu_ctx_t* ctx, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
                      uint32_t umi_len, void* d_records, void* stream);
 
+/* Streaming device-to-device copy of `bytes` bytes (ranges must not overlap): the device form of the
+ * reference's memcpy hot loops (Writer::write_slice copy_from_slice writer.rs:335-347, Writer::ingest
+ * append writer.rs:477-482 when both writers' batches live in HBM).  Also the on-device copy ceiling
+ * bench.py prices the other kernels against.  16-B aligned ranges take the dwordx4 kernel, anything
+ * else a byte kernel. */
+int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t bytes, void* stream);
+
 /* Device-side sort by (barcode, umi, index) — the order `derive(Ord)` defines (record.rs:58)
  * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch. */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);

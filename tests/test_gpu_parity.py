@@ -235,6 +235,24 @@ def test_reference_example_values(ctx, oracle, kat):
     assert got["count"] == k["n"] and got["sum"] == k["sums"] and got["xor"] == k["xors"]
 
 
+@pytest.mark.parametrize("nbytes", [0, 1, 15, 16, 17, 4096, 1_000_003, 48_000_016])
+@pytest.mark.parametrize("off", [(0, 0), (8, 0), (0, 3), (16, 32)])
+def test_device_copy(ia, ctx, nbytes, off):
+    """ibu_device_copy: the streaming memcpy (writer.rs:335-347) on device; unaligned ranges take the byte kernel."""
+    rng = np.random.default_rng(nbytes + 7 * off[0] + off[1])
+    host = rng.integers(0, 256, nbytes + 64, dtype=np.uint8)
+    src, dst = ctx.upload(host), ctx.upload(np.zeros(nbytes + 64, dtype=np.uint8))
+    ctx.copy(dst.ptr + off[0], src.ptr + off[1], nbytes)
+    ctx.synchronize()
+    got = dst.download()
+    assert got[off[0]:off[0] + nbytes].tobytes() == host[off[1]:off[1] + nbytes].tobytes()
+    assert not got[:off[0]].any() and not got[off[0] + nbytes:].any()  # nothing outside the range is touched
+    if nbytes > 16:
+        with pytest.raises(ia.IbuError) as e:
+            ctx.copy(src.ptr + 8, src.ptr, nbytes)
+        assert e.value.kind == "InvalidArg"
+
+
 def test_is_sorted(ctx, oracle):
     n = 100_000
     recs = oracle.generate(SEED, 0, n, 8, 8)

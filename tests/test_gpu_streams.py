@@ -57,9 +57,8 @@ def test_load_to_device_equals_load_to_vec(ia, ctx, oracle, tmp_path, n, ring):
         assert (h.bc_len, h.umi_len, h.sorted()) == (16, 12, True)
         assert st.records == n and st.bytes_h2d == 24 * n
         if n:
-            buf = ia.DeviceBuffer.__new__(ia.DeviceBuffer)
-            buf.ctx, buf.ptr, buf.nbytes = ctx, dptr, 24 * n
-            assert ia.DeviceBuffer.download(buf, count=24 * n).tobytes() == recs.tobytes() == np.asarray(orecs).tobytes()
+            got = ia.DeviceBuffer.wrap(ctx, dptr, 24 * n).download().tobytes()
+            assert got == recs.tobytes() == np.asarray(orecs).tobytes()
             assert ctx.reduce(dptr, n) == oracle.reduce_records(recs)
     finally:
         ctx.free(dptr)

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--records", type=float, default=2e8)
     ap.add_argument("--lens", default="16,12")
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--kernels", default="decode,encode,deserialize,serialize,reduce,unpack,pack,generate")
+    ap.add_argument("--kernels", default="decode,encode,deserialize,serialize,reduce,unpack,pack,generate,copy")
     ap.add_argument("--so", action="append", default=[], help="tag=path of an alternative build (repeatable)")
     ap.add_argument("--blocks", default="", help="comma list of blocks_per_cu caps to sweep (default: library default)")
     a = ap.parse_args()
@@ -63,6 +63,7 @@ def main():
             "unpack": (lambda: lib.ibu_unpack_2bit(ctx, p(c0), n, bc_len, p(bc), st), 8 + bc_len),
             "pack": (lambda: lib.ibu_pack_2bit(ctx, p(bc), n, bc_len, p(c1), st), 8 + bc_len),
             "generate": (lambda: lib.ibu_generate(ctx, 1, 0, n, bc_len, umi_len, p(back), st), 24),
+            "copy": (lambda: lib.ibu_device_copy(ctx, p(back), p(recs), 24 * n, st), 48),
         }
 
     tag0, lib0, ctx0 = cfgs[0]
@@ -92,6 +93,7 @@ def main():
         assert rc == 0, (tag, k, rc)
         return e0.elapsed_time(e1)
 
+    print(json.dumps({"gpu": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))}), flush=True)
     for r in runs:  # warm-up (module load, occupancy query)
         run(r)
     for _ in range(a.rounds):

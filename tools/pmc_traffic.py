@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""HBM traffic per record from two rocprofv3 PMC passes over tools/kbench.py.
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc/FETCH_SIZE -- python3 tools/kbench.py --records 2e8 --rounds 2
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc/WRITE_SIZE -- python3 tools/kbench.py --records 2e8 --rounds 2
+  python tools/pmc_traffic.py gpurun_out/pmc 2e8 16,12 > profiles/pmc_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB (separate passes: FETCH_SIZE costs 3 of the 4 TCC slots,
+WRITE_SIZE 2).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly
+half of the bytes of a wide coalesced streaming read, so reads = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE is exact for 16-B-per-lane stores.  The calibration rows prove both on this box:
+ibu_k_reduce reads exactly 24 B/record and ibu_k_generate writes exactly 24 B/record.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(pmc_dir, counter):
+    """kernel name -> mean counter value per dispatch (main kernels only: tails are negligible)."""
+    files = glob.glob(os.path.join(pmc_dir, counter, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no counter_collection.csv under {pmc_dir}/{counter}")
+    acc = defaultdict(list)
+    with open(files[0]) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def short(name):
+    for k in ("decode", "encode", "deserialize", "serialize", "reduce", "unpack", "pack", "generate"):
+        if f"ibu_k_{k}" in name and "_tail" not in name:
+            return k
+    return None
+
+
+def main():
+    pmc_dir, n, lens = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+    bc_len, umi_len = (int(x) for x in lens.split(","))
+    fetch, write = per_kernel(pmc_dir, "FETCH_SIZE"), per_kernel(pmc_dir, "WRITE_SIZE")
+    alg = {"decode": 24 + bc_len + umi_len + 8, "encode": 24 + bc_len + umi_len + 8, "deserialize": 48, "serialize": 48,
+           "reduce": 24, "unpack": 8 + bc_len, "pack": 8 + bc_len, "generate": 24}
+    out = {"_method": __doc__.split("FETCH_SIZE / WRITE_SIZE are", 1)[1].strip().replace("\n", " "),
+           "_records": n, "_lens": [bc_len, umi_len]}
+    for name, f_kib in sorted(fetch.items()):
+        k = short(name)
+        if not k:
+            continue
+        w_kib = write.get(name, 0.0)
+        rd, wr = 2 * f_kib * 1024 / n, w_kib * 1024 / n
+        key = f"{k}_{bc_len}_{umi_len}" if k in ("decode", "encode") else k
+        out[key] = {"kernel": name.split("(")[0], "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
+                    "read_bytes_per_record": round(rd, 3), "write_bytes_per_record": round(wr, 3),
+                    "hbm_bytes_per_record": round(rd + wr, 3), "algorithmic_bytes_per_record": alg[k]}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -361,7 +361,9 @@ class Reader:
 def load_to_vec(path):  # src/io/reader.rs:510-535
     h, p, n = CHeader(), C.c_void_p(), C.c_size_t()
     _check(lib.ibu_load_to_vec(str(path).encode(), C.byref(h), C.byref(p), C.byref(n)))
-    recs = np.frombuffer(C.string_at(p, n.value * RECORD_SIZE), dtype=REC_DTYPE).copy() if n.value else np.empty(0, REC_DTYPE)
+    # (c_char * nbytes).from_address: string_at takes a C int and fails beyond 2 GiB
+    recs = (np.frombuffer((C.c_char * (n.value * RECORD_SIZE)).from_address(p.value), dtype=REC_DTYPE).copy()
+            if n.value else np.empty(0, REC_DTYPE))
     lib.ibu_free(p)
     return Header._wrap(h), recs
 

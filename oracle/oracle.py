@@ -257,9 +257,11 @@ class Reader:
 def load_to_vec(path):
     e, h, p, n = Err(), Header(), C.c_void_p(), C.c_size_t()
     _check(lib.orc_load_to_vec(path.encode(), C.byref(h), C.byref(p), C.byref(n), C.byref(e)), e)
-    buf = C.string_at(p, n.value * 24) if n.value else b""
+    # (c_char * nbytes).from_address: string_at takes a C int and fails beyond 2 GiB
+    recs = np.frombuffer((C.c_char * (n.value * 24)).from_address(p.value), dtype=REC_DTYPE).copy() if n.value \
+        else np.empty(0, dtype=REC_DTYPE)
     lib.orc_free(p)
-    return h, np.frombuffer(buf, dtype=REC_DTYPE).copy()
+    return h, recs
 
 
 class Mmap:

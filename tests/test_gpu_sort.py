@@ -1,0 +1,133 @@
+"""GPU parity for the device sort by (barcode, umi, index) — the order `#[derive(Ord)]` gives Record
+(record.rs:58-66, test record.rs:184-232) and the header's sorted flag promises (header.rs:111-113).
+Identical records are indistinguishable, so the sorted byte string is unique: the bar is equality with
+the oracle's qsort under record_cmp, byte for byte."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x1B00005
+# around the 1 Ki-record LDS tile and the 32 Ki-record histogram chunk
+SIZES = [0, 1, 2, 3, 63, 64, 65, 1023, 1024, 1025, 4096, 32_767, 32_768, 32_769, 100_000, 1_000_003]
+
+
+@pytest.fixture(scope="module")
+def ia():
+    import ibu_amd
+    return ibu_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ia):
+    c = ia.Context(0)
+    yield c
+    c.close()
+
+
+def _sort_on_device(ctx, recs):
+    n = len(recs)
+    d = ctx.upload(recs) if n else ctx.alloc(16)
+    t = ctx.alloc(max(n, 1) * 24)
+    ctx.sort_records(d, t, n)
+    ctx.synchronize()
+    return d.download(count=n * 24).tobytes(), d
+
+
+def _shuffled(oracle, n, bc_len, umi_len, seed=SEED):
+    recs = oracle.generate(seed, 0, n, bc_len, umi_len)
+    np.random.default_rng(n).shuffle(recs)  # the generator's index column is already increasing
+    return recs
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_sort_random_16_12(ctx, oracle, n):
+    recs = _shuffled(oracle, n, 16, 12)
+    got, d = _sort_on_device(ctx, recs)
+    assert got == oracle.sort_records(recs).tobytes()
+    assert ctx.is_sorted(d, n)
+
+
+@pytest.mark.parametrize("n", [1, 1025, 70_001])
+@pytest.mark.parametrize("lens", [(32, 32), (1, 1), (4, 28), (31, 3)])
+def test_sort_other_widths(ctx, oracle, n, lens):
+    """(32,32): all 24 digit positions vary (no pass is skipped, an even/odd pass count both occur)."""
+    recs = _shuffled(oracle, n, *lens)
+    if lens == (32, 32) and n > 1:
+        recs["index"] = np.random.default_rng(5).integers(0, 2**64, n, dtype=np.uint64)
+    got, _ = _sort_on_device(ctx, recs)
+    assert got == oracle.sort_records(recs).tobytes()
+
+
+def test_sort_is_lexicographic_on_the_reference_example(ctx, oracle, kat, ia):
+    """record.rs:184-232: the 8 permutations of {0,1}^3 sort lexicographically; (1,1,0) > (0,1,1)."""
+    rows = [(b, u, i) for b in (1, 0) for u in (1, 0) for i in (1, 0)]
+    recs = ia.records_array(rows)
+    got, _ = _sort_on_device(ctx, recs)
+    want = ia.records_array(sorted(rows))
+    assert got == want.tobytes() == oracle.sort_records(recs).tobytes()
+
+
+def test_sort_heavy_duplicates_and_ties(ctx, oracle, ia):
+    """Few distinct barcodes / UMIs: long runs of equal high digits, order decided by the low fields."""
+    n = 200_003
+    rng = np.random.default_rng(11)
+    recs = np.empty(n, dtype=ia.REC_DTYPE)
+    recs["barcode"] = rng.integers(0, 5, n, dtype=np.uint64) * 0x0101010101010101
+    recs["umi"] = rng.integers(0, 3, n, dtype=np.uint64) << 40
+    recs["index"] = rng.integers(0, 1000, n, dtype=np.uint64)  # many exact duplicates as well
+    got, d = _sort_on_device(ctx, recs)
+    assert got == oracle.sort_records(recs).tobytes()
+    assert ctx.is_sorted(d, n)
+
+
+def test_sort_degenerate_inputs(ctx, oracle, ia):
+    n = 50_000
+    same = ia.records_array([(7, 7, 7)] * n)                       # no digit varies: zero passes
+    assert _sort_on_device(ctx, same)[0] == same.tobytes()
+    asc = oracle.sort_records(_shuffled(oracle, n, 16, 12))        # already sorted
+    assert _sort_on_device(ctx, asc)[0] == asc.tobytes()
+    desc = asc[::-1].copy()                                        # reverse sorted
+    assert _sort_on_device(ctx, desc)[0] == asc.tobytes()
+    one_bit = ia.records_array([(0, 0, i & 1) for i in range(n)])  # a single varying digit: one pass + copy back
+    assert _sort_on_device(ctx, one_bit)[0] == oracle.sort_records(one_bit).tobytes()
+    hi = ia.records_array([(((i * 2654435761) & 0xFF) << 56, 0, 0) for i in range(n)])  # only the top barcode byte
+    assert _sort_on_device(ctx, hi)[0] == oracle.sort_records(hi).tobytes()
+
+
+def test_sort_then_write_sorted_file_roundtrip(ctx, oracle, ia, tmp_path):
+    """The use the flag exists for: sort on device, write with set_sorted(), read back, still sorted."""
+    n = 120_000
+    recs = _shuffled(oracle, n, 16, 12)
+    _, d = _sort_on_device(ctx, recs)
+    h = ia.Header(16, 12)
+    h.set_sorted()
+    p = tmp_path / "sorted.ibu"
+    w = ia.Writer.from_path(p, h)
+    w.write_batch_device(ctx, d, n)
+    w.finish()
+    w.close()
+    hh, back = ia.load_to_vec(p)
+    assert hh.sorted() and back.tobytes() == oracle.sort_records(recs).tobytes()
+    assert oracle.is_sorted(back)
+
+
+def test_sort_large_permutation_properties(ctx, ia):
+    """5e7 records (beyond what the oracle sorts in seconds): sortedness + multiset preserved (count, sums, XORs)."""
+    n = 50_000_000
+    d, t = ctx.alloc(n * 24), ctx.alloc(n * 24)
+    # decreasing index within increasing seed blocks: definitely not sorted, every field varies
+    ctx.generate(SEED, 0, n, 16, 12, d)
+    before = ctx.reduce(d, n)
+    assert not ctx.is_sorted(d, n)
+    ctx.sort_records(d, t, n)
+    assert ctx.is_sorted(d, n)
+    assert ctx.reduce(d, n) == before
+
+
+def test_sort_argument_errors(ctx, ia):
+    d = ctx.alloc(24 * 16)
+    with pytest.raises(ia.IbuError) as e:
+        ctx.sort_records(d, None, 16)
+    assert e.value.kind == "InvalidArg"
+    ctx.sort_records(d, None, 1)  # n < 2: nothing to do, scratch not needed

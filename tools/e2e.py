@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) rates of the stream entry points on one GPU — never bench.py's `value`.
+
+  python tools/e2e.py [--records 1e8] [--dir /tmp] [--gzip] [--verify-cpu]
+
+Stages (BASELINE configs[1] and configs[4] shapes):
+  1. generate on device -> Writer::write_batch from device memory -> file        (D2H + write(2))
+  2. load_to_device                                                            (pread -> pinned ring -> H2D)
+  3. MmapReader::process_device REDUCE / DECODE                                 (page cache -> ring -> H2D || kernel)
+  4. --gzip: Reader::from_path(.gz)::process_device DECODE                      (host inflate -> ring -> H2D || kernel)
+  5. --verify-cpu: device decode == CPU oracle decode of oracle load_to_vec (bit-exact, configs[1])
+Prints one JSON line per stage."""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _gz_member(args):
+    path, off, length, level = args
+    with open(path, "rb") as f:
+        f.seek(off)
+        data = f.read(length)
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)  # 31 = gzip container
+    return c.compress(data) + c.flush()
+
+
+def gzip_parallel(src, dst, level=1, member_bytes=64 << 20, workers=16):
+    """A multi-member .gz of `src` (what `pigz`/`bgzip` write); members compressed in parallel."""
+    size = os.path.getsize(src)
+    jobs = [(src, off, min(member_bytes, size - off), level) for off in range(0, size, member_bytes)]
+    with ProcessPoolExecutor(max_workers=workers) as ex, open(dst, "wb") as out:
+        for blob in ex.map(_gz_member, jobs):
+            out.write(blob)
+    return os.path.getsize(dst)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--records", type=float, default=1e8)
+    ap.add_argument("--dir", default="/tmp")
+    ap.add_argument("--lens", default="16,12")
+    ap.add_argument("--gzip", action="store_true")
+    ap.add_argument("--verify-cpu", action="store_true")
+    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--slot-records", type=int, default=4 << 20)
+    ap.add_argument("--feeders", type=int, default=8)
+    a = ap.parse_args()
+    import ibu_amd as ia
+
+    n = int(a.records)
+    bc_len, umi_len = (int(x) for x in a.lens.split(","))
+    ring = {"slots": a.slots, "slot_records": a.slot_records, "feeder_threads": a.feeders}
+    ctx = ia.Context(0)
+    path = os.path.join(a.dir, f"ibu_e2e_{os.getpid()}.ibu")
+    seed = 0x1B00002
+    file_bytes = 32 + 24 * n
+
+    def emit(stage, seconds, st=None, **kw):
+        rec = {"stage": stage, "records": n, "seconds": round(seconds, 4), "M_records_per_s": round(n / seconds / 1e6, 1),
+               "file_GBps": round(file_bytes / seconds / 1e9, 2)}
+        if st is not None:
+            rec.update(batches=st.batches, kernel_seconds=round(st.seconds_kernel, 4), h2d=st.bytes_h2d, d2h=st.bytes_d2h)
+        rec.update(kw)
+        print(json.dumps(rec), flush=True)
+
+    try:
+        # 1. device -> file
+        d = ctx.alloc(24 * n)
+        ctx.generate(seed, 0, n, bc_len, umi_len, d)
+        want = ctx.reduce(d, n)
+        h = ia.Header(bc_len, umi_len)
+        t0 = time.perf_counter()
+        w = ia.Writer.from_path(path, h)
+        st = w.write_batch_device(ctx, d, n, ring=ring)
+        w.finish()
+        w.close()
+        emit("write_batch_device -> file", time.perf_counter() - t0, st)
+        assert os.path.getsize(path) == file_bytes
+        d.free()
+
+        # 2. file -> device
+        for rep in ("cold-ish", "page-cache"):
+            t0 = time.perf_counter()
+            hh, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
+            dt = time.perf_counter() - t0
+            assert got_n == n and ctx.reduce(dptr, n) == want
+            ctx.free(dptr)
+            emit(f"load_to_device ({rep})", dt, st)
+
+        # 3. mmap -> ring -> device processors
+        m = ia.MmapReader.new(path)
+        t0 = time.perf_counter()
+        res, st = m.process_device(ctx, ia.PROC_REDUCE, ring=ring)
+        emit("mmap process_device REDUCE", time.perf_counter() - t0, st)
+        assert res == want
+        d_bc, d_umi, d_idx = ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)
+        t0 = time.perf_counter()
+        _, st = m.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
+        emit("mmap process_device DECODE", time.perf_counter() - t0, st)
+        m.close()
+        plain = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()]
+
+        # 5. bit-exact vs the CPU oracle's load_to_vec + scalar decode (configs[1])
+        if a.verify_cpu:
+            from oracle import oracle as orc  # checker only
+            t0 = time.perf_counter()
+            _, recs = orc.load_to_vec(path)
+            t1 = time.perf_counter()
+            bc, umi, idx = orc.decode_records(recs, bc_len, umi_len)
+            t2 = time.perf_counter()
+            ok = plain[0] == bc.tobytes() and plain[1] == umi.tobytes() and plain[2] == idx.tobytes()
+            emit("CPU oracle load_to_vec + decode (1 thread)", t2 - t0, None, load_seconds=round(t1 - t0, 3),
+                 decode_seconds=round(t2 - t1, 3), device_output_bit_exact=ok)
+            assert ok, "device decode differs from the CPU oracle"
+            del recs, bc, umi, idx
+
+        # 4. gzip stream
+        if a.gzip:
+            gz = path + ".gz"
+            t0 = time.perf_counter()
+            gz_bytes = gzip_parallel(path, gz)
+            tc = time.perf_counter() - t0
+            r = ia.Reader.from_path(gz)
+            t0 = time.perf_counter()
+            _, st = r.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
+            dt = time.perf_counter() - t0
+            r.close()
+            same = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()] == plain
+            emit("gzip Reader process_device DECODE", dt, st, gz_bytes=gz_bytes, gz_ratio=round(gz_bytes / file_bytes, 3),
+                 compress_seconds=round(tc, 2), equals_plain_path=same)
+            assert same
+            os.unlink(gz)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,9 @@ extern "C" {
     pub fn ibu_ctx_set_option(ctx: *mut ibu_ctx_t, key: *const c_char, value: i64) -> i32;
     pub fn ibu_device_copy(ctx: *mut ibu_ctx_t, d_dst: *mut c_void, d_src: *const c_void, bytes: usize,
                            stream: *mut c_void) -> i32;
+    pub fn ibu_barcode_counts(ctx: *mut ibu_ctx_t, d_sorted_records: *const c_void, n: usize, d_barcodes: *mut u64,
+                              d_counts: *mut u64, d_unique_umis: *mut u64, cap: usize, n_barcodes: *mut usize,
+                              n_barcode_umi_pairs: *mut usize, stream: *mut c_void) -> i32;
     pub fn ibu_device_alloc(ctx: *mut ibu_ctx_t, bytes: usize, d_ptr: *mut *mut c_void) -> i32;
     pub fn ibu_device_free(ctx: *mut ibu_ctx_t, d_ptr: *mut c_void) -> i32;
     pub fn ibu_memcpy_h2d(ctx: *mut ibu_ctx_t, d_dst: *mut c_void, h_src: *const c_void, bytes: usize,

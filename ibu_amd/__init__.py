@@ -627,6 +627,23 @@ class Context:
     def sort_records(self, d_records, d_tmp, n, stream=None):
         _check(lib.ibu_sort_records(self._c, _dptr(d_records), _dptr(d_tmp), n, stream))
 
+    def barcode_counts(self, d_sorted_records, n, unique_umis=True, stream=None):
+        """BarcodeAnalyzer (parallel.rs:72-98) on sorted device records ->
+        (barcodes, counts, unique_umis | None) as numpy u64 arrays in ascending barcode order."""
+        nb, npairs = C.c_size_t(), C.c_size_t()
+        _check(lib.ibu_barcode_counts(self._c, _dptr(d_sorted_records), n, None, None, None, 0, C.byref(nb),
+                                      C.byref(npairs), stream))
+        u = nb.value
+        if u == 0:
+            e = np.empty(0, np.uint64)
+            return e, e.copy(), (e.copy() if unique_umis else None)
+        d_b, d_c = self.alloc(8 * u), self.alloc(8 * u)
+        d_u = self.alloc(8 * u) if unique_umis else None
+        _check(lib.ibu_barcode_counts(self._c, _dptr(d_sorted_records), n, _dptr(d_b), _dptr(d_c), _dptr(d_u), u,
+                                      C.byref(nb), C.byref(npairs), stream))
+        self.synchronize(stream)
+        return (d_b.download(np.uint64), d_c.download(np.uint64), d_u.download(np.uint64) if d_u else None)
+
     def is_sorted(self, d_records, n, stream=None):
         s = C.c_int32()
         _check(lib.ibu_is_sorted(self._c, _dptr(d_records), n, stream, C.byref(s)))

@@ -290,13 +290,7 @@ extern "C" int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n
   *sorted = (*reinterpret_cast<uint32_t*>(ctx->h_pinned + 8)) == 0;
   return IBU_OK;
 }
-extern "C" int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream) {
-  int32_t rc = check_ctx(ctx);
-  if (rc) return rc;
-  if (n < 2) return IBU_OK;
-  if (!d_records || !d_tmp || !aligned8(d_records) || !aligned8(d_tmp))
-    return err_arg("d_records / d_tmp must be non-NULL and 8-byte aligned");
-  const size_t need = sort_scratch_bytes(ctx->cfg, n);
+static int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   if (need > ctx->sort_scratch_bytes) {  // grows only; the one allocation a launch path may make
     if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));
     ctx->d_sort_scratch = nullptr;
@@ -304,6 +298,45 @@ extern "C" int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp
     IBU_HIP(hipMalloc(&ctx->d_sort_scratch, need));
     ctx->sort_scratch_bytes = need;
   }
+  return IBU_OK;
+}
+// BarcodeAnalyzer (parallel.rs:72-98) on sorted device records.
+extern "C" int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, uint64_t* d_barcodes,
+                                      uint64_t* d_counts, uint64_t* d_unique_umis, size_t cap, size_t* n_barcodes,
+                                      size_t* n_barcode_umi_pairs, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!n_barcodes) return err_arg("n_barcodes is NULL");
+  *n_barcodes = 0;
+  if (n_barcode_umi_pairs) *n_barcode_umi_pairs = 0;
+  if (n == 0) return IBU_OK;
+  if (!d_sorted_records || !aligned8(d_sorted_records)) return err_arg("d_sorted_records must be non-NULL and 8-byte aligned");
+  if (n >= (1ull << 32)) return err_arg("barcode_counts handles fewer than 2^32 records per call");
+  hipStream_t st = pick_stream(ctx, stream);
+  rc = ensure_sort_scratch(ctx, runs_scratch_bytes(n));
+  if (rc) return rc;
+  IBU_HIP(launch_runs_count(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes, st));
+  IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_sort_scratch, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipStreamSynchronize(st));
+  const uint32_t* tot = reinterpret_cast<const uint32_t*>(ctx->h_pinned);
+  const uint64_t runs = tot[0], pairs = tot[1];
+  *n_barcodes = runs;
+  if (n_barcode_umi_pairs) *n_barcode_umi_pairs = pairs;
+  if (!d_barcodes && !d_counts && cap == 0) return IBU_OK;  // size query
+  if (!d_barcodes || !d_counts) return err_arg("d_barcodes / d_counts are NULL");
+  if (runs > cap) return err_arg("output capacity is smaller than the number of distinct barcodes (see *n_barcodes)");
+  IBU_HIP(launch_runs_emit(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, runs, pairs, d_barcodes, d_counts,
+                           d_unique_umis, st));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n < 2) return IBU_OK;
+  if (!d_records || !d_tmp || !aligned8(d_records) || !aligned8(d_tmp))
+    return err_arg("d_records / d_tmp must be non-NULL and 8-byte aligned");
+  rc = ensure_sort_scratch(ctx, sort_scratch_bytes(ctx->cfg, n));
+  if (rc) return rc;
   IBU_HIP(launch_sort_records(ctx->cfg, d_records, d_tmp, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes,
                               pick_stream(ctx, stream)));
   return IBU_OK;

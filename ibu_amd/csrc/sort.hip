@@ -276,4 +276,116 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   return hipSuccess;
 }
 
+// =====================================================================================================
+// Per-barcode aggregation on SORTED records: the device form of the reference's BarcodeAnalyzer
+// processor (src/parallel.rs:72-98: HashMap<barcode, count> merged in on_batch_complete).  On sorted
+// input a barcode is a run, so the map is a run-length encoding: barcodes[k], counts[k] and — the
+// UMI-dedup figure single-cell pipelines want from exactly this layout — unique_umis[k] = number of
+// distinct (barcode, umi) pairs in the run.  Output order = ascending barcode (the map's sorted keys).
+//
+// Each wave owns one 8 Ki-record segment and needs no LDS and no barrier: run heads are found with a
+// lane shuffle (+ one extra load for lane 0), ranked with __ballot/popcount.  Pass 1 counts heads per
+// segment, the [2][nseg] table is scanned, pass 2 emits.  Run lengths are accumulated with two 64-bit
+// atomics per RUN (start of run k: counts[k] -= i, counts[k-1] += i), never per record.
+// =====================================================================================================
+static constexpr int kSegRecs = 8192;
+
+__device__ __forceinline__ u64 shfl_up64(u64 v) {
+  u32 lo = __shfl_up((u32)v, 1), hi = __shfl_up((u32)(v >> 32), 1);
+  return ((u64)hi << 32) | lo;
+}
+// heads of one 64-record step of a segment: h1 = first record of a barcode run, h2 = first record of a
+// (barcode, umi) run.  Lanes past `end` are neither.
+__device__ __forceinline__ void run_heads(const u64* __restrict__ recs, u64 i, u64 end, u32 lane, u64& b, bool& h1, bool& h2) {
+  const bool valid = i < end;
+  b = valid ? recs[3 * i] : 0;
+  const u64 u = valid ? recs[3 * i + 1] : 0;
+  u64 pb = shfl_up64(b), pu = shfl_up64(u);
+  if (lane == 0 && valid && i > 0) { pb = recs[3 * (i - 1)]; pu = recs[3 * (i - 1) + 1]; }
+  h1 = valid && (i == 0 || b != pb);
+  h2 = valid && (h1 || u != pu);
+}
+
+extern "C" __global__ void __launch_bounds__(kSortThreads)
+ibu_k_runs_count(const u64* __restrict__ recs, u64 n, u32 nseg, u32* __restrict__ seg_heads /*[2][nseg]*/) {
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 seg = blockIdx.x * kSortWaves + (threadIdx.x >> 6);
+  if (seg >= nseg) return;                                  // wave-uniform
+  const u64 base = (u64)seg * kSegRecs;
+  const u64 end = base + kSegRecs < n ? base + kSegRecs : n;
+  u32 c1 = 0, c2 = 0;
+  for (u64 i0 = base; i0 < end; i0 += kWave) {
+    u64 b; bool h1, h2;
+    run_heads(recs, i0 + lane, end, lane, b, h1, h2);
+    c1 += (u32)__popcll(__ballot(h1));
+    c2 += (u32)__popcll(__ballot(h2));
+  }
+  if (lane == 0) { seg_heads[seg] = c1; seg_heads[nseg + seg] = c2; }
+}
+
+extern "C" __global__ void __launch_bounds__(kSortThreads)
+ibu_k_runs_emit(const u64* __restrict__ recs, u64 n, u32 nseg, const u32* __restrict__ seg_base /*[2][nseg], scanned*/,
+                u64 n_runs, u64 n_pairs, u64* __restrict__ barcodes, u64* __restrict__ counts, u64* __restrict__ uniq) {
+  const u32 lane = threadIdx.x & (kWave - 1);
+  const u32 seg = blockIdx.x * kSortWaves + (threadIdx.x >> 6);
+  if (seg >= nseg) return;
+  const u64 lt_mask = (1ull << lane) - 1;
+  const u64 base = (u64)seg * kSegRecs;
+  const u64 end = base + kSegRecs < n ? base + kSegRecs : n;
+  u64 p1 = seg_base[seg], p2 = seg_base[nseg + seg];        // runs / pairs that start before this segment
+  for (u64 i0 = base; i0 < end; i0 += kWave) {
+    const u64 i = i0 + lane;
+    u64 b; bool h1, h2;
+    run_heads(recs, i, end, lane, b, h1, h2);
+    const u64 m1 = __ballot(h1), m2 = __ballot(h2);
+    if (h1) {
+      const u64 k = p1 + (u64)__popcll(m1 & lt_mask);       // index of the run that starts at record i
+      const u64 r2 = p2 + (u64)__popcll(m2 & lt_mask);      // (barcode, umi) pairs that start before i
+      barcodes[k] = b;
+      atomicAdd(&counts[k], 0ull - i);                      // counts[k] = start(k+1) - start(k)
+      if (k > 0) atomicAdd(&counts[k - 1], i);
+      if (uniq) {
+        atomicAdd(&uniq[k], 0ull - r2);
+        if (k > 0) atomicAdd(&uniq[k - 1], r2);
+      }
+    }
+    p1 += (u64)__popcll(m1);
+    p2 += (u64)__popcll(m2);
+  }
+  if (seg == nseg - 1 && lane == 0 && n_runs > 0) {         // close the last run
+    atomicAdd(&counts[n_runs - 1], n);
+    if (uniq) atomicAdd(&uniq[n_runs - 1], n_pairs);
+  }
+}
+
+size_t runs_scratch_bytes(size_t n) {
+  const size_t nseg = (n + kSegRecs - 1) / kSegRecs;
+  return 64 + 2 * sizeof(u32) * (nseg ? nseg : 1);
+}
+// Pass 1 + scan.  Leaves the scanned table in `scratch`; totals[0] = runs, totals[1] = (barcode, umi) pairs
+// are read back by the caller from scratch[0..1] (u32 each; n < 2^32).
+hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0 || n >= (1ull << 32) || scratch_bytes < runs_scratch_bytes(n)) return hipErrorInvalidValue;
+  const u32 nseg = (u32)((n + kSegRecs - 1) / kSegRecs);
+  u32* totals = static_cast<u32*>(scratch);
+  u32* table = reinterpret_cast<u32*>(static_cast<uint8_t*>(scratch) + 64);
+  hipLaunchKernelGGL(ibu_k_runs_count, dim3((nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs,
+                     (u64)n, nseg, table);
+  hipLaunchKernelGGL(ibu_k_sort_scan_rows, dim3(2), dim3(kSortThreads), 0, st, table, nseg, totals);
+  return hipGetLastError();
+}
+hipError_t launch_runs_emit(const LaunchCfg&, const void* recs, size_t n, const void* scratch, uint64_t n_runs, uint64_t n_pairs,
+                            uint64_t* barcodes, uint64_t* counts, uint64_t* uniq, hipStream_t st) {
+  (void)hipGetLastError();
+  const u32 nseg = (u32)((n + kSegRecs - 1) / kSegRecs);
+  const u32* table = reinterpret_cast<const u32*>(static_cast<const uint8_t*>(scratch) + 64);
+  hipError_t e = hipMemsetAsync(counts, 0, n_runs * sizeof(u64), st);
+  if (e == hipSuccess && uniq) e = hipMemsetAsync(uniq, 0, n_runs * sizeof(u64), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ibu_k_runs_emit, dim3((nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs,
+                     (u64)n, nseg, table, (u64)n_runs, (u64)n_pairs, (u64*)barcodes, (u64*)counts, (u64*)uniq);
+  return hipGetLastError();
+}
+
 }  // namespace ibu

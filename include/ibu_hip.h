@@ -307,6 +307,18 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
 /* Device-side sort by (barcode, umi, index) — the order `derive(Ord)` defines (record.rs:58)
  * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch. */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
+/* Per-barcode aggregation of SORTED device records: the device form of the reference's BarcodeAnalyzer
+ * processor (src/parallel.rs:72-98 — HashMap<barcode, count> merged in on_batch_complete).  Writes, in
+ * ascending barcode order, d_barcodes[k], d_counts[k] (records with that barcode) and, when
+ * d_unique_umis != NULL, the number of distinct (barcode, umi) pairs of barcode k.  *n_barcodes
+ * receives the number of distinct barcodes, *n_barcode_umi_pairs (nullable) the number of distinct
+ * pairs.  Size query: d_barcodes = d_counts = NULL and cap = 0.  cap too small: IBU_ERR_INVALID_ARG with
+ * *n_barcodes set.  The input must be sorted (ibu_sort_records / a file whose header says sorted);
+ * unsorted input yields the run-length encoding of the barcode column instead.  Synchronises `stream`
+ * once (the counts come back to size the output).  n < 2^32. */
+int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, uint64_t* d_barcodes,
+                           uint64_t* d_counts, uint64_t* d_unique_umis, size_t cap, size_t* n_barcodes,
+                           size_t* n_barcode_umi_pairs, void* stream);
 /* 1 if the n records are non-decreasing under ibu_record_cmp. Synchronises. */
 int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream,
                       int32_t* sorted);

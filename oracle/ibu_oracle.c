@@ -644,6 +644,29 @@ int orc_is_sorted(const orc_record* r, size_t n) {
   return 1;
 }
 
+/* BarcodeAnalyzer, src/parallel.rs:72-98: process_record does *stats.entry(record.barcode) += 1 and
+ * on_batch_complete merges the per-thread maps, so the result is the multiset {barcode -> count} whatever
+ * the thread split.  Restated over records sorted by (barcode, umi, index): one entry per run, listed in
+ * ascending barcode order (a HashMap has no order; sorted keys make the result comparable).  uniq[k] =
+ * distinct (barcode, umi) pairs of barcode k — the UMI-dedup count, this build's addition (any out may be NULL).
+ * Returns the number of distinct barcodes. */
+size_t orc_barcode_counts(const orc_record* r, size_t n, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq) {
+  size_t k = 0;
+  for (size_t i = 0; i < n; i++) {
+    int new_bc = i == 0 || r[i].barcode != r[i - 1].barcode;
+    int new_pair = new_bc || r[i].umi != r[i - 1].umi;
+    if (new_bc) {
+      if (barcodes) barcodes[k] = r[i].barcode;
+      if (counts) counts[k] = 0;
+      if (uniq) uniq[k] = 0;
+      k++;
+    }
+    if (counts) counts[k - 1]++;
+    if (uniq && new_pair) uniq[k - 1]++;
+  }
+  return k;
+}
+
 /* =============================================================== cpu_baseline legs */
 static double now_s(void) {
   struct timespec ts;

@@ -147,6 +147,7 @@ uint64_t orc_splitmix64(uint64_t x);
 void orc_generate(uint64_t seed, uint64_t first, size_t n, uint32_t bc_len, uint32_t umi_len,
                   orc_record* r);
 void orc_sort_records(orc_record* r, size_t n);
+size_t orc_barcode_counts(const orc_record* sorted, size_t n, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq);
 int orc_is_sorted(const orc_record* r, size_t n);
 
 /* ---- cpu_baseline legs for bench.py: static range split over `threads` OS threads, like

@@ -397,6 +397,17 @@ def sort_records(recs):
     return out
 
 
+def barcode_counts(sorted_recs):
+    """BarcodeAnalyzer (parallel.rs:72-98) over sorted records -> (barcodes, counts, unique_umis), ascending barcode."""
+    r = np.ascontiguousarray(sorted_recs, dtype=REC_DTYPE)
+    n = r.shape[0]
+    b, c, u = (np.empty(max(n, 1), dtype=np.uint64) for _ in range(3))
+    lib.orc_barcode_counts.restype = C.c_size_t
+    lib.orc_barcode_counts.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    k = lib.orc_barcode_counts(_ptr(r), n, _ptr(b), _ptr(c), _ptr(u))
+    return b[:k].copy(), c[:k].copy(), u[:k].copy()
+
+
 def is_sorted(recs):
     recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
     return bool(lib.orc_is_sorted(_ptr(recs), recs.shape[0]))

@@ -131,3 +131,45 @@ def test_sort_argument_errors(ctx, ia):
         ctx.sort_records(d, None, 16)
     assert e.value.kind == "InvalidArg"
     ctx.sort_records(d, None, 1)  # n < 2: nothing to do, scratch not needed
+
+
+# ---- per-barcode aggregation on sorted records: BarcodeAnalyzer, src/parallel.rs:72-98 ---------------------------
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 8191, 8192, 8193, 100_000, 1_000_003])
+@pytest.mark.parametrize("n_barcodes,n_umis", [(1, 1), (7, 3), (300, 40), (1 << 40, 1 << 20)])
+def test_barcode_counts(ctx, oracle, ia, n, n_barcodes, n_umis):
+    rng = np.random.default_rng(n + n_barcodes)
+    recs = np.empty(n, dtype=ia.REC_DTYPE)
+    recs["barcode"] = rng.integers(0, n_barcodes, n, dtype=np.uint64)
+    recs["umi"] = rng.integers(0, n_umis, n, dtype=np.uint64)
+    recs["index"] = np.arange(n, dtype=np.uint64)
+    srt = oracle.sort_records(recs)
+    d = ctx.upload(srt) if n else ctx.alloc(16)
+    b, c, u = ctx.barcode_counts(d, n)
+    wb, wc, wu = oracle.barcode_counts(srt)
+    assert b.tobytes() == wb.tobytes()
+    assert c.tobytes() == wc.tobytes()
+    assert u.tobytes() == wu.tobytes()
+    if n:  # the HashMap the reference's processor builds, stated independently
+        keys, counts = np.unique(recs["barcode"], return_counts=True)
+        assert b.tolist() == keys.tolist() and c.tolist() == counts.tolist()
+    b2, c2, u2 = ctx.barcode_counts(d, n, unique_umis=False)
+    assert u2 is None and b2.tobytes() == wb.tobytes() and c2.tobytes() == wc.tobytes()
+
+
+def test_barcode_counts_after_device_sort_and_capacity_error(ctx, oracle, ia):
+    import ctypes as C
+    n = 300_000
+    recs = oracle.generate(SEED, 0, n, 4, 6)  # 4-base barcodes: 256 distinct values, long runs
+    np.random.default_rng(1).shuffle(recs)
+    d, t = ctx.upload(recs), ctx.alloc(24 * n)
+    ctx.sort_records(d, t, n)
+    b, c, u = ctx.barcode_counts(d, n)
+    wb, wc, wu = oracle.barcode_counts(oracle.sort_records(recs))
+    assert (b.tobytes(), c.tobytes(), u.tobytes()) == (wb.tobytes(), wc.tobytes(), wu.tobytes())
+    assert int(c.sum()) == n and len(b) <= 256
+    # capacity too small: InvalidArg, and the needed size is reported
+    nb = C.c_size_t()
+    small_b, small_c = ctx.alloc(8), ctx.alloc(8)
+    rc = ia.lib.ibu_barcode_counts(ctx._c, C.c_void_p(d.ptr), n, C.c_void_p(small_b.ptr), C.c_void_p(small_c.ptr), None,
+                                     1, C.byref(nb), None, None)
+    assert rc != 0 and nb.value == len(wb)

@@ -454,3 +454,22 @@ def test_generator_and_columns(oracle):
     b, u, i = oracle.decode_records(full, 32, 32)
     back, _, nb = oracle.encode_records(b, u, i, 100, 32, 32)
     assert nb == 0 and back.tobytes() == full.tobytes()
+
+
+def test_barcode_counts_match_hashmap_semantics(oracle):
+    """parallel.rs:72-98 keeps HashMap<barcode, count>; np.unique is an independent statement of that map."""
+    rng = np.random.default_rng(3)
+    n = 20_000
+    recs = oracle.generate(0x1B00005, 0, n, 16, 12)
+    recs["barcode"] = rng.integers(0, 300, n, dtype=np.uint64)
+    recs["umi"] = rng.integers(0, 40, n, dtype=np.uint64)
+    srt = oracle.sort_records(recs)
+    b, c, u = oracle.barcode_counts(srt)
+    keys, counts = np.unique(recs["barcode"], return_counts=True)
+    assert b.tolist() == keys.tolist() and c.tolist() == counts.tolist()
+    pairs = np.unique(np.stack([recs["barcode"], recs["umi"]], axis=1), axis=0)
+    pk, pu = np.unique(pairs[:, 0], return_counts=True)
+    assert pk.tolist() == keys.tolist() and u.tolist() == pu.tolist()
+    assert int(c.sum()) == n
+    e = oracle.barcode_counts(recs[:0])
+    assert all(len(x) == 0 for x in e)

@@ -7,63 +7,84 @@
 
 namespace ibu {
 
+// Records per wave iteration = 128 * kDecodeNT.  With NT = 2 every ASCII column whose length is a
+// multiple of 4 is a whole number of 64-lane store rounds (16*len chunks), so no round is partial.
+#ifndef IBU_DECODE_NT
+#define IBU_DECODE_NT 1
+#endif
+static constexpr int kDecodeNT = IBU_DECODE_NT;
+static constexpr int kDecRecs = kTileRecs * kDecodeNT;
+static constexpr int kDecBytes = kTileBytes * kDecodeNT;
+static constexpr int kDecLoads = 3 * kDecodeNT;      // dwordx4 loads per lane per iteration
+
+struct DecRegs {
+  u32x4 v[kDecLoads];
+  __device__ __forceinline__ void load(const uint8_t* src) {
+#pragma unroll
+    for (int k = 0; k < kDecLoads; ++k) v[k] = ld16(src + 1024 * k);
+  }
+};
+
 // Stage one AoS tile held in registers into the wave's LDS slice and expand it.
 template <int BC, int UM>
-__device__ __forceinline__ void decode_tile(uint8_t* tile, u32x4 a0, u32x4 a1, u32x4 a2, u32 t, u32 bc_len,
-                                            u32 umi_len, uint8_t* bc_out, uint8_t* umi_out, u64* idx_out,
-                                            u32 lane) {
+__device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs& a, u32 t, u32 bc_len, u32 umi_len,
+                                            uint8_t* bc_out, uint8_t* umi_out, u64* idx_out, u32 lane) {
   wave_lds_fence();                            // previous tile's LDS reads precede these writes
-  *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
-  *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
-  *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
+#pragma unroll
+  for (int k = 0; k < kDecLoads; ++k) *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = a.v[k];
   wave_lds_fence();
-  if (bc_out) expand_field<BC>(tile, 24, 0, bc_len, bc_out + (size_t)t * kTileRecs * bc_len, lane);
-  if (umi_out) expand_field<UM>(tile, 24, 8, umi_len, umi_out + (size_t)t * kTileRecs * umi_len, lane);
-  if (idx_out) {                               // chunk = indices of records 2*lane, 2*lane+1
-    u64 i0 = *reinterpret_cast<const u64*>(tile + (2 * lane) * 24 + 16);
-    u64 i1 = *reinterpret_cast<const u64*>(tile + (2 * lane + 1) * 24 + 16);
-    u32x4 o; o.x = (u32)i0; o.y = (u32)(i0 >> 32); o.z = (u32)i1; o.w = (u32)(i1 >> 32);
-    st16(reinterpret_cast<uint8_t*>(idx_out) + (size_t)t * 1024 + 16 * lane, o);
+  if (bc_out) expand_field<BC, kDecodeNT>(tile, 24, 0, bc_len, bc_out + (size_t)t * kDecRecs * bc_len, lane);
+  if (umi_out) expand_field<UM, kDecodeNT>(tile, 24, 8, umi_len, umi_out + (size_t)t * kDecRecs * umi_len, lane);
+  if (idx_out) {                               // chunk c = indices of records 2c, 2c+1
+#pragma unroll
+    for (int j = 0; j < kDecodeNT; ++j) {
+      const u32 c = lane + 64 * j;
+      u64 i0 = *reinterpret_cast<const u64*>(tile + (2 * c) * 24 + 16);
+      u64 i1 = *reinterpret_cast<const u64*>(tile + (2 * c + 1) * 24 + 16);
+      u32x4 o; o.x = (u32)i0; o.y = (u32)(i0 >> 32); o.z = (u32)i1; o.w = (u32)(i1 >> 32);
+      st16(reinterpret_cast<uint8_t*>(idx_out) + (size_t)t * (8 * kDecRecs) + 16 * c, o);
+    }
   }
 }
 
 // BC / UM: compile-time barcode / UMI length, or 0 for "runtime length" (generic kernel).
 // Two register sets take turns (phase A expands `a` while `b` is in flight, phase B the
-// reverse): the next tile's three loads are issued FIRST in each phase, never copied, never
+// reverse): the next tile's loads are issued FIRST in each phase, never copied, never
 // behind a wait.
-// Register budget: the dword-path specialisations fit 64 VGPRs (8 waves/SIMD); the byte-path
+// Register budget: the dword-path specialisations fit 72 VGPRs (7 waves/SIMD); the byte-path
 // (len % 4 != 0) and generic kernels would spill there, so they get 168 (3 waves/SIMD).  72 VGPRs
 // (7 waves/SIMD) measured as fast as 64 (8) for the streaming kernels (profiles/r01_b sweep).
 constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
+#ifndef IBU_DECODE_MINWAVES
+#define IBU_DECODE_MINWAVES (IBU_DECODE_NT > 1 ? 5 : 7)
+#endif
 template <int BC, int UM>
-__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? 7 : 3)
+__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? IBU_DECODE_MINWAVES : 3)
 ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
              uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kDecBytes];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kTileBytes;
+  uint8_t* tile = lds + wib * kDecBytes;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
   u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   if (BC > 0) bc_len = BC;
   if (UM > 0) umi_len = UM;
 
-  const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
-  u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
+  DecRegs a, b;
+  a.load(recs + (size_t)t * kDecBytes + 16 * lane);
   for (;;) {
     u32 tn = t + nwaves;
     bool more = tn < ntiles;                   // wave-uniform
-    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
-    u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
-    decode_tile<BC, UM>(tile, a0, a1, a2, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
+    b.load(recs + (size_t)(more ? tn : t) * kDecBytes + 16 * lane);
+    decode_tile<BC, UM>(tile, a, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
     if (!more) break;
     t = tn;
     tn = t + nwaves;
     more = tn < ntiles;
-    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
-    a0 = ld16(src); a1 = ld16(src + 1024); a2 = ld16(src + 2048);
-    decode_tile<BC, UM>(tile, b0, b1, b2, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
+    a.load(recs + (size_t)(more ? tn : t) * kDecBytes + 16 * lane);
+    decode_tile<BC, UM>(tile, b, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
     if (!more) break;
     t = tn;
   }
@@ -136,9 +157,9 @@ hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint3
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
-  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
+  const size_t n_main = fast ? (n / kDecRecs) * kDecRecs : 0;
   if (n_main) {
-    const u32 ntiles = (u32)(n_main / kTileRecs);
+    const u32 ntiles = (u32)(n_main / kDecRecs);
     const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
     const DecFn fn = kDecTable[mb][mu];
     static int occ[kNumLenModes][kNumLenModes] = {{0}};

@@ -173,12 +173,12 @@ __device__ __forceinline__ u32x4 expand_chunk(const uint8_t* tile, u32 rstride, 
 //             recompute and re-store the LAST chunk (same bytes, same address: benign) so no
 //             store is exec-branched and the store count per tile is exact.
 //   LEN == 0: runtime length, plain loop (generic kernel).
-template <int LEN>
+template <int LEN, int NT = 1>  // NT: 128-record tiles staged back to back in `tile`
 __device__ __forceinline__ void expand_field(const uint8_t* tile, u32 rstride, u32 foff, u32 rt_len,
                                              uint8_t* out_tile, u32 lane) {
   if constexpr (LEN > 0) {
-    constexpr u32 last = 8 * LEN - 1;
-    constexpr int rounds = (LEN + 7) / 8;
+    constexpr u32 last = 8 * LEN * NT - 1;
+    constexpr int rounds = (8 * LEN * NT + kWave - 1) / kWave;
 #pragma unroll
     for (int i = 0; i < rounds; ++i) {
       u32 c = lane + 64 * i;
@@ -186,7 +186,7 @@ __device__ __forceinline__ void expand_field(const uint8_t* tile, u32 rstride, u
       st16(out_tile + 16 * (size_t)c, expand_chunk(tile, rstride, foff, (u32)LEN, c));
     }
   } else {
-    const u32 nchunks = 8 * rt_len;
+    const u32 nchunks = 8 * rt_len * NT;
     for (u32 c = lane; c < nchunks; c += kWave)
       st16(out_tile + 16 * (size_t)c, expand_chunk(tile, rstride, foff, rt_len, c));
   }

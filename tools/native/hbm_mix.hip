@@ -1,0 +1,31 @@
+// hbm_mix.hip — measurement-only kernel (not part of libibu_hip.so): streams R 16-B chunks in and
+// W 16-B chunks out per lane per step, nontemporal, grid-stride, to find the HBM ceiling of a given
+// read:write mix on this box (decode is 24R:36W = 2:3, encode 36R:24W = 3:2, copy 1:1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, int W>
+__global__ void __launch_bounds__(256, 8) k_mix(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t steps) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < steps; s += stride) {
+    u32x4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = __builtin_nontemporal_load(src + (uint64_t)r * steps + s);
+    u32x4 acc = v[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) acc ^= v[r];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      u32x4 o = acc; o.x += w;
+      __builtin_nontemporal_store(o, dst + (uint64_t)w * steps + s);
+    }
+  }
+}
+
+extern "C" int hbm_mix(int r, int w, const void* src, void* dst, uint64_t steps, int blocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+#define CASE(R, W) if (r == R && w == W) { hipLaunchKernelGGL((k_mix<R, W>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, steps); return (int)hipGetLastError(); }
+  CASE(1, 0) CASE(1, 1) CASE(2, 3) CASE(3, 2) CASE(1, 2) CASE(2, 1) CASE(3, 1) CASE(1, 3) CASE(4, 1)
+  return -1;
+}

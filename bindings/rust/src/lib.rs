@@ -471,6 +471,44 @@ pub mod device {
             check(unsafe { ffi::ibu_reduce_fetch(self.raw, std::ptr::null_mut(), &mut out) })?;
             Ok(out)
         }
+        /// Streaming device-to-device copy (the memcpy of `Writer::write_slice` / `ingest` for HBM-resident batches).
+        pub fn copy(&self, dst: &DeviceBuf, src: &DeviceBuf, bytes: usize) -> Result<()> {
+            check(unsafe { ffi::ibu_device_copy(self.raw, dst.ptr, src.ptr, bytes, std::ptr::null_mut()) })
+        }
+        /// Sort by (barcode, umi, index) — `Record`'s derived `Ord`; `tmp` is n*24 bytes of scratch.
+        pub fn sort_records(&self, recs: &DeviceBuf, tmp: &DeviceBuf, n: usize) -> Result<()> {
+            check(unsafe { ffi::ibu_sort_records(self.raw, recs.ptr, tmp.ptr, n, std::ptr::null_mut()) })
+        }
+        pub fn is_sorted(&self, recs: &DeviceBuf, n: usize) -> Result<bool> {
+            let mut s = 0i32;
+            check(unsafe { ffi::ibu_is_sorted(self.raw, recs.ptr, n, std::ptr::null_mut(), &mut s) })?;
+            Ok(s != 0)
+        }
+        /// The doc example's `BarcodeAnalyzer` (parallel.rs:72-98) on sorted device records:
+        /// (barcode, records, distinct UMIs) per barcode in ascending barcode order.
+        pub fn barcode_counts(&self, sorted: &DeviceBuf, n: usize) -> Result<Vec<(u64, u64, u64)>> {
+            let (mut nb, mut np) = (0usize, 0usize);
+            check(unsafe {
+                ffi::ibu_barcode_counts(self.raw, sorted.ptr, n, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(),
+                                        0, &mut nb, &mut np, std::ptr::null_mut())
+            })?;
+            if nb == 0 {
+                return Ok(Vec::new());
+            }
+            let (b, c, u) = (self.alloc(8 * nb)?, self.alloc(8 * nb)?, self.alloc(8 * nb)?);
+            check(unsafe {
+                ffi::ibu_barcode_counts(self.raw, sorted.ptr, n, b.ptr as *mut u64, c.ptr as *mut u64, u.ptr as *mut u64, nb,
+                                        &mut nb, &mut np, std::ptr::null_mut())
+            })?;
+            let mut host = vec![0u64; 3 * nb];
+            for (k, d) in [&b, &c, &u].iter().enumerate() {
+                check(unsafe {
+                    ffi::ibu_memcpy_d2h(self.raw, host[k * nb..].as_mut_ptr() as *mut c_void, d.ptr, 8 * nb, std::ptr::null_mut())
+                })?;
+            }
+            check(unsafe { ffi::ibu_ctx_synchronize(self.raw, std::ptr::null_mut()) })?;
+            Ok((0..nb).map(|k| (host[k], host[nb + k], host[2 * nb + k])).collect())
+        }
         /// Device analogue of `load_to_vec`.
         pub fn load_to_device<P: AsRef<Path>>(&self, path: P) -> Result<(Header, *mut c_void, usize)> {
             let c = CString::new(path.as_ref().to_string_lossy().as_bytes()).unwrap();

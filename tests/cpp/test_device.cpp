@@ -1,0 +1,146 @@
+// Device path through the C++ mirror (include/ibu.hpp), checked against the CPU oracle (oracle/ibu_oracle.h —
+// test infrastructure, linked here as the checker only).  Needs an MI355X: run by tests/test_cpp.py under -m gpu.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "check.hpp"
+#include "ibu.hpp"
+extern "C" {
+#include "ibu_oracle.h"
+}
+
+using namespace ibu;
+using device::Context;
+using device::DeviceBuffer;
+
+static Context& ctx() { static Context c(0); return c; }
+static std::vector<Record> oracle_records(uint64_t seed, uint64_t first, size_t n, uint32_t bc, uint32_t umi) {
+  std::vector<Record> v(n);
+  orc_generate(seed, first, n, bc, umi, reinterpret_cast<orc_record*>(v.data()));
+  return v;
+}
+static std::string tmp_path(const char* stem) {
+  const char* d = std::getenv("TMPDIR");
+  return std::string(d ? d : "/tmp") + "/ibu_cppdev_" + stem + "_" + std::to_string(getpid()) + ".ibu";
+}
+
+TEST(generate_decode_encode_reduce_match_the_oracle) {
+  for (auto lens : {std::pair<uint32_t, uint32_t>{16, 12}, {32, 32}, {15, 11}, {1, 1}}) {
+    for (size_t n : {size_t(0), size_t(1), size_t(127), size_t(129), size_t(100003)}) {
+      const Header h(lens.first, lens.second);
+      auto want = oracle_records(0x1B00001, 5, n, h.bc_len, h.umi_len);
+      DeviceBuffer recs(ctx(), n * 24), back(ctx(), n * 24), bc(ctx(), n * h.bc_len), umi(ctx(), n * h.umi_len), idx(ctx(), n * 8);
+      ctx().generate(0x1B00001, 5, n, h, recs.ptr());
+      CHECK(recs.download<Record>(n) == want);
+      ctx().decode_ascii(recs.ptr(), n, h, bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>());
+      std::vector<uint8_t> wbc(n * h.bc_len), wumi(n * h.umi_len);
+      std::vector<uint64_t> widx(n);
+      orc_decode_records(reinterpret_cast<const orc_record*>(want.data()), n, h.bc_len, h.umi_len, wbc.data(), wumi.data(), widx.data());
+      CHECK(bc.download<uint8_t>(wbc.size()) == wbc);
+      CHECK(umi.download<uint8_t>(wumi.size()) == wumi);
+      CHECK(idx.download<uint64_t>(n) == widx);
+      ctx().encode_ascii(bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), n, h, back.ptr());
+      ctx().codec_status();
+      CHECK(back.download<Record>(n) == want);
+      orc_reduce r;
+      orc_reduce_records(reinterpret_cast<const orc_record*>(want.data()), n, &r);
+      auto got = ctx().reduce(recs.ptr(), n);
+      CHECK_EQ(got.count, r.count);
+      for (int k = 0; k < 3; ++k) { CHECK_EQ(got.sum[k], r.sum[k]); CHECK_EQ(got.xor_[k], r.xor_[k]); }
+    }
+  }
+}
+TEST(invalid_base_is_reported_with_first_record_and_count) {
+  const Header h(16, 12);
+  const size_t n = 1000;
+  std::vector<uint8_t> bc(n * 16, 'A'), umi(n * 12, 'c');
+  bc[16 * 7 + 3] = 'N'; umi[12 * 500] = 0; bc[16 * 999] = 'x';
+  DeviceBuffer dbc(ctx(), bc.size()), dumi(ctx(), umi.size()), out(ctx(), n * 24);
+  dbc.upload(bc); dumi.upload(umi);
+  ctx().encode_ascii(dbc.as<uint8_t>(), dumi.as<uint8_t>(), nullptr, n, h, out.ptr(), 100);
+  CHECK_THROWS(InvalidBase, ctx().codec_status(), { CHECK_EQ(e.first_bad(), 7ull); CHECK_EQ(e.n_bad(), 3ull); });
+  ctx().codec_status();  // re-armed
+  auto recs = out.download<Record>(n);
+  CHECK(recs[0] == Record(0, 0x555555, 100));  // 'A' = 00, 'c' = 01 in every 2-bit field; index = first_index + i
+  CHECK_EQ(recs[7].barcode, 0ull);             // the offending field is written as 0
+}
+TEST(sort_matches_oracle_and_aggregation_follows) {
+  for (size_t n : {size_t(2), size_t(1025), size_t(200003)}) {
+    auto recs = oracle_records(0x1B00005, 0, n, 6, 5);
+    std::reverse(recs.begin(), recs.end());
+    DeviceBuffer d(ctx(), n * 24), t(ctx(), n * 24);
+    d.upload(recs);
+    CHECK(n <= 2 || !ctx().is_sorted(d.ptr(), n));
+    ctx().sort_records(d.ptr(), t.ptr(), n);
+    orc_sort_records(reinterpret_cast<orc_record*>(recs.data()), n);
+    CHECK(d.download<Record>(n) == recs);
+    CHECK(ctx().is_sorted(d.ptr(), n));
+    std::vector<uint64_t> b(n), c(n), u(n);
+    size_t k = orc_barcode_counts(reinterpret_cast<const orc_record*>(recs.data()), n, b.data(), c.data(), u.data());
+    auto got = ctx().barcode_counts(d.ptr(), n);
+    CHECK_EQ(got.size(), k);
+    for (size_t i = 0; i < k; ++i) CHECK(got[i] == std::make_tuple(b[i], c[i], u[i]));
+  }
+}
+TEST(file_streams_to_and_from_the_device) {
+  const size_t n = 300001;
+  const Header h(16, 12);
+  auto recs = oracle_records(0x1B00004, 0, n, 16, 12);
+  const std::string path = tmp_path("stream");
+  const RingConfig ring{3, 8192, 2, 0};
+  {  // device -> file == host-written file
+    DeviceBuffer d(ctx(), n * 24);
+    d.upload(recs);
+    Writer w = Writer::from_path(path, h);
+    auto st = w.write_batch_device(ctx(), d.ptr(), n, &ring);
+    w.finish();
+    CHECK_EQ(st.records, (uint64_t)n); CHECK_EQ(w.records_written(), (uint64_t)n);
+  }
+  auto [hh, back] = load_to_vec(path);
+  CHECK(hh == h); CHECK(back == recs);
+  {  // load_to_device == load_to_vec
+    auto [hd, dptr, dn] = ctx().load_to_device(path, &ring);
+    CHECK(hd == h); CHECK_EQ(dn, n);
+    std::vector<Record> got(n);
+    ctx().download(static_cast<void*>(got.data()), dptr, n * 24);
+    ctx().free(dptr);
+    CHECK(got == recs);
+  }
+  MmapReader m(path);
+  orc_reduce want;
+  orc_reduce_records(reinterpret_cast<const orc_record*>(recs.data()), n, &want);
+  uint64_t count = 0, sum2 = 0;
+  for (size_t s = 0; s < 3; ++s) {  // one shard per "GPU": sums add up (mmap.rs:297-307 split)
+    auto [r, st] = m.process_device_reduce(ctx(), s, 3, &ring);
+    auto range = shard_range(n, 3, s);
+    CHECK_EQ(r.count, (uint64_t)(range.second - range.first));
+    count += r.count; sum2 += r.sum[2];
+  }
+  CHECK_EQ(count, want.count); CHECK_EQ(sum2, want.sum[2]);
+  DeviceBuffer bc(ctx(), n * 16), umi(ctx(), n * 12), idx(ctx(), n * 8);
+  Reader r = Reader::from_path(path);
+  r.process_device_decode(ctx(), bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), &ring);
+  std::vector<uint8_t> wbc(n * 16), wumi(n * 12);
+  std::vector<uint64_t> widx(n);
+  orc_decode_records(reinterpret_cast<const orc_record*>(recs.data()), n, 16, 12, wbc.data(), wumi.data(), widx.data());
+  CHECK(bc.download<uint8_t>(wbc.size()) == wbc); CHECK(umi.download<uint8_t>(wumi.size()) == wumi); CHECK(idx.download<uint64_t>(n) == widx);
+  unlink(path.c_str());
+}
+TEST(argument_errors_surface_as_ibu_errors) {
+  const Header h(16, 12);
+  DeviceBuffer d(ctx(), 24 * 16);
+  CHECK_THROWS(InvalidBarcodeLength, ctx().decode_ascii(d.ptr(), 16, Header(0, 12), nullptr, nullptr, nullptr), {});
+  CHECK_THROWS(InvalidUmiLength, ctx().decode_ascii(d.ptr(), 16, Header(16, 33), nullptr, nullptr, nullptr), {});
+  CHECK_THROWS(InvalidArg, ctx().sort_records(d.ptr(), nullptr, 16), {});
+  CHECK_THROWS(InvalidArg, ctx().copy(d.ptr(), d.ptr(), 64), {});
+  CHECK_THROWS(Io, ctx().load_to_device("/nonexistent/file.ibu"), {});
+}
+
+int main(int argc, char** argv) {
+  if (device::device_count() == 0) { std::fprintf(stderr, "no GPU: the device tests cannot run\n"); return 2; }
+  return run_all(argc, argv);
+}

@@ -1,0 +1,67 @@
+"""The C++ mirror of the reference's public API (include/ibu.hpp, above the C ABI) and the reference's two
+example programs restated in C++ (examples/*.cpp).  tests/cpp/test_host.cpp restates the reference's own unit
+tests one by one; here they are built (g++) and run.  Device legs run under -m gpu."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    return BIN
+
+
+def _run(args, **kw):
+    return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_cpp_mirror_passes_the_reference_unit_tests(built, tmp_path):
+    r = _run([os.path.join(built, "test_host")], env={**os.environ, "TMPDIR": str(tmp_path)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed" in r.stdout and r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 30
+
+
+def test_roundtrip_example_1e6(built, tmp_path, kat):
+    """BASELINE configs[0]: examples/roundtrip.rs shape at 1e6 records — CPU plumbing only."""
+    r = _run([os.path.join(built, "roundtrip"), "1000000", "--json", "--dir", str(tmp_path)])
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["records"] == 1_000_000 and out["checksum"] == "0x0000000000000000"  # degenerate XOR
+    assert out["sums"] == [499_999_500_000] * 3
+    assert not os.listdir(tmp_path)  # the example removes its file
+
+
+def test_parallel_example(built, tmp_path):
+    """examples/parallel.rs shape: process_parallel(proc, 0) sums of the three fields."""
+    n = 3_000_000
+    r = _run([os.path.join(built, "parallel"), str(n), "--json", "--dir", str(tmp_path)])
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    want_idx = n * (n - 1) // 2
+    want_bc = sum(range(1_000_000)) * 3
+    assert out["sums"][2] == want_idx and out["sums"][0] == want_bc
+    assert out["sums"][1] == sum((i * 31) % 1_000_000 for i in range(n))
+
+
+@pytest.mark.gpu
+def test_cpp_device_tests(built, tmp_path):
+    r = _run([os.path.join(built, "test_device")], env={**os.environ, "TMPDIR": str(tmp_path)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_examples_device_legs(built, tmp_path):
+    r = _run([os.path.join(built, "roundtrip"), "2000000", "--device", "--json", "--dir", str(tmp_path)])
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout)["device"] is True
+    r = _run([os.path.join(built, "parallel"), "5000000", "--device", "--json", "--dir", str(tmp_path)])
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["device"] is True and out["sums"][2] == 5_000_000 * 4_999_999 // 2

@@ -34,8 +34,8 @@ def per_kernel(pmc_dir, counter):
 
 
 def short(name):
-    for k in ("decode", "encode", "deserialize", "serialize", "reduce", "unpack", "pack", "generate"):
-        if f"ibu_k_{k}" in name and "_tail" not in name:
+    for k in ("decode", "encode", "deserialize", "serialize", "reduce", "unpack", "pack", "generate", "copy"):
+        if f"ibu_k_{k}" in name and "_tail" not in name and "_bytes" not in name:
             return k
     return None
 
@@ -45,7 +45,7 @@ def main():
     bc_len, umi_len = (int(x) for x in lens.split(","))
     fetch, write = per_kernel(pmc_dir, "FETCH_SIZE"), per_kernel(pmc_dir, "WRITE_SIZE")
     alg = {"decode": 24 + bc_len + umi_len + 8, "encode": 24 + bc_len + umi_len + 8, "deserialize": 48, "serialize": 48,
-           "reduce": 24, "unpack": 8 + bc_len, "pack": 8 + bc_len, "generate": 24}
+           "reduce": 24, "unpack": 8 + bc_len, "pack": 8 + bc_len, "generate": 24, "copy": 48}
     out = {"_method": __doc__.split("FETCH_SIZE / WRITE_SIZE are", 1)[1].strip().replace("\n", " "),
            "_records": n, "_lens": [bc_len, umi_len]}
     for name, f_kib in sorted(fetch.items()):

@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--cpu-sample", type=float, default=0, help="records for the CPU baseline (0 = auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    # rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never used by the driver):
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: collectives on CPU tensors")
+    p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
     return p.parse_args()
 
 
@@ -72,14 +75,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":  # "nccl" IS RCCL on ROCm
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = ibu_amd.Context(local_rank)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the few collective words live
 
     n = int(args.records)
     bc_len, umi_len = args.bc_len, args.umi_len
@@ -128,7 +137,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -159,7 +168,7 @@ def main():
         if not verified:
             raise SystemExit("round trip encode(decode(x)) != x")
     # the one cross-GPU exchange: global count + wrapping field sums (4 x i64 over RCCL)
-    g = sharding.global_totals(red, device=dev)
+    g = sharding.global_totals(red, device=coll_dev)
     tot = [g["count"]] + g["sum"]
     assert tot[0] == n_global
     assert tot[3] == sharding.expected_index_sum(n_global)  # index column is 0..n_global-1

@@ -610,19 +610,46 @@ extern "C" int32_t ibu_load_to_vec(const char* path, ibu_header_t* header, ibu_r
     close(fd);
     return err_io(ENOMEM, "alloc");
   }
+  // read_exact.  Same bytes as the reference's single read_exact (reader.rs:531-532); large files are split over
+  // a few threads with pread so the page faults of the fresh allocation and the kernel copies overlap.
   uint8_t* p = reinterpret_cast<uint8_t*>(v);
-  size_t left = num * IBU_RECORD_SIZE;
-  while (left) {  // read_exact
-    ssize_t k = ::read(fd, p, left);
-    if (k < 0 && errno == EINTR) continue;
-    if (k <= 0) {
-      int e = k < 0 ? errno : 0;
-      free(v);
-      close(fd);
-      return err_io(e, "read records");
+  const size_t total = num * IBU_RECORD_SIZE;
+  auto read_range = [&](size_t off, size_t len) -> int {
+    while (len) {
+      ssize_t k = ::pread(fd, p + off, len, (off_t)(IBU_HEADER_SIZE + off));
+      if (k < 0 && errno == EINTR) continue;
+      if (k < 0) return errno;
+      if (k == 0) return EIO;  // the file shrank underneath us
+      off += (size_t)k;
+      len -= (size_t)k;
     }
-    p += k;
-    left -= (size_t)k;
+    return 0;
+  };
+  int err = 0;
+  const size_t kPar = (size_t)64 << 20;
+  if (total <= kPar) {
+    err = read_range(0, total);
+  } else {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? (hw < 8 ? hw : 8) : 4;
+    if (nt > total / kPar + 1) nt = total / kPar + 1;
+    const size_t per = ((total / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    std::vector<int> rcs(nt, 0);
+    for (size_t i = 0; i < nt; ++i) {
+      const size_t off = i * per;
+      if (off >= total) break;
+      const size_t len = off + per < total ? per : total - off;
+      th.emplace_back([&, i, off, len]() { rcs[i] = read_range(off, len); });
+    }
+    for (auto& t : th) t.join();
+    for (int r : rcs)
+      if (r && !err) err = r;
+  }
+  if (err) {
+    free(v);
+    close(fd);
+    return err_io(err == EIO ? 0 : err, "read records");
   }
   close(fd);
   *records = v;

@@ -19,9 +19,12 @@ namespace ibu {
 
 static constexpr int kSortThreads = 256;
 static constexpr int kSortWaves = kSortThreads / kWave;       // 4
-static constexpr int kSortTile = 1024;                        // records per LDS tile (24 KiB)
+#ifndef IBU_SORT_TILE
+#define IBU_SORT_TILE 1024
+#endif
+static constexpr int kSortTile = IBU_SORT_TILE;               // records per LDS tile (24 KiB at 1024)
 static constexpr int kSortRounds = kSortTile / kSortThreads;  // records per thread per tile
-static constexpr int kSortTilesPerChunk = 32;
+static constexpr int kSortTilesPerChunk = 32768 / kSortTile;
 static constexpr int kSortChunk = kSortTile * kSortTilesPerChunk;  // records per histogram row
 static constexpr int kBins = 256;
 
@@ -148,17 +151,30 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
   const u64 rec0 = (u64)blockIdx.x * kSortChunk;
   const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
 
+  // Full, 16-B aligned tiles are prefetched one tile ahead into registers (the global-load latency of tile
+  // k+1 hides behind the ranking of tile k); the ragged last tile of the input takes the plain 8-byte path.
+  constexpr int kPre = kSortTile * 24 / 16 / kSortThreads;   // dwordx4 per thread per tile
+  u32x4 pre[kPre];
+  auto full_tile = [&](u64 tb) { return aligned && tb + kSortTile <= n; };
+  auto prefetch = [&](u64 tb) {
+    const u32x4* g = reinterpret_cast<const u32x4*>(src + 3 * tb);
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) pre[k] = ld16(g + tid + kSortThreads * k);
+  };
+  if (full_tile(rec0)) prefetch(rec0);
+
   for (int tile = 0; tile < kSortTilesPerChunk; ++tile) {
     const u64 tbase = rec0 + (u64)tile * kSortTile;
     if (tbase >= n) break;                                   // block-uniform
     const u32 cnt = n - tbase < (u64)kSortTile ? (u32)(n - tbase) : (u32)kSortTile;
     __syncthreads();                                         // previous tile fully written out
     // a. stage the tile (coalesced) and clear the per-wave counters
-    if (cnt == (u32)kSortTile && aligned) {
-      const u32x4* g = reinterpret_cast<const u32x4*>(src + 3 * tbase);
+    if (full_tile(tbase)) {
       u32x4* s = reinterpret_cast<u32x4*>(stage);
 #pragma unroll
-      for (int k = 0; k < kSortTile * 24 / 16 / kSortThreads; ++k) s[tid + kSortThreads * k] = g[tid + kSortThreads * k];
+      for (int k = 0; k < kPre; ++k) s[tid + kSortThreads * k] = pre[k];
+      const u64 nb = tbase + kSortTile;
+      if (tile + 1 < kSortTilesPerChunk && full_tile(nb)) prefetch(nb);
     } else {
       for (u32 w = tid; w < 3 * cnt; w += kSortThreads) stage[w] = src[3 * tbase + w];
     }
@@ -217,7 +233,7 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
     // e. write out: consecutive lanes write consecutive 8-byte words of each run
     for (u32 w = tid; w < 3 * cnt; w += kSortThreads) {
       const u32 s = (u32)(((u64)w * 0xAAAAAAABull) >> 33);   // w / 3
-      dst[3 * (u64)dest[s] + (w - 3 * s)] = stage[w];
+      dst[3 * (u64)dest[s] + (w - 3 * s)] = stage[w];  // plain store: L2 merges the pieces of a run (nontemporal: -20 %)
     }
   }
 }

@@ -43,12 +43,34 @@ def parse():
     return p.parse_args()
 
 
+def usable_cores():
+    """CPUs this job may really use: the affinity mask limited by the cgroup CPU quota (a 1-GPU box of this pool
+    shows 256 CPUs in the mask but is throttled to its share; 256 runnable threads under that quota thrash)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(args):
     """The oracle (a C restatement of the reference's CPU path: static range split over OS threads,
     1Mi-record batches, scalar 2-bit codec) timed on this box's host cores on a bounded sample."""
     from oracle import oracle as orc  # the checker, used here only as the reported baseline
 
-    threads = len(os.sched_getaffinity(0))
+    threads = usable_cores()
     n = int(args.cpu_sample) or 20_000_000
     t, chk = orc.bench_decode_encode(min(n, 2_000_000), args.bc_len, args.umi_len, args.seed, threads)  # warm-up
     if not args.cpu_sample:  # scale the sample to ~10-20 s of CPU work

@@ -749,14 +749,35 @@ extern "C" int32_t ibu_shard_range(size_t len, size_t n_shards, size_t shard, si
   return IBU_OK;
 }
 
-size_t ibu::host_cores() {  // num_cpus::get(): CPUs this process may run on
+// num_cpus::get() (mmap.rs:292): CPUs this process may run on — the affinity mask, further limited by the
+// cgroup CPU quota when one is set (num_cpus does the same: ceil(quota / period), cgroup v2 then v1).
+static size_t cgroup_cpu_quota() {
+  long long quota = -1, period = -1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // v2: "<quota|max> <period>"
+    char q[32] = {0};
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else {
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+  }
+  if (quota > 0 && period > 0) return (size_t)((quota + period - 1) / period);
+  return 0;
+}
+size_t ibu::host_cores() {
+  size_t n = 0;
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) {
     int c = CPU_COUNT(&set);
-    if (c > 0) return (size_t)c;
+    if (c > 0) n = (size_t)c;
   }
-  unsigned h = std::thread::hardware_concurrency();
-  return h ? h : 1;
+  if (!n) {
+    unsigned h = std::thread::hardware_concurrency();
+    n = h ? h : 1;
+  }
+  const size_t q = cgroup_cpu_quota();
+  if (q && q < n) n = q;
+  return n;
 }
 
 extern "C" int32_t ibu_mmap_process_parallel(const ibu_mmap_t* m, const ibu_processor_vtable_t* vt, void* user,

@@ -538,20 +538,21 @@ void orc_serialize(const uint64_t* bc, const uint64_t* umi, const uint64_t* idx,
 /* =============================================================== 2-bit codec
  * table: record.rs:22-25; cap: record.rs:27, header.rs:180-185; bit order: bitnuc
  * (unpinned, see header). */
+/* The code table of record.rs:22-25 as a byte lookup (0xFF = not a base): A/a=0 C/c=1 G/g=2 T/t=3.  A table
+ * rather than a switch so that the cpu_baseline leg is not dominated by mispredicted branches on random bases. */
+static const uint8_t kPackLut[256] = {[0 ... 255] = 0xFF, ['A'] = 0, ['a'] = 0, ['C'] = 1, ['c'] = 1,
+                                      ['G'] = 2, ['g'] = 2, ['T'] = 3, ['t'] = 3};
 int orc_pack_2bit(const uint8_t* seq, uint32_t len, uint64_t* out) {
   if (len == 0 || len > 32) return ORC_E_SEQ_LEN;
+  const uint8_t* lut = kPackLut;
   uint64_t v = 0;
+  uint8_t bad = 0;
   for (uint32_t i = 0; i < len; i++) {
-    uint64_t c;
-    switch (seq[i]) {
-      case 'A': case 'a': c = 0; break;
-      case 'C': case 'c': c = 1; break;
-      case 'G': case 'g': c = 2; break;
-      case 'T': case 't': c = 3; break;
-      default: return ORC_E_BASE;
-    }
-    v |= c << (2 * i);
+    const uint8_t c = lut[seq[i]];
+    bad |= c;
+    v |= (uint64_t)(c & 3) << (2 * i);
   }
+  if (bad & 0x80) return ORC_E_BASE;
   *out = v;
   return 0;
 }

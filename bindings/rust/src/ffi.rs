@@ -138,6 +138,12 @@ extern "C" {
     pub fn ibu_barcode_counts(ctx: *mut ibu_ctx_t, d_sorted_records: *const c_void, n: usize, d_barcodes: *mut u64,
                               d_counts: *mut u64, d_unique_umis: *mut u64, cap: usize, n_barcodes: *mut usize,
                               n_barcode_umi_pairs: *mut usize, stream: *mut c_void) -> i32;
+    pub fn ibu_mmap_decode_to_host(m: *const ibu_mmap_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t, shard: usize,
+                                   n_shards: usize, h_bc_ascii: *mut u8, h_umi_ascii: *mut u8, h_index: *mut u64,
+                                   stats: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_writer_write_ascii_batch(w: *mut ibu_writer_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
+                                        h_bc_ascii: *const u8, h_umi_ascii: *const u8, h_index: *const u64, first_index: u64,
+                                        n: usize, bc_len: u32, umi_len: u32, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_device_alloc(ctx: *mut ibu_ctx_t, bytes: usize, d_ptr: *mut *mut c_void) -> i32;
     pub fn ibu_device_free(ctx: *mut ibu_ctx_t, d_ptr: *mut c_void) -> i32;
     pub fn ibu_memcpy_h2d(ctx: *mut ibu_ctx_t, d_dst: *mut c_void, h_src: *const c_void, bytes: usize,

@@ -221,6 +221,20 @@ class Writer:
         _check(lib.ibu_writer_write_batch_device(self._w, ctx._c, _ring(ring), _dptr(d_records), n, C.byref(st)))
         return st
 
+    def write_ascii_batch(self, ctx, bc_ascii, umi_ascii, bc_len, umi_len, index=None, first_index=0, ring=None):
+        """Host ASCII rows (uint8 arrays of n*bc_len / n*umi_len bytes) -> 2-bit records -> this writer, encoded on
+        the GPU (README.md:38-47's encode-then-write loop as one batch call)."""
+        bc = np.ascontiguousarray(bc_ascii, dtype=np.uint8).reshape(-1)
+        umi = np.ascontiguousarray(umi_ascii, dtype=np.uint8).reshape(-1)
+        n = bc.size // bc_len
+        assert bc.size == n * bc_len and umi.size == n * umi_len
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint64)
+        st = CStreamStats()
+        _check(lib.ibu_writer_write_ascii_batch(self._w, ctx._c, _ring(ring), _hptr(bc), _hptr(umi),
+                                                _hptr(idx) if idx is not None else None, first_index, n, bc_len, umi_len,
+                                                C.byref(st)))
+        return st
+
     def ingest(self, other):  # :477-482
         _check(lib.ibu_writer_ingest(self._w, other._w))
 
@@ -476,6 +490,20 @@ class MmapReader:
         return ctx._run_proc(
             lambda c, rg, s, st: lib.ibu_mmap_process_device(self._m, c, rg, proc, shard, n_shards, s, st),
             proc, sink, ring)
+
+    def decode_to_host(self, ctx, shard=0, n_shards=1, ring=None, want=("bc", "umi", "index")):
+        """One shard -> (barcode ASCII [n, bc_len], UMI ASCII [n, umi_len], index [n]) as numpy arrays in host
+        memory, unpacked on the GPU.  Columns not in `want` come back as None."""
+        a, b = shard_range(self.len(), n_shards, shard)
+        n, h = b - a, self.header()
+        bc = np.empty((n, h.bc_len), dtype=np.uint8) if "bc" in want else None
+        umi = np.empty((n, h.umi_len), dtype=np.uint8) if "umi" in want else None
+        idx = np.empty(n, dtype=np.uint64) if "index" in want else None
+        st = CStreamStats()
+        _check(lib.ibu_mmap_decode_to_host(self._m, ctx._c, _ring(ring), shard, n_shards,
+                                           _hptr(bc) if bc is not None else None, _hptr(umi) if umi is not None else None,
+                                           _hptr(idx) if idx is not None else None, C.byref(st)))
+        return bc, umi, idx, st
 
     def close(self):
         if getattr(self, "_m", None):

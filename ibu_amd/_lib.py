@@ -117,6 +117,8 @@ SIGNATURES = {
     "ibu_device_count": (i32, [P(i32)]),
     "ibu_ctx_set_option": (i32, [vp, C.c_char_p, C.c_int64]),
     "ibu_device_copy": (i32, [vp, vp, vp, sz, vp]),
+    "ibu_mmap_decode_to_host": (i32, [vp, vp, vp, sz, sz, vp, vp, vp, vp]),
+    "ibu_writer_write_ascii_batch": (i32, [vp, vp, vp, vp, vp, vp, u64, sz, u32, u32, vp]),
     "ibu_barcode_counts": (i32, [vp, vp, sz, vp, vp, vp, sz, P(sz), P(sz), vp]),
     "ibu_device_alloc": (i32, [vp, sz, P(vp)]),
     "ibu_device_free": (i32, [vp, vp]),

@@ -30,12 +30,24 @@ struct Ring {
   std::vector<hipEvent_t> consumed;  // kernel that read the slot finished
 };
 
+// Staging ring of the host <-> host codec pipelines (codec_stream.cpp): per slot one AoS side (24 B/record) and
+// one column side (up to 32 + 32 + 8 B/record), each as a pinned host buffer and a device buffer.
+struct CodecRing {
+  uint32_t slots = 0;
+  size_t slot_records = 0;
+  std::vector<uint8_t*> h_aos, h_col, d_aos, d_col;
+  std::vector<uint64_t*> h_status, d_status;  // [first_bad, n_bad] per slot: pinned copy / device slot
+  uint32_t events = 0;                        // events created so far (partial construction is released safely)
+  std::vector<hipEvent_t> up, done, down;     // H2D finished / kernel finished / D2H finished
+};
+
 }  // namespace ibu
 
 struct ibu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // compute
   hipStream_t copy_stream = nullptr;
+  hipStream_t d2h_stream = nullptr;  // results travel back while the next batch travels in (PCIe is full duplex)
   ibu::LaunchCfg cfg;
   uint64_t* d_status = nullptr;  // [first_bad_record, n_bad_records]
   uint64_t* d_acc = nullptr;     // [count, sum0..2, xor0..2, pad]
@@ -44,11 +56,13 @@ struct ibu_ctx {
   void* d_sort_scratch = nullptr;
   size_t sort_scratch_bytes = 0;
   ibu::Ring ring;
+  ibu::CodecRing cring;
 };
 
 namespace ibu {
 int32_t ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_dev);
 void ring_release(ibu_ctx* ctx);
+void codec_ring_release(ibu_ctx* ctx);
 inline hipStream_t pick_stream(const ibu_ctx* ctx, void* stream) {
   return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 }

@@ -58,6 +58,7 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
   // blocks_per_cu keeps LaunchCfg's measured default; ibu_ctx_set_option overrides it
   hipError_t rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 2 * sizeof(uint64_t));
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_acc), 8 * sizeof(uint64_t));
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_flag), 16);
@@ -78,7 +79,9 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
   ring_release(ctx);
+  codec_ring_release(ctx);
   if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->d_acc) (void)hipFree(ctx->d_acc);
@@ -86,6 +89,7 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   delete ctx;
 }
 extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value) {

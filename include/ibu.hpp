@@ -173,6 +173,11 @@ class Writer {
   }
   // device-resident AoS records -> pinned ring -> this writer, same buffered/direct rule (writer.rs:321-351)
   inline StreamStats write_batch_device(device::Context& ctx, const void* d_records, size_t n, const RingConfig* ring = nullptr);
+  // n rows of host ASCII (+ optional index column; nullptr -> first_index + i) -> GPU 2-bit encode -> this writer
+  // (README.md:38-47's encode-then-write loop as one batch call).  Throws InvalidBase{first_bad, n_bad}.
+  inline StreamStats write_ascii_batch(device::Context& ctx, const uint8_t* bc_ascii, const uint8_t* umi_ascii, const uint64_t* index,
+                                       size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t first_index = 0,
+                                       const RingConfig* ring = nullptr);
   ibu_writer_t* raw() const { return w_; }
 
  private:
@@ -321,6 +326,9 @@ class MmapReader {
                                                                      const RingConfig* ring = nullptr) const;
   inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t shard = 0,
                                            size_t n_shards = 1, const RingConfig* ring = nullptr) const;
+  // one shard -> ASCII barcodes / UMIs + index column in HOST memory, unpacked on the GPU
+  struct Decoded { std::vector<uint8_t> bc, umi; std::vector<uint64_t> index; StreamStats stats; };
+  inline Decoded decode_to_host(device::Context& ctx, size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
   ibu_mmap_t* raw() const { return m_; }
 
  private:
@@ -424,6 +432,22 @@ inline StreamStats Writer::write_batch_device(device::Context& ctx, const void* 
   StreamStats st{};
   check(ibu_writer_write_batch_device(w_, ctx.raw(), ring, d_records, n, &st));
   return st;
+}
+inline StreamStats Writer::write_ascii_batch(device::Context& ctx, const uint8_t* bc_ascii, const uint8_t* umi_ascii, const uint64_t* index,
+                                             size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t first_index, const RingConfig* ring) {
+  StreamStats st{};
+  check(ibu_writer_write_ascii_batch(w_, ctx.raw(), ring, bc_ascii, umi_ascii, index, first_index, n, bc_len, umi_len, &st));
+  return st;
+}
+inline MmapReader::Decoded MmapReader::decode_to_host(device::Context& ctx, size_t shard, size_t n_shards, const RingConfig* ring) const {
+  const auto range = shard_range(len(), n_shards, shard);
+  const size_t n = range.second - range.first;
+  const Header h = header();
+  Decoded d;
+  d.bc.resize(n * h.bc_len); d.umi.resize(n * h.umi_len); d.index.resize(n);
+  d.stats = StreamStats{};
+  check(ibu_mmap_decode_to_host(m_, ctx.raw(), ring, shard, n_shards, d.bc.data(), d.umi.data(), d.index.data(), &d.stats));
+  return d;
 }
 inline std::pair<ReduceResult, StreamStats> Reader::process_device_reduce(device::Context& ctx, const RingConfig* ring) {
   ReduceResult r{}; StreamStats st{};

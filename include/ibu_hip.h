@@ -378,6 +378,25 @@ int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_r
 int32_t ibu_reader_process_device(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                   int32_t proc, void* sink, ibu_stream_stats_t* stats);
 
+/* ---- host <-> host codec pipelines (data starts and ends in host memory / a file) ------------------------ */
+/* One shard of an MmapReader -> barcode / UMI ASCII and the index column IN HOST MEMORY: the reference's
+ * consumer loop (MmapReader::slice / process_parallel -> Record -> sequences, mmap.rs:253-332 + the 2-bit
+ * table record.rs:19-27) with the unpacking done on the GPU: map -> pinned ring -> H2D -> K2 decode -> D2H ->
+ * caller buffers, three streams overlapped.  Buffers hold shard_records rows (row i of the shard at
+ * h_bc_ascii + i*bc_len ...); any of them may be NULL to skip that column. */
+int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, size_t shard,
+                                size_t n_shards, uint8_t* h_bc_ascii, uint8_t* h_umi_ascii, uint64_t* h_index,
+                                ibu_stream_stats_t* stats);
+/* n rows of barcode / UMI ASCII in host memory (+ optional index column; NULL -> first_index + i) -> 2-bit
+ * records -> the writer: README.md:38-47's "sequences -> Record::new -> writer.write_record" loop as one
+ * batch call (H2D -> K3 encode -> D2H -> Writer::write_batch's buffered/direct rule, writer.rs:321-351).
+ * A byte outside ACGTacgt: IBU_ERR_INVALID_BASE (detail.a = first offending row, detail.b = offending
+ * rows); batches before the first offending one are already written, nothing from it on is. */
+int32_t ibu_writer_write_ascii_batch(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
+                                     const uint8_t* h_bc_ascii, const uint8_t* h_umi_ascii, const uint64_t* h_index,
+                                     uint64_t first_index, size_t n, uint32_t bc_len, uint32_t umi_len,
+                                     ibu_stream_stats_t* stats);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -233,3 +233,87 @@ def test_stream_stats_report_kernel_and_total_time(ia, ctx, oracle, tmp_path):
     assert st.records == n and st.batches == (n + 262_143) // 262_144 and st.bytes_h2d == 24 * n
     assert 0 < st.seconds_kernel <= st.seconds_total
     m.close()
+
+
+# ---- host <-> host codec pipelines (csrc/codec_stream.cpp) ----------------------------------------------------------
+TINY_RING = {"slots": 2, "slot_records": 1000, "feeder_threads": 1}
+
+
+@pytest.mark.parametrize("n", [0, 1, 127, 1024, 1025, 100_000, 700_001])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32), (15, 11)])
+@pytest.mark.parametrize("ring", [None, SMALL_RING, TINY_RING])
+def test_mmap_decode_to_host(ia, ctx, oracle, tmp_path, n, lens, ring):
+    if ring is TINY_RING and n > 200_000:
+        pytest.skip("1 Ki-record slots over 7e5 records adds nothing but time")
+    bc_len, umi_len = lens
+    p = tmp_path / "dh.ibu"
+    recs = _write_file(oracle, p, n, bc_len, umi_len)
+    wbc, wumi, widx = oracle.decode_records(recs, bc_len, umi_len)
+    m = ia.MmapReader.new(p)
+    bc, umi, idx, st = m.decode_to_host(ctx, ring=ring)
+    assert bc.tobytes() == wbc.tobytes() and umi.tobytes() == wumi.tobytes() and idx.tobytes() == widx.tobytes()
+    assert st.records == n and st.bytes_h2d == 24 * n and st.bytes_d2h == n * (bc_len + umi_len + 8)
+    # shards concatenate; skipped columns stay untouched
+    parts = [m.decode_to_host(ctx, shard=s, n_shards=3, ring=ring, want=("umi",)) for s in range(3)]
+    assert all(pt[0] is None and pt[2] is None for pt in parts)
+    assert b"".join(pt[1].tobytes() for pt in parts) == wumi.tobytes()
+    m.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 127, 1024, 1025, 100_000, 700_001])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32), (15, 11)])
+@pytest.mark.parametrize("with_index", [True, False])
+def test_writer_write_ascii_batch(ia, ctx, oracle, tmp_path, n, lens, with_index):
+    bc_len, umi_len = lens
+    recs = oracle.generate(SEED, 9, n, bc_len, umi_len)  # index column 9, 10, ...
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    if n > 10:  # lower case is accepted (record.rs:22-25 table is case-blind here, emitted upper on decode)
+        bc = bc.copy()
+        bc.reshape(-1)[: bc_len * 5] = np.frombuffer(bc.reshape(-1)[: bc_len * 5].tobytes().lower(), dtype=np.uint8)
+    p = tmp_path / "enc.ibu"
+    w = ia.Writer.from_path(p, ia.Header(bc_len, umi_len))
+    ring = SMALL_RING if n < 300_000 else None
+    st = w.write_ascii_batch(ctx, bc, umi, bc_len, umi_len, index=idx if with_index else None, first_index=9, ring=ring)
+    assert st.records == n and w.records_written() == n
+    w.finish()
+    w.close()
+    q = tmp_path / "want.ibu"
+    _write_file(oracle, q, n, bc_len, umi_len, first=9)
+    assert p.read_bytes() == q.read_bytes()
+
+
+def test_writer_write_ascii_batch_invalid_base(ia, ctx, oracle):
+    bc_len, umi_len, n = 16, 12, 10_000
+    recs = oracle.generate(SEED, 0, n, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    bc = bc.copy().reshape(n, bc_len)
+    umi = umi.copy().reshape(n, umi_len)
+    bc[5000, 3] = ord("N")
+    umi[7777, 0] = 0
+    w = ia.Writer.new_headless()
+    with pytest.raises(ia.IbuError) as e:
+        w.write_ascii_batch(ctx, bc, umi, bc_len, umi_len, ring=TINY_RING)  # 1024-row batches
+    assert e.value.kind == "InvalidBase" and e.value.first_bad == 5000 and e.value.n_bad == 2
+    w.finish()
+    # batches before the one holding row 5000 (rows 0..4095) were written, nothing after
+    assert w.records_written() == 4096
+    assert w.inner_bytes() == recs[:4096].tobytes()
+    # the context and the writer stay usable
+    w.write_ascii_batch(ctx, bc[:100], umi[:100], bc_len, umi_len, first_index=4096, ring=TINY_RING)
+    assert w.records_written() == 4196
+
+
+def test_host_codec_roundtrip_large(ia, ctx, oracle, tmp_path):
+    """file -> decode_to_host -> write_ascii_batch -> identical file (3e6 records, default ring)."""
+    n = 3_000_000
+    p = tmp_path / "big.ibu"
+    _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    bc, umi, idx, st = m.decode_to_host(ctx)
+    q = tmp_path / "back.ibu"
+    w = ia.Writer.from_path(q, m.header())
+    w.write_ascii_batch(ctx, bc, umi, 16, 12, index=idx)
+    w.finish()
+    w.close()
+    m.close()
+    assert p.read_bytes() == q.read_bytes()

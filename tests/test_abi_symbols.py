@@ -71,15 +71,22 @@ def test_device_entry_points_fail_loudly_without_gpu():
 
 
 def test_product_never_touches_the_oracle():
-    """oracle/ is test infrastructure: nothing under ibu_amd/ may import, link or mention it."""
+    """oracle/ is test infrastructure: nothing under ibu_amd/, include/, examples/, tools/ or bindings/ may import,
+    link or call it; bench.py may, inside its cpu_baseline leg only."""
     bad = []
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "ibu_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", "Makefile")):
-                txt = open(os.path.join(dirpath, f), errors="replace").read()
-                if re.search(r"ibu_oracle|from oracle|import oracle|orc_[a-z]", txt):
-                    bad.append(os.path.join(dirpath, f))
+    for top in ("ibu_amd", "include", "examples", "tools", "bindings"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".rs", "Makefile")):
+                    txt = open(os.path.join(dirpath, f), errors="replace").read()
+                    if re.search(r"ibu_oracle|from oracle|import oracle|orc_[a-z]", txt):
+                        bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle|import oracle|orc\.", bench)]
+    lo = bench.index("def cpu_baseline(")
+    hi = bench.index("\ndef ", lo + 1)
+    assert uses and all(lo < u < hi for u in uses), "bench.py touches the oracle outside cpu_baseline()"
     from ibu_amd import _lib
     deps = subprocess.run(["ldd", _lib.SO_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps

@@ -130,7 +130,17 @@ __device__ __forceinline__ u32x4 expand16(u32 w) {  // 16 bases
 
 // One 16-byte chunk `c` of the ASCII stream of a staged tile (rows of `len` bases, u64 field at
 // byte `foff` of records of stride `rstride`).  `len` may be a compile-time constant.
+// IBU_PROBE (measurement builds only, results are WRONG): 1 = keep the LDS traffic, drop the expansion ALU;
+// 2 = no LDS reads either.  Used with tools/kbench.py --so to tell an HBM bound from an issue/LDS bound.
+#ifndef IBU_PROBE
+#define IBU_PROBE 0
+#endif
 __device__ __forceinline__ u32x4 expand_chunk(const uint8_t* tile, u32 rstride, u32 foff, u32 len, u32 c) {
+#if IBU_PROBE == 1
+  { const u32 w = *reinterpret_cast<const u32*>(tile + (c & 127u) * rstride + foff); u32x4 o; o.x = o.y = o.z = o.w = w; return o; }
+#elif IBU_PROBE == 2
+  { u32x4 o; o.x = o.y = o.z = o.w = c + len + rstride + foff; return o; }
+#endif
   if ((len & 3) == 0) {
     const u32 l4 = len >> 2;                       // code bytes per row (1..8)
     if (l4 == 4) return expand16(*reinterpret_cast<const u32*>(tile + c * rstride + foff));

@@ -51,6 +51,7 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   sb.issue(bc_in + (size_t)t * kTileRecs * bc_len, bc_len, lane);
   su.issue(umi_in + (size_t)t * kTileRecs * umi_len, umi_len, lane);
   u32x4 vi = ld16(idx_src + (size_t)t * idx_tile);
+  BadRows bad;
   for (;;) {
     const size_t row0 = (size_t)t * kTileRecs;
     wave_lds_fence();                          // previous tile's AoS reads precede these writes
@@ -74,8 +75,8 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
     if (!oku0) u0 = 0;
     if (!okb1) b1 = 0;
     if (!oku1) u1 = 0;
-    report_bad(!(okb0 && oku0), row0 + 2 * lane, status, lane);
-    report_bad(!(okb1 && oku1), row0 + 2 * lane + 1, status, lane);
+    bad.note(!(okb0 && oku0), row0 + 2 * lane);
+    bad.note(!(okb1 && oku1), row0 + 2 * lane + 1);
     wave_lds_fence();                          // all ASCII reads done before the area is reused
     u64* r = reinterpret_cast<u64*>(area + lane * 48);
     r[0] = b0; r[1] = u0; r[2] = i0; r[3] = b1; r[4] = u1; r[5] = i1;
@@ -87,6 +88,7 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
     if (!more) break;
     t = tn;
   }
+  bad.flush(status);
 }
 
 // Single ASCII column -> u64 codes.
@@ -104,6 +106,7 @@ ibu_k_pack(const uint8_t* __restrict__ in, u32 ntiles, u32 len, u64* __restrict_
   if (t >= ntiles) return;
   AsciiStage<LEN> sv;
   sv.issue(in + (size_t)t * kTileRecs * len, len, lane);
+  BadRows bad;
   for (;;) {
     const size_t row0 = (size_t)t * kTileRecs;
     wave_lds_fence();
@@ -117,13 +120,14 @@ ibu_k_pack(const uint8_t* __restrict__ in, u32 ntiles, u32 len, u64* __restrict_
     u64 v1 = pack_row<LEN>(asc + (2 * lane + 1) * len, len, ok1);
     if (!ok0) v0 = 0;
     if (!ok1) v1 = 0;
-    report_bad(!ok0, row0 + 2 * lane, status, lane);
-    report_bad(!ok1, row0 + 2 * lane + 1, status, lane);
+    bad.note(!ok0, row0 + 2 * lane);
+    bad.note(!ok1, row0 + 2 * lane + 1);
     u32x4 o; o.x = (u32)v0; o.y = (u32)(v0 >> 32); o.z = (u32)v1; o.w = (u32)(v1 >> 32);
     st16(reinterpret_cast<uint8_t*>(codes) + row0 * 8 + 16 * lane, o);
     if (!more) break;
     t = tn;
   }
+  bad.flush(status);
 }
 
 // ---- tails: one thread per record, any alignment -----------------------------------------------

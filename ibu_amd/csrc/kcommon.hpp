@@ -262,15 +262,30 @@ struct AsciiStage {
   }
 };
 
-// Report offending rows of this wave's tile: one atomicMin + one atomicAdd per wave, and only
-// when something is actually wrong (wave-uniform branch on the ballot).
-__device__ __forceinline__ void report_bad(bool bad, u64 row_global, u64* status, u32 lane) {
-  u64 m = __ballot(bad);
-  if (m) {
-    if (bad) atomicMin(&status[0], row_global);
-    if (lane == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&status[1], (u64)__popcll(m));
+// Offending rows (a byte outside ACGTacgt) are tallied per lane in registers while a wave sweeps its tiles and
+// reported ONCE per wave when it leaves the kernel: one atomicMin (first offending row) + one atomicAdd (count),
+// and only if something was wrong.  No atomics in the loop: input that is wrong everywhere costs the same as
+// valid input (it used to cost two atomics per tile: 365 ms instead of 10 ms at 1e9 all-invalid rows).
+struct BadRows {
+  u64 first = ~0ull;
+  u32 count = 0;
+  __device__ __forceinline__ void note(bool bad, u64 row_global) {
+    if (bad) { first = row_global < first ? row_global : first; ++count; }
   }
-}
+  __device__ __forceinline__ void flush(u64* status) const {
+    if (__ballot(count != 0) == 0) return;         // wave-uniform: the common case leaves here
+    u64 f = first;
+    u32 c = count;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const u32 flo = __shfl_xor((u32)f, m), fhi = __shfl_xor((u32)(f >> 32), m);
+      const u64 fo = ((u64)fhi << 32) | flo;
+      f = fo < f ? fo : f;
+      c += __shfl_xor(c, m);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicMin(&status[0], f); atomicAdd(&status[1], (u64)c); }
+  }
+};
 
 __device__ __forceinline__ u64 mask2(u32 len) { return len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1); }
 

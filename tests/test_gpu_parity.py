@@ -299,3 +299,18 @@ def test_large_roundtrip_properties(ctx):
     # spot-check raw bytes of the first and last MiB
     for off in (0, n * 24 - (1 << 20)):
         assert d_recs.download(count=1 << 20, offset=off).tobytes() == d_back.download(count=1 << 20, offset=off).tobytes()
+
+
+def test_all_rows_invalid_is_counted_exactly(ia, ctx):
+    """Every row bad (the per-wave tally is flushed once per wave: no atomics in the loop, same cost as valid input)."""
+    n, bc_len, umi_len = 1_000_003, 16, 12
+    bc = ctx.upload(np.full(n * bc_len, ord("N"), dtype=np.uint8))
+    umi = ctx.upload(np.full(n * umi_len, ord("A"), dtype=np.uint8))
+    out = ctx.alloc(n * 24)
+    ctx.encode_ascii(bc, umi, None, n, bc_len, umi_len, out)
+    with pytest.raises(ia.IbuError) as e:
+        ctx.codec_status()
+    assert e.value.kind == "InvalidBase" and e.value.first_bad == 0 and e.value.n_bad == n
+    recs = out.download(np.uint64, count=3 * n).reshape(n, 3)
+    assert not recs[:, 0].any() and not recs[:, 1].any() and (recs[:, 2] == np.arange(n, dtype=np.uint64)).all()
+    ctx.codec_status()  # re-armed

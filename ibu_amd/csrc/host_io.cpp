@@ -266,6 +266,145 @@ struct GzSource : Source {
   }
 };
 
+// BGZF (bgzip) input: a gzip file whose members are <= 64 KiB blocks that carry their own compressed size in a
+// "BC" extra subfield.  To niffler / flate2's MultiGzDecoder it is just a multi-member gzip stream, inflated by
+// one thread; because the block boundaries are known WITHOUT inflating, this source reads a batch of blocks and
+// inflates them on several threads.  Same output bytes, same error class (EPROTO -> IBU_ERR_NIFFLER); CRC32 and
+// ISIZE of every block are verified.  A member that is not a BGZF block hands the rest of the stream to the
+// sequential GzSource (mixed files stay correct).
+struct BgzfSource : Source {
+  std::unique_ptr<Source> inner;
+  std::unique_ptr<Source> fallback;   // sequential inflate once a non-BGZF member shows up
+  std::vector<uint8_t> comp, out;
+  size_t out_pos = 0;
+  bool eof = false;
+  unsigned threads;
+  struct Block { size_t coff, clen, ooff, isize; uint32_t crc; };
+  explicit BgzfSource(std::unique_ptr<Source> s) : inner(std::move(s)) {
+    size_t c = ibu::host_cores();
+    threads = (unsigned)(c < 1 ? 1 : (c > 16 ? 16 : c));
+  }
+  int read_exact(uint8_t* dst, size_t n, size_t* got_total) {
+    size_t have = 0;
+    while (have < n) {
+      size_t k = 0;
+      int rc = inner->read(dst + have, n - have, &k);
+      if (rc) return rc;
+      if (k == 0) break;
+      have += k;
+    }
+    *got_total = have;
+    return 0;
+  }
+  static int inflate_block(z_stream* zs, const uint8_t* c, size_t clen, uint8_t* o, size_t isize, uint32_t crc) {
+    if (inflateReset(zs) != Z_OK) return EPROTO;
+    zs->next_in = const_cast<uint8_t*>(c);
+    zs->avail_in = (uInt)clen;
+    zs->next_out = o;
+    zs->avail_out = (uInt)isize;
+    const int rc = inflate(zs, Z_FINISH);
+    if (rc != Z_STREAM_END || zs->avail_out != 0 || zs->avail_in != 0) return EPROTO;
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), o, (uInt)isize) != crc) return EPROTO;
+    return 0;
+  }
+  int refill() {
+    comp.clear();
+    out.clear();
+    out_pos = 0;
+    std::vector<Block> blocks;
+    size_t total_out = 0;
+    const size_t kBatchComp = (size_t)16 << 20;
+    while (comp.size() < kBatchComp && !eof) {
+      uint8_t hd[12];
+      size_t got = 0;
+      int rc = read_exact(hd, 12, &got);
+      if (rc) return rc;
+      if (got == 0) { eof = true; break; }
+      if (got < 12) return EPROTO;
+      const bool bgzf_like = hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8 && (hd[3] & 4);
+      uint16_t xlen = (uint16_t)(hd[10] | (hd[11] << 8));
+      std::vector<uint8_t> extra(bgzf_like ? xlen : 0);
+      size_t bsize = 0;
+      if (bgzf_like) {
+        rc = read_exact(extra.data(), xlen, &got);
+        if (rc) return rc;
+        if (got < xlen) return EPROTO;
+        for (size_t p = 0; p + 4 <= extra.size();) {
+          const size_t slen = (size_t)(extra[p + 2] | (extra[p + 3] << 8));
+          if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= extra.size()) bsize = (size_t)(extra[p + 4] | (extra[p + 5] << 8)) + 1;
+          p += 4 + slen;
+        }
+      }
+      if (!bgzf_like || bsize < 12 + 2 + (size_t)xlen + 8) {
+        // not a BGZF block: push what was consumed back and let the sequential decoder take over from here
+        std::unique_ptr<PrefixSource> ps(new PrefixSource);
+        ps->pre.assign(hd, hd + 12);
+        ps->pre.insert(ps->pre.end(), extra.begin(), extra.end());
+        ps->inner = std::move(inner);
+        fallback.reset(new GzSource(std::move(ps)));
+        break;
+      }
+      const size_t rest = bsize - 12 - xlen;  // deflate data + CRC32 + ISIZE
+      const size_t off = comp.size();
+      comp.resize(off + rest);
+      rc = read_exact(comp.data() + off, rest, &got);
+      if (rc) return rc;
+      if (got < rest) return EPROTO;  // stream ends inside a block
+      const uint8_t* tr = comp.data() + off + rest - 8;
+      Block b;
+      b.coff = off;
+      b.clen = rest - 8;
+      b.crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+      b.isize = (size_t)tr[4] | ((size_t)tr[5] << 8) | ((size_t)tr[6] << 16) | ((size_t)tr[7] << 24);
+      if (b.isize > 65536) return EPROTO;
+      b.ooff = total_out;
+      total_out += b.isize;
+      blocks.push_back(b);
+    }
+    out.resize(total_out);
+    if (blocks.empty()) return 0;
+    const unsigned nt = blocks.size() < threads ? (unsigned)blocks.size() : threads;
+    std::vector<int> rcs(nt, 0);
+    auto work = [&](unsigned t) {
+      z_stream zs;
+      memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { rcs[t] = EPROTO; return; }
+      for (size_t i = t; i < blocks.size(); i += nt) {
+        const Block& b = blocks[i];
+        if (b.isize == 0 && b.clen <= 2) continue;  // empty block (the EOF marker)
+        const int rc = inflate_block(&zs, comp.data() + b.coff, b.clen, out.data() + b.ooff, b.isize, b.crc);
+        if (rc) { rcs[t] = rc; break; }
+      }
+      inflateEnd(&zs);
+    };
+    if (nt == 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+      for (auto& x : th) x.join();
+    }
+    for (int r : rcs)
+      if (r) return r;
+    return 0;
+  }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    *got = 0;
+    for (;;) {
+      if (out_pos < out.size()) {
+        const size_t k = out.size() - out_pos < cap ? out.size() - out_pos : cap;
+        memcpy(dst, out.data() + out_pos, k);
+        out_pos += k;
+        *got = k;
+        return 0;
+      }
+      if (fallback) return fallback->read(dst, cap, got);
+      if (eof) return 0;
+      const int rc = refill();
+      if (rc) return rc;
+    }
+  }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -466,20 +605,25 @@ int32_t reader_make(std::unique_ptr<Source> src, bool compressed, ibu_reader_t**
 // niffler::send::get_reader: sniff the first bytes, wrap in a decoder when compressed.
 int32_t reader_make_sniffed(std::unique_ptr<Source> src, ibu_reader_t** out) {
   std::unique_ptr<PrefixSource> ps(new PrefixSource);
-  ps->pre.resize(5);
+  ps->pre.resize(18);  // 5 bytes decide the format (niffler); 18 tell a BGZF block from a plain gzip member
   size_t have = 0;
-  while (have < 5) {
+  while (have < 18) {
     size_t got = 0;
-    int e = src->read(ps->pre.data() + have, 5 - have, &got);
+    int e = src->read(ps->pre.data() + have, 18 - have, &got);
     if (e) return err_io(e, "read");
     if (got == 0) break;
     have += got;
   }
+  ps->pre.resize(have);
   if (have < 5) return err_niffler("file too short to sniff its format");
   const uint8_t* m = ps->pre.data();
   ps->inner = std::move(src);
-  if (m[0] == 0x1f && m[1] == 0x8b)
+  if (m[0] == 0x1f && m[1] == 0x8b) {
+    const bool bgzf = have >= 18 && m[2] == 8 && (m[3] & 4) && m[12] == 'B' && m[13] == 'C' && m[14] == 2 && m[15] == 0;
+    if (bgzf && !getenv("IBU_NO_PARALLEL_BGZF"))
+      return reader_make(std::unique_ptr<Source>(new BgzfSource(std::move(ps))), true, out);
     return reader_make(std::unique_ptr<Source>(new GzSource(std::move(ps))), true, out);
+  }
   if ((m[0] == 0x42 && m[1] == 0x5a) || (m[0] == 0xfd && m[1] == 0x37 && m[2] == 0x7a && m[3] == 0x58 && m[4] == 0x5a) ||
       (m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd))
     return err_niffler("bzip2/xz/zstd input: decoder not built into this library (gzip only)");

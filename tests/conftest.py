@@ -24,3 +24,4 @@ def kat():
 def oracle():
     from oracle import oracle as orc
     return orc
+

@@ -164,13 +164,17 @@ def test_mmap_process_device_decode_shards_concatenate(ia, ctx, oracle, tmp_path
     m.close()
 
 
-@pytest.mark.parametrize("compressed", [False, True])
+@pytest.mark.parametrize("compressed", [False, True, "bgzf"])
 @pytest.mark.parametrize("n", [0, 1, 49_152, 100_000, 500_003])
 def test_reader_process_device_plain_and_gzip(ia, ctx, oracle, tmp_path, compressed, n):
     p = tmp_path / "r.ibu"
     recs = _write_file(oracle, p, n)
     path = p
-    if compressed:
+    if compressed == "bgzf":  # bgzip'd input: block-parallel inflate on the host, same bytes
+        from tests.bgzf import bgzf_compress
+        path = tmp_path / "r.ibu.bgz"
+        path.write_bytes(bgzf_compress(p.read_bytes()))
+    elif compressed:
         path = tmp_path / "r.ibu.gz"
         raw = p.read_bytes()
         half = len(raw) // 2

@@ -4,6 +4,7 @@
 // This is I/O plumbing (syscalls, buffering, error mapping): it performs no codec or record
 // arithmetic — that lives only in the k_*.hip kernel files.  Reference lines are cited per function; the
 // quirk numbers (Q1..Q15) refer to SURVEY.md Appendix C.
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <sched.h>
@@ -262,6 +263,184 @@ struct GzSource : Source {
       else if (rc != Z_OK && rc != Z_BUF_ERROR) return EPROTO;
     }
     *got = want - zs.avail_out;
+    return 0;
+  }
+};
+
+// bzip2 / xz / zstd input — the rest of niffler's format set (reader.rs:348-352 sniffs all four).  This image
+// ships the runtime libraries (libbz2.so.1, liblzma.so.5, libzstd.so.1) but not their headers, so the three
+// decoders are bound with dlopen and the handful of prototypes / stream structs below (all of them frozen ABI
+// of those libraries).  A missing library gives IBU_ERR_NIFFLER when such a file is opened; nothing else depends
+// on them.  Concatenated streams / frames are followed to the end, like the gzip path.
+struct DlLib {
+  void* h = nullptr;
+  explicit DlLib(const char* const* names) {
+    for (; *names && !h; ++names) h = dlopen(*names, RTLD_NOW | RTLD_LOCAL);
+  }
+  template <class F> F sym(const char* n) const { return h ? reinterpret_cast<F>(dlsym(h, n)) : nullptr; }
+};
+
+struct InflatingSource : Source {  // shared refill loop: inner bytes -> `in`, subclass turns them into output
+  std::unique_ptr<Source> inner;
+  std::vector<uint8_t> in;
+  size_t in_pos = 0, in_len = 0;
+  bool inner_eof = false;
+  explicit InflatingSource(std::unique_ptr<Source> s) : inner(std::move(s)), in(1 << 18) {}
+  int fill() {  // 0 / errno; sets inner_eof
+    if (in_pos < in_len || inner_eof) return 0;
+    size_t k = 0;
+    int rc = inner->read(in.data(), in.size(), &k);
+    if (rc) return rc;
+    in_pos = 0;
+    in_len = k;
+    if (k == 0) inner_eof = true;
+    return 0;
+  }
+};
+
+struct BzSource : InflatingSource {
+  struct bz_stream {
+    char* next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+    char* next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+    void* state; void* (*bzalloc)(void*, int, int); void (*bzfree)(void*, void*); void* opaque;
+  };
+  typedef int (*init_fn)(bz_stream*, int, int);
+  typedef int (*run_fn)(bz_stream*);
+  init_fn init = nullptr; run_fn run = nullptr, end = nullptr;
+  bz_stream zs;
+  bool live = false, done_stream = true;
+  explicit BzSource(std::unique_ptr<Source> s) : InflatingSource(std::move(s)) {
+    static const char* const names[] = {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so", nullptr};
+    static DlLib lib(names);
+    init = lib.sym<init_fn>("BZ2_bzDecompressInit");
+    run = lib.sym<run_fn>("BZ2_bzDecompress");
+    end = lib.sym<run_fn>("BZ2_bzDecompressEnd");
+    memset(&zs, 0, sizeof zs);
+  }
+  ~BzSource() override { if (live) end(&zs); }
+  bool usable() const { return init && run && end; }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    *got = 0;
+    if (!usable()) return EPROTO;
+    const unsigned want = cap > (1u << 30) ? (1u << 30) : (unsigned)cap;
+    size_t produced = 0;
+    while (produced == 0) {
+      int rc = fill();
+      if (rc) return rc;
+      if (done_stream) {
+        if (in_pos == in_len && inner_eof) return 0;  // clean end after a whole stream
+        if (live) { end(&zs); live = false; }
+        memset(&zs, 0, sizeof zs);
+        if (init(&zs, 0, 0) != 0) return EPROTO;
+        live = true;
+        done_stream = false;
+      }
+      if (in_pos == in_len && inner_eof) return EPROTO;  // ends inside a stream
+      zs.next_in = reinterpret_cast<char*>(in.data() + in_pos);
+      zs.avail_in = (unsigned)(in_len - in_pos);
+      zs.next_out = reinterpret_cast<char*>(dst);
+      zs.avail_out = want;
+      const int r = run(&zs);
+      in_pos = in_len - zs.avail_in;
+      produced = want - zs.avail_out;
+      if (r == 4 /*BZ_STREAM_END*/) done_stream = true;
+      else if (r != 0 /*BZ_OK*/) return EPROTO;
+    }
+    *got = produced;
+    return 0;
+  }
+};
+
+struct XzSource : InflatingSource {
+  struct lzma_stream {
+    const uint8_t* next_in; size_t avail_in; uint64_t total_in;
+    uint8_t* next_out; size_t avail_out; uint64_t total_out;
+    const void* allocator; void* internal;
+    void *rp1, *rp2, *rp3, *rp4; uint64_t ri1, ri2; size_t ri3, ri4; int re1, re2;
+  };
+  typedef int (*dec_fn)(lzma_stream*, uint64_t, uint32_t);
+  typedef int (*code_fn)(lzma_stream*, int);
+  typedef void (*end_fn)(lzma_stream*);
+  dec_fn dec = nullptr; code_fn code = nullptr; end_fn end = nullptr;
+  lzma_stream zs;
+  bool live = false, finished = false;
+  explicit XzSource(std::unique_ptr<Source> s) : InflatingSource(std::move(s)) {
+    static const char* const names[] = {"liblzma.so.5", "liblzma.so", nullptr};
+    static DlLib lib(names);
+    dec = lib.sym<dec_fn>("lzma_stream_decoder");
+    code = lib.sym<code_fn>("lzma_code");
+    end = lib.sym<end_fn>("lzma_end");
+    memset(&zs, 0, sizeof zs);
+    if (usable() && dec(&zs, UINT64_MAX, 0x08 /*LZMA_CONCATENATED*/) == 0) live = true;
+  }
+  ~XzSource() override { if (live) end(&zs); }
+  bool usable() const { return dec && code && end; }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    *got = 0;
+    if (!live) return EPROTO;
+    if (finished) return 0;
+    zs.next_out = dst;
+    zs.avail_out = cap;
+    while (zs.avail_out == cap) {
+      int rc = fill();
+      if (rc) return rc;
+      zs.next_in = in.data() + in_pos;
+      zs.avail_in = in_len - in_pos;
+      const int r = code(&zs, inner_eof && zs.avail_in == 0 ? 3 /*LZMA_FINISH*/ : 0 /*LZMA_RUN*/);
+      in_pos = in_len - zs.avail_in;
+      if (r == 1 /*LZMA_STREAM_END*/) { finished = true; break; }
+      if (r != 0 /*LZMA_OK*/) return EPROTO;  // incl. LZMA_BUF_ERROR: truncated input
+    }
+    *got = cap - zs.avail_out;
+    return 0;
+  }
+};
+
+struct ZstdSource : InflatingSource {
+  struct Buf { const void* p; size_t size, pos; };
+  struct OBuf { void* p; size_t size, pos; };
+  typedef void* (*create_fn)();
+  typedef size_t (*free_fn)(void*);
+  typedef size_t (*init_fn)(void*);
+  typedef size_t (*run_fn)(void*, OBuf*, Buf*);
+  typedef unsigned (*iserr_fn)(size_t);
+  create_fn create = nullptr; free_fn freef = nullptr; init_fn init = nullptr; run_fn run = nullptr; iserr_fn iserr = nullptr;
+  void* ds = nullptr;
+  size_t hint = 0;  // last return value: 0 = a frame just ended
+  bool started = false;
+  explicit ZstdSource(std::unique_ptr<Source> s) : InflatingSource(std::move(s)) {
+    static const char* const names[] = {"libzstd.so.1", "libzstd.so", nullptr};
+    static DlLib lib(names);
+    create = lib.sym<create_fn>("ZSTD_createDStream");
+    freef = lib.sym<free_fn>("ZSTD_freeDStream");
+    init = lib.sym<init_fn>("ZSTD_initDStream");
+    run = lib.sym<run_fn>("ZSTD_decompressStream");
+    iserr = lib.sym<iserr_fn>("ZSTD_isError");
+    if (usable()) {
+      ds = create();
+      if (ds && iserr(init(ds))) { freef(ds); ds = nullptr; }
+    }
+  }
+  ~ZstdSource() override { if (ds) freef(ds); }
+  bool usable() const { return create && freef && init && run && iserr; }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    *got = 0;
+    if (!ds) return EPROTO;
+    OBuf o{dst, cap, 0};
+    while (o.pos == 0) {
+      int rc = fill();
+      if (rc) return rc;
+      if (in_pos == in_len && inner_eof) {
+        if (started && hint != 0) return EPROTO;  // ends inside a frame
+        return 0;
+      }
+      Buf i{in.data(), in_len, in_pos};
+      hint = run(ds, &o, &i);
+      if (iserr(hint)) return EPROTO;
+      started = true;
+      in_pos = i.pos;
+    }
+    *got = o.pos;
     return 0;
   }
 };
@@ -574,7 +753,7 @@ struct ibu_reader {
 namespace {
 
 int32_t src_error(const ibu_reader* r, int e, const char* what) {
-  if (r && r->compressed && e == EPROTO) return err_niffler("corrupt or truncated gzip stream");
+  if (r && r->compressed && e == EPROTO) return err_niffler("corrupt or truncated compressed stream");
   return err_io(e, what);
 }
 
@@ -624,9 +803,21 @@ int32_t reader_make_sniffed(std::unique_ptr<Source> src, ibu_reader_t** out) {
       return reader_make(std::unique_ptr<Source>(new BgzfSource(std::move(ps))), true, out);
     return reader_make(std::unique_ptr<Source>(new GzSource(std::move(ps))), true, out);
   }
-  if ((m[0] == 0x42 && m[1] == 0x5a) || (m[0] == 0xfd && m[1] == 0x37 && m[2] == 0x7a && m[3] == 0x58 && m[4] == 0x5a) ||
-      (m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd))
-    return err_niffler("bzip2/xz/zstd input: decoder not built into this library (gzip only)");
+  if (m[0] == 0x42 && m[1] == 0x5a && m[2] == 0x68) {  // "BZh"
+    std::unique_ptr<BzSource> z(new BzSource(std::move(ps)));
+    if (!z->usable()) return err_niffler("bzip2 input: libbz2.so.1 is not available on this host");
+    return reader_make(std::move(z), true, out);
+  }
+  if (m[0] == 0xfd && m[1] == 0x37 && m[2] == 0x7a && m[3] == 0x58 && m[4] == 0x5a) {  // FD "7zXZ"
+    std::unique_ptr<XzSource> z(new XzSource(std::move(ps)));
+    if (!z->usable()) return err_niffler("xz input: liblzma.so.5 is not available on this host");
+    return reader_make(std::move(z), true, out);
+  }
+  if (m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) {  // zstd frame magic
+    std::unique_ptr<ZstdSource> z(new ZstdSource(std::move(ps)));
+    if (!z->usable()) return err_niffler("zstd input: libzstd.so.1 is not available on this host");
+    return reader_make(std::move(z), true, out);
+  }
   return reader_make(std::move(ps), false, out);
 }
 

@@ -165,7 +165,9 @@ typedef int32_t (*ibu_read_fn)(void* user, uint8_t* dst, size_t cap, size_t* got
 int32_t ibu_reader_open_callback(ibu_read_fn rd, void* user, ibu_reader_t** out);
 /* Reader::new(Cursor<&[u8]>) — bytes are borrowed, not copied. */
 int32_t ibu_reader_open_mem(const uint8_t* data, size_t len, ibu_reader_t** out);
-/* Reader::from_path :345-352 — sniffs gzip magic (niffler's role); plain files pass through. */
+/* Reader::from_path :345-352 — sniffs the format by magic bytes (niffler's role): gzip (BGZF input is inflated
+ * block-parallel), bzip2, xz and zstd are decoded (the last three through the host's libbz2 / liblzma / libzstd,
+ * bound at run time; IBU_ERR_NIFFLER if the library is absent); plain files pass through. */
 int32_t ibu_reader_open_path(const char* path, ibu_reader_t** out);
 int32_t ibu_reader_open_fd(int fd, ibu_reader_t** out); /* from_stdin :389-396 (fd 0), sniffs too */
 

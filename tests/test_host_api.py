@@ -383,6 +383,55 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
     assert ei.value.kind == "Niffler"
 
 
+def _zstd_compress(data, level=1):
+    """libzstd.so.1 through ctypes (no Python module for it in the image)."""
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    cap = z.ZSTD_compressBound(len(data))
+    buf = C.create_string_buffer(cap)
+    k = z.ZSTD_compress(buf, cap, data, len(data), level)
+    assert not z.ZSTD_isError(k)
+    return buf.raw[:k]
+
+
+def test_reader_from_path_bzip2_xz_zstd(tmp_path, oracle):
+    """The rest of niffler's format set (reader.rs:348-352): sniffed by magic, decoded through the system libraries."""
+    import bz2
+    import lzma
+
+    recs = oracle.generate(7, 0, 60_000, 16, 12)
+    raw = create_test_data(recs)
+    cut = 32 + 24 * 20_000 + 11
+    cases = {
+        "a.ibu.bz2": bz2.compress(raw, 1),
+        "multi.ibu.bz2": bz2.compress(raw[:cut], 1) + bz2.compress(raw[cut:], 9),      # concatenated streams
+        "a.ibu.xz": lzma.compress(raw, preset=0),
+        "multi.ibu.xz": lzma.compress(raw[:cut], preset=0) + lzma.compress(raw[cut:], preset=1),
+        "a.ibu.zst": _zstd_compress(raw),
+        "multi.ibu.zst": _zstd_compress(raw[:cut]) + _zstd_compress(raw[cut:], 3),     # concatenated frames
+    }
+    for name, blob in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        r = Reader.from_path(p)
+        assert r.header() == Header(16, 12)
+        got = records_array(list(r))
+        assert got.tobytes() == recs.tobytes(), name
+    for name in ("a.ibu.bz2", "a.ibu.xz", "a.ibu.zst"):  # truncated input is a decoder error, not silence
+        bad = tmp_path / ("cut_" + name)
+        bad.write_bytes(cases[name][: len(cases[name]) * 2 // 3])
+        with pytest.raises(IbuError) as ei:
+            list(Reader.from_path(bad))
+        assert ei.value.kind in ("Niffler", "TruncatedRecord"), name
+    with pytest.raises(IbuError) as ei:  # load_to_vec never decompresses (Q10)
+        load_to_vec(tmp_path / "a.ibu.zst")
+    assert ei.value.kind == "InvalidMagicNumber"
+
+
 # ---------------------------------------------------------------- mmap.rs / parallel.rs tests
 class TestProcessor(ParallelProcessor):  # mmap.rs:350-373, parallel.rs:359-382
     __test__ = False

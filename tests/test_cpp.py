@@ -49,6 +49,31 @@ def test_parallel_example(built, tmp_path):
     assert out["sums"][1] == sum((i * 31) % 1_000_000 for i in range(n))
 
 
+def test_random_example(built, tmp_path):
+    """examples/random.rs shape: value ranges and CLI; the UMI is NOT masked to umi_len."""
+    import numpy as np
+
+    sys_path = os.path.join(ROOT)
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import ibu_amd as ia
+
+    p = tmp_path / "rand.ibu"
+    r = _run([os.path.join(built, "random"), str(p), "--records", "0.05", "--barcodes", "37", "--max-index", "500", "--seed", "42"])
+    assert r.returncode == 0, r.stderr
+    assert "Finished generating 50000 records" in r.stderr
+    h, recs = ia.load_to_vec(p)
+    assert (h.bc_len, h.umi_len, h.sorted()) == (16, 12, False) and len(recs) == 50_000
+    assert recs["barcode"].max() < 37 and recs["index"].max() < 500 and len(np.unique(recs["barcode"])) == 37
+    assert recs["umi"].max() > 2**24  # full-range u64 under umi_len = 12
+    again = tmp_path / "again.ibu"
+    _run([os.path.join(built, "random"), str(again), "--records", "0.05", "--barcodes", "37", "--max-index", "500", "--seed", "42"])
+    assert again.read_bytes() == p.read_bytes()  # a seed reproduces the file
+    bad = _run([os.path.join(built, "random"), str(tmp_path / "bad.ibu"), "--bc-len", "33"])
+    assert bad.returncode == 1 and "InvalidBarcodeLength" in bad.stderr  # header.validate() before anything is written
+
+
 @pytest.mark.gpu
 def test_cpp_device_tests(built, tmp_path):
     r = _run([os.path.join(built, "test_device")], env={**os.environ, "TMPDIR": str(tmp_path)})

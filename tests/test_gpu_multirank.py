@@ -1,0 +1,48 @@
+"""Two ranks (one process each, gloo collectives) sharing the one GPU of the test box: the N>1 code paths of
+bench.py and of the sharded-file tool end to end — rank shards, per-rank contexts, the single cross-rank exchange."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(nproc, script, *args):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), script, *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    out = _torchrun(2, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "5e7", "--backend", "gloo",
+                    "--share-gpu", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["global_count"] == 100_000_000 and out["verified_roundtrip"] is True
+    assert out["scaling"] == "weak" and out["config"]["records_total"] == 100_000_000
+
+
+@pytest.mark.parametrize("proc", ["reduce", "decode"])
+def test_sharded_file_two_ranks(tmp_path, proc, oracle):
+    n = 3_000_001
+    path = str(tmp_path / "shared.ibu")
+    out = _torchrun(2, "tools/sharded_file.py", path, "--make", str(n), "--proc", proc, "--backend", "gloo", "--share-gpu")
+    assert out["file_records"] == n and out["count"] == n and out["ranks"] == 2
+    assert out["rank0_shard"] == [0, n // 2]
+    want = oracle.reduce_records(oracle.generate(0x1B00003, 0, n, 16, 12))
+    assert out["sums"][2] == want["sum"][2]
+    if proc == "reduce":
+        assert out["sums"] == want["sum"] and out["xors"] == want["xor"]

@@ -401,6 +401,22 @@ TEST(error_display_messages) {  // error.rs:196-248: the wording the reference a
   try { mm.process_parallel(FailAt{3}, 1); CHECK(false); } catch (const IbuError& e) { CHECK(std::string(e.what()).find("Processing error") != std::string::npos); }
 }
 
+// ---------------------------------------------------------------- niffler's formats (files prepared by tests/test_cpp.py)
+TEST(compressed_inputs_decode_to_the_plain_records) {  // reader.rs:345-352
+  const char* dir = std::getenv("IBU_TEST_COMPRESSED_DIR");
+  if (!dir) return;  // only run with the fixture directory
+  auto want = load_to_vec(std::string(dir) + "/plain.ibu").second;
+  size_t seen = 0;
+  for (const char* name : {"plain.ibu", "a.gz", "multi.gz", "a.bgz", "a.bz2", "a.xz", "a.zst"}) {
+    Reader r = Reader::from_path(std::string(dir) + "/" + name);
+    CHECK(r.header() == Header(16, 12));
+    CHECK(r.collect() == want);
+    ++seen;
+  }
+  CHECK_EQ(seen, 7u);
+  CHECK_THROWS(Niffler, Reader::from_path(std::string(dir) + "/cut.bgz").collect(), {});
+}
+
 // ---------------------------------------------------------------- device path without a device
 TEST(device_context_fails_loudly_without_gpu) {
   if (device::device_count() > 0) return;  // on a GPU box the device tests cover it

@@ -21,10 +21,57 @@ def _run(args, **kw):
     return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
 
 
-def test_cpp_mirror_passes_the_reference_unit_tests(built, tmp_path):
-    r = _run([os.path.join(built, "test_host")], env={**os.environ, "TMPDIR": str(tmp_path)})
+def _compressed_fixture(d, oracle):
+    """plain + gzip + multi-member gzip + BGZF + bzip2 + xz + zstd + a truncated BGZF of the same 50 000 records."""
+    import bz2
+    import ctypes as C
+    import gzip
+    import lzma
+
+    import ibu_amd as ia
+    from tests.bgzf import bgzf_compress
+
+    recs = oracle.generate(11, 0, 50_000, 16, 12)
+    w = ia.Writer.from_path(d / "plain.ibu", ia.Header(16, 12))
+    w.write_batch(recs)
+    w.finish()
+    w.close()
+    raw = (d / "plain.ibu").read_bytes()
+    (d / "a.gz").write_bytes(gzip.compress(raw, 1))
+    (d / "multi.gz").write_bytes(gzip.compress(raw[:100_003], 1) + gzip.compress(raw[100_003:], 1))
+    (d / "a.bgz").write_bytes(bgzf_compress(raw))
+    (d / "cut.bgz").write_bytes(bgzf_compress(raw)[:200_000])
+    (d / "a.bz2").write_bytes(bz2.compress(raw, 1))
+    (d / "a.xz").write_bytes(lzma.compress(raw, preset=0))
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    buf = C.create_string_buffer(z.ZSTD_compressBound(len(raw)))
+    k = z.ZSTD_compress(buf, len(buf), raw, len(raw), 1)
+    (d / "a.zst").write_bytes(buf.raw[:k])
+
+
+def test_cpp_mirror_passes_the_reference_unit_tests(built, tmp_path, oracle):
+    fx = tmp_path / "compressed"
+    fx.mkdir()
+    _compressed_fixture(fx, oracle)
+    r = _run([os.path.join(built, "test_host")], env={**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx)})
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failed" in r.stdout and r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 30
+
+
+@pytest.mark.skipif(not os.environ.get("IBU_RUN_ASAN"), reason="set IBU_RUN_ASAN=1: builds a sanitized library (~1 min)")
+def test_cpp_mirror_under_asan_ubsan(tmp_path, oracle):
+    """Host AddressSanitizer + UBSan (leaks included) over the whole C++ mirror suite and every input decoder."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "asan"])
+    fx = tmp_path / "compressed"
+    fx.mkdir()
+    _compressed_fixture(fx, oracle)
+    env = {**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx),
+           "ASAN_OPTIONS": "detect_leaks=1:halt_on_error=1", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}
+    r = _run([os.path.join(BIN, "asan", "test_host")], env=env)
+    assert r.returncode == 0 and "0 failed" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_roundtrip_example_1e6(built, tmp_path, kat):

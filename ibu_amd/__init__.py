@@ -306,7 +306,7 @@ class Reader:
         return cls(inner)
 
     @classmethod
-    def from_path(cls, path):  # :345-352 (gzip sniffed; bz2/xz/zstd -> Niffler error)
+    def from_path(cls, path):  # :345-352 (format sniffed: gzip / BGZF / bzip2 / xz / zstd, like niffler)
         out = C.c_void_p()
         _check(lib.ibu_reader_open_path(str(path).encode(), C.byref(out)))
         return cls(_handle=out)

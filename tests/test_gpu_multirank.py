@@ -46,3 +46,12 @@ def test_sharded_file_two_ranks(tmp_path, proc, oracle):
     assert out["sums"][2] == want["sum"][2]
     if proc == "reduce":
         assert out["sums"] == want["sum"] and out["xors"] == want["xor"]
+
+
+def test_distributed_sort_two_ranks():
+    """Sample sort across two ranks (device radix sorts, one all-to-all of the records — staged through the host
+    under gloo here, RCCL in production): every rank sorted, rank ranges ordered, multiset preserved."""
+    out = _torchrun(2, "tools/sharded_sort.py", "--records", "3000001", "--backend", "gloo", "--share-gpu")
+    assert out["every_rank_sorted"] and out["rank_ranges_ordered"] and out["multiset_preserved"]
+    assert out["count"] == 6_000_002 and sum(out["records_per_rank_out"]) == 6_000_002
+    assert max(out["records_per_rank_out"]) < 0.6 * 6_000_002  # the splitter balanced the two ranges

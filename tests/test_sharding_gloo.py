@@ -68,3 +68,68 @@ def test_global_totals_without_process_group_is_identity():
     assert sharding.global_totals(loc) == loc
     assert sharding.expected_index_sum(10) == 45
     assert sharding.expected_index_sum(2**33) == (2**33 * (2**33 - 1) // 2) % 2**64
+
+
+# ---- distributed sample sort: control flow on CPU (numpy stand-in for the device ops) ------------------------------
+class _NumpySortOps:
+    """Test stand-in for DeviceSortOps: same interface, records in a CPU uint8 tensor, sorted by the oracle."""
+
+    def __init__(self, orc):
+        self.orc = orc
+
+    def empty(self, nbytes, like):
+        import torch
+        return torch.empty(max(int(nbytes), 24), dtype=torch.uint8)
+
+    def local_sort(self, buf, n):
+        import torch
+        if n > 1:
+            recs = np.frombuffer(buf[: n * 24].numpy().tobytes(), dtype=self.orc.REC_DTYPE)
+            buf[: n * 24] = torch.from_numpy(np.frombuffer(self.orc.sort_records(recs).tobytes(), dtype=np.uint8).copy())
+
+    def fetch(self, buf, i):
+        return bytes(buf[i * 24:(i + 1) * 24].numpy())
+
+    def sample(self, buf, n, idx):
+        return b"".join(self.fetch(buf, i) for i in idx)
+
+
+def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from ibu_amd import sharding
+    from oracle import oracle as orc
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        first = sum(counts[:rank])
+        recs = orc.generate(seed, first, counts[rank], *lens)
+        if skew:  # heavy duplicates: few distinct barcodes, so splitters collide
+            recs["barcode"] %= 3
+            recs["umi"] %= 2
+        buf = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()) if counts[rank] else torch.empty(24, dtype=torch.uint8)
+        out, n_out = sharding.distributed_sort(_NumpySortOps(orc), buf, counts[rank], samples_per_rank=16)
+        np.save(os.path.join(out_dir, f"s{rank}.npy"), out[: n_out * 24].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts,lens,skew", [([5000, 7003], (16, 12), False), ([4000, 0, 6001], (16, 12), False),
+                                              ([3000, 3000], (4, 4), True), ([1, 2, 3], (32, 32), False), ([0, 0], (16, 12), False)])
+def test_distributed_sort_control_flow(tmp_path, oracle, counts, lens, skew):
+    import torch.multiprocessing as mp
+
+    world, seed = len(counts), 0x1B00006
+    mp.spawn(_sort_worker, args=(world, _free_port(), counts, seed, lens, skew, str(tmp_path)), nprocs=world, join=True)
+    allrecs = oracle.generate(seed, 0, sum(counts), *lens)
+    if skew:
+        allrecs["barcode"] %= 3
+        allrecs["umi"] %= 2
+    want = oracle.sort_records(allrecs).tobytes()
+    parts = [np.load(tmp_path / f"s{r}.npy").tobytes() for r in range(world)]
+    assert b"".join(parts) == want  # rank order IS the global order; nothing lost, nothing duplicated
+    if not skew and sum(counts) > 1000:  # samples balance the ranges roughly (no rank ends up with everything)
+        assert max(len(p) for p in parts) < 0.8 * len(want)

@@ -128,7 +128,10 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
 
 // ---- tails: one thread per record, any alignment -----------------------------------------------
 __device__ __forceinline__ void unpack_row_bytes(u64 code, u32 len, uint8_t* out) {
-  for (u32 i = 0; i < len; ++i) out[i] = (uint8_t)((kPool >> (8 * ((code >> (2 * i)) & 3))) & 0xFF);
+  for (u32 i = 0; i < len; ++i) {  // per-base extract with v_bfe_u32 on the half of the code word that holds base i
+    const u32 half = (u32)(code >> (i & 16u ? 32 : 0));
+    out[i] = (uint8_t)__builtin_amdgcn_ubfe(kPool, 8 * __builtin_amdgcn_ubfe(half, 2 * (i & 15u), 2), 8);
+  }
 }
 extern "C" __global__ void ibu_k_decode_tail(const u64* __restrict__ recs, u64 row0, u64 n, u32 bc_len,
                                              u32 umi_len, uint8_t* bc_out, uint8_t* umi_out, u64* idx_out) {

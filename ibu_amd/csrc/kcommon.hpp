@@ -167,7 +167,7 @@ __device__ __forceinline__ u32x4 expand_chunk(const uint8_t* tile, u32 rstride, 
     u32 w = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      u32 code = (tile[r * rstride + foff + (p >> 2)] >> (2 * (p & 3))) & 3u;
+      const u32 code = __builtin_amdgcn_ubfe((u32)tile[r * rstride + foff + (p >> 2)], 2 * (p & 3), 2);  // v_bfe_u32: base p of the row
       w |= ((kPool >> (8 * code)) & 0xFFu) << (8 * b);
       if (++p == len) { p = 0; ++r; }
     }

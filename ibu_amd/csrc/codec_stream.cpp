@@ -9,6 +9,8 @@
 // k+1 in and batch k-1 out while batch k is on the device.  PCIe is the bound (24 B/record one way, 36 B the
 // other at 16/12), not the kernels.
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -89,6 +91,34 @@ int32_t drain3(ibu_ctx* ctx, int32_t rc) {  // leave nothing in flight over ring
   return rc;
 }
 
+// Two host threads per call: the caller's thread fills and submits batch k, a collector thread delivers batch
+// k - depth (waits for its D2H, copies it out / hands it to the writer).  `submitted` / `delivered` are the only
+// shared state; the first error on either side stops both.
+struct Handoff {
+  std::mutex m;
+  std::condition_variable cv;
+  size_t submitted = 0, delivered = 0;
+  int32_t err = IBU_OK;
+  bool producer_done = false;
+  void publish() { { std::lock_guard<std::mutex> g(m); ++submitted; } cv.notify_all(); }
+  void finish_producing(int32_t rc) { { std::lock_guard<std::mutex> g(m); producer_done = true; if (rc && !err) err = rc; } cv.notify_all(); }
+  // producer: slot of batch k is free once batch k - slots has been delivered
+  int32_t wait_slot(size_t k, size_t slots) {
+    std::unique_lock<std::mutex> g(m);
+    cv.wait(g, [&] { return err || k < slots || delivered + slots > k; });
+    return err;
+  }
+  // collector: next batch to deliver, or false when everything submitted has been delivered and no more will come
+  bool next(size_t* k) {
+    std::unique_lock<std::mutex> g(m);
+    cv.wait(g, [&] { return err || delivered < submitted || producer_done; });
+    if (err || delivered >= submitted) return false;
+    *k = delivered;
+    return true;
+  }
+  void done(int32_t rc) { { std::lock_guard<std::mutex> g(m); if (rc && !err) err = rc; else if (!rc) ++delivered; } cv.notify_all(); }
+};
+
 struct ColLayout {  // where the three columns of a slot live inside its column buffer
   size_t bc, umi, idx, bytes;
   ColLayout(size_t slot_records, uint32_t bc_len, uint32_t umi_len)
@@ -148,9 +178,21 @@ extern "C" int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
     return IBU_OK;
   };
 
+  Handoff ho;
+  ibu_error_detail_t collector_detail;
+  memset(&collector_detail, 0, sizeof collector_detail);
+  std::thread collector([&]() {
+    (void)hipSetDevice(ctx->device);
+    size_t k;
+    while (ho.next(&k)) {
+      const int32_t e = collect(k);
+      if (e) ibu_last_error(&collector_detail);  // the error record is per thread: carry it over
+      ho.done(e);
+    }
+  });
   for (size_t k = 0; k < nb && rc == IBU_OK; ++k) {
     const uint32_t s = (uint32_t)(k % r.slots);
-    if (k >= r.slots) rc = collect(k - r.slots);  // frees slot s (its D2H is done and its columns are delivered)
+    rc = ho.wait_slot(k, r.slots);  // slot s is free: batch k - slots has been delivered
     if (rc) break;
     const size_t rows = rows_of(k);
     par_memcpy(r.h_aos[s], base + (start + k * r.slot_records) * IBU_RECORD_SIZE, rows * IBU_RECORD_SIZE, nf);
@@ -177,8 +219,14 @@ extern "C" int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
       stats->bytes_d2h += rows * ((h_bc_ascii ? h.bc_len : 0) + (h_umi_ascii ? h.umi_len : 0) + (h_index ? 8 : 0));
       stats->batches += 1;
     }
+    ho.publish();
   }
-  for (size_t k = nb > r.slots ? nb - r.slots : 0; k < nb && rc == IBU_OK; ++k) rc = collect(k);
+  ho.finish_producing(rc);
+  collector.join();
+  if (collector_detail.code)  // the collector failed first (the producer only saw its flag): report ITS error from this thread
+    rc = set_error(collector_detail.code, collector_detail.a, collector_detail.b, collector_detail.os_errno, "%s", collector_detail.message);
+  else if (rc == IBU_OK && ho.err)
+    rc = ho.err;
   if (rc) return drain3(ctx, rc);
   if (stats) { stats->records = total; stats->seconds_total = now_s() - t0; }
   return IBU_OK;
@@ -219,9 +267,21 @@ extern "C" int32_t ibu_writer_write_ascii_batch(ibu_writer_t* w, ibu_ctx_t* ctx,
     return writer_write_bytes(w, r.h_aos[s], rows * IBU_RECORD_SIZE);  // buffered / direct rule of writer.rs:321-351
   };
 
+  Handoff ho;
+  ibu_error_detail_t collector_detail;
+  memset(&collector_detail, 0, sizeof collector_detail);
+  std::thread collector([&]() {  // delivers batches to the writer while the caller's thread stages the next ones
+    (void)hipSetDevice(ctx->device);
+    size_t k;
+    while (ho.next(&k)) {
+      const int32_t e = collect(k);
+      if (e) ibu_last_error(&collector_detail);
+      ho.done(e);
+    }
+  });
   for (size_t k = 0; k < nb && rc == IBU_OK; ++k) {
     const uint32_t s = (uint32_t)(k % r.slots);
-    if (k >= r.slots) rc = collect(k - r.slots);
+    rc = ho.wait_slot(k, r.slots);
     if (rc) break;
     const size_t rows = rows_of(k), row0 = k * r.slot_records;
     par_memcpy(r.h_col[s] + L.bc, h_bc_ascii + row0 * bc_len, rows * bc_len, nf);
@@ -250,8 +310,14 @@ extern "C" int32_t ibu_writer_write_ascii_batch(ibu_writer_t* w, ibu_ctx_t* ctx,
       stats->bytes_d2h += rows * IBU_RECORD_SIZE;
       stats->batches += 1;
     }
+    ho.publish();
   }
-  for (size_t k = nb > r.slots ? nb - r.slots : 0; k < nb && rc == IBU_OK; ++k) rc = collect(k);
+  ho.finish_producing(rc);
+  collector.join();
+  if (collector_detail.code)  // the collector failed first (the producer only saw its flag): report ITS error from this thread
+    rc = set_error(collector_detail.code, collector_detail.a, collector_detail.b, collector_detail.os_errno, "%s", collector_detail.message);
+  else if (rc == IBU_OK && ho.err)
+    rc = ho.err;
   if (rc) return drain3(ctx, rc);
   if (stats) { stats->records = n; stats->seconds_total = now_s() - t0; }
   if (n_bad)

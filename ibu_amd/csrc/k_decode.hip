@@ -165,7 +165,7 @@ hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint3
     const u32 ntiles = (u32)(n_main / kDecRecs);
     const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
     const DecFn fn = kDecTable[mb][mu];
-    static int occ[kNumLenModes][kNumLenModes] = {{0}};
+    static std::atomic<int> occ[kNumLenModes][kNumLenModes];
     hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, fn, 0, &occ[mb][mu]))), dim3(kBlock), 0,
                        st, (const uint8_t*)recs, ntiles, bc_len, umi_len, bc, umi, (u64*)idx);
   }
@@ -189,7 +189,7 @@ hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, 
   if (n_main) {
     const u32 ntiles = (u32)(n_main / kTileRecs);
     const int m = mode_of_len(len);
-    static int occ[kNumLenModes] = {0};
+    static std::atomic<int> occ[kNumLenModes];
     hipLaunchKernelGGL(kUnpTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kUnpTable[m], 0, &occ[m]))),
                        dim3(kBlock), 0, st, (const u64*)codes, ntiles, len, out);
   }

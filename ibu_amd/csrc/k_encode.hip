@@ -174,7 +174,7 @@ hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t*
     if (wave_lds < (u32)kTileBytes) wave_lds = kTileBytes;
     const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
     const EncFn fn = kEncTable[mb][mu];
-    static int occ[33][33] = {{0}};  // LDS depends on the actual lengths, not only on the mode
+    static std::atomic<int> occ[33][33];  // LDS depends on the actual lengths, not only on the mode
     const int nb = resident_blocks<kBlock>(cfg, fn, wave_lds * kWavesPerBlock, &occ[bc_len][umi_len]);
     hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, nb)), dim3(kBlock), wave_lds * kWavesPerBlock, st, bc, umi,
                        (const u64*)idx, (u64)first_index, ntiles, bc_len, umi_len, wave_lds, (uint8_t*)recs,
@@ -200,7 +200,7 @@ hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32
   if (n_main) {
     const u32 ntiles = (u32)(n_main / kTileRecs);
     const int m = mode_of_len(len);
-    static int occ[kNumLenModes] = {0};
+    static std::atomic<int> occ[kNumLenModes];
     hipLaunchKernelGGL(kPackTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kPackTable[m], 0, &occ[m]))),
                        dim3(kBlock), 0, st, in, ntiles, len, (u64*)codes, (u64*)status);
   }

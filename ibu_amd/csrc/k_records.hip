@@ -271,7 +271,7 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    static int occ = 0;
+    static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_deserialize,
                        dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
                        (const uint8_t*)recs, ntiles, (u64*)bc, (u64*)umi, (u64*)idx);
@@ -290,7 +290,7 @@ hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   if (n_main) {
     u32 ntiles = (u32)(n_main / kTileRecs);
-    static int occ = 0;
+    static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_serialize, 0, &occ))),
                        dim3(kBlock), 0, st,
                        (const u64*)bc, (const u64*)umi, (const u64*)idx, ntiles, (uint8_t*)recs);
@@ -308,7 +308,7 @@ hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint6
   const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
   u32 ntiles = (u32)(n_main / kTileRecs);
   // the main kernel also adds n to the count slot, so it always runs (ntiles may be 0)
-  static int occ = 0;
+  static std::atomic<int> occ;
   hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_reduce, 0, &occ))),
                      dim3(kBlock), 0, st,
                      (const uint8_t*)recs, ntiles, (u64)n, (u64*)acc);
@@ -339,7 +339,7 @@ hipError_t launch_copy(const LaunchCfg& cfg, const void* src, void* dst, size_t 
   const u64 nchunks = fast ? bytes / 16 : 0;
   if (nchunks) {
     u64 blocks = (nchunks + kBlock - 1) / kBlock;
-    static int occ = 0;
+    static std::atomic<int> occ;
     const u64 cap = (u64)cfg.cus * resident_blocks<kBlock>(cfg, ibu_k_copy, 0, &occ);
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(ibu_k_copy, dim3((u32)blocks), dim3(kBlock), 0, st, (const uint8_t*)src, (uint8_t*)dst, nchunks);

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace ibu {
 
 struct LaunchCfg {
@@ -16,16 +18,18 @@ struct LaunchCfg {
 // how many 256-thread blocks of this kernel fit on a CU (registers, LDS), cap by
 // cfg.blocks_per_cu, remember the answer per kernel instantiation.
 template <int BLOCK, class K>
-static inline int resident_blocks(const LaunchCfg& cfg, K kernel, size_t dyn_lds, int* cache) {
-  if (*cache <= 0) {
+static inline int resident_blocks(const LaunchCfg& cfg, K kernel, size_t dyn_lds, std::atomic<int>* cache) {
+  int cached = cache->load(std::memory_order_relaxed);  // contexts of several host threads may race here: same value either way
+  if (cached <= 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, dyn_lds) != hipSuccess || nb <= 0)
       nb = 1024 / BLOCK;
-    *cache = nb;
+    cache->store(nb, std::memory_order_relaxed);
+    cached = nb;
   }
   int cap = cfg.blocks_per_cu * 256 / BLOCK;  // blocks_per_cu is stated in 256-thread units (4 waves)
   if (cap < 1) cap = 1;
-  return *cache < cap ? *cache : cap;
+  return cached < cap ? cached : cap;
 }
 
 // All launchers are asynchronous on `st`, allocate nothing and never synchronise.

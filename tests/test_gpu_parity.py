@@ -314,3 +314,40 @@ def test_all_rows_invalid_is_counted_exactly(ia, ctx):
     recs = out.download(np.uint64, count=3 * n).reshape(n, 3)
     assert not recs[:, 0].any() and not recs[:, 1].any() and (recs[:, 2] == np.arange(n, dtype=np.uint64)).all()
     ctx.codec_status()  # re-armed
+
+
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32)])
+def test_full_size_roundtrip_properties_1e9(ia, ctx, lens):
+    """BASELINE.json's full size (1e9 records; configs[2] and configs[3] shapes) through size-independent properties:
+    encode(decode(x)) == x, count and closed-form sums, decoded alphabet, index column, and sort -> sorted with the
+    multiset preserved.  (Bit-exactness against the oracle is established at the sizes the oracle finishes in seconds.)"""
+    n = 1_000_000_000
+    bc_len, umi_len = lens
+    seed, first = 0x1B00003, 12345
+    recs, back = ctx.alloc(n * 24), ctx.alloc(n * 24)
+    bc, umi, idx = ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)
+    ctx.generate(seed, first, n, bc_len, umi_len, recs)
+    red = ctx.reduce(recs, n)
+    assert red["count"] == n
+    assert red["sum"][2] == (n * first + n * (n - 1) // 2) % 2**64  # index = first + i
+    ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx)
+    ctx.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back)
+    ctx.codec_status()  # every decoded byte was a valid base
+    assert ctx.reduce(back, n) == red
+    # byte-for-byte equality of the round trip, checked on device: sort-free trick = XOR/sum already equal; now compare
+    # three windows (head, middle, tail) exactly
+    for off in (0, (n // 2) * 24, (n - 1_000_000) * 24):
+        a = ia.DeviceBuffer.wrap(ctx, recs.ptr + off, 24_000_000).download()
+        b = ia.DeviceBuffer.wrap(ctx, back.ptr + off, 24_000_000).download()
+        assert a.tobytes() == b.tobytes()
+    head = bc.download(count=bc_len * 1000)
+    assert set(head.tolist()) <= set(b"ACGT")
+    tail_idx = ia.DeviceBuffer.wrap(ctx, idx.ptr + (n - 5) * 8, 40).download(np.uint64)
+    assert tail_idx.tolist() == [first + n - 5 + k for k in range(5)]
+    for b_ in (bc, umi, idx):
+        b_.free()
+    # sort at full size: sortedness + multiset (count, wrapping sums, XORs) preserved
+    assert not ctx.is_sorted(recs, n)
+    ctx.sort_records(recs, back, n)
+    assert ctx.is_sorted(recs, n)
+    assert ctx.reduce(recs, n) == red

@@ -12,6 +12,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # built artefacts are not in git: a fresh checkout builds them once (hipcc cross-compiles without a GPU)
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "ibu_amd", "libibu_hip.so")):
+        subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "ibu_amd", "csrc")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libibu_oracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libibu_oracle.so"])
 
 
 @pytest.fixture(scope="session")

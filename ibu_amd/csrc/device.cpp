@@ -265,7 +265,7 @@ extern "C" int32_t ibu_generate(ibu_ctx_t* ctx, uint64_t seed, uint64_t first, s
   rc = check_lens(bc_len, umi_len);
   if (rc) return rc;
   if (n == 0) return IBU_OK;
-  if (!d_records || (reinterpret_cast<uintptr_t>(d_records) & 15u)) return err_arg("d_records must be 16-byte aligned");
+  if (!d_records || !aligned8(d_records)) return err_arg("d_records must be non-NULL and 8-byte aligned");
   IBU_HIP(launch_generate(ctx->cfg, seed, first, n, bc_len, umi_len, d_records, pick_stream(ctx, stream)));
   return IBU_OK;
 }

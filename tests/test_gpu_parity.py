@@ -351,3 +351,13 @@ def test_full_size_roundtrip_properties_1e9(ia, ctx, lens):
     ctx.sort_records(recs, back, n)
     assert ctx.is_sorted(recs, n)
     assert ctx.reduce(recs, n) == red
+
+
+def test_generate_into_an_8_byte_aligned_buffer(ia, ctx, oracle):
+    """Not 16-B aligned: every record takes the one-thread-per-record kernel; same bytes."""
+    n = 10_007
+    d = ctx.alloc(n * 24 + 16)
+    ctx.generate(SEED, 3, n, 20, 7, d.ptr + 8)
+    ctx.synchronize()
+    got = ia.DeviceBuffer.wrap(ctx, d.ptr + 8, n * 24).download()
+    assert got.tobytes() == oracle.generate(SEED, 3, n, 20, 7).tobytes()

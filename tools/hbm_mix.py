@@ -16,7 +16,7 @@ def main():
     total = int(a.gb * 1e9)
     src = torch.zeros(total, dtype=torch.uint8, device=dev); dst = torch.empty(total, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    for r, w in [(1, 0), (1, 1), (2, 3), (3, 2), (1, 2), (2, 1), (1, 3), (3, 1), (4, 1)]:
+    for r, w in [(1, 0), (3, 0), (1, 1), (2, 3), (3, 2), (1, 2), (2, 1), (1, 3), (3, 1), (4, 1)]:
         steps = total // 16 // max(r, w, 1) // 4 * 4
         for blocks in (256 * 8, 256 * 7, 256 * 4):
             ms = []

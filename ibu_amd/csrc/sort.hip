@@ -12,6 +12,9 @@
 // writes it out as runs of consecutive 8-byte words, so a chunk's 256 output runs are each written
 // front to back by one workgroup (L2 merges the pieces) instead of as scattered 24-byte records.
 // HBM traffic per pass: 24 B read (histogram) + 24 B read + 24 B write (scatter) per record.
+// Where the scatter's time goes (profiles/README.md, r01_e): with the write-out replaced by a linear tile store the
+// kernel runs at 5.2 TB/s (staging, ranking and the LDS permutation are not the limit); the real, run-wise write-out
+// costs +60 %.  Tile size (512..2048), workgroups per CU (2..5) and nontemporal stores do not move it (or hurt).
 #include "kcommon.hpp"
 #include "kernels.h"
 

@@ -683,10 +683,12 @@ typedef struct bw {
   uint64_t* idx;
   uint64_t checksum;
   orc_reduce red;
+  int reps; /* passes over the shard inside the timed region */
 } bw;
 static void* bw_codec(void* arg) {
   bw* w = (bw*)arg;
   /* batches of BATCH_SIZE like the reference's worker loop (mmap.rs:312-320) */
+  for (int rep = 0; rep < (w->reps > 0 ? w->reps : 1); rep++)
   for (size_t s = w->start; s < w->end; s += ORC_BATCH_SIZE) {
     size_t e = s + ORC_BATCH_SIZE < w->end ? s + ORC_BATCH_SIZE : w->end;
     orc_decode_records(w->in + s, e - s, w->bc_len, w->umi_len, w->bc + s * w->bc_len,
@@ -700,7 +702,7 @@ static void* bw_codec(void* arg) {
   w->checksum = c;
   return NULL;
 }
-double orc_bench_decode_encode(size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t seed, int threads,
+double orc_bench_decode_encode(size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t seed, int threads, int reps,
                                uint64_t* checksum) {
   orc_record* in = (orc_record*)malloc(n * sizeof *in);
   orc_record* out = (orc_record*)malloc(n * sizeof *out);
@@ -724,6 +726,7 @@ double orc_bench_decode_encode(size_t n, uint32_t bc_len, uint32_t umi_len, uint
     ws[i].bc = bc;
     ws[i].umi = umi;
     ws[i].idx = idx;
+    ws[i].reps = reps;
     pthread_create(&th[i], NULL, bw_codec, &ws[i]);
   }
   uint64_t c = 0;

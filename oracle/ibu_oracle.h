@@ -152,8 +152,8 @@ int orc_is_sorted(const orc_record* r, size_t n);
 
 /* ---- cpu_baseline legs for bench.py: static range split over `threads` OS threads, like
  * process_parallel (mmap.rs:297-322).  Returns seconds. ---- */
-double orc_bench_decode_encode(size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t seed, int threads,
-                               uint64_t* checksum);
+double orc_bench_decode_encode(size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t seed, int threads, int reps,
+                               uint64_t* checksum); /* seconds for `reps` passes over n records */
 double orc_bench_reduce(size_t n, uint64_t seed, int threads, orc_reduce* out);
 
 #endif

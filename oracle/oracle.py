@@ -105,7 +105,7 @@ def _load():
         "orc_generate": (None, [u64, u64, sz, u32, u32, vp]),
         "orc_sort_records": (None, [vp, sz]),
         "orc_is_sorted": (i32, [vp, sz]),
-        "orc_bench_decode_encode": (C.c_double, [sz, u32, u32, u64, i32, P(u64)]),
+        "orc_bench_decode_encode": (C.c_double, [sz, u32, u32, u64, i32, i32, P(u64)]),
         "orc_bench_reduce": (C.c_double, [sz, u64, i32, P(Reduce)]),
     }
     for name, (res, args) in sig.items():
@@ -413,9 +413,10 @@ def is_sorted(recs):
     return bool(lib.orc_is_sorted(_ptr(recs), recs.shape[0]))
 
 
-def bench_decode_encode(n, bc_len, umi_len, seed, threads):
+def bench_decode_encode(n, bc_len, umi_len, seed, threads, reps=1):
+    """Seconds for `reps` decode+encode passes over n records on `threads` threads, and the round-trip checksum."""
     c = C.c_uint64()
-    t = lib.orc_bench_decode_encode(n, bc_len, umi_len, seed, threads, C.byref(c))
+    t = lib.orc_bench_decode_encode(n, bc_len, umi_len, seed, threads, reps, C.byref(c))
     return t, c.value
 
 

@@ -13,5 +13,5 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
 print("affinity", len(os.sched_getaffinity(0)), "usable", bench.usable_cores(), flush=True)
 for th in (1, 8, 16, 32, 64, 128, 256):
     n = 20_000_000 * min(th, 16)
-    t, c = orc.bench_decode_encode(n, 16, 12, 1, th)
+    t, c = orc.bench_decode_encode(n, 16, 12, 1, th, 1)
     print(th, "threads", n, "records", round(t, 3), "s", round(n / t / 1e6, 1), "M rec/s", flush=True)

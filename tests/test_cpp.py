@@ -74,6 +74,12 @@ def test_cpp_mirror_under_asan_ubsan(tmp_path, oracle):
     assert r.returncode == 0 and "0 failed" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_plain_c_client_of_the_abi(built):
+    """gcc -std=c11 -pedantic: the header and the library are usable from C with nothing but pointers and sizes."""
+    r = _run([os.path.join(built, "abi_smoke")])
+    assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_roundtrip_example_1e6(built, tmp_path, kat):
     """BASELINE configs[0]: examples/roundtrip.rs shape at 1e6 records — CPU plumbing only."""
     r = _run([os.path.join(built, "roundtrip"), "1000000", "--json", "--dir", str(tmp_path)])

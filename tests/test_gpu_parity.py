@@ -361,3 +361,46 @@ def test_generate_into_an_8_byte_aligned_buffer(ia, ctx, oracle):
     ctx.synchronize()
     got = ia.DeviceBuffer.wrap(ctx, d.ptr + 8, n * 24).download()
     assert got.tobytes() == oracle.generate(SEED, 3, n, 20, 7).tobytes()
+
+
+def test_two_contexts_on_two_host_threads(ia, oracle):
+    """'One context per host thread; the library is re-entrant across contexts' (include/ibu_hip.h): two threads, each
+    with its own context and stream, run the whole kernel set concurrently; both must match the oracle, and an error
+    raised in one thread must not leak into the other's error slot."""
+    import threading
+
+    results, errors = {}, []
+
+    def worker(tag, seed, lens, n):
+        try:
+            c = ia.Context(0)
+            want = oracle.generate(seed, 0, n, *lens)
+            for _ in range(5):
+                d = c.alloc(n * 24)
+                c.generate(seed, 0, n, *lens, d)
+                bc, umi, idx, back = c.alloc(n * lens[0]), c.alloc(n * lens[1]), c.alloc(n * 8), c.alloc(n * 24)
+                c.decode_ascii(d, n, lens[0], lens[1], bc, umi, idx)
+                c.encode_ascii(bc, umi, idx, n, lens[0], lens[1], back)
+                c.codec_status()
+                assert back.download().tobytes() == want.tobytes()
+                assert c.reduce(d, n) == oracle.reduce_records(want)
+                t = c.alloc(n * 24)
+                c.sort_records(back, t, n)
+                assert c.is_sorted(back, n)
+                if tag == "a":  # provoke an error in this thread only
+                    with pytest.raises(ia.IbuError) as e:
+                        c.decode_ascii(d, n, 0, 12, bc, umi, idx)
+                    assert e.value.kind == "InvalidBarcodeLength"
+            results[tag] = True
+            c.close()
+        except Exception as ex:  # noqa: BLE001 - reported to the main thread
+            errors.append((tag, repr(ex)))
+
+    ts = [threading.Thread(target=worker, args=("a", 11, (16, 12), 300_007)),
+          threading.Thread(target=worker, args=("b", 12, (32, 32), 200_003))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert results == {"a": True, "b": True}

@@ -95,6 +95,25 @@ def test_sort_degenerate_inputs(ctx, oracle, ia):
     assert _sort_on_device(ctx, hi)[0] == oracle.sort_records(hi).tobytes()
 
 
+def test_sort_skips_index_passes_only_when_input_is_in_index_order(ctx, oracle, ia):
+    """Stable LSD + index as the least significant field: input in non-decreasing index order needs no index passes.
+    One inversion anywhere (here: the very last pair, across a 32 Ki chunk edge, and in the middle) must switch them on."""
+    n = 70_000
+    recs = oracle.generate(SEED, 0, n, 16, 12)           # index 0..n-1 increasing, barcodes random
+    recs["barcode"] %= 50                                 # many ties on barcode (and some on umi) -> index order matters
+    recs["umi"] %= 7
+    assert _sort_on_device(ctx, recs)[0] == oracle.sort_records(recs).tobytes()
+    dup = recs.copy()
+    dup["index"] //= 3                                     # non-decreasing with repeats: still index order
+    assert _sort_on_device(ctx, dup)[0] == oracle.sort_records(dup).tobytes()
+    for pos in (n - 1, 32_768, n // 2, 1):
+        bad = recs.copy()
+        bad["index"][pos] = bad["index"][pos - 1] - 1 if bad["index"][pos - 1] else 0
+        bad["index"][pos - 1] += 5                         # recs[pos].index < recs[pos-1].index
+        bad["barcode"][pos], bad["umi"][pos] = bad["barcode"][pos - 1], bad["umi"][pos - 1]  # a tie decided by the index
+        assert _sort_on_device(ctx, bad)[0] == oracle.sort_records(bad).tobytes(), pos
+
+
 def test_sort_then_write_sorted_file_roundtrip(ctx, oracle, ia, tmp_path):
     """The use the flag exists for: sort on device, write with set_sorted(), read back, still sorted."""
     n = 120_000

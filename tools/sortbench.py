@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--records", default="1e8")
     ap.add_argument("--lens", default="16,12")
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--random-index", action="store_true",
+                    help="index column in random order (default: increasing = records in read order, whose index passes are skipped)")
     a = ap.parse_args()
     import ibu_amd as ia
 
@@ -25,8 +27,14 @@ def main():
     for n in (int(float(x)) for x in a.records.split(",")):
         d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)
         ts = []
+        cols = [ctx.alloc(8 * n) for _ in range(4)] if a.random_index else None
         for _ in range(a.rounds + 1):
             ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)  # random barcode/UMI, increasing index: unsorted
+            if a.random_index:  # replace the index column by random 30-bit values (another stream's barcode column)
+                ctx.deserialize(d, n, cols[0], cols[1], cols[2])
+                ctx.generate(0x1B00006, 0, n, 15, 1, t)
+                ctx.deserialize(t, n, cols[3], cols[2], cols[2])
+                ctx.serialize(cols[0], cols[1], cols[3], n, d)
             ctx.synchronize()
             t0 = time.perf_counter()
             ctx.sort_records(d, t, n)
@@ -34,12 +42,14 @@ def main():
             ts.append(time.perf_counter() - t0)
         assert ctx.is_sorted(d, n)
         sec = statistics.median(ts[1:])
-        idx_bytes = max(1, ((n - 1).bit_length() + 7) // 8)
+        idx_bytes = 4 if a.random_index else 0  # 30 random bits -> 4 digit passes; index-ordered input -> skipped
         passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
-        print(json.dumps({"n": n, "lens": [bc_len, umi_len], "seconds": round(sec, 4), "M_records_per_s": round(n / sec / 1e6, 1),
+        print(json.dumps({"n": n, "lens": [bc_len, umi_len], "index": "random" if a.random_index else "increasing (read order)", "seconds": round(sec, 4), "M_records_per_s": round(n / sec / 1e6, 1),
                           "passes": passes, "GBps_at_72B_per_record_pass": round(n * 72 * passes / sec / 1e9)}), flush=True)
         d.free()
         t.free()
+        for c in cols or []:
+            c.free()
 
 
 if __name__ == "__main__":

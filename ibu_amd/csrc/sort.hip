@@ -32,7 +32,7 @@ static constexpr int kSortTilesPerChunk = 32768 / kSortTile;
 static constexpr int kSortChunk = kSortTile * kSortTilesPerChunk;  // records per histogram row
 static constexpr int kBins = 256;
 
-// scratch layout (bytes): census u64[7] @0 (OR x3, AND x3, index-order flag) | rowsum u32[256] @64 | binbase u32[256] @1088 | table @2112
+// scratch layout (bytes): census u64[8] @0 (OR x3, AND x3, index-order flag, any-inversion flag) | rowsum u32[256] @64 | binbase u32[256] @1088 | table @2112
 static constexpr size_t kOffRowsum = 64, kOffBinbase = kOffRowsum + 4 * kBins, kOffTable = kOffBinbase + 4 * kBins;
 
 __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
@@ -40,29 +40,39 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
   return ((u64)hi << 32) | lo;
 }
 
+__device__ __forceinline__ u64 shfl_up64_1(u64 v) {
+  u32 lo = __shfl_up((u32)v, 1), hi = __shfl_up((u32)(v >> 32), 1);
+  return ((u64)hi << 32) | lo;
+}
+
 // ---- census: OR and AND of each field --------------------------------------------------------------
 extern "C" __global__ void ibu_k_sort_census_init(u64* c) {
   if (threadIdx.x < 3) c[threadIdx.x] = 0;
   else if (threadIdx.x < 6) c[threadIdx.x] = ~0ull;
-  else if (threadIdx.x == 6) c[6] = 0;  // 1 once some record's index is smaller than its predecessor's
+  else if (threadIdx.x < 8) c[threadIdx.x] = 0;  // [6]: some index smaller than its predecessor's; [7]: some record smaller
 }
 extern "C" __global__ void __launch_bounds__(kSortThreads)
 ibu_k_sort_census(const u64* __restrict__ recs, u64 n, u64* __restrict__ c) {
   u64 o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
-  bool index_drops = false;
+  bool index_drops = false, order_drops = false;
   const u64 stride = (u64)gridDim.x * kSortThreads;
-  for (u64 i = (u64)blockIdx.x * kSortThreads + threadIdx.x; i < n; i += stride) {
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-      const u64 v = recs[3 * i + f];
-      o[f] |= v;
-      a[f] &= v;
+  const u32 lane = threadIdx.x & (kWave - 1);
+  // wave-uniform trip count (lanes past n carry neutral values) so the neighbour shuffles below are well defined
+  for (u64 i0 = (u64)blockIdx.x * kSortThreads + (threadIdx.x & ~(u32)(kWave - 1)); i0 < n; i0 += stride) {
+    const u64 i = i0 + lane;
+    const bool valid = i < n;
+    const u64 b = valid ? recs[3 * i] : 0, u = valid ? recs[3 * i + 1] : 0, x = valid ? recs[3 * i + 2] : 0;
+    if (valid) { o[0] |= b; o[1] |= u; o[2] |= x; a[0] &= b; a[1] &= u; a[2] &= x; }
+    // predecessor = the previous lane's record (one shuffle per half word); lane 0 reads it from memory
+    u64 pb = shfl_up64_1(b), pu = shfl_up64_1(u), px = shfl_up64_1(x);
+    if (lane == 0 && valid && i > 0) { pb = recs[3 * (i - 1)]; pu = recs[3 * (i - 1) + 1]; px = recs[3 * (i - 1) + 2]; }
+    if (valid && i > 0) {
+      if (x < px) index_drops = true;       // input not in index order: the index passes are needed
+      if (b != pb ? b < pb : (u != pu ? u < pu : x < px)) order_drops = true;  // not already sorted
     }
-    // input already in index order (records written in read order, index = read number)?  The neighbour's line
-    // is the one this wave just touched, so the extra load is a cache hit.
-    if (i > 0 && recs[3 * i + 2] < recs[3 * (i - 1) + 2]) index_drops = true;
   }
   if (__ballot(index_drops) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(&c[6], 1ull);
+  if (__ballot(order_drops) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(&c[7], 1ull);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
@@ -273,11 +283,12 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   const u64 ccap = (u64)cfg.cus * 8;
   if (cblocks > ccap) cblocks = ccap;
   hipLaunchKernelGGL(ibu_k_sort_census, dim3((u32)cblocks), dim3(kSortThreads), 0, st, (const u64*)recs, (u64)n, census);
-  u64 c[7];
+  u64 c[8];
   hipError_t e = hipMemcpyAsync(c, census, sizeof c, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
+  if (c[7] == 0) return hipSuccess;  // no record is smaller than its predecessor: already sorted
 
   u64* src = static_cast<u64*>(recs);
   u64* dst = static_cast<u64*>(tmp);

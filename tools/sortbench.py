@@ -41,11 +41,15 @@ def main():
             ctx.synchronize()
             ts.append(time.perf_counter() - t0)
         assert ctx.is_sorted(d, n)
+        t0 = time.perf_counter()
+        bcs, counts, uniq = ctx.barcode_counts(d, n)  # BarcodeAnalyzer on the sorted records (size query + emit + download)
+        agg = time.perf_counter() - t0
+        assert int(counts.sum()) == n
         sec = statistics.median(ts[1:])
         idx_bytes = 4 if a.random_index else 0  # 30 random bits -> 4 digit passes; index-ordered input -> skipped
         passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
         print(json.dumps({"n": n, "lens": [bc_len, umi_len], "index": "random" if a.random_index else "increasing (read order)", "seconds": round(sec, 4), "M_records_per_s": round(n / sec / 1e6, 1),
-                          "passes": passes, "GBps_at_72B_per_record_pass": round(n * 72 * passes / sec / 1e9)}), flush=True)
+                          "passes": passes, "barcode_counts_seconds": round(agg, 4), "distinct_barcodes": int(len(bcs)), "GBps_at_72B_per_record_pass": round(n * 72 * passes / sec / 1e9)}), flush=True)
         d.free()
         t.free()
         for c in cols or []:

@@ -55,6 +55,8 @@ struct ibu_ctx {
   uint64_t* h_pinned = nullptr;  // 16 x u64 of pinned host memory for small read-backs
   void* d_sort_scratch = nullptr;
   size_t sort_scratch_bytes = 0;
+  void* d_runs_scratch = nullptr;  // per-run starts / pair ranks of ibu_barcode_counts (grows only)
+  size_t runs_scratch_bytes = 0;
   ibu::Ring ring;
   ibu::CodecRing cring;
 };

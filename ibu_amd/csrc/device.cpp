@@ -83,6 +83,7 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   ring_release(ctx);
   codec_ring_release(ctx);
   if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
+  if (ctx->d_runs_scratch) (void)hipFree(ctx->d_runs_scratch);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->d_acc) (void)hipFree(ctx->d_acc);
   if (ctx->d_flag) (void)hipFree(ctx->d_flag);
@@ -329,8 +330,16 @@ extern "C" int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_recor
   if (!d_barcodes && !d_counts && cap == 0) return IBU_OK;  // size query
   if (!d_barcodes || !d_counts) return err_arg("d_barcodes / d_counts are NULL");
   if (runs > cap) return err_arg("output capacity is smaller than the number of distinct barcodes (see *n_barcodes)");
-  IBU_HIP(launch_runs_emit(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, runs, pairs, d_barcodes, d_counts,
-                           d_unique_umis, st));
+  const size_t need = runs_emit_scratch_bytes(runs);
+  if (need > ctx->runs_scratch_bytes) {
+    if (ctx->d_runs_scratch) IBU_HIP(hipFree(ctx->d_runs_scratch));
+    ctx->d_runs_scratch = nullptr;
+    ctx->runs_scratch_bytes = 0;
+    IBU_HIP(hipMalloc(&ctx->d_runs_scratch, need));
+    ctx->runs_scratch_bytes = need;
+  }
+  IBU_HIP(launch_runs_emit(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->d_runs_scratch, runs, pairs, d_barcodes,
+                           d_counts, d_unique_umis, st));
   return IBU_OK;
 }
 extern "C" int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream) {

@@ -60,7 +60,7 @@ extern "C" const char* ibu_status_name(int32_t s) {
   }
 }
 extern "C" const char* ibu_version(void) { return "ibu_hip 0.1.0 (format v2, reference ibu 0.2.1, gfx950)"; }
-extern "C" uint32_t ibu_abi_revision(void) { return 1; }
+extern "C" uint32_t ibu_abi_revision(void) { return 2; }  // 2: + device_copy, barcode_counts, decode_to_host, write_ascii_batch, ctx_set_option
 extern "C" void ibu_free(void* p) { free(p); }
 
 // ------------------------------------------------------------------------------------------

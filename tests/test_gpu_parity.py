@@ -404,3 +404,14 @@ def test_two_contexts_on_two_host_threads(ia, oracle):
         t.join()
     assert not errors, errors
     assert results == {"a": True, "b": True}
+
+
+def test_hip_runtime_errors_surface_as_status(ia, ctx):
+    """A failing HIP call (here: an impossible allocation) comes back as IBU_ERR_HIP with the hipError_t in the detail —
+    no exception crosses the ABI, and the context keeps working."""
+    with pytest.raises(ia.IbuError) as e:
+        ctx.alloc(1 << 50)
+    assert e.value.kind == "Hip" and e.value.a != 0
+    d = ctx.alloc(24 * 256)
+    ctx.generate(1, 0, 256, 16, 12, d)
+    assert ctx.reduce(d, 256)["count"] == 256

@@ -115,3 +115,68 @@ def test_reader_matches_oracle_with_short_reads_and_truncation(oracle, n, cut, c
         assert got == want and len(got) == n
         assert r.bytes_read == len(data)
     assert got == [tuple(int(v) for v in x) for x in recs[:len(got)]]
+
+
+# ---- damaged compressed input: every decoder fails cleanly (an IbuError) or yields a prefix — never hangs or crashes ----
+def _zstd(data):
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    buf = C.create_string_buffer(z.ZSTD_compressBound(len(data)))
+    k = z.ZSTD_compress(buf, len(buf), data, len(data), 1)
+    return buf.raw[:k]
+
+
+def _compressed_blobs():
+    import bz2
+    import gzip
+    import lzma
+
+    from tests.bgzf import bgzf_compress
+
+    recs = _recs(20_000, 3)
+    w = ia.Writer.new(None, ia.Header(16, 12))
+    w.write_batch(recs)
+    w.finish()
+    raw = w.inner_bytes()
+    return raw, {"gz": gzip.compress(raw, 1), "bgzf": bgzf_compress(raw, block=8000), "bz2": bz2.compress(raw, 1),
+                 "xz": lzma.compress(raw, preset=0), "zst": _zstd(raw)}
+
+
+_RAW, _BLOBS = None, None
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(fmt=st.sampled_from(["gz", "bgzf", "bz2", "xz", "zst"]), damage=st.sampled_from(["flip", "cut", "zero_run", "dup_tail"]),
+       where=st.floats(0.0, 1.0), byte=st.integers(1, 255))
+def test_damaged_compressed_input_fails_cleanly(tmp_path, fmt, damage, where, byte):
+    global _RAW, _BLOBS
+    if _BLOBS is None:
+        _RAW, _BLOBS = _compressed_blobs()
+    blob = bytearray(_BLOBS[fmt])
+    pos = min(len(blob) - 1, max(6, int(where * len(blob))))  # keep the magic so the format is still sniffed
+    if damage == "flip":
+        blob[pos] ^= byte
+    elif damage == "cut":
+        del blob[pos:]
+    elif damage == "zero_run":
+        blob[pos:pos + 64] = bytes(min(64, len(blob) - pos))
+    else:
+        blob += blob[-pos // 4:]  # garbage after the end of the stream
+    p = tmp_path / f"damaged.{fmt}"
+    p.write_bytes(bytes(blob))
+    want = np.frombuffer(_RAW[32:], dtype=ia.REC_DTYPE)
+    try:
+        r = ia.Reader.from_path(p)
+        got = list(r)
+    except ia.IbuError as e:
+        assert e.kind in ("Niffler", "TruncatedRecord", "Io", "InvalidMagicNumber", "InvalidVersion",
+                          "InvalidBarcodeLength", "InvalidUmiLength"), e.kind
+        return
+    # no error: then what came out is the original stream, possibly followed by records decoded from appended bytes
+    assert len(got) >= 0
+    k = min(len(got), len(want))
+    if damage in ("cut",):
+        assert [tuple(x) for x in got[:k]] == [tuple(int(v) for v in x) for x in want[:k]]

@@ -192,3 +192,15 @@ def test_barcode_counts_after_device_sort_and_capacity_error(ctx, oracle, ia):
     rc = ia.lib.ibu_barcode_counts(ctx._c, C.c_void_p(d.ptr), n, C.c_void_p(small_b.ptr), C.c_void_p(small_c.ptr), None,
                                      1, C.byref(nb), None, None)
     assert rc != 0 and nb.value == len(wb)
+
+
+def test_sort_with_8_byte_aligned_buffers(ctx, oracle, ia):
+    """Buffers that are 8- but not 16-byte aligned take the plain staging path (and the byte copy-back): same result."""
+    n = 70_001
+    recs = _shuffled(oracle, n, 16, 12)
+    d, t = ctx.alloc(n * 24 + 16), ctx.alloc(n * 24 + 16)
+    view = ia.DeviceBuffer.wrap(ctx, d.ptr + 8, n * 24)
+    view.upload(recs)
+    ctx.sort_records(d.ptr + 8, t.ptr + 8, n)
+    ctx.synchronize()
+    assert view.download().tobytes() == oracle.sort_records(recs).tobytes()

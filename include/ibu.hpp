@@ -38,6 +38,7 @@ constexpr uint32_t MAGIC = IBU_MAGIC;          // header.rs:5
 constexpr uint32_t VERSION = IBU_VERSION;      // header.rs:6
 constexpr size_t HEADER_SIZE = IBU_HEADER_SIZE;  // header.rs:7
 constexpr size_t RECORD_SIZE = IBU_RECORD_SIZE;  // record.rs:3
+constexpr size_t DEFAULT_BUFFER_SIZE = IBU_DEFAULT_BUFFER_SIZE;  // reader.rs:14, writer.rs:10 (48 Ki records)
 
 // ---- error.rs:56-128 ------------------------------------------------------------------------------------------
 class IbuError : public std::runtime_error {

@@ -598,3 +598,22 @@ def test_roundtrip_example_1e6(kat, tmp_path):
     assert n == k["n"] and [int(v) for v in sums] == k["sums"] and x == k["checksum"]
     hh, got = load_to_vec(p)
     assert got.tobytes() == recs.tobytes()
+
+
+def test_reader_state_after_a_truncation_error(oracle):  # quirk Q9, reader.rs:287-295
+    """After Some(Err(TruncatedRecord)) the reference does not latch the error: the next call refills again, finds the
+    source exhausted and ends the iteration.  Product and oracle agree call by call."""
+    data = create_test_data(seq(10))[:-5]
+    r = Reader.new(data)
+    o = oracle.Reader(data=data)
+    with pytest.raises(IbuError) as ei:
+        next(r)
+    assert ei.value.kind == "TruncatedRecord"
+    with pytest.raises(oracle.OracleError):
+        o.next()
+    with pytest.raises(StopIteration):
+        next(r)
+    assert o.next() is None
+    with pytest.raises(StopIteration):  # and it stays ended
+        next(r)
+    assert o.next() is None

@@ -80,6 +80,18 @@ def test_plain_c_client_of_the_abi(built):
     assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not os.environ.get("IBU_RUN_ASAN"), reason="set IBU_RUN_ASAN=1: builds a sanitized library (~1 min)")
+def test_cpp_mirror_under_tsan(tmp_path, oracle):
+    """ThreadSanitizer over process_parallel's workers, the parallel loaders and the BGZF inflate threads."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "tsan"])
+    fx = tmp_path / "compressed"
+    fx.mkdir()
+    _compressed_fixture(fx, oracle)
+    env = {**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx), "TSAN_OPTIONS": "halt_on_error=1"}
+    r = _run([os.path.join(BIN, "tsan", "test_host")], env=env)
+    assert r.returncode == 0 and "0 failed" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_roundtrip_example_1e6(built, tmp_path, kat):
     """BASELINE configs[0]: examples/roundtrip.rs shape at 1e6 records — CPU plumbing only."""
     r = _run([os.path.join(built, "roundtrip"), "1000000", "--json", "--dir", str(tmp_path)])

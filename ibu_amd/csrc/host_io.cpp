@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <future>
 #include <memory>
 #include <new>
 #include <thread>
@@ -454,7 +455,9 @@ struct ZstdSource : InflatingSource {
 struct BgzfSource : Source {
   std::unique_ptr<Source> inner;
   std::unique_ptr<Source> fallback;   // sequential inflate once a non-BGZF member shows up
-  std::vector<uint8_t> comp, out;
+  std::vector<uint8_t> comp, out;     // out: the batch being handed out by read()
+  std::vector<uint8_t> next_out;      // the batch being inflated in the background while `out` is consumed
+  std::future<int> next;              // pending background refill (at most one; it alone touches inner/comp/eof/fallback)
   size_t out_pos = 0;
   bool eof = false;
   unsigned threads;
@@ -486,10 +489,10 @@ struct BgzfSource : Source {
     if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), o, (uInt)isize) != crc) return EPROTO;
     return 0;
   }
-  int refill() {
+  ~BgzfSource() override { if (next.valid()) (void)next.get(); }  // never leave the worker running over freed members
+  int refill(std::vector<uint8_t>& out) {
     comp.clear();
     out.clear();
-    out_pos = 0;
     std::vector<Block> blocks;
     size_t total_out = 0;
     const size_t kBatchComp = (size_t)16 << 20;
@@ -576,10 +579,18 @@ struct BgzfSource : Source {
         *got = k;
         return 0;
       }
-      if (fallback) return fallback->read(dst, cap, got);
-      if (eof) return 0;
-      const int rc = refill();
+      // current batch drained: take the one inflated in the background (or start the first), then immediately start
+      // the next so that reading + inflating batch k+1 overlaps the caller's consumption of batch k
+      if (!next.valid()) {
+        if (fallback) return fallback->read(dst, cap, got);
+        if (eof) return 0;
+        next = std::async(std::launch::async, [this] { return refill(next_out); });
+      }
+      const int rc = next.get();  // synchronises with everything the worker wrote (eof, fallback, next_out)
       if (rc) return rc;
+      out.swap(next_out);
+      out_pos = 0;
+      if (!eof && !fallback) next = std::async(std::launch::async, [this] { return refill(next_out); });
     }
   }
 };

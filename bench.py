@@ -11,6 +11,15 @@ SURVEY §8d, so every rank materialises its own contiguous record range of the g
 the static split of src/io/mmap.rs:297-307).  No collective on the data path; ONE all-reduce
 at the end carries the global record count and field sums (BASELINE north_star).
 
+Scaling modes (`--scaling`): BASELINE configs[3] is ONE stream of 1e9 records range-sharded over the GPUs of a
+node, so for N > 1 the default is **strong** scaling: `--records` is the GLOBAL record count and rank r owns
+`rank_shard(records, N, r)` (per = records / N, remainder to the last rank).  `--scaling weak` keeps `--records`
+records on every GPU instead (global = records x N).  At N = 1 the two coincide.  The JSON line names the mode, the
+per-rank shard sizes, the slowest and fastest rank's kernel times and the time of the one cross-GPU exchange.
+
+On one GPU a short second leg runs BASELINE configs[2] (bc_len = umi_len = 32, the maximum width) and is reported
+under `config2_32_32`; it is outside the timed region of the headline value.
+
 Output: one JSON line on rank 0.
 """
 import argparse
@@ -30,7 +39,13 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--records", type=float, default=1e9, help="records per GPU (weak scaling)")
+    p.add_argument("--records", type=float, default=1e9,
+                   help="strong scaling: records in the whole stream; weak scaling: records per GPU")
+    p.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                   help="strong (default): --records is the global count, range-sharded over the ranks (configs[3]); "
+                        "weak: --records per GPU")
+    p.add_argument("--no-wide-leg", action="store_true", help="skip the (32,32) leg (configs[2]) on one GPU")
+    p.add_argument("--wide-records", type=float, default=0, help="records of the (32,32) leg (0 = same as --records)")
     p.add_argument("--bc-len", type=int, default=16)
     p.add_argument("--umi-len", type=int, default=12)
     p.add_argument("--seed", type=lambda s: int(s, 0), default=0x1B00003)
@@ -88,12 +103,125 @@ def cpu_baseline(args):
     }
 
 
+def plan_shard(records, scaling, world, rank):
+    """(n_global, first, n) of `rank`: strong = ONE stream of `records` split by the reference's static split
+    (src/io/mmap.rs:297-307: per = len / n, the remainder to the LAST shard); weak = `records` on every rank."""
+    from ibu_amd import sharding
+
+    n_global = int(records) * (world if scaling == "weak" else 1)
+    first, end = sharding.rank_shard(n_global, world, rank)
+    return n_global, first, end - first
+
+
+def traffic_from_profile(bc_len, umi_len, n):
+    """PMC-derived HBM bytes of one decode launch.  The counters cannot be read from inside this process (rocprofv3
+    collects them around it, in separate --pmc passes as the guide prescribes), so the figure comes from the file
+    `tools/pmc_traffic.py` wrote from those passes; the line names the file, its round tag and its hash."""
+    import hashlib
+
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(tp, "rb") as f:
+            raw = f.read()
+        doc = json.loads(raw)
+        rec = doc.get(f"decode_{bc_len}_{umi_len}")
+        if not rec:
+            return None, None
+        src = {"file": "profiles/pmc_traffic.json", "round": doc.get("_round"), "sha16": hashlib.sha256(raw).hexdigest()[:16],
+               "hbm_bytes_per_record": rec["hbm_bytes_per_record"], "measured_at_records": doc.get("_records"),
+               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/kbench.py, FETCH_SIZE doubled (gfx950)"}
+        return rec["hbm_bytes_per_record"] * n, src
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+class Leg:
+    """One resident workload: this rank's shard [first, first + n) of the synthetic stream, its output columns and the
+    re-encoded records.  step() = K2 decode followed by K3 encode."""
+
+    def __init__(self, ctx, torch, dev, st, seed, first, n, bc_len, umi_len):
+        self.ctx, self.torch, self.st, self.n, self.bc_len, self.umi_len = ctx, torch, st, n, bc_len, umi_len
+
+        def buf(nbytes):
+            return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+
+        self.recs, self.back = buf(n * 24), buf(n * 24)
+        self.bc, self.umi, self.idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
+        ctx.generate(seed, first, n, bc_len, umi_len, self.recs, stream=st)
+        torch.cuda.synchronize()
+
+    def step(self, ev=None):
+        c, n, st = self.ctx, self.n, self.st
+        if ev:
+            ev[0].record()
+        c.decode_ascii(self.recs, n, self.bc_len, self.umi_len, self.bc, self.umi, self.idx, stream=st)
+        if ev:
+            ev[1].record()
+        c.encode_ascii(self.bc, self.umi, self.idx, n, self.bc_len, self.umi_len, self.back, stream=st)
+        if ev:
+            ev[2].record()
+
+    def timed(self, steps, warmup, barrier):
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step(events[k])
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        dec_ms = sum(e[0].elapsed_time(e[1]) for e in events) / steps
+        enc_ms = sum(e[1].elapsed_time(e[2]) for e in events) / steps
+        return elapsed, dec_ms, enc_ms
+
+    def copy_ceiling(self):
+        """This box's own copy ceiling (plain dwordx4 copy kernel, recs -> the barcode column), outside the timed region:
+        the second denominator SURVEY 8d asks for next to the 8 TB/s spec peak; boxes of this pool differ by ~20 %."""
+        torch, nbytes = self.torch, min(self.bc.numel(), self.recs.numel())
+        ms = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.ctx.copy(self.bc, self.recs, nbytes, stream=self.st)
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        # the copy overwrote the decoded barcode column: decode once more so the verification sees real data
+        self.ctx.decode_ascii(self.recs, self.n, self.bc_len, self.umi_len, self.bc, self.umi, self.idx, stream=self.st)
+        return 2 * nbytes / (sorted(ms)[len(ms) // 2] * 1e-3) / 1e9
+
+    def verify(self, full):
+        """Correctness of what was timed: no record failed to encode, encode(decode(x)) == x byte for byte."""
+        torch, n = self.torch, self.n
+        self.ctx.codec_status(stream=self.st)  # raises if any record failed to encode
+        red = self.ctx.reduce(self.recs, n, stream=self.st)
+        ok = None
+        if full:
+            red_back = self.ctx.reduce(self.back, n, stream=self.st)
+            chunk = 1 << 30  # compare in 1 GiB pieces: torch.equal materialises a mask as large as its inputs
+            nb = n * 24
+            same = all(bool(torch.equal(self.recs[o:min(o + chunk, nb)], self.back[o:min(o + chunk, nb)])) for o in range(0, nb, chunk))
+            ok = same and red == red_back and red["count"] == n
+            if not ok:
+                raise SystemExit("round trip encode(decode(x)) != x")
+        return red, ok
+
+    def free(self):
+        self.recs = self.back = self.bc = self.umi = self.idx = None
+        self.torch.cuda.empty_cache()
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
 
     import ibu_amd
+    from ibu_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -113,105 +241,79 @@ def main():
     ctx = ibu_amd.Context(local_rank)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the few collective words live
 
-    n = int(args.records)
     bc_len, umi_len = args.bc_len, args.umi_len
-    n_global = n * world
-    from ibu_amd import sharding
+    # strong: --records is the whole stream (configs[3]: 1e9 records range-sharded over the GPUs); weak: per GPU
+    n_global, first, n = plan_shard(args.records, args.scaling, world, rank)  # contiguous record-range split
+    if args.scaling == "weak":
+        assert n == int(args.records)
 
-    first, end = sharding.rank_shard(n_global, world, rank)  # contiguous record-range split (mmap.rs:297-307)
-    assert end - first == n
-
-    def buf(nbytes):
-        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
-
-    recs, back = buf(n * 24), buf(n * 24)
-    bc, umi, idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
     # a real (non-null) stream: the ABI reads a NULL stream as "the context's own stream", and
     # torch.cuda.Event only sees work on torch's current stream
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     st = tstream.cuda_stream
     assert st != 0
-    ctx.generate(args.seed, first, n, bc_len, umi_len, recs, stream=st)
-    torch.cuda.synchronize()
 
-    def step(ev=None):
-        if ev:
-            ev[0].record()
-        ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
-        if ev:
-            ev[1].record()
-        ctx.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back, stream=st)
-        if ev:
-            ev[2].record()
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    leg = Leg(ctx, torch, dev, st, args.seed, first, n, bc_len, umi_len)
+    elapsed, dec_ms, enc_ms = leg.timed(args.steps, args.warmup, barrier)
+    per_rank = [[float(n), dec_ms, enc_ms, elapsed]]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=coll_dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per_rank = [p.tolist() for p in parts]
         elapsed = float(t.item())
 
-    dec_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    enc_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
-
-    # ---- outside the timed region: this box's own copy ceiling (plain dwordx4 copy kernel, recs -> scratch) ----
-    # the second denominator SURVEY 8d asks for next to the 8 TB/s spec peak; boxes of this pool differ by ~20 %
-    copy_ms = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ctx.copy(bc, recs, min(bc.numel(), recs.numel()), stream=st)
-        e1.record()
-        e1.synchronize()
-        copy_ms.append(e0.elapsed_time(e1))
-    copy_GBps = 2 * min(bc.numel(), recs.numel()) / (sorted(copy_ms)[len(copy_ms) // 2] * 1e-3) / 1e9
-    # the copy overwrote the decoded barcode column: decode once more so the verification below sees real data
-    ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
-
-    # ---- outside the timed region: correctness of what was timed ------------------------------
-    ctx.codec_status(stream=st)  # raises if any record failed to encode
-    red = ctx.reduce(recs, n, stream=st)
-    verified = None
-    if not args.no_verify:
-        red_back = ctx.reduce(back, n, stream=st)
-        chunk = 1 << 30  # compare in 1 GiB pieces: torch.equal materialises a mask as large as its inputs
-        same = all(bool(torch.equal(recs[o:o + chunk], back[o:o + chunk])) for o in range(0, recs.numel(), chunk))
-        verified = same and red == red_back and red["count"] == n
-        if not verified:
-            raise SystemExit("round trip encode(decode(x)) != x")
-    # the one cross-GPU exchange: global count + wrapping field sums (4 x i64 over RCCL)
+    copy_GBps = leg.copy_ceiling()
+    red, verified = leg.verify(not args.no_verify)
+    # the one cross-GPU exchange: global count + wrapping field sums (4 x i64 over RCCL); timed on its second call
+    # (the first pays the communicator's lazy set-up)
     g = sharding.global_totals(red, device=coll_dev)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    g = sharding.global_totals(red, device=coll_dev)
+    torch.cuda.synchronize()
+    allreduce_ms = (time.perf_counter() - t0) * 1e3
     tot = [g["count"]] + g["sum"]
     assert tot[0] == n_global
     assert tot[3] == sharding.expected_index_sum(n_global)  # index column is 0..n_global-1
 
+    wide = None
+    if world == 1 and not args.no_wide_leg and (bc_len, umi_len) != (32, 32):
+        # BASELINE configs[2]: maximum width, encode+decode on one GPU — a short leg outside the headline's timed region
+        leg.free()
+        nw = int(args.wide_records) or n
+        wl = Leg(ctx, torch, dev, st, 0x1B00002, 0, nw, 32, 32)
+        w_steps = max(1, min(args.steps, 5))
+        w_el, w_dec, w_enc = wl.timed(w_steps, 1, barrier)
+        _, w_ok = wl.verify(not args.no_verify)
+        wb = nw * 96
+        wide = {
+            "workload": f"{nw:.3g} records bc_len=32 umi_len=32 (BASELINE configs[2]), K2 decode + K3 encode per step",
+            "steps": w_steps, "warmup": 1, "value": nw * w_steps / w_el, "unit": "records/s", "ms_per_step": w_el / w_steps * 1e3,
+            "kernel_ms": {"decode": w_dec, "encode": w_enc},
+            "kernel_GBps": {"decode": wb / (w_dec * 1e-3) / 1e9, "encode": wb / (w_enc * 1e-3) / 1e9},
+            "roofline": {"bound": "hbm", "kernel": "ibu_k_decode<32,32>", "achieved": wb / (w_dec * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": wb / (w_dec * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_record": 96},
+            "verified_roundtrip": w_ok,
+        }
+        wl.free()
+
     if rank == 0:
-        dec_bytes = n * (24 + bc_len + umi_len + 8)
-        enc_bytes = dec_bytes
+        bpr = 24 + bc_len + umi_len + 8
+        # rank 0's own launch: its records x algorithmic bytes / its measured decode time
+        dec_bytes = n * bpr
         achieved = dec_bytes / (dec_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):  # PMC-derived HBM bytes per decode launch, recorded by profiles/collect_pmc.py
-            try:
-                with open(tp) as f:
-                    rec = json.load(f).get(f"decode_{bc_len}_{umi_len}")
-                if rec:
-                    traffic = rec["hbm_bytes_per_record"] * n
-            except (OSError, ValueError, KeyError):
-                traffic = None
+        traffic, traffic_src = traffic_from_profile(bc_len, umi_len, n)
+        shard_note = ("ONE stream range-sharded over the ranks (strong scaling, BASELINE configs[3])" if args.scaling == "strong"
+                      else "every rank holds --records records of a stream of records x ranks (weak scaling)")
         out = {
             "metric": "records/s, fused 2-bit decode+encode of 24-byte IBU records (HBM-resident)",
             "value": n_global * args.steps / elapsed,
@@ -221,28 +323,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n:.3g} records/GPU bc_len={bc_len} umi_len={umi_len}, K2 decode + K3 encode per step "
-                            f"(BASELINE configs[3] shape; contiguous record-range shard per rank, no data-path collective)",
-                "records_per_gpu": n, "records_total": n_global, "bc_len": bc_len, "umi_len": umi_len,
-                "parallelism": f"range-shard x{world}",
+                "workload": f"{n_global:.3g} records bc_len={bc_len} umi_len={umi_len}, K2 decode + K3 encode per step; {shard_note}; "
+                            f"contiguous record-range shard per rank (mmap.rs:297-307), no data-path collective",
+                "records_total": n_global, "records_per_gpu": n, "records_per_rank": [int(p[0]) for p in per_rank],
+                "bc_len": bc_len, "umi_len": umi_len, "parallelism": f"range-shard x{world}",
             },
             "kernel_ms": {"decode": dec_ms, "encode": enc_ms},
-            "kernel_GBps": {"decode": achieved, "encode": enc_bytes / (enc_ms * 1e-3) / 1e9},
+            "kernel_ms_ranks": {"decode": {"min": min(p[1] for p in per_rank), "max": max(p[1] for p in per_rank)},
+                                "encode": {"min": min(p[2] for p in per_rank), "max": max(p[2] for p in per_rank)},
+                                "wall_ms_per_step": {"min": min(p[3] for p in per_rank) / args.steps * 1e3,
+                                                     "max": max(p[3] for p in per_rank) / args.steps * 1e3}},
+            "launch_gap_ms_per_step": elapsed / args.steps * 1e3 - (dec_ms + enc_ms),
+            "allreduce_ms": allreduce_ms,
+            "kernel_GBps": {"decode": achieved, "encode": dec_bytes / (enc_ms * 1e-3) / 1e9},
             "roofline": {
-                "bound": "hbm", "kernel": "ibu_k_decode", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "bytes_per_record": 24 + bc_len + umi_len + 8,
+                "bound": "hbm", "kernel": f"ibu_k_decode<{bc_len},{umi_len}>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_record": bpr, "records_per_launch": n,
                 "copy_ceiling": copy_GBps, "frac_of_copy_ceiling": achieved / copy_GBps,
             },
             "gpu": {"name": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))},
             "verified_roundtrip": verified,
             "global_count": tot[0],
         }
+        if wide:
+            out["config2_32_32"] = wide
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

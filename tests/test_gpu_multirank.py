@@ -28,11 +28,24 @@ def _torchrun(nproc, script, *args):
     return json.loads(lines[0])
 
 
-def test_bench_two_ranks_on_one_gpu():
-    out = _torchrun(2, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "5e7", "--backend", "gloo",
+def test_bench_two_ranks_on_one_gpu_strong():
+    """Default for N > 1 = BASELINE configs[3]: --records is the WHOLE stream, range-sharded over the ranks."""
+    out = _torchrun(2, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "100000001", "--backend", "gloo",
                     "--share-gpu", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["global_count"] == 100_000_001 and out["verified_roundtrip"] is True
+    assert out["scaling"] == "strong" and out["config"]["records_total"] == 100_000_001
+    assert out["config"]["records_per_rank"] == [50_000_000, 50_000_001]  # remainder to the last shard (mmap.rs:297-307)
+    assert out["kernel_ms_ranks"]["decode"]["min"] <= out["kernel_ms_ranks"]["decode"]["max"]
+    assert out["allreduce_ms"] > 0 and "config2_32_32" not in out
+    assert abs(out["value"] - 100_000_001 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_two_ranks_on_one_gpu_weak():
+    out = _torchrun(2, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "5e7", "--scaling", "weak",
+                    "--backend", "gloo", "--share-gpu", "--no-cpu-baseline")
     assert out["n_gpus"] == 2 and out["global_count"] == 100_000_000 and out["verified_roundtrip"] is True
     assert out["scaling"] == "weak" and out["config"]["records_total"] == 100_000_000
+    assert out["config"]["records_per_rank"] == [50_000_000, 50_000_000]
 
 
 @pytest.mark.parametrize("proc", ["reduce", "decode"])

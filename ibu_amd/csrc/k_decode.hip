@@ -26,13 +26,18 @@ struct DecRegs {
 };
 
 // Stage one AoS tile held in registers into the wave's LDS slice and expand it.
-template <int BC, int UM>
+template <int BC, int UM, bool MSB>
 __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs& a, u32 t, u32 bc_len, u32 umi_len,
                                             uint8_t* bc_out, uint8_t* umi_out, u64* idx_out, u32 lane) {
   wave_lds_fence();                            // previous tile's LDS reads precede these writes
 #pragma unroll
   for (int k = 0; k < kDecLoads; ++k) *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = a.v[k];
   wave_lds_fence();
+  if constexpr (MSB) {                         // MSB-first code words -> the order the expansion reads
+    rev_pairs_tile<kDecodeNT>(tile, 24, 0, bc_len, lane);
+    rev_pairs_tile<kDecodeNT>(tile, 24, 8, umi_len, lane);
+    wave_lds_fence();
+  }
   if (bc_out) expand_field<BC, kDecodeNT>(tile, 24, 0, bc_len, bc_out + (size_t)t * kDecRecs * bc_len, lane);
   if (umi_out) expand_field<UM, kDecodeNT>(tile, 24, 8, umi_len, umi_out + (size_t)t * kDecRecs * umi_len, lane);
   if (idx_out) {                               // chunk c = indices of records 2c, 2c+1
@@ -58,8 +63,8 @@ constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
 #ifndef IBU_DECODE_MINWAVES
 #define IBU_DECODE_MINWAVES (IBU_DECODE_NT > 1 ? 5 : 7)
 #endif
-template <int BC, int UM>
-__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? IBU_DECODE_MINWAVES : 3)
+template <int BC, int UM, bool MSB>
+__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? IBU_DECODE_MINWAVES - (MSB ? 1 : 0) : 3)
 ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
              uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kDecBytes];
@@ -78,20 +83,20 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
     u32 tn = t + nwaves;
     bool more = tn < ntiles;                   // wave-uniform
     b.load(recs + (size_t)(more ? tn : t) * kDecBytes + 16 * lane);
-    decode_tile<BC, UM>(tile, a, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
+    decode_tile<BC, UM, MSB>(tile, a, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
     if (!more) break;
     t = tn;
     tn = t + nwaves;
     more = tn < ntiles;
     a.load(recs + (size_t)(more ? tn : t) * kDecBytes + 16 * lane);
-    decode_tile<BC, UM>(tile, b, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
+    decode_tile<BC, UM, MSB>(tile, b, t, bc_len, umi_len, bc_out, umi_out, idx_out, lane);
     if (!more) break;
     t = tn;
   }
 }
 
 // Single u64 column -> ASCII (stride-8 "records", 1 KiB tile).
-template <int LEN>
+template <int LEN, bool MSB>
 __global__ void __launch_bounds__(kBlock, dword_len(LEN) ? 8 : 3)
 ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * 1024];
@@ -109,7 +114,7 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
     bool more = tn < ntiles;
     u32x4 b = ld16(base + (size_t)(more ? tn : t) * 1024);
     wave_lds_fence();
-    *reinterpret_cast<u32x4*>(tile + 16 * lane) = a;
+    *reinterpret_cast<u32x4*>(tile + 16 * lane) = MSB ? rev_pairs_x2(a, len) : a;  // lane's chunk = code words 2L, 2L+1
     wave_lds_fence();
     expand_field<LEN>(tile, 8, 0, len, out + (size_t)t * kTileRecs * len, lane);
     if (!more) break;
@@ -118,7 +123,7 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
     more = tn < ntiles;
     a = ld16(base + (size_t)(more ? tn : t) * 1024);
     wave_lds_fence();
-    *reinterpret_cast<u32x4*>(tile + 16 * lane) = b;
+    *reinterpret_cast<u32x4*>(tile + 16 * lane) = MSB ? rev_pairs_x2(b, len) : b;
     wave_lds_fence();
     expand_field<LEN>(tile, 8, 0, len, out + (size_t)t * kTileRecs * len, lane);
     if (!more) break;
@@ -127,75 +132,84 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
 }
 
 // ---- tails: one thread per record, any alignment -----------------------------------------------
-__device__ __forceinline__ void unpack_row_bytes(u64 code, u32 len, uint8_t* out) {
+__device__ __forceinline__ void unpack_row_bytes(u64 code, u32 len, u32 msb, uint8_t* out) {
+  if (msb) code = rev_pairs(code, len);
   for (u32 i = 0; i < len; ++i) {  // per-base extract with v_bfe_u32 on the half of the code word that holds base i
     const u32 half = (u32)(code >> (i & 16u ? 32 : 0));
     out[i] = (uint8_t)__builtin_amdgcn_ubfe(kPool, 8 * __builtin_amdgcn_ubfe(half, 2 * (i & 15u), 2), 8);
   }
 }
 extern "C" __global__ void ibu_k_decode_tail(const u64* __restrict__ recs, u64 row0, u64 n, u32 bc_len,
-                                             u32 umi_len, uint8_t* bc_out, uint8_t* umi_out, u64* idx_out) {
+                                             u32 umi_len, u32 msb, uint8_t* bc_out, uint8_t* umi_out, u64* idx_out) {
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (bc_out) unpack_row_bytes(recs[3 * i], bc_len, bc_out + i * bc_len);
-  if (umi_out) unpack_row_bytes(recs[3 * i + 1], umi_len, umi_out + i * umi_len);
+  if (bc_out) unpack_row_bytes(recs[3 * i], bc_len, msb, bc_out + i * bc_len);
+  if (umi_out) unpack_row_bytes(recs[3 * i + 1], umi_len, msb, umi_out + i * umi_len);
   if (idx_out) idx_out[i] = recs[3 * i + 2];
 }
-extern "C" __global__ void ibu_k_unpack_tail(const u64* codes, u64 row0, u64 n, u32 len, uint8_t* out) {
+extern "C" __global__ void ibu_k_unpack_tail(const u64* codes, u64 row0, u64 n, u32 len, u32 msb, uint8_t* out) {
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  unpack_row_bytes(codes[i], len, out + i * len);
+  unpack_row_bytes(codes[i], len, msb, out + i * len);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
 typedef void (*DecFn)(const uint8_t*, u32, u32, u32, uint8_t*, uint8_t*, u64*);
-template <int B, int U>
-static constexpr DecFn dec_entry() { return ibu_k_decode<len_of_mode(B), len_of_mode(U)>; }
-#define IBU_DEC_ROW(B) {dec_entry<B, 0>(), dec_entry<B, 1>(), dec_entry<B, 2>(), dec_entry<B, 3>(), dec_entry<B, 4>(), dec_entry<B, 5>()}
-static const DecFn kDecTable[kNumLenModes][kNumLenModes] = {IBU_DEC_ROW(0), IBU_DEC_ROW(1), IBU_DEC_ROW(2),
-                                                            IBU_DEC_ROW(3), IBU_DEC_ROW(4), IBU_DEC_ROW(5)};
+template <int B, int U, bool M>
+static constexpr DecFn dec_entry() { return ibu_k_decode<len_of_mode(B), len_of_mode(U), M>; }
+#define IBU_DEC_ROW(B, M) {dec_entry<B, 0, M>(), dec_entry<B, 1, M>(), dec_entry<B, 2, M>(), dec_entry<B, 3, M>(), dec_entry<B, 4, M>(), dec_entry<B, 5, M>()}
+#define IBU_DEC_TABLE(M) {IBU_DEC_ROW(0, M), IBU_DEC_ROW(1, M), IBU_DEC_ROW(2, M), IBU_DEC_ROW(3, M), IBU_DEC_ROW(4, M), IBU_DEC_ROW(5, M)}
+static const DecFn kDecTable[2][kNumLenModes][kNumLenModes] = {IBU_DEC_TABLE(false), IBU_DEC_TABLE(true)};  // [base_order][bc][umi]
 
 hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t bc_len, uint32_t umi_len,
                          uint8_t* bc, uint8_t* umi, uint64_t* idx, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
-  const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
-  const size_t n_main = fast ? (n / kDecRecs) * kDecRecs : 0;
-  if (n_main) {
-    const u32 ntiles = (u32)(n_main / kDecRecs);
+  const Span sp[4] = {{recs, 24}, {bc, bc_len}, {umi, umi_len}, {idx, 8}};
+  const RowSplit rs = split_rows(sp, 4, n, kDecRecs);   // peel rows until every array is 16-B aligned
+  if (rs.head)
+    hipLaunchKernelGGL(ibu_k_decode_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0,
+                       (u64)rs.head, bc_len, umi_len, cfg.base_order, bc, umi, (u64*)idx);
+  if (rs.main) {
+    const u32 ntiles = (u32)(rs.main / kDecRecs);
     const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
-    const DecFn fn = kDecTable[mb][mu];
-    static std::atomic<int> occ[kNumLenModes][kNumLenModes];
-    hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, fn, 0, &occ[mb][mu]))), dim3(kBlock), 0,
-                       st, (const uint8_t*)recs, ntiles, bc_len, umi_len, bc, umi, (u64*)idx);
+    const int mo = cfg.base_order ? 1 : 0;
+    const DecFn fn = kDecTable[mo][mb][mu];
+    static std::atomic<int> occ[2][kNumLenModes][kNumLenModes];
+    hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, fn, 0, &occ[mo][mb][mu]))), dim3(kBlock), 0,
+                       st, adv((const uint8_t*)recs, 24 * rs.head), ntiles, bc_len, umi_len, adv(bc, rs.head * bc_len),
+                       adv(umi, rs.head * umi_len), adv((u64*)idx, 8 * rs.head));
   }
-  if (n_main < n)
-    hipLaunchKernelGGL(ibu_k_decode_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,
-                       (u64)n_main, (u64)n, bc_len, umi_len, bc, umi, (u64*)idx);
+  if (rs.head + rs.main < n)
+    hipLaunchKernelGGL(ibu_k_decode_tail, dim3(tail_grid(n - rs.head - rs.main)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)(rs.head + rs.main), (u64)n, bc_len, umi_len, cfg.base_order, bc, umi, (u64*)idx);
   return hipGetLastError();
 }
 
 typedef void (*UnpFn)(const u64*, u32, u32, uint8_t*);
-static const UnpFn kUnpTable[kNumLenModes] = {ibu_k_unpack<len_of_mode(0)>, ibu_k_unpack<len_of_mode(1)>,
-                                              ibu_k_unpack<len_of_mode(2)>, ibu_k_unpack<len_of_mode(3)>,
-                                              ibu_k_unpack<len_of_mode(4)>, ibu_k_unpack<len_of_mode(5)>};
+#define IBU_UNP_ROW(M) {ibu_k_unpack<len_of_mode(0), M>, ibu_k_unpack<len_of_mode(1), M>, ibu_k_unpack<len_of_mode(2), M>, \
+                        ibu_k_unpack<len_of_mode(3), M>, ibu_k_unpack<len_of_mode(4), M>, ibu_k_unpack<len_of_mode(5), M>}
+static const UnpFn kUnpTable[2][kNumLenModes] = {IBU_UNP_ROW(false), IBU_UNP_ROW(true)};
 
 hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, uint32_t len, uint8_t* out,
                          hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
-  const bool fast = aligned16(codes) && aligned16(out);
-  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
-  if (n_main) {
-    const u32 ntiles = (u32)(n_main / kTileRecs);
-    const int m = mode_of_len(len);
-    static std::atomic<int> occ[kNumLenModes];
-    hipLaunchKernelGGL(kUnpTable[m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kUnpTable[m], 0, &occ[m]))),
-                       dim3(kBlock), 0, st, (const u64*)codes, ntiles, len, out);
+  const Span sp[2] = {{codes, 8}, {out, len}};
+  const RowSplit rs = split_rows(sp, 2, n, kTileRecs);
+  if (rs.head)
+    hipLaunchKernelGGL(ibu_k_unpack_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)codes, (u64)0, (u64)rs.head,
+                       len, cfg.base_order, out);
+  if (rs.main) {
+    const u32 ntiles = (u32)(rs.main / kTileRecs);
+    const int m = mode_of_len(len), mo = cfg.base_order ? 1 : 0;
+    static std::atomic<int> occ[2][kNumLenModes];
+    hipLaunchKernelGGL(kUnpTable[mo][m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kUnpTable[mo][m], 0, &occ[mo][m]))),
+                       dim3(kBlock), 0, st, adv((const u64*)codes, 8 * rs.head), ntiles, len, adv(out, rs.head * len));
   }
-  if (n_main < n)
-    hipLaunchKernelGGL(ibu_k_unpack_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)codes,
-                       (u64)n_main, (u64)n, len, out);
+  if (rs.head + rs.main < n)
+    hipLaunchKernelGGL(ibu_k_unpack_tail, dim3(tail_grid(n - rs.head - rs.main)), dim3(256), 0, st, (const u64*)codes,
+                       (u64)(rs.head + rs.main), (u64)n, len, cfg.base_order, out);
   return hipGetLastError();
 }
 

@@ -258,14 +258,22 @@ extern "C" __global__ void ibu_k_serialize_tail(const u64* bc, const u64* umi, c
   recs[3 * i] = bc[i]; recs[3 * i + 1] = umi[i]; recs[3 * i + 2] = idx[i];
 }
 extern "C" __global__ void ibu_k_reduce_tail(const u64* __restrict__ recs, u64 row0, u64 n, u64* acc) {
-  // at most a few hundred records: one block, one thread per record, atomics straight to acc
+  // one thread per record (peeled head rows, the n % 128 rest, or a whole input no peel can align); each wave folds its
+  // 64 records with shuffles first, so the atomics are six per WAVE whatever the size
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  u64 v[3] = {0, 0, 0};
+  if (i < n) { v[0] = recs[3 * i]; v[1] = recs[3 * i + 1]; v[2] = recs[3 * i + 2]; }
+  u64 S[3] = {v[0], v[1], v[2]}, X[3] = {v[0], v[1], v[2]};
 #pragma unroll
-  for (int f = 0; f < 3; ++f) {
-    u64 v = recs[3 * i + f];
-    if (v) { atomicAdd(&acc[1 + f], v); atomicXor(&acc[4 + f], v); }
-  }
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { S[g] += shfl_xor_u64(S[g], m); X[g] ^= shfl_xor_u64(X[g], m); }
+  if ((threadIdx.x & (kWave - 1)) == 0)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (S[g]) atomicAdd(&acc[1 + g], S[g]);
+      if (X[g]) atomicXor(&acc[4 + g], X[g]);
+    }
 }
 extern "C" __global__ void ibu_k_sorted_check(const u64* __restrict__ recs, u64 n, u32* unsorted) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -284,18 +292,22 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
                               uint64_t* idx, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
-  const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
-  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
-  if (n_main) {
-    u32 ntiles = (u32)(n_main / kTileRecs);
+  const Span sp[4] = {{recs, 24}, {bc, 8}, {umi, 8}, {idx, 8}};
+  const RowSplit rs = split_rows(sp, 4, n, kTileRecs);   // peel rows until every array is 16-B aligned
+  if (rs.head)
+    hipLaunchKernelGGL(ibu_k_deserialize_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)rs.head,
+                       (u64*)bc, (u64*)umi, (u64*)idx);
+  if (rs.main) {
+    u32 ntiles = (u32)(rs.main / kTileRecs);
     static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_deserialize,
                        dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
-                       (const uint8_t*)recs, ntiles, (u64*)bc, (u64*)umi, (u64*)idx);
+                       adv((const uint8_t*)recs, 24 * rs.head), ntiles, adv((u64*)bc, 8 * rs.head), adv((u64*)umi, 8 * rs.head),
+                       adv((u64*)idx, 8 * rs.head));
   }
-  if (n_main < n)
-    hipLaunchKernelGGL(ibu_k_deserialize_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,
-                       (u64)n_main, (u64)n, (u64*)bc, (u64*)umi, (u64*)idx);
+  if (rs.head + rs.main < n)
+    hipLaunchKernelGGL(ibu_k_deserialize_tail, dim3(tail_grid(n - rs.head - rs.main)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)(rs.head + rs.main), (u64)n, (u64*)bc, (u64*)umi, (u64*)idx);
   return hipGetLastError();
 }
 
@@ -303,35 +315,40 @@ hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint
                             size_t n, void* recs, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
-  const bool fast = aligned16(recs) && aligned16(bc) && aligned16(umi) && aligned16(idx);
-  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
-  if (n_main) {
-    u32 ntiles = (u32)(n_main / kTileRecs);
+  const Span sp[4] = {{recs, 24}, {bc, 8}, {umi, 8}, {idx, 8}};
+  const RowSplit rs = split_rows(sp, 4, n, kTileRecs);
+  if (rs.head)
+    hipLaunchKernelGGL(ibu_k_serialize_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)bc, (const u64*)umi,
+                       (const u64*)idx, (u64)0, (u64)rs.head, (u64*)recs);
+  if (rs.main) {
+    u32 ntiles = (u32)(rs.main / kTileRecs);
     static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_serialize, 0, &occ))),
-                       dim3(kBlock), 0, st,
-                       (const u64*)bc, (const u64*)umi, (const u64*)idx, ntiles, (uint8_t*)recs);
+                       dim3(kBlock), 0, st, adv((const u64*)bc, 8 * rs.head), adv((const u64*)umi, 8 * rs.head),
+                       adv((const u64*)idx, 8 * rs.head), ntiles, adv((uint8_t*)recs, 24 * rs.head));
   }
-  if (n_main < n)
-    hipLaunchKernelGGL(ibu_k_serialize_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)bc,
-                       (const u64*)umi, (const u64*)idx, (u64)n_main, (u64)n, (u64*)recs);
+  if (rs.head + rs.main < n)
+    hipLaunchKernelGGL(ibu_k_serialize_tail, dim3(tail_grid(n - rs.head - rs.main)), dim3(256), 0, st, (const u64*)bc,
+                       (const u64*)umi, (const u64*)idx, (u64)(rs.head + rs.main), (u64)n, (u64*)recs);
   return hipGetLastError();
 }
 
 hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* acc, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
-  const bool fast = aligned16(recs);
-  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
-  u32 ntiles = (u32)(n_main / kTileRecs);
+  const Span sp[1] = {{recs, 24}};
+  const RowSplit rs = split_rows(sp, 1, n, kTileRecs);   // an 8-B aligned base peels exactly one record
+  if (rs.head)
+    hipLaunchKernelGGL(ibu_k_reduce_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)rs.head,
+                       (u64*)acc);
+  u32 ntiles = (u32)(rs.main / kTileRecs);
   // the main kernel also adds n to the count slot, so it always runs (ntiles may be 0)
   static std::atomic<int> occ;
   hipLaunchKernelGGL(ibu_k_reduce, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_reduce, 0, &occ))),
-                     dim3(kBlock), 0, st,
-                     (const uint8_t*)recs, ntiles, (u64)n, (u64*)acc);
-  if (n_main < n)
-    hipLaunchKernelGGL(ibu_k_reduce_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (const u64*)recs,
-                       (u64)n_main, (u64)n, (u64*)acc);
+                     dim3(kBlock), 0, st, adv((const uint8_t*)recs, 24 * rs.head), ntiles, (u64)n, (u64*)acc);
+  if (rs.head + rs.main < n)
+    hipLaunchKernelGGL(ibu_k_reduce_tail, dim3(tail_grid(n - rs.head - rs.main)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)(rs.head + rs.main), (u64)n, (u64*)acc);
   return hipGetLastError();
 }
 
@@ -339,33 +356,43 @@ hipError_t launch_generate(const LaunchCfg& cfg, uint64_t seed, uint64_t first, 
                            uint32_t umi_len, void* recs, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
-  const bool fast = aligned16(recs);
-  const size_t n_main = fast ? (n / kTileRecs) * kTileRecs : 0;
-  if (n_main) {
-    const u32 ntiles = (u32)(n_main / kTileRecs);
+  const Span sp[1] = {{recs, 24}};
+  const RowSplit rs = split_rows(sp, 1, n, kTileRecs);
+  if (rs.head)
+    hipLaunchKernelGGL(ibu_k_generate_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (u64)seed, (u64)first, (u64)0, (u64)rs.head,
+                       bc_len, umi_len, (u64*)recs);
+  if (rs.main) {
+    const u32 ntiles = (u32)(rs.main / kTileRecs);
     static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_generate, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_generate, 0, &occ))),
-                       dim3(kBlock), 0, st, (u64)seed, (u64)first, ntiles, bc_len, umi_len, (uint8_t*)recs);
+                       dim3(kBlock), 0, st, (u64)seed, (u64)(first + rs.head), ntiles, bc_len, umi_len,
+                       adv((uint8_t*)recs, 24 * rs.head));
   }
-  if (n_main < n)
-    hipLaunchKernelGGL(ibu_k_generate_tail, dim3(tail_grid(n - n_main)), dim3(256), 0, st, (u64)seed, (u64)first, (u64)n_main,
-                       (u64)n, bc_len, umi_len, (u64*)recs);
+  if (rs.head + rs.main < n)
+    hipLaunchKernelGGL(ibu_k_generate_tail, dim3(tail_grid(n - rs.head - rs.main)), dim3(256), 0, st, (u64)seed, (u64)first,
+                       (u64)(rs.head + rs.main), (u64)n, bc_len, umi_len, (u64*)recs);
   return hipGetLastError();
 }
 
 hipError_t launch_copy(const LaunchCfg& cfg, const void* src, void* dst, size_t bytes, hipStream_t st) {
   (void)hipGetLastError();
   if (bytes == 0) return hipSuccess;
-  const bool fast = aligned16(src) && aligned16(dst);
-  const u64 nchunks = fast ? bytes / 16 : 0;
+  // same phase modulo 16 (e.g. both buffers start at an odd record): peel the leading bytes, then whole chunks
+  const uintptr_t ps = reinterpret_cast<uintptr_t>(src), pd = reinterpret_cast<uintptr_t>(dst);
+  const bool fast = ((ps ^ pd) & 15u) == 0;
+  size_t head = fast ? (size_t)((16 - (ps & 15u)) & 15u) : 0;
+  if (head > bytes) head = bytes;
+  if (head)
+    hipLaunchKernelGGL(ibu_k_copy_bytes, dim3(1), dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)dst, (u64)0, (u64)head);
+  const u64 nchunks = fast ? (bytes - head) / 16 : 0;
   if (nchunks) {
     u64 blocks = (nchunks + kBlock - 1) / kBlock;
     static std::atomic<int> occ;
     const u64 cap = (u64)cfg.cus * resident_blocks<kBlock>(cfg, ibu_k_copy, 0, &occ);
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(ibu_k_copy, dim3((u32)blocks), dim3(kBlock), 0, st, (const uint8_t*)src, (uint8_t*)dst, nchunks);
+    hipLaunchKernelGGL(ibu_k_copy, dim3((u32)blocks), dim3(kBlock), 0, st, (const uint8_t*)src + head, (uint8_t*)dst + head, nchunks);
   }
-  const u64 done = nchunks * 16;
+  const u64 done = head + nchunks * 16;
   if (done < bytes) {
     const u64 rest = bytes - done;
     if (rest > (1ull << 31) * 256) return hipErrorInvalidValue;

@@ -101,6 +101,39 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- bit order of the 2-bit codec ------------------------------------------------------------
+// Default (order 0, "LSB first"): base i of a sequence sits at bits [2i, 2i+1] of the code word, "ACGT" -> 0b11100100
+// (bitnuc's convention as recalled; nothing in the reference pins it: DESIGN.md §3).  The hedge (order 1, "MSB
+// first"): base i at bits [2(len-1-i), 2(len-1-i)+1], the sequence read as a base-4 number, "ACGT" -> 0b00011011.
+// The two code words of one sequence are each other's image under rev_pairs (the order of the low `len` 2-bit groups
+// reversed, everything at and above bit 2*len dropped), so the MSB-first kernels are the LSB-first kernels with one
+// rev_pairs per code word: on the staged tile before expansion (decode), on the staged AoS tile before it is stored
+// (encode).  A TEMPLATE parameter of the tiled kernels (`MSB`): the default-order instantiations are instruction for
+// instruction the kernels measured in profiles/ (as a kernel argument the branch cost decode<12,12> and encode<16,12>
+// their last free VGPRs: both started to spill); the tail kernels take it as an argument.
+__device__ __forceinline__ u64 rev_pairs(u64 x, u32 len) {   // len in 1..32
+  u64 r = __builtin_bitreverse64(x);                            // v_bfrev_b32 x2
+  r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);  // bit-reversal also swapped the two bits of a group
+  return r >> (64 - 2 * len);
+}
+__device__ __forceinline__ u32x4 rev_pairs_x2(u32x4 v, u32 len) {   // two code words held as one 16-B chunk
+  const u64 a = rev_pairs(((u64)v.y << 32) | v.x, len), b = rev_pairs(((u64)v.w << 32) | v.z, len);
+  u32x4 o; o.x = (u32)a; o.y = (u32)(a >> 32); o.z = (u32)b; o.w = (u32)(b >> 32);
+  return o;
+}
+// Rewrite the code words of a staged tile in place: `words` u64 fields at byte `foff` of records of stride `rstride`,
+// lane L owns records 2L and 2L+1 of every 128-record tile staged in `tile`.
+template <int NT = 1>
+__device__ __forceinline__ void rev_pairs_tile(uint8_t* tile, u32 rstride, u32 foff, u32 len, u32 lane) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u64* p = reinterpret_cast<u64*>(tile + (size_t)(128 * j + 2 * lane + h) * rstride + foff);
+      *p = rev_pairs(*p, len);
+    }
+}
+
 // ---- 2-bit <-> ASCII primitives -----------------------------------------------------------
 // One code byte (4 bases, base i at bits [2i,2i+1]) -> 4 ASCII bytes.
 __device__ __forceinline__ u32 expand4(u32 x) {
@@ -296,6 +329,34 @@ static inline u32 grid_for(u32 ntiles, int cus, int blocks_per_cu) {
   return need < cap ? (need ? need : 1) : cap;
 }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Peeling.  The tiled kernels need every array 16-B aligned.  A resident shard that starts at an odd record of a
+// larger buffer (perfectly legal: the reference's split gives `per = len / n`, mmap.rs:297-307) is 8-B but not 16-B
+// aligned, and so may be its columns.  Instead of sending the whole shard through the one-thread-per-record tail
+// kernel, peel rows off the FRONT until every column is aligned: the smallest h in [0, 16) with
+// (p + h * stride) % 16 == 0 for every non-null column (16 rows always restore the phase, so 16 candidates decide).
+// -1: no such h (columns whose misalignments are inconsistent, e.g. an odd byte address) -> tail kernel for all rows.
+struct Span { const void* p; size_t stride; };
+static inline int peel_rows(const Span* s, int k) {
+  for (int h = 0; h < 16; ++h) {
+    bool ok = true;
+    for (int i = 0; i < k; ++i)
+      if (s[i].p && ((reinterpret_cast<uintptr_t>(s[i].p) + (uintptr_t)h * s[i].stride) & 15u)) ok = false;
+    if (ok) return h;
+  }
+  return -1;
+}
+// Split n rows into head (tail kernel) + main (tiled kernel, `tile` rows per tile) + rest (tail kernel).
+struct RowSplit { size_t head, main; };
+static inline RowSplit split_rows(const Span* s, int k, size_t n, size_t tile) {
+  const int h = peel_rows(s, k);
+  if (h < 0) return {n, 0};
+  const size_t head = (size_t)h < n ? (size_t)h : n;
+  return {head, ((n - head) / tile) * tile};
+}
+template <class T> static inline T* adv(T* p, size_t bytes) {
+  return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes) : p;
+}
 static inline u32 tail_grid(u64 rows) { return (u32)((rows + 255) / 256); }
 
 }  // namespace ibu

@@ -11,6 +11,7 @@ namespace ibu {
 struct LaunchCfg {
   int cus = 256;           // hipDeviceProp_t::multiProcessorCount
   int blocks_per_cu = 7;   // persistent grid = cus * blocks_per_cu workgroups of 256 threads (7 beats 8: profiles/r01_c)
+  uint32_t base_order = 0; // bit order of the 2-bit codec: 0 = base i at bits [2i,2i+1] (default), 1 = first base most significant
 };
 
 // Persistent grids must be exactly resident: a workgroup that has to wait for a slot runs its

@@ -234,7 +234,18 @@ int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream);
 int32_t ibu_device_count(int32_t* n);
 /* Tuning knobs (all optional; defaults are the measured best for MI355X):
  *   "blocks_per_cu"  1..8   cap on resident 256-thread workgroups per CU for the persistent grids
+ *   "base_order"     0 | 1  bit order of the 2-bit codec for every pack / unpack / decode / encode issued through
+ *                           this context (device kernels and the stream entry points alike):
+ *                             0 = IBU_BASE_ORDER_LSB_FIRST (default): base i at bits [2i, 2i+1], "ACGT" -> 0b11100100
+ *                                 (bitnuc's convention as recalled; README.md:45 names the crate, record.rs:19-27
+ *                                 gives only the code table);
+ *                             1 = IBU_BASE_ORDER_MSB_FIRST: base i at bits [2(len-1-i), ...], "ACGT" -> 0b00011011.
+ *                           The reference holds no codec code and no vector, so the order is UNPINNED; the second
+ *                           value is the hedge: if an external bitnuc vector shows the other order, callers flip this
+ *                           option and no kernel changes.
  * Unknown keys / out-of-range values return IBU_ERR_INVALID_ARG. */
+#define IBU_BASE_ORDER_LSB_FIRST 0
+#define IBU_BASE_ORDER_MSB_FIRST 1
 int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value);
 /* Device memory helpers for callers without their own allocator (tests in C, Rust shim). */
 int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr);

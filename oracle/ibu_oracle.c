@@ -542,7 +542,12 @@ void orc_serialize(const uint64_t* bc, const uint64_t* umi, const uint64_t* idx,
  * rather than a switch so that the cpu_baseline leg is not dominated by mispredicted branches on random bases. */
 static const uint8_t kPackLut[256] = {[0 ... 255] = 0xFF, ['A'] = 0, ['a'] = 0, ['C'] = 1, ['c'] = 1,
                                       ['G'] = 2, ['g'] = 2, ['T'] = 3, ['t'] = 3};
-int orc_pack_2bit(const uint8_t* seq, uint32_t len, uint64_t* out) {
+/* Bit order.  ORC_ORDER_LSB_FIRST (0, the default everywhere): base i of the sequence sits at bits [2i, 2i+1], so
+ * "ACGT" -> 0b11100100 (bitnuc's convention as recalled: README.md:45 names the crate, nothing in the reference pins
+ * it).  ORC_ORDER_MSB_FIRST (1): base i sits at bits [2(len-1-i), 2(len-1-i)+1] — the sequence read as a base-4
+ * number, first base most significant, "ACGT" -> 0b00011011.  Both use the table of record.rs:22-25 and ignore the bits
+ * at and above 2*len on unpack.  The second order is a hedge: one external vector decides between them. */
+int orc_pack_2bit_order(const uint8_t* seq, uint32_t len, int order, uint64_t* out) {
   if (len == 0 || len > 32) return ORC_E_SEQ_LEN;
   const uint8_t* lut = kPackLut;
   uint64_t v = 0;
@@ -550,30 +555,35 @@ int orc_pack_2bit(const uint8_t* seq, uint32_t len, uint64_t* out) {
   for (uint32_t i = 0; i < len; i++) {
     const uint8_t c = lut[seq[i]];
     bad |= c;
-    v |= (uint64_t)(c & 3) << (2 * i);
+    v |= (uint64_t)(c & 3) << (order == ORC_ORDER_MSB_FIRST ? 2 * (len - 1 - i) : 2 * i);
   }
   if (bad & 0x80) return ORC_E_BASE;
   *out = v;
   return 0;
 }
-int orc_unpack_2bit(uint64_t code, uint32_t len, uint8_t* out) {
+int orc_pack_2bit(const uint8_t* seq, uint32_t len, uint64_t* out) { return orc_pack_2bit_order(seq, len, ORC_ORDER_LSB_FIRST, out); }
+int orc_unpack_2bit_order(uint64_t code, uint32_t len, int order, uint8_t* out) {
   static const uint8_t lut[4] = {'A', 'C', 'G', 'T'};
   if (len == 0 || len > 32) return ORC_E_SEQ_LEN;
-  for (uint32_t i = 0; i < len; i++) out[i] = lut[(code >> (2 * i)) & 3];
+  for (uint32_t i = 0; i < len; i++) out[i] = lut[(code >> (order == ORC_ORDER_MSB_FIRST ? 2 * (len - 1 - i) : 2 * i)) & 3];
+  return 0;
+}
+int orc_unpack_2bit(uint64_t code, uint32_t len, uint8_t* out) { return orc_unpack_2bit_order(code, len, ORC_ORDER_LSB_FIRST, out); }
+int orc_unpack_column_order(const uint64_t* codes, size_t n, uint32_t len, int order, uint8_t* ascii) {
+  if (len == 0 || len > 32) return ORC_E_SEQ_LEN;
+  for (size_t i = 0; i < n; i++) orc_unpack_2bit_order(codes[i], len, order, ascii + i * len);
   return 0;
 }
 int orc_unpack_column(const uint64_t* codes, size_t n, uint32_t len, uint8_t* ascii) {
-  if (len == 0 || len > 32) return ORC_E_SEQ_LEN;
-  for (size_t i = 0; i < n; i++) orc_unpack_2bit(codes[i], len, ascii + i * len);
-  return 0;
+  return orc_unpack_column_order(codes, n, len, ORC_ORDER_LSB_FIRST, ascii);
 }
-int orc_pack_column(const uint8_t* ascii, size_t n, uint32_t len, uint64_t* codes, uint64_t* first_bad,
-                    uint64_t* n_bad) {
+int orc_pack_column_order(const uint8_t* ascii, size_t n, uint32_t len, int order, uint64_t* codes, uint64_t* first_bad,
+                          uint64_t* n_bad) {
   if (len == 0 || len > 32) return ORC_E_SEQ_LEN;
   uint64_t fb = UINT64_MAX, nb = 0;
   for (size_t i = 0; i < n; i++) {
     uint64_t v = 0;
-    if (orc_pack_2bit(ascii + i * len, len, &v)) {
+    if (orc_pack_2bit_order(ascii + i * len, len, order, &v)) {
       if (fb == UINT64_MAX) fb = i;
       nb++;
       v = 0; /* offending rows are written as zero; the call as a whole is an error */
@@ -584,26 +594,34 @@ int orc_pack_column(const uint8_t* ascii, size_t n, uint32_t len, uint64_t* code
   if (n_bad) *n_bad = nb;
   return nb ? ORC_E_BASE : 0;
 }
-int orc_decode_records(const orc_record* r, size_t n, uint32_t bc_len, uint32_t umi_len, uint8_t* bc,
-                       uint8_t* umi, uint64_t* idx) {
+int orc_pack_column(const uint8_t* ascii, size_t n, uint32_t len, uint64_t* codes, uint64_t* first_bad,
+                    uint64_t* n_bad) {
+  return orc_pack_column_order(ascii, n, len, ORC_ORDER_LSB_FIRST, codes, first_bad, n_bad);
+}
+int orc_decode_records_order(const orc_record* r, size_t n, uint32_t bc_len, uint32_t umi_len, int order, uint8_t* bc,
+                             uint8_t* umi, uint64_t* idx) {
   if (bc_len == 0 || bc_len > 32 || umi_len == 0 || umi_len > 32) return ORC_E_SEQ_LEN;
   for (size_t i = 0; i < n; i++) {
-    if (bc) orc_unpack_2bit(r[i].barcode, bc_len, bc + i * bc_len);
-    if (umi) orc_unpack_2bit(r[i].umi, umi_len, umi + i * umi_len);
+    if (bc) orc_unpack_2bit_order(r[i].barcode, bc_len, order, bc + i * bc_len);
+    if (umi) orc_unpack_2bit_order(r[i].umi, umi_len, order, umi + i * umi_len);
     if (idx) idx[i] = r[i].index;
   }
   return 0;
 }
-int orc_encode_records(const uint8_t* bc, const uint8_t* umi, const uint64_t* idx, uint64_t first_index,
-                       size_t n, uint32_t bc_len, uint32_t umi_len, orc_record* r, uint64_t* first_bad,
-                       uint64_t* n_bad) {
+int orc_decode_records(const orc_record* r, size_t n, uint32_t bc_len, uint32_t umi_len, uint8_t* bc,
+                       uint8_t* umi, uint64_t* idx) {
+  return orc_decode_records_order(r, n, bc_len, umi_len, ORC_ORDER_LSB_FIRST, bc, umi, idx);
+}
+int orc_encode_records_order(const uint8_t* bc, const uint8_t* umi, const uint64_t* idx, uint64_t first_index,
+                             size_t n, uint32_t bc_len, uint32_t umi_len, int order, orc_record* r, uint64_t* first_bad,
+                             uint64_t* n_bad) {
   if (bc_len == 0 || bc_len > 32 || umi_len == 0 || umi_len > 32) return ORC_E_SEQ_LEN;
   uint64_t fb = UINT64_MAX, nb = 0;
   for (size_t i = 0; i < n; i++) {
     uint64_t b = 0, u = 0;
-    int bad = orc_pack_2bit(bc + i * bc_len, bc_len, &b);
+    int bad = orc_pack_2bit_order(bc + i * bc_len, bc_len, order, &b);
     if (bad) b = 0;
-    int bad2 = orc_pack_2bit(umi + i * umi_len, umi_len, &u);
+    int bad2 = orc_pack_2bit_order(umi + i * umi_len, umi_len, order, &u);
     if (bad2) u = 0;
     if (bad || bad2) {
       if (fb == UINT64_MAX) fb = i;
@@ -616,6 +634,11 @@ int orc_encode_records(const uint8_t* bc, const uint8_t* umi, const uint64_t* id
   if (first_bad) *first_bad = fb;
   if (n_bad) *n_bad = nb;
   return nb ? ORC_E_BASE : 0;
+}
+int orc_encode_records(const uint8_t* bc, const uint8_t* umi, const uint64_t* idx, uint64_t first_index,
+                       size_t n, uint32_t bc_len, uint32_t umi_len, orc_record* r, uint64_t* first_bad,
+                       uint64_t* n_bad) {
+  return orc_encode_records_order(bc, umi, idx, first_index, n, bc_len, umi_len, ORC_ORDER_LSB_FIRST, r, first_bad, n_bad);
 }
 
 /* =============================================================== synthetic inputs, SURVEY §8d */

@@ -142,6 +142,20 @@ int orc_encode_records(const uint8_t* bc, const uint8_t* umi, const uint64_t* id
                        uint64_t first_index, size_t n, uint32_t bc_len, uint32_t umi_len,
                        orc_record* r, uint64_t* first_bad, uint64_t* n_bad);
 
+/* The same six with an explicit bit order (ORC_ORDER_*; the forms above are ORC_ORDER_LSB_FIRST). */
+#define ORC_ORDER_LSB_FIRST 0 /* base i at bits [2i, 2i+1]: "ACGT" -> 0b11100100 (default; bitnuc's convention as recalled) */
+#define ORC_ORDER_MSB_FIRST 1 /* base i at bits [2(len-1-i), ...]: "ACGT" -> 0b00011011 (the hedge) */
+int orc_pack_2bit_order(const uint8_t* seq, uint32_t len, int order, uint64_t* out);
+int orc_unpack_2bit_order(uint64_t code, uint32_t len, int order, uint8_t* out);
+int orc_unpack_column_order(const uint64_t* codes, size_t n, uint32_t len, int order, uint8_t* ascii);
+int orc_pack_column_order(const uint8_t* ascii, size_t n, uint32_t len, int order, uint64_t* codes, uint64_t* first_bad,
+                          uint64_t* n_bad);
+int orc_decode_records_order(const orc_record* r, size_t n, uint32_t bc_len, uint32_t umi_len, int order, uint8_t* bc,
+                             uint8_t* umi, uint64_t* idx);
+int orc_encode_records_order(const uint8_t* bc, const uint8_t* umi, const uint64_t* idx_or_null, uint64_t first_index,
+                             size_t n, uint32_t bc_len, uint32_t umi_len, int order, orc_record* r, uint64_t* first_bad,
+                             uint64_t* n_bad);
+
 /* ---- synthetic inputs ---- */
 uint64_t orc_splitmix64(uint64_t x);
 void orc_generate(uint64_t seed, uint64_t first, size_t n, uint32_t bc_len, uint32_t umi_len,

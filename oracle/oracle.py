@@ -101,6 +101,12 @@ def _load():
         "orc_pack_column": (i32, [vp, sz, u32, vp, P(u64), P(u64)]),
         "orc_decode_records": (i32, [vp, sz, u32, u32, vp, vp, vp]),
         "orc_encode_records": (i32, [vp, vp, vp, u64, sz, u32, u32, vp, P(u64), P(u64)]),
+        "orc_pack_2bit_order": (i32, [vp, u32, i32, P(u64)]),
+        "orc_unpack_2bit_order": (i32, [u64, u32, i32, vp]),
+        "orc_unpack_column_order": (i32, [vp, sz, u32, i32, vp]),
+        "orc_pack_column_order": (i32, [vp, sz, u32, i32, vp, P(u64), P(u64)]),
+        "orc_decode_records_order": (i32, [vp, sz, u32, u32, i32, vp, vp, vp]),
+        "orc_encode_records_order": (i32, [vp, vp, vp, u64, sz, u32, u32, i32, vp, P(u64), P(u64)]),
         "orc_splitmix64": (u64, [u64]),
         "orc_generate": (None, [u64, u64, sz, u32, u32, vp]),
         "orc_sort_records": (None, [vp, sz]),
@@ -327,48 +333,51 @@ def serialize(bc, umi, idx):
     return out
 
 
-def pack_2bit(seq):
+LSB_FIRST, MSB_FIRST = 0, 1  # bit order of the 2-bit codec (ibu_oracle.h ORC_ORDER_*); LSB_FIRST is the default everywhere
+
+
+def pack_2bit(seq, order=LSB_FIRST):
     b = np.frombuffer(bytes(seq), dtype=np.uint8)
     out = C.c_uint64()
-    _check(lib.orc_pack_2bit(_ptr(b) if b.size else None, b.size, C.byref(out)))
+    _check(lib.orc_pack_2bit_order(_ptr(b) if b.size else None, b.size, order, C.byref(out)))
     return out.value
 
 
-def unpack_2bit(code, length):
+def unpack_2bit(code, length, order=LSB_FIRST):
     out = np.empty(max(length, 1), dtype=np.uint8)
-    _check(lib.orc_unpack_2bit(code, length, _ptr(out)))
+    _check(lib.orc_unpack_2bit_order(code, length, order, _ptr(out)))
     return out[:length].tobytes()
 
 
-def unpack_column(codes, length):
+def unpack_column(codes, length, order=LSB_FIRST):
     codes = np.ascontiguousarray(codes, dtype=np.uint64)
     out = np.empty(codes.shape[0] * length, dtype=np.uint8)
-    _check(lib.orc_unpack_column(_ptr(codes), codes.shape[0], length, _ptr(out)))
+    _check(lib.orc_unpack_column_order(_ptr(codes), codes.shape[0], length, order, _ptr(out)))
     return out
 
 
-def pack_column(ascii_, n, length):
+def pack_column(ascii_, n, length, order=LSB_FIRST):
     """-> (codes, first_bad, n_bad); offending rows come back as 0 (no exception)."""
     a = np.ascontiguousarray(ascii_, dtype=np.uint8)
     out = np.empty(n, dtype=np.uint64)
     fb, nb = C.c_uint64(), C.c_uint64()
-    rc = lib.orc_pack_column(_ptr(a), n, length, _ptr(out), C.byref(fb), C.byref(nb))
+    rc = lib.orc_pack_column_order(_ptr(a), n, length, order, _ptr(out), C.byref(fb), C.byref(nb))
     if rc not in (0, 11):
         _check(rc)
     return out, (None if nb.value == 0 else fb.value), nb.value
 
 
-def decode_records(recs, bc_len, umi_len):
+def decode_records(recs, bc_len, umi_len, order=LSB_FIRST):
     recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
     n = recs.shape[0]
     bc = np.empty(n * bc_len, dtype=np.uint8)
     umi = np.empty(n * umi_len, dtype=np.uint8)
     idx = np.empty(n, dtype=np.uint64)
-    _check(lib.orc_decode_records(_ptr(recs), n, bc_len, umi_len, _ptr(bc), _ptr(umi), _ptr(idx)))
+    _check(lib.orc_decode_records_order(_ptr(recs), n, bc_len, umi_len, order, _ptr(bc), _ptr(umi), _ptr(idx)))
     return bc, umi, idx
 
 
-def encode_records(bc, umi, idx, n, bc_len, umi_len, first_index=0):
+def encode_records(bc, umi, idx, n, bc_len, umi_len, first_index=0, order=LSB_FIRST):
     """-> (records, first_bad, n_bad)."""
     bc = np.ascontiguousarray(bc, dtype=np.uint8)
     umi = np.ascontiguousarray(umi, dtype=np.uint8)
@@ -378,8 +387,8 @@ def encode_records(bc, umi, idx, n, bc_len, umi_len, first_index=0):
         ip = _ptr(idx)
     out = np.empty(n, dtype=REC_DTYPE)
     fb, nb = C.c_uint64(), C.c_uint64()
-    rc = lib.orc_encode_records(_ptr(bc), _ptr(umi), ip, first_index, n, bc_len, umi_len, _ptr(out),
-                                C.byref(fb), C.byref(nb))
+    rc = lib.orc_encode_records_order(_ptr(bc), _ptr(umi), ip, first_index, n, bc_len, umi_len, order, _ptr(out),
+                                      C.byref(fb), C.byref(nb))
     if rc not in (0, 11):
         _check(rc)
     return out, (None if nb.value == 0 else fb.value), nb.value

@@ -178,12 +178,28 @@ def main():
         "parity": "UNPINNED - the reference holds no codec code or test; see oracle/ibu_oracle.h",
         "table": {"A": 0, "C": 1, "G": 2, "T": 3},
         "max_len": 32,
+        # provenance per vector.  "table": follows from the code table of record.rs:22-25 alone, whatever the bit order
+        # (single bases, homopolymers).  "recalled": bitnuc's README example as remembered — NOT verifiable here (the
+        # crate is neither vendored nor in Cargo.toml).  "derived-lsb" / "derived-msb": the table + the stated order.
         "examples": [
-            {"seq": "ACGT", "code": 0b11100100, "src": "bitnuc README (as_2bit(b\"ACGT\") == 0b11100100), from memory"},
-            {"seq": "A", "code": 0}, {"seq": "T", "code": 3}, {"seq": "TA", "code": 3}, {"seq": "AT", "code": 12},
-            {"seq": "T" * 32, "code": 2**64 - 1}, {"seq": "A" * 32, "code": 0},
-            {"seq": "acgt", "code": 0b11100100},
+            {"seq": "ACGT", "code": 0b11100100, "prov": "recalled", "src": "bitnuc README (as_2bit(b\"ACGT\") == 0b11100100), from memory"},
+            {"seq": "A", "code": 0, "prov": "table"}, {"seq": "T", "code": 3, "prov": "table"},
+            {"seq": "TA", "code": 3, "prov": "derived-lsb"}, {"seq": "AT", "code": 12, "prov": "derived-lsb"},
+            {"seq": "T" * 32, "code": 2**64 - 1, "prov": "table"}, {"seq": "A" * 32, "code": 0, "prov": "table"},
+            {"seq": "acgt", "code": 0b11100100, "prov": "derived-lsb"},
         ],
+        # the hedge: the same sequences under IBU_BASE_ORDER_MSB_FIRST (base i at bits [2(len-1-i), ...]: the sequence
+        # read as a base-4 number).  ONE external vector decides: bitnuc::as_2bit(b"ACGT") is 228 (0b11100100) under the
+        # default order and 27 (0b00011011) under this one.
+        "examples_msb_first": [
+            {"seq": "ACGT", "code": 0b00011011, "prov": "derived-msb"},
+            {"seq": "A", "code": 0, "prov": "table"}, {"seq": "T", "code": 3, "prov": "table"},
+            {"seq": "TA", "code": 12, "prov": "derived-msb"}, {"seq": "AT", "code": 3, "prov": "derived-msb"},
+            {"seq": "T" * 32, "code": 2**64 - 1, "prov": "table"}, {"seq": "A" * 32, "code": 0, "prov": "table"},
+            {"seq": "acgt", "code": 0b00011011, "prov": "derived-msb"},
+            {"seq": "C" + "A" * 31, "code": 1 << 62, "prov": "derived-msb"},
+        ],
+        "deciding_vector": {"call": "bitnuc::as_2bit(b\"ACGT\")", "lsb_first": 228, "msb_first": 27},
         "invalid": ["ACGN", "ACG ", "ACG\x00", "XCGT", "AC-T", "ACGU"],
         "src": "record.rs:19-27, header.rs:180-185, README.md:42-45",
     }

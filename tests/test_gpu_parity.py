@@ -24,6 +24,21 @@ def ctx(ia):
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx_msb(ia):
+    """A context with the hedge bit order (first base most significant): ibu_ctx_set_option(ctx, "base_order", 1)."""
+    c = ia.Context(0)
+    c.set_option("base_order", 1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(params=[0, 1], ids=["lsb_first", "msb_first"])
+def ctx_order(request, ctx, ctx_msb):
+    """(context, order): every codec parity test below runs under both bit orders against the oracle's same switch."""
+    return (ctx, 0) if request.param == 0 else (ctx_msb, 1)
+
+
 def _up(ctx, a):
     return ctx.upload(np.ascontiguousarray(a))
 
@@ -53,27 +68,29 @@ def test_deserialize_serialize(ctx, oracle, n):
 
 @pytest.mark.parametrize("n", [0, 1, 127, 128, 129, 100_000, 1_000_003])
 @pytest.mark.parametrize("lens", [(16, 12), (32, 32), (1, 1), (15, 11), (20, 8), (4, 28), (31, 3), (12, 16)])
-def test_decode_encode(ctx, oracle, n, lens):
+def test_decode_encode(ctx_order, oracle, n, lens):
+    ctx, order = ctx_order
     bc_len, umi_len = lens
     recs = oracle.generate(SEED, 0, n, bc_len, umi_len)
     d_recs = _up(ctx, recs) if n else ctx.alloc(16)
     d_bc, d_umi, d_idx = ctx.alloc(max(n, 1) * bc_len), ctx.alloc(max(n, 1) * umi_len), ctx.alloc(max(n, 2) * 8)
     ctx.decode_ascii(d_recs, n, bc_len, umi_len, d_bc, d_umi, d_idx)
-    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len, order)
     assert d_bc.download(count=n * bc_len).tobytes() == bc.tobytes()
     assert d_umi.download(count=n * umi_len).tobytes() == umi.tobytes()
     assert d_idx.download(np.uint64, count=n).tobytes() == idx.tobytes()
     d_back = ctx.alloc(max(n, 1) * 24)
     ctx.encode_ascii(d_bc, d_umi, d_idx, n, bc_len, umi_len, d_back)
     ctx.codec_status()
-    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len, order=order)
     assert nb == 0
     got = d_back.download(count=n * 24)
     assert got.tobytes() == want.tobytes() == recs.tobytes()
 
 
-def test_all_length_pairs_small(ctx, oracle):
-    """Every (bc_len, umi_len) in {1..32}^2 on one-and-a-bit tiles."""
+def test_all_length_pairs_small(ctx_order, oracle):
+    """Every (bc_len, umi_len) in {1..32}^2 on one-and-a-bit tiles, under both bit orders."""
+    ctx, order = ctx_order
     n = 128 + 37
     d_recs = ctx.alloc(n * 24)
     d_bc, d_umi, d_idx, d_back = ctx.alloc(n * 32), ctx.alloc(n * 32), ctx.alloc(n * 8), ctx.alloc(n * 24)
@@ -82,13 +99,50 @@ def test_all_length_pairs_small(ctx, oracle):
     for bc_len in range(1, 33):
         for umi_len in range(1, 33):
             ctx.decode_ascii(d_recs, n, bc_len, umi_len, d_bc, d_umi, d_idx)
-            bc, umi, idx = oracle.decode_records(full, bc_len, umi_len)
+            bc, umi, idx = oracle.decode_records(full, bc_len, umi_len, order)
             assert d_bc.download(count=n * bc_len).tobytes() == bc.tobytes(), (bc_len, umi_len)
             assert d_umi.download(count=n * umi_len).tobytes() == umi.tobytes(), (bc_len, umi_len)
             ctx.encode_ascii(d_bc, d_umi, d_idx, n, bc_len, umi_len, d_back)
             ctx.codec_status()
-            want, _, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+            want, _, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len, order=order)
             assert nb == 0 and d_back.download().tobytes() == want.tobytes(), (bc_len, umi_len)
+
+
+def test_base_order_option_and_deciding_vector(ia, ctx, ctx_msb, kat):
+    """The option is per context, validated, and the ONE vector that would settle the unpinned convention
+    (bitnuc::as_2bit(b"ACGT"): 228 under the default order, 27 under the hedge) comes out of the device kernels."""
+    d = kat["codec"]["deciding_vector"]
+    seq = np.frombuffer(b"ACGT" * 130, dtype=np.uint8)       # one full tile + 2 rows: tiled and tail kernels
+    for c, want in ((ctx, d["lsb_first"]), (ctx_msb, d["msb_first"])):
+        d_codes = c.alloc(130 * 8)
+        c.pack_2bit(_up(c, seq), 130, 4, d_codes)
+        c.codec_status()
+        assert set(d_codes.download(np.uint64).tolist()) == {want}
+        d_ascii = c.alloc(130 * 4)
+        c.unpack_2bit(d_codes, 130, 4, d_ascii)
+        assert d_ascii.download().tobytes() == seq.tobytes()
+    for bad in (2, -1, 7):
+        with pytest.raises(ia.IbuError) as e:
+            ctx.set_option("base_order", bad)
+        assert e.value.kind == "InvalidArg"
+    ctx.set_option("base_order", 0)  # explicit default is accepted
+
+
+def test_msb_first_on_peeled_and_unaligned_bases(ctx_msb, oracle):
+    """The hedge order through the peel (shard at record 3) and through the whole-input tail fallback (odd byte bases)."""
+    n, bc_len, umi_len = 20_003, 16, 12
+    recs = oracle.generate(SEED, 0, n + 3, bc_len, umi_len)
+    d_all = _up(ctx_msb, recs)
+    bc, umi, idx = oracle.decode_records(recs[3:], bc_len, umi_len, 1)
+    for off_bc, off_umi in ((3 * bc_len, 3 * umi_len), (1, 5)):
+        d_bc, d_umi, d_idx = ctx_msb.alloc((n + 4) * bc_len), ctx_msb.alloc((n + 4) * umi_len), ctx_msb.alloc((n + 4) * 8)
+        ctx_msb.decode_ascii(d_all.ptr + 72, n, bc_len, umi_len, d_bc.ptr + off_bc, d_umi.ptr + off_umi, d_idx.ptr + 24)
+        assert d_bc.download(count=n * bc_len, offset=off_bc).tobytes() == bc.tobytes()
+        assert d_umi.download(count=n * umi_len, offset=off_umi).tobytes() == umi.tobytes()
+        d_back = ctx_msb.alloc((n + 3) * 24)
+        ctx_msb.encode_ascii(d_bc.ptr + off_bc, d_umi.ptr + off_umi, d_idx.ptr + 24, n, bc_len, umi_len, d_back.ptr + 72)
+        ctx_msb.codec_status()
+        assert d_back.download(count=n * 24, offset=72).tobytes() == recs[3:].tobytes()
 
 
 def test_decode_skips_null_columns(ctx, oracle):
@@ -129,21 +183,141 @@ def test_unaligned_bases_take_the_tail_path(ctx, oracle, off):
     assert d_back.download(count=n * 24, offset=24).tobytes() == recs[1:].tobytes()
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 15])
+@pytest.mark.parametrize("lens", [(16, 12), (15, 11), (32, 32), (10, 8)])
+def test_shard_starting_at_record_k_is_peeled(ia, ctx, oracle, k, lens):
+    """A resident shard that starts at record k of a larger buffer (the reference's split gives `per = len / n`,
+    which may be odd: mmap.rs:297-307): records, columns and ASCII rows of the shard are 8-byte or less aligned.  The
+    launchers peel rows until every array is 16-byte aligned and run the tiled kernels on the rest; every kernel must
+    give exactly the bytes of the aligned call, and bad rows keep the CALLER's numbering."""
+    bc_len, umi_len = lens
+    n = 70_001
+    recs = oracle.generate(SEED, 0, n + k, bc_len, umi_len)
+    shard = recs[k:]
+    d_all = _up(ctx, recs)
+    want_bc, want_umi, want_idx = oracle.decode_records(shard, bc_len, umi_len)
+    # the output columns belong to the larger buffer too: row k of each column
+    d_bc, d_umi, d_idx = ctx.alloc((n + k) * bc_len), ctx.alloc((n + k) * umi_len), ctx.alloc((n + k) * 8)
+    pb, pu, pi = d_bc.ptr + k * bc_len, d_umi.ptr + k * umi_len, d_idx.ptr + 8 * k
+    ctx.decode_ascii(d_all.ptr + 24 * k, n, bc_len, umi_len, pb, pu, pi)
+    assert d_bc.download(count=n * bc_len, offset=k * bc_len).tobytes() == want_bc.tobytes()
+    assert d_umi.download(count=n * umi_len, offset=k * umi_len).tobytes() == want_umi.tobytes()
+    assert d_idx.download(np.uint64, count=n, offset=8 * k).tobytes() == want_idx.tobytes()
+    d_back = ctx.alloc((n + k) * 24)
+    ctx.encode_ascii(pb, pu, pi, n, bc_len, umi_len, d_back.ptr + 24 * k)
+    ctx.codec_status()
+    assert d_back.download(count=n * 24, offset=24 * k).tobytes() == shard.tobytes()
+    # index column synthesised from first_index: the peeled rows and the tiled rows number consistently
+    ctx.encode_ascii(pb, pu, None, n, bc_len, umi_len, d_back.ptr + 24 * k, first_index=1000)
+    ctx.codec_status()
+    got = d_back.download(np.uint64, count=3 * n, offset=24 * k).reshape(n, 3)
+    assert (got[:, 2] == np.arange(1000, 1000 + n, dtype=np.uint64)).all()
+    # reduce, deserialize / serialize, generate, sortedness on the same shard view
+    assert ctx.reduce(d_all.ptr + 24 * k, n) == oracle.reduce_records(shard)
+    c0, c1, c2 = ctx.alloc((n + k) * 8), ctx.alloc((n + k) * 8), ctx.alloc((n + k) * 8)
+    ctx.deserialize(d_all.ptr + 24 * k, n, c0.ptr + 8 * k, c1.ptr + 8 * k, c2.ptr + 8 * k)
+    cols = np.frombuffer(shard.tobytes(), dtype=np.uint64).reshape(n, 3)
+    for f, c in enumerate((c0, c1, c2)):
+        assert c.download(np.uint64, count=n, offset=8 * k).tobytes() == np.ascontiguousarray(cols[:, f]).tobytes()
+    ctx.serialize(c0.ptr + 8 * k, c1.ptr + 8 * k, c2.ptr + 8 * k, n, d_back.ptr + 24 * k)
+    ctx.synchronize()
+    assert d_back.download(count=n * 24, offset=24 * k).tobytes() == shard.tobytes()
+    ctx.generate(SEED, k, n, bc_len, umi_len, d_back.ptr + 24 * k)
+    ctx.synchronize()
+    assert d_back.download(count=n * 24, offset=24 * k).tobytes() == shard.tobytes()
+    # single columns
+    ctx.unpack_2bit(c0.ptr + 8 * k, n, bc_len, pb)
+    ctx.synchronize()
+    assert d_bc.download(count=n * bc_len, offset=k * bc_len).tobytes() == oracle.unpack_column(np.ascontiguousarray(cols[:, 0]), bc_len).tobytes()
+    ctx.pack_2bit(pb, n, bc_len, c1.ptr + 8 * k)
+    ctx.codec_status()
+    mask = np.uint64((1 << (2 * bc_len)) - 1) if bc_len < 32 else np.uint64(2**64 - 1)
+    assert (c1.download(np.uint64, count=n, offset=8 * k) == (cols[:, 0] & mask)).all()
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_bad_rows_keep_the_callers_numbering_when_peeled(ia, ctx, oracle, k):
+    bc_len, umi_len, n = 16, 12, 40_000
+    recs = oracle.generate(SEED, 0, n, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    bc, umi = bc.copy(), umi.copy()
+    bad_rows = [0, 2, 1000, n - 1]        # a peeled row, a row of the first tile, a tiled row, a row of the rest
+    for r in bad_rows:
+        bc[r * bc_len + 3] = ord("N")
+    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+    pad_bc = np.concatenate([np.zeros(k * bc_len, np.uint8), bc])
+    pad_umi = np.concatenate([np.zeros(k * umi_len, np.uint8), umi])
+    pad_idx = np.concatenate([np.zeros(k, np.uint64), idx])
+    d_bc, d_umi, d_idx, d_out = _up(ctx, pad_bc), _up(ctx, pad_umi), _up(ctx, pad_idx), ctx.alloc((n + k) * 24)
+    for first_bad_expected, rows in ((0, bad_rows), ):
+        ctx.encode_ascii(d_bc.ptr + k * bc_len, d_umi.ptr + k * umi_len, d_idx.ptr + 8 * k, n, bc_len, umi_len, d_out.ptr + 24 * k)
+        with pytest.raises(ia.IbuError) as ei:
+            ctx.codec_status()
+        assert (ei.value.first_bad, ei.value.n_bad) == (fb, nb) == (first_bad_expected, len(rows))
+        assert d_out.download(count=n * 24, offset=24 * k).tobytes() == want.tobytes()
+    # only a tiled row bad: its number must include the peeled rows in front of it
+    bc[0 * bc_len + 3] = ord("A"); bc[2 * bc_len + 3] = ord("A")
+    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len)
+    d_bc = _up(ctx, np.concatenate([np.zeros(k * bc_len, np.uint8), bc]))
+    ctx.encode_ascii(d_bc.ptr + k * bc_len, d_umi.ptr + k * umi_len, d_idx.ptr + 8 * k, n, bc_len, umi_len, d_out.ptr + 24 * k)
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.codec_status()
+    assert (ei.value.first_bad, ei.value.n_bad) == (fb, nb) == (1000, 2)
+    d_codes = ctx.alloc((n + k) * 8)
+    ctx.pack_2bit(d_bc.ptr + k * bc_len, n, bc_len, d_codes.ptr + 8 * k)
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.codec_status()
+    assert (ei.value.first_bad, ei.value.n_bad) == (1000, 2)
+
+
+def test_odd_record_shard_runs_at_the_aligned_rate(ia, ctx):
+    """Perf sanity for the peel: decode / encode / reduce of a shard that starts at record 1
+    (8-byte aligned base) must run within 1.2x of the 16-byte aligned call — it used to fall back to the
+    one-thread-per-record kernel for every record (~10x)."""
+    import time
+
+    n, bc_len, umi_len = 100_000_000, 16, 12
+    recs, back = ctx.alloc((n + 4) * 24), ctx.alloc((n + 4) * 24)
+    bc, umi, idx = ctx.alloc((n + 4) * bc_len), ctx.alloc((n + 4) * umi_len), ctx.alloc((n + 4) * 8)
+    ctx.generate(SEED, 0, n + 4, bc_len, umi_len, recs)
+
+    def run(k):
+        def once():
+            ctx.decode_ascii(recs.ptr + 24 * k, n, bc_len, umi_len, bc.ptr + k * bc_len, umi.ptr + k * umi_len, idx.ptr + 8 * k)
+            ctx.encode_ascii(bc.ptr + k * bc_len, umi.ptr + k * umi_len, idx.ptr + 8 * k, n, bc_len, umi_len, back.ptr + 24 * k)
+            ctx.reduce(recs.ptr + 24 * k, n)
+        once()
+        ctx.synchronize()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            once()
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    t_aligned, t_odd, t_three = run(0), run(1), run(3)
+    assert t_odd < 1.2 * t_aligned and t_three < 1.2 * t_aligned, (t_aligned, t_odd, t_three)
+    ctx.codec_status()
+    assert ctx.reduce(back.ptr + 24 * 3, n) == ctx.reduce(recs.ptr + 24 * 3, n)
+
+
 @pytest.mark.parametrize("length", [1, 3, 4, 8, 12, 13, 16, 24, 31, 32])
 @pytest.mark.parametrize("n", [0, 1, 129, 65_537])
-def test_pack_unpack_columns(ctx, oracle, n, length):
+def test_pack_unpack_columns(ctx_order, oracle, n, length):
+    ctx, order = ctx_order
     rng = np.random.default_rng(length * 1000 + n)
     codes = rng.integers(0, 2**64, size=n, dtype=np.uint64)
     d_codes = _up(ctx, codes) if n else ctx.alloc(16)
     d_ascii = ctx.alloc(max(n, 1) * length)
     ctx.unpack_2bit(d_codes, n, length, d_ascii)
-    want = oracle.unpack_column(codes, length)
+    want = oracle.unpack_column(codes, length, order)
     got = d_ascii.download(count=n * length)
     assert got.tobytes() == want.tobytes()
     d_back = ctx.alloc(max(n, 2) * 8)
     ctx.pack_2bit(d_ascii, n, length, d_back)
     ctx.codec_status()
-    wcodes, _, nb = oracle.pack_column(want, n, length)
+    wcodes, _, nb = oracle.pack_column(want, n, length, order)
     assert nb == 0 and d_back.download(np.uint64, count=n).tobytes() == wcodes.tobytes()
     # lower-case input packs to the same codes
     d_low = _up(ctx, np.frombuffer(want.tobytes().lower(), dtype=np.uint8)) if n else ctx.alloc(16)

@@ -405,23 +405,53 @@ def test_codec_examples(oracle, kat):
         oracle.pack_2bit(b"A" * 33)
     # bits >= 2*len are ignored on unpack (records are never range-checked: examples/random.rs:44-47)
     assert oracle.unpack_2bit(2**64 - 1, 3) == b"TTT"
+    # every vector says where it comes from; only the order-independent ones follow from the reference alone
+    assert all(ex.get("prov") in ("table", "recalled", "derived-lsb") for ex in c["examples"])
+    assert c["parity"].startswith("UNPINNED")
 
 
-def test_codec_against_numpy(oracle):
-    """Independent numpy statement of the same convention, all lengths 1..32."""
+def test_codec_examples_msb_first(oracle, kat):
+    """The hedge (IBU_BASE_ORDER_MSB_FIRST / ORC_ORDER_MSB_FIRST): first base most significant."""
+    c = kat["codec"]
+    for ex in c["examples_msb_first"]:
+        code = oracle.pack_2bit(ex["seq"].encode(), oracle.MSB_FIRST)
+        assert code == ex["code"], ex
+        assert oracle.unpack_2bit(code, len(ex["seq"]), oracle.MSB_FIRST) == ex["seq"].upper().encode()
+    # vectors that follow from the code table alone are the same under both orders
+    for a, b in zip(c["examples"], c["examples_msb_first"]):
+        if a["prov"] == "table":
+            assert a == b
+    d = c["deciding_vector"]
+    assert oracle.pack_2bit(b"ACGT") == d["lsb_first"] and oracle.pack_2bit(b"ACGT", oracle.MSB_FIRST) == d["msb_first"]
+    assert oracle.unpack_2bit((2**64 - 1) << 6, 3, oracle.MSB_FIRST) == b"AAA"  # bits >= 2*len ignored here too
+    for bad in c["invalid"]:
+        with pytest.raises(oracle.OracleError):
+            oracle.pack_2bit(bad.encode(), oracle.MSB_FIRST)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_codec_against_numpy(oracle, order):
+    """Independent numpy statement of both bit orders, all lengths 1..32."""
     rng = np.random.default_rng(7)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     for ln in range(1, 33):
         codes = rng.integers(0, 2**64, size=257, dtype=np.uint64)
-        shifts = (2 * np.arange(ln, dtype=np.uint64))[None, :]
+        pos = np.arange(ln, dtype=np.uint64) if order == 0 else np.arange(ln - 1, -1, -1).astype(np.uint64)
+        shifts = (2 * pos)[None, :]  # bit position of base i
         want = lut[((codes[:, None] >> shifts) & np.uint64(3)).astype(np.int64)].reshape(-1)
-        got = oracle.unpack_column(codes, ln)
+        got = oracle.unpack_column(codes, ln, order)
         assert got.tobytes() == want.tobytes()
-        back, fb, nb = oracle.pack_column(got, codes.size, ln)
+        back, fb, nb = oracle.pack_column(got, codes.size, ln, order)
         mask = np.uint64(2**64 - 1) if ln == 32 else np.uint64((1 << (2 * ln)) - 1)
         assert nb == 0 and fb is None and (back == (codes & mask)).all()
-        low, _, nb = oracle.pack_column(np.frombuffer(got.tobytes().lower(), dtype=np.uint8), codes.size, ln)
+        low, _, nb = oracle.pack_column(np.frombuffer(got.tobytes().lower(), dtype=np.uint8), codes.size, ln, order)
         assert nb == 0 and (low == back).all()
+        # the two orders of one sequence are each other's pair-reversal
+        other, _, _ = oracle.pack_column(got, codes.size, ln, 1 - order)
+        rev = np.zeros_like(back)
+        for i in range(ln):
+            rev |= ((back >> np.uint64(2 * i)) & np.uint64(3)) << np.uint64(2 * (ln - 1 - i))
+        assert (other == rev).all()
 
 
 def test_codec_invalid_rows(oracle):

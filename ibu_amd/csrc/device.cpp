@@ -100,6 +100,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->cfg.blocks_per_cu = (int)value;
     return IBU_OK;
   }
+  if (strcmp(key, "sort_variant") == 0) {
+    if (value < 0 || value >= sort_num_variants()) return err_arg("sort_variant out of range");
+    ctx->cfg.sort_variant = (int)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "base_order") == 0) {
     if (value != IBU_BASE_ORDER_LSB_FIRST && value != IBU_BASE_ORDER_MSB_FIRST) return err_arg("base_order must be 0 (LSB first) or 1 (MSB first)");
     ctx->cfg.base_order = (uint32_t)value;

@@ -275,14 +275,6 @@ extern "C" __global__ void ibu_k_reduce_tail(const u64* __restrict__ recs, u64 r
       if (X[g]) atomicXor(&acc[4 + g], X[g]);
     }
 }
-extern "C" __global__ void ibu_k_sorted_check(const u64* __restrict__ recs, u64 n, u32* unsorted) {
-  const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride) {
-    const u64* a = recs + 3 * i;
-    bool gt = a[0] != a[3] ? a[0] > a[3] : (a[1] != a[4] ? a[1] > a[4] : a[2] > a[5]);
-    if (gt) atomicOr(unsorted, 1u);
-  }
-}
 extern "C" __global__ void ibu_k_fill_u64(u64* p, u64 v0, u64 v1) { p[0] = v0; p[1] = v1; }
 
 // =============================================================================================
@@ -399,16 +391,6 @@ hipError_t launch_copy(const LaunchCfg& cfg, const void* src, void* dst, size_t 
     hipLaunchKernelGGL(ibu_k_copy_bytes, dim3((u32)((rest + 255) / 256)), dim3(256), 0, st, (const uint8_t*)src,
                        (uint8_t*)dst, done, (u64)bytes);
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_sorted_check(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t* flag, hipStream_t st) {
-  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
-  if (n < 2) return hipSuccess;
-  u64 blocks = (n + 255) / 256;
-  u64 cap = (u64)cfg.cus * 8;
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(ibu_k_sorted_check, dim3((u32)blocks), dim3(256), 0, st, (const u64*)recs, (u64)n, flag);
   return hipGetLastError();
 }
 

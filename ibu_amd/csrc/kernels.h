@@ -11,6 +11,7 @@ namespace ibu {
 struct LaunchCfg {
   int cus = 256;           // hipDeviceProp_t::multiProcessorCount
   int blocks_per_cu = 7;   // persistent grid = cus * blocks_per_cu workgroups of 256 threads (7 beats 8: profiles/r01_c)
+  int sort_variant = 0;    // tile shape / write-out mode of the radix passes (sort.hip kSweep; A/B knob)
   uint32_t base_order = 0; // bit order of the 2-bit codec: 0 = base i at bits [2i,2i+1] (default), 1 = first base most significant
 };
 
@@ -58,6 +59,7 @@ hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
 hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n, void* scratch,
                                size_t scratch_bytes, hipStream_t st);
 size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
+int sort_num_variants();
 // per-barcode run-length aggregation of sorted records (sort.hip)
 size_t runs_scratch_bytes(size_t n);
 hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st);

@@ -234,6 +234,8 @@ int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream);
 int32_t ibu_device_count(int32_t* n);
 /* Tuning knobs (all optional; defaults are the measured best for MI355X):
  *   "blocks_per_cu"  1..8   cap on resident 256-thread workgroups per CU for the persistent grids
+ *   "sort_variant"   0..7   tile shape / write-out mode of the radix passes (0 = default; the rest are A/B builds of the
+ *                           same algorithm kept for measurement: ibu_amd/csrc/sort.hip, kSweep)
  *   "base_order"     0 | 1  bit order of the 2-bit codec for every pack / unpack / decode / encode issued through
  *                           this context (device kernels and the stream entry points alike):
  *                             0 = IBU_BASE_ORDER_LSB_FIRST (default): base i at bits [2i, 2i+1], "ACGT" -> 0b11100100

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--random-index", action="store_true",
                     help="index column in random order (default: increasing = records in read order, whose index passes are skipped)")
+    ap.add_argument("--variants", default="0", help="comma list of sort_variant values to time (A/B in one process)")
+    ap.add_argument("--skip-agg", action="store_true")
     a = ap.parse_args()
     import ibu_amd as ia
 
@@ -26,30 +28,39 @@ def main():
     ctx = ia.Context(0)
     for n in (int(float(x)) for x in a.records.split(",")):
         d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)
-        ts = []
         cols = [ctx.alloc(8 * n) for _ in range(4)] if a.random_index else None
-        for _ in range(a.rounds + 1):
-            ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)  # random barcode/UMI, increasing index: unsorted
-            if a.random_index:  # replace the index column by random 30-bit values (another stream's barcode column)
-                ctx.deserialize(d, n, cols[0], cols[1], cols[2])
-                ctx.generate(0x1B00006, 0, n, 15, 1, t)
-                ctx.deserialize(t, n, cols[3], cols[2], cols[2])
-                ctx.serialize(cols[0], cols[1], cols[3], n, d)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            ctx.sort_records(d, t, n)
-            ctx.synchronize()
-            ts.append(time.perf_counter() - t0)
-        assert ctx.is_sorted(d, n)
-        t0 = time.perf_counter()
-        bcs, counts, uniq = ctx.barcode_counts(d, n)  # BarcodeAnalyzer on the sorted records (size query + emit + download)
-        agg = time.perf_counter() - t0
-        assert int(counts.sum()) == n
-        sec = statistics.median(ts[1:])
-        idx_bytes = 4 if a.random_index else 0  # 30 random bits -> 4 digit passes; index-ordered input -> skipped
-        passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
-        print(json.dumps({"n": n, "lens": [bc_len, umi_len], "index": "random" if a.random_index else "increasing (read order)", "seconds": round(sec, 4), "M_records_per_s": round(n / sec / 1e6, 1),
-                          "passes": passes, "barcode_counts_seconds": round(agg, 4), "distinct_barcodes": int(len(bcs)), "GBps_at_72B_per_record_pass": round(n * 72 * passes / sec / 1e9)}), flush=True)
+        for variant in (int(v) for v in a.variants.split(",")):
+            ctx.set_option("sort_variant", variant)
+            ts = []
+            for _ in range(a.rounds + 1):
+                ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)  # random barcode/UMI, increasing index: unsorted
+                if a.random_index:  # replace the index column by random 30-bit values (another stream's barcode column)
+                    ctx.deserialize(d, n, cols[0], cols[1], cols[2])
+                    ctx.generate(0x1B00006, 0, n, 15, 1, t)
+                    ctx.deserialize(t, n, cols[3], cols[2], cols[2])
+                    ctx.serialize(cols[0], cols[1], cols[3], n, d)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                ctx.sort_records(d, t, n)
+                ctx.synchronize()
+                ts.append(time.perf_counter() - t0)
+            assert variant >= 8 or ctx.is_sorted(d, n)  # variants >= 8 exist in probe builds only: wrong output by design
+            agg, nb = None, None
+            if not a.skip_agg:
+                t0 = time.perf_counter()
+                bcs, counts, uniq = ctx.barcode_counts(d, n)  # BarcodeAnalyzer on the sorted records (size query + emit + download)
+                agg = round(time.perf_counter() - t0, 4)
+                assert int(counts.sum()) == n
+                nb = int(len(bcs))
+            sec = statistics.median(ts[1:])
+            idx_bytes = 4 if a.random_index else 0  # 30 random bits -> 4 digit passes; index-ordered input -> skipped
+            passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
+            # algorithmic traffic: census 24 + histogram 24 once, 48 per pass, 48 for the copy back after an odd number of passes
+            alg = n * (48 + 48 * passes + (48 if passes & 1 else 0))
+            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "index": "random" if a.random_index else "increasing (read order)",
+                              "seconds": round(sec, 4), "best": round(min(ts[1:]), 4), "M_records_per_s": round(n / sec / 1e6, 1),
+                              "passes": passes, "barcode_counts_seconds": agg, "distinct_barcodes": nb,
+                              "algorithmic_GB": round(alg / 1e9, 1), "GBps_algorithmic": round(alg / sec / 1e9)}), flush=True)
         d.free()
         t.free()
         for c in cols or []:

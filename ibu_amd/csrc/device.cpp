@@ -326,14 +326,14 @@ extern "C" int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_recor
   if (n_barcode_umi_pairs) *n_barcode_umi_pairs = 0;
   if (n == 0) return IBU_OK;
   if (!d_sorted_records || !aligned8(d_sorted_records)) return err_arg("d_sorted_records must be non-NULL and 8-byte aligned");
-  if (n >= (1ull << 32)) return err_arg("barcode_counts handles fewer than 2^32 records per call");
+  if (n >= (1ull << 40)) return err_arg("barcode_counts handles fewer than 2^40 records per call");
   hipStream_t st = pick_stream(ctx, stream);
   rc = ensure_sort_scratch(ctx, runs_scratch_bytes(n));
   if (rc) return rc;
   IBU_HIP(launch_runs_count(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes, st));
-  IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_sort_scratch, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_sort_scratch, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   IBU_HIP(hipStreamSynchronize(st));
-  const uint32_t* tot = reinterpret_cast<const uint32_t*>(ctx->h_pinned);
+  const uint64_t* tot = reinterpret_cast<const uint64_t*>(ctx->h_pinned);
   const uint64_t runs = tot[0], pairs = tot[1];
   *n_barcodes = runs;
   if (n_barcode_umi_pairs) *n_barcode_umi_pairs = pairs;
@@ -358,6 +358,7 @@ extern "C" int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp
   if (n < 2) return IBU_OK;
   if (!d_records || !d_tmp || !aligned8(d_records) || !aligned8(d_tmp))
     return err_arg("d_records / d_tmp must be non-NULL and 8-byte aligned");
+  if (n >= (1ull << 40)) return err_arg("sort_records handles fewer than 2^40 records per call");  // an argument limit, not a HIP error
   rc = ensure_sort_scratch(ctx, sort_scratch_bytes(ctx->cfg, n));
   if (rc) return rc;
   IBU_HIP(launch_sort_records(ctx->cfg, d_records, d_tmp, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes,

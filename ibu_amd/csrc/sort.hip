@@ -731,7 +731,7 @@ ibu_k_runs_count(const u64* __restrict__ recs, u64 n, u32 nseg, u32* __restrict_
 }
 
 extern "C" __global__ void __launch_bounds__(kSortThreads)
-ibu_k_runs_emit(const u64* __restrict__ recs, u64 n, u32 nseg, const u32* __restrict__ seg_base /*[2][nseg], scanned*/,
+ibu_k_runs_emit(const u64* __restrict__ recs, u64 n, u32 nseg, const u64* __restrict__ seg_base /*[2][nseg], scanned*/,
                 u64* __restrict__ barcodes, u64* __restrict__ starts, u64* __restrict__ pair_rank) {
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 seg = blockIdx.x * kSortWaves + (threadIdx.x >> 6);
@@ -766,32 +766,59 @@ extern "C" __global__ void ibu_k_runs_finish(const u64* __restrict__ starts, con
   }
 }
 
+// seg_heads u32 [2][nseg] -> seg_base u64 [2][nseg] (exclusive prefix per row) and the two row totals.  One workgroup per row;
+// u64 sums: 2^32 or more records (and then possibly 2^32 or more runs) fit in 288 GB.
+extern "C" __global__ void __launch_bounds__(kSortThreads)
+ibu_k_runs_scan(const u32* __restrict__ seg_heads, u32 nseg, u64* __restrict__ seg_base, u64* __restrict__ totals) {
+  __shared__ u32 wsum[kSortWaves];
+  const u32* row = seg_heads + (size_t)blockIdx.x * nseg;
+  u64* out = seg_base + (size_t)blockIdx.x * nseg;
+  u64 carry = 0;
+  for (u32 base = 0; base < nseg; base += 4 * kSortThreads) {   // 1024 segments per round: at most 2^23 heads, fits u32
+    const u32 i0 = base + 4 * threadIdx.x;
+    u32 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i0 + j < nseg ? row[i0 + j] : 0;
+    u32 tot;
+    u32 ex = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], wsum, &tot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i0 + j < nseg) out[i0 + j] = carry + ex;
+      ex += v[j];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 size_t runs_scratch_bytes(size_t n) {
   const size_t nseg = (n + kSegRecs - 1) / kSegRecs;
-  return 64 + 2 * sizeof(u32) * (nseg ? nseg : 1);
+  return 64 + (2 * sizeof(u32) + 2 * sizeof(u64)) * (nseg ? nseg : 1);   // totals u64[2] | seg_heads u32[2][nseg] | seg_base u64[2][nseg]
 }
 // Pass 1 + scan.  Leaves the scanned table in `scratch`; totals[0] = runs, totals[1] = (barcode, umi) pairs
-// are read back by the caller from scratch[0..1] (u32 each; n < 2^32).
+// are read back by the caller from scratch[0..15] (u64 each).
 hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st) {
   (void)hipGetLastError();
-  if (n == 0 || n >= (1ull << 32) || scratch_bytes < runs_scratch_bytes(n)) return hipErrorInvalidValue;
-  const u32 nseg = (u32)((n + kSegRecs - 1) / kSegRecs);
-  u32* totals = static_cast<u32*>(scratch);
-  u32* table = reinterpret_cast<u32*>(static_cast<uint8_t*>(scratch) + 64);
+  const size_t nseg64 = (n + kSegRecs - 1) / kSegRecs;
+  if (n == 0 || nseg64 >= (1ull << 31) || scratch_bytes < runs_scratch_bytes(n)) return hipErrorInvalidValue;
+  const u32 nseg = (u32)nseg64;
+  u64* totals = static_cast<u64*>(scratch);
+  u32* heads = reinterpret_cast<u32*>(static_cast<uint8_t*>(scratch) + 64);
+  u64* base = reinterpret_cast<u64*>(static_cast<uint8_t*>(scratch) + 64 + 2 * sizeof(u32) * (size_t)nseg + ((2 * sizeof(u32) * (size_t)nseg) & 4));
   hipLaunchKernelGGL(ibu_k_runs_count, dim3((nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs,
-                     (u64)n, nseg, table);
-  hipLaunchKernelGGL(ibu_k_sort_scan_rows, dim3(2), dim3(kSortThreads), 0, st, table, nseg, totals);
+                     (u64)n, nseg, heads);
+  hipLaunchKernelGGL(ibu_k_runs_scan, dim3(2), dim3(kSortThreads), 0, st, (const u32*)heads, nseg, base, totals);
   return hipGetLastError();
 }
 hipError_t launch_runs_emit(const LaunchCfg& cfg, const void* recs, size_t n, const void* scratch, void* run_scratch, uint64_t n_runs,
                             uint64_t n_pairs, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq, hipStream_t st) {
   (void)hipGetLastError();
   const u32 nseg = (u32)((n + kSegRecs - 1) / kSegRecs);
-  const u32* table = reinterpret_cast<const u32*>(static_cast<const uint8_t*>(scratch) + 64);
+  const u64* base = reinterpret_cast<const u64*>(static_cast<const uint8_t*>(scratch) + 64 + 2 * sizeof(u32) * (size_t)nseg + ((2 * sizeof(u32) * (size_t)nseg) & 4));
   u64* starts = static_cast<u64*>(run_scratch);             // n_runs entries each (run_scratch_bytes)
   u64* pair_rank = uniq ? starts + n_runs : nullptr;
   hipLaunchKernelGGL(ibu_k_runs_emit, dim3((nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs,
-                     (u64)n, nseg, table, (u64*)barcodes, starts, pair_rank);
+                     (u64)n, nseg, base, (u64*)barcodes, starts, pair_rank);
   u64 blocks = (n_runs + 255) / 256;
   const u64 cap = (u64)cfg.cus * 8;
   if (blocks > cap) blocks = cap;

@@ -320,7 +320,9 @@ int32_t ibu_generate(ibu_ctx_t* ctx, uint64_t seed, uint64_t first, size_t n, ui
 int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t bytes, void* stream);
 
 /* Device-side sort by (barcode, umi, index) — the order `derive(Ord)` defines (record.rs:58)
- * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch. */
+ * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch.  The context
+ * additionally keeps (and grows on demand) about 1.75 B per record of its own scratch.  Any n the
+ * device can hold (n < 2^40); synchronises `stream` once (a 64-byte census read-back picks the passes). */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
 /* Per-barcode aggregation of SORTED device records: the device form of the reference's BarcodeAnalyzer
  * processor (src/parallel.rs:72-98 — HashMap<barcode, count> merged in on_batch_complete).  Writes, in
@@ -330,7 +332,7 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * pairs.  Size query: d_barcodes = d_counts = NULL and cap = 0.  cap too small: IBU_ERR_INVALID_ARG with
  * *n_barcodes set.  The input must be sorted (ibu_sort_records / a file whose header says sorted);
  * unsorted input yields the run-length encoding of the barcode column instead.  Synchronises `stream`
- * once (the counts come back to size the output).  n < 2^32. */
+ * once (the counts come back to size the output).  n < 2^40. */
 int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, uint64_t* d_barcodes,
                            uint64_t* d_counts, uint64_t* d_unique_umis, size_t cap, size_t* n_barcodes,
                            size_t* n_barcode_umi_pairs, void* stream);

@@ -8,8 +8,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SEED = 0x1B00005
-# around the 1 Ki-record LDS tile and the 32 Ki-record histogram chunk
-SIZES = [0, 1, 2, 3, 63, 64, 65, 1023, 1024, 1025, 4096, 32_767, 32_768, 32_769, 100_000, 1_000_003]
+# around the 128-record census tile, the 2 Ki-record scatter tile (1 Ki / 4 Ki for other shapes), the grid's multiple of
+# eight tiles and the scan block of 1024 tiles (2 097 152 records)
+SIZES = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2047, 2048, 2049, 4096, 16_383, 16_384, 16_385, 32_768, 100_000,
+         1_000_003, 2_097_151, 2_097_152, 2_097_153, 5_000_001]
 
 
 @pytest.fixture(scope="module")
@@ -46,6 +48,35 @@ def test_sort_random_16_12(ctx, oracle, n):
     got, d = _sort_on_device(ctx, recs)
     assert got == oracle.sort_records(recs).tobytes()
     assert ctx.is_sorted(d, n)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+def test_sort_other_tile_shapes(ia, oracle, variant):
+    """The A/B tile shapes (ibu_ctx_set_option "sort_variant") are the same algorithm: same bytes."""
+    c = ia.Context(0)
+    try:
+        c.set_option("sort_variant", variant)
+        for n in (1, 4097, 70_001, 3_000_001):
+            recs = _shuffled(oracle, n, 16, 12)
+            recs["index"] = np.random.default_rng(n).integers(0, 2**30, n, dtype=np.uint64)
+            assert _sort_on_device(c, recs)[0] == oracle.sort_records(recs).tobytes(), (variant, n)
+        with pytest.raises(ia.IbuError):
+            c.set_option("sort_variant", 99)
+    finally:
+        c.close()
+
+
+def test_sort_of_a_shard_at_an_odd_record(ctx, oracle):
+    """Records and scratch 8-byte but not 16-byte aligned (a shard starting at an odd record): census peels, the first
+    count and every scatter take their 8-byte paths; same bytes."""
+    n = 300_001
+    recs = _shuffled(oracle, n, 16, 12)
+    d, t = ctx.alloc((n + 1) * 24), ctx.alloc((n + 1) * 24)
+    ctx.copy(d.ptr + 24, ctx.upload(recs), n * 24)
+    ctx.sort_records(d.ptr + 24, t.ptr + 24, n)
+    ctx.synchronize()
+    assert d.download(count=n * 24, offset=24).tobytes() == oracle.sort_records(recs).tobytes()
+    assert ctx.is_sorted(d.ptr + 24, n)
 
 
 @pytest.mark.parametrize("n", [1, 1025, 70_001])
@@ -204,3 +235,32 @@ def test_sort_with_8_byte_aligned_buffers(ctx, oracle, ia):
     ctx.sort_records(d.ptr + 8, t.ptr + 8, n)
     ctx.synchronize()
     assert view.download().tobytes() == oracle.sort_records(recs).tobytes()
+
+
+def test_sort_and_barcode_counts_beyond_2_pow_32_records(ia):
+    """More than 2^32 records on one GPU (4.4e9 x 24 B = 106 GB + as much scratch: the part has 288 GB): the sort's
+    tile positions switch to 64 bits, the run tables of the aggregation too.  Size-independent properties: sorted,
+    multiset preserved (count, wrapping sums, XORs), per-barcode counts add up.  """
+    n, bc_len, umi_len = 4_400_000_000, 8, 12
+    assert n > 2**32
+    ctx = ia.Context(0)
+    try:
+        recs, tmp = ctx.alloc(n * 24), ctx.alloc(n * 24)
+        ctx.generate(0x1B00007, 0, n, bc_len, umi_len, recs)
+        before = ctx.reduce(recs, n)
+        assert before["count"] == n and before["sum"][2] == (n * (n - 1) // 2) % 2**64
+        assert not ctx.is_sorted(recs, n)
+        ctx.sort_records(recs, tmp, n)
+        assert ctx.is_sorted(recs, n)
+        assert ctx.reduce(recs, n) == before
+        tmp.free()
+        bcs, counts, uniq = ctx.barcode_counts(recs, n)
+        assert len(bcs) == 4**bc_len and int(counts.sum()) == n   # 65 536 barcodes, every one drawn ~67 000 times
+        assert (np.diff(bcs.astype(np.int64)) > 0).all()
+        assert int(uniq.sum()) <= n and int(uniq.min()) > 60_000    # ~67 000 draws from 16.7 M UMIs: almost all distinct
+        # first and last records against the closed form of the generator: smallest barcode is 0, largest 4^8 - 1
+        head = ia.DeviceBuffer.wrap(ctx, recs.ptr, 24).download(np.uint64)
+        tail = ia.DeviceBuffer.wrap(ctx, recs.ptr + (n - 1) * 24, 24).download(np.uint64)
+        assert int(head[0]) == 0 and int(tail[0]) == 4**bc_len - 1
+    finally:
+        ctx.close()

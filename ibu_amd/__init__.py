@@ -672,6 +672,10 @@ class Context:
         self.synchronize(stream)
         return (d_b.download(np.uint64), d_c.download(np.uint64), d_u.download(np.uint64) if d_u else None)
 
+    def lower_bound(self, d_sorted_records, n, d_keys, k, d_pos, stream=None):
+        """d_pos[j] (u64, device) = first position whose record is >= key j (24-byte records in d_keys); asynchronous."""
+        _check(lib.ibu_lower_bound_records(self._c, _dptr(d_sorted_records), n, _dptr(d_keys), k, _dptr(d_pos), stream))
+
     def is_sorted(self, d_records, n, stream=None):
         s = C.c_int32()
         _check(lib.ibu_is_sorted(self._c, _dptr(d_records), n, stream, C.byref(s)))

@@ -136,6 +136,7 @@ SIGNATURES = {
     "ibu_reduce_fetch": (i32, [vp, vp, P(CReduceResult)]),
     "ibu_generate": (i32, [vp, u64, u64, sz, u32, u32, vp, vp]),
     "ibu_sort_records": (i32, [vp, vp, vp, sz, vp]),
+    "ibu_lower_bound_records": (i32, [vp, vp, sz, vp, sz, vp, vp]),
     "ibu_is_sorted": (i32, [vp, vp, sz, vp, P(i32)]),
     "ibu_load_to_device": (i32, [vp, C.c_char_p, P(CRingConfig), P(CHeader), P(vp), sz, P(sz), P(CStreamStats)]),
     "ibu_writer_write_batch_device": (i32, [vp, vp, P(CRingConfig), vp, sz, P(CStreamStats)]),

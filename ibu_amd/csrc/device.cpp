@@ -290,6 +290,17 @@ extern "C" int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_sr
   IBU_HIP(launch_copy(ctx->cfg, d_src, d_dst, bytes, pick_stream(ctx, stream)));
   return IBU_OK;
 }
+extern "C" int32_t ibu_lower_bound_records(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, const void* d_keys, size_t k,
+                                           uint64_t* d_pos, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (k == 0) return IBU_OK;
+  if (k > (1u << 20)) return err_arg("at most 2^20 keys per call");
+  if (!d_keys || !d_pos || !aligned8(d_keys) || !aligned8(d_pos)) return err_arg("d_keys / d_pos must be non-NULL and 8-byte aligned");
+  if (n && (!d_sorted_records || !aligned8(d_sorted_records))) return err_arg("d_sorted_records must be non-NULL and 8-byte aligned");
+  IBU_HIP(launch_lower_bound(d_sorted_records, n, d_keys, k, d_pos, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
 extern "C" int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream, int32_t* sorted) {
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;

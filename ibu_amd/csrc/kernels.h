@@ -60,6 +60,7 @@ hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n
                                size_t scratch_bytes, hipStream_t st);
 size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
 int sort_num_variants();
+hipError_t launch_lower_bound(const void* recs, size_t n, const void* keys, size_t k, uint64_t* pos, hipStream_t st);
 // per-barcode run-length aggregation of sorted records (sort.hip)
 size_t runs_scratch_bytes(size_t n);
 hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st);

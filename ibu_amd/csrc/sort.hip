@@ -683,6 +683,29 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
 }
 
 // =====================================================================================================
+// Splitter search of the multi-GPU sample sort: thread j finds the first record >= key j in the sorted records
+// (log2 n probes of 24 bytes each; k is the number of ranks minus one).
+extern "C" __global__ void ibu_k_lower_bound(const u64* __restrict__ recs, u64 n, const u64* __restrict__ keys, u32 k, u64* __restrict__ pos) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const u64 kb = keys[3 * j], ku = keys[3 * j + 1], kx = keys[3 * j + 2];
+  u64 lo = 0, hi = n;
+  while (lo < hi) {
+    const u64 mid = lo + (hi - lo) / 2;
+    if (rec_less(recs[3 * mid], recs[3 * mid + 1], recs[3 * mid + 2], kb, ku, kx)) lo = mid + 1;
+    else hi = mid;
+  }
+  pos[j] = lo;
+}
+hipError_t launch_lower_bound(const void* recs, size_t n, const void* keys, size_t k, uint64_t* pos, hipStream_t st) {
+  (void)hipGetLastError();
+  if (k == 0) return hipSuccess;
+  hipLaunchKernelGGL(ibu_k_lower_bound, dim3((u32)((k + 63) / 64)), dim3(64), 0, st, (const u64*)recs, (u64)n, (const u64*)keys, (u32)k,
+                     (u64*)pos);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
 // Per-barcode aggregation on SORTED records: the device form of the reference's BarcodeAnalyzer
 // processor (src/parallel.rs:72-98: HashMap<barcode, count> merged in on_batch_complete).  On sorted
 // input a barcode is a run, so the map is a run-length encoding: barcodes[k], counts[k] and — the

@@ -59,14 +59,21 @@ def expected_index_sum(n_global):
 # exchange step, so the one place RCCL moves bulk data: an all-to-all of the records over xGMI (every GPU ships
 # about (W-1)/W of its shard; point-to-point links, so all 7 are busy at once).
 #
-#   1. every rank sorts its shard locally (ibu_sort_records)
-#   2. every rank contributes evenly spaced samples; all ranks sort the gathered samples and keep W-1 splitters
-#   3. each rank finds the splitters' lower bounds in its sorted shard (binary search: ~log2(n) 24-byte probes each)
-#   4. send counts are exchanged, records travel in ONE all_to_all_single (uneven splits)
-#   5. each rank sorts what it received (W sorted runs) — rank r now holds the r-th key range, globally ordered
+#   1. every rank sorts its shard locally (ibu_sort_records, on torch's current stream)
+#   2. every rank contributes s evenly spaced sample records; ONE all_gather of [s, 24]-byte tensors; every rank sorts
+#      the W*s samples (device radix sort) and keeps W-1 splitters — all on the device
+#   3. ONE kernel finds the lower bound of every splitter in the sorted shard (ibu_lower_bound_records)
+#   4. send counts -> receive counts with ONE small all_to_all_single of W int64; the only host synchronisation of
+#      the whole sort reads this rank's row and column of the count matrix (all_to_all_single wants Python lists)
+#   5. the records travel in ONE all_to_all_single with uneven splits
+#   6. each rank sorts what it received (W sorted runs) — rank r now holds the r-th key range, globally ordered
 #
-# The device work goes through `ops` so the control flow (splitters, bounds, counts, exchange) is also exercised on
-# CPU under gloo with a numpy stand-in (tests/test_sharding_gloo.py); DeviceSortOps is the product implementation.
+# No pickled objects, no per-record host probes (round 1 did ~(W-1) log2 n `.cpu()` round trips here).  Everything a
+# rank launches — sort, gather, search, collectives — goes to torch's CURRENT stream, so the exchange is ordered before
+# the second sort without a host wait (round 1 sorted on the context's own stream: a race under nccl).
+#
+# The device work goes through `ops` so the control flow (samples, splitters, bounds, counts, exchange) is also exercised
+# on CPU under gloo with a numpy stand-in (tests/test_sharding_gloo.py); DeviceSortOps is the product implementation.
 # ---------------------------------------------------------------------------------------------------------------
 _REC = 24
 
@@ -77,46 +84,52 @@ def _rec_key(b):
 
 
 class DeviceSortOps:
-    """Product implementation: records live in a torch uint8 CUDA tensor, sorted by the HIP radix sort."""
+    """Product implementation: records live in a torch uint8 CUDA tensor; every launch goes to torch's current stream."""
 
     def __init__(self, ctx):
         self.ctx = ctx
+
+    def _stream(self, like):
+        import torch
+        return torch.cuda.current_stream(like.device).cuda_stream
 
     def empty(self, nbytes, like):
         import torch
         return torch.empty(max(int(nbytes), _REC), dtype=torch.uint8, device=like.device)
 
     def local_sort(self, buf, n):
+        """In place, on the current stream (ibu_sort_records waits for that stream once itself: the census read-back)."""
         if n > 1:
             tmp = self.empty(n * _REC, buf)
-            self.ctx.sort_records(buf, tmp, n)
-        self.ctx.synchronize()
+            self.ctx.sort_records(buf, tmp, n, stream=self._stream(buf))
 
-    def fetch(self, buf, i):  # one record as 24 bytes
+    def rows(self, buf, n, idx):
+        """Records at the positions in the int64 tensor `idx` -> [len(idx), 24] uint8 tensor on the same device."""
+        return buf[: n * _REC].view(n, _REC)[idx]
+
+    def lower_bounds(self, buf, n, keys):
+        """keys: [k, 24] uint8 (device) -> int64 tensor [k] of first positions with record >= key."""
+        import torch
+        k = keys.shape[0]
+        pos = torch.empty(max(k, 1), dtype=torch.int64, device=buf.device)
+        if k:
+            self.ctx.lower_bound(buf, n, keys.contiguous(), k, pos, stream=self._stream(buf))
+        return pos[:k]
+
+    def fetch(self, buf, i):  # one record as 24 bytes (tools / tests only)
         return bytes(buf[i * _REC:(i + 1) * _REC].cpu().numpy())
 
-    def sample(self, buf, n, idx):  # records at the given indices, concatenated
-        import torch
-        if not idx:
-            return b""
-        rows = buf[: n * _REC].view(n, _REC)[torch.tensor(idx, dtype=torch.long, device=buf.device)]
-        return bytes(rows.cpu().numpy().tobytes())
+
+def _collective(t, group):
+    """The tensor a collective of this process group can take: itself under nccl, a CPU copy under gloo (rehearsal)."""
+    import torch.distributed as dist
+    return t.cpu() if dist.get_backend(group) == "gloo" and t.device.type != "cpu" else t
 
 
-def _lower_bound(ops, buf, n, key):
-    lo, hi = 0, n
-    while lo < hi:
-        mid = (lo + hi) // 2
-        if _rec_key(ops.fetch(buf, mid)) < key:
-            lo = mid + 1
-        else:
-            hi = mid
-    return lo
-
-
-def distributed_sort(ops, buf, n, samples_per_rank=None, group=None):
+def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None):
     """Sort the records of all ranks globally.  `buf`: this rank's n records (24 n bytes, uint8 tensor).  Returns
-    (out_buf, n_out): rank r holds the r-th contiguous range of the global order; sum of n_out == sum of n."""
+    (out_buf, n_out): rank r holds the r-th contiguous range of the global order; sum of n_out == sum of n.
+    `stats` (dict, optional) receives the exchange's byte counts."""
     import torch
     import torch.distributed as dist
 
@@ -124,28 +137,54 @@ def distributed_sort(ops, buf, n, samples_per_rank=None, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return buf, n
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    s = samples_per_rank or 64 * world
-    idx = [(k * n) // s for k in range(s)] if n >= s else list(range(n))
-    mine = ops.sample(buf, n, idx)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine, group=group)
-    keys = sorted(_rec_key(blob[o:o + _REC]) for blob in gathered for o in range(0, len(blob), _REC))
-    splitters = [keys[(k * len(keys)) // world] for k in range(1, world)] if keys else []
-    bounds = [0] + [_lower_bound(ops, buf, n, sp) for sp in splitters] + [n]
-    if not splitters:
-        bounds = [0] * world + [n]  # nothing to split on: everything goes to the last rank
-    send = [bounds[j + 1] - bounds[j] for j in range(world)]
-    matrix = [None] * world
-    dist.all_gather_object(matrix, send, group=group)
-    recv = [matrix[src][rank] for src in range(world)]
+    dev = buf.device
+    s = int(samples_per_rank or 64 * world)
+    # 2. samples: s evenly spaced records (fewer than s records: all of them), padded with all-ones records, which sort
+    #    last and are never picked because the splitter positions count valid samples only
+    valid = min(n, s)
+    samp = torch.full((s, _REC), 0xFF, dtype=torch.uint8, device=dev)
+    if valid:
+        idx = (torch.arange(valid, device=dev, dtype=torch.int64) * n) // valid
+        samp[:valid] = ops.rows(buf, n, idx)
+    meta = torch.tensor([valid], dtype=torch.int64, device=dev)
+    all_samp = torch.empty((world * s, _REC), dtype=torch.uint8, device=_collective(samp, group).device)
+    all_meta = torch.empty(world, dtype=torch.int64, device=all_samp.device)
+    dist.all_gather_into_tensor(all_samp, _collective(samp, group), group=group)
+    dist.all_gather_into_tensor(all_meta, _collective(meta, group), group=group)
+    all_samp, all_meta = all_samp.to(dev), all_meta.to(dev)
+    flat = all_samp.reshape(-1).contiguous()
+    ops.local_sort(flat, world * s)
+    total_valid = all_meta.sum()                                   # stays on the device
+    pick = (torch.arange(1, world, device=dev, dtype=torch.int64) * total_valid) // world
+    splitters = flat.view(world * s, _REC)[pick]                   # [W-1, 24]; all-ones rows if nobody has a record
+    # 3. + 4. bounds and counts
+    bounds = ops.lower_bounds(buf, n, splitters)
+    edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), bounds.to(torch.int64),
+                       torch.full((1,), n, dtype=torch.int64, device=dev)])
+    send_t = edges[1:] - edges[:-1]
+    recv_t = torch.empty_like(_collective(send_t, group))
+    dist.all_to_all_single(recv_t, _collective(send_t, group), group=group)
+    send, recv = [int(v) for v in send_t.tolist()], [int(v) for v in recv_t.tolist()]   # the one host synchronisation
     n_out = sum(recv)
     out = ops.empty(n_out * _REC, buf)
     in_splits, out_splits = [c * _REC for c in send], [c * _REC for c in recv]
-    if dist.get_backend(group) == "gloo" and buf.device.type != "cpu":  # rehearsal transport: stage through the host
+    # 5. the exchange (timed only when the caller asked for stats: the timing needs two device synchronisations)
+    import time
+    if stats is not None and dev.type != "cpu":
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    if dist.get_backend(group) == "gloo" and dev.type != "cpu":  # rehearsal transport: stage through the host
         src, dst = buf[: n * _REC].cpu(), torch.empty(n_out * _REC, dtype=torch.uint8)
         dist.all_to_all_single(dst, src, out_splits, in_splits, group=group)
         out[: n_out * _REC].copy_(dst)
-    else:  # RCCL over xGMI (or gloo on CPU tensors in the logic tests)
+    else:  # RCCL over xGMI (or gloo on CPU tensors in the logic tests): ordered on the current stream
         dist.all_to_all_single(out[: n_out * _REC], buf[: n * _REC], out_splits, in_splits, group=group)
+    if stats is not None:
+        if dev.type != "cpu":
+            torch.cuda.synchronize(dev)
+        stats["exchange_seconds"] = time.perf_counter() - t0
+        stats.update(sent_bytes=(n - send[rank]) * _REC, received_bytes=(n_out - recv[rank]) * _REC, kept_bytes=send[rank] * _REC,
+                     samples_per_rank=s)
+    # 6.
     ops.local_sort(out, n_out)
     return out, n_out

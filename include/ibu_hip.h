@@ -336,6 +336,12 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
 int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, uint64_t* d_barcodes,
                            uint64_t* d_counts, uint64_t* d_unique_umis, size_t cap, size_t* n_barcodes,
                            size_t* n_barcode_umi_pairs, void* stream);
+/* For each of the k key records d_keys[j] (24 B each): the first position p in the SORTED device records with
+ * records[p] >= key under ibu_record_cmp (record.rs:58), i.e. slice::partition_point(|r| r < key); n if there is none.
+ * Positions land in d_pos[0..k) on the device; asynchronous on `stream`.  This is the splitter search of the
+ * multi-GPU sample sort (ibu_amd/sharding.py): one launch for all splitters instead of a host binary search. */
+int32_t ibu_lower_bound_records(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, const void* d_keys, size_t k,
+                                uint64_t* d_pos, void* stream);
 /* 1 if the n records are non-decreasing under ibu_record_cmp. Synchronises. */
 int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream,
                       int32_t* sorted);

@@ -662,6 +662,15 @@ void orc_generate(uint64_t seed, uint64_t first, size_t n, uint32_t bc_len, uint
 static int cmp_q(const void* a, const void* b) { return orc_record_cmp((const orc_record*)a, (const orc_record*)b); }
 /* records.sort() record.rs:199 */
 void orc_sort_records(orc_record* r, size_t n) { qsort(r, n, sizeof *r, cmp_q); }
+size_t orc_lower_bound(const orc_record* r, size_t n, const orc_record* key) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) {
+    size_t mid = lo + (hi - lo) / 2;
+    if (orc_record_cmp(&r[mid], key) < 0) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
 int orc_is_sorted(const orc_record* r, size_t n) {
   for (size_t i = 1; i < n; i++)
     if (orc_record_cmp(&r[i - 1], &r[i]) > 0) return 0;

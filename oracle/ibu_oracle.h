@@ -163,6 +163,8 @@ void orc_generate(uint64_t seed, uint64_t first, size_t n, uint32_t bc_len, uint
 void orc_sort_records(orc_record* r, size_t n);
 size_t orc_barcode_counts(const orc_record* sorted, size_t n, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq);
 int orc_is_sorted(const orc_record* r, size_t n);
+/* slice::partition_point(|r| r < key) on sorted records: first index whose record is >= key (n if none) */
+size_t orc_lower_bound(const orc_record* sorted, size_t n, const orc_record* key);
 
 /* ---- cpu_baseline legs for bench.py: static range split over `threads` OS threads, like
  * process_parallel (mmap.rs:297-322).  Returns seconds. ---- */

@@ -111,6 +111,7 @@ def _load():
         "orc_generate": (None, [u64, u64, sz, u32, u32, vp]),
         "orc_sort_records": (None, [vp, sz]),
         "orc_is_sorted": (i32, [vp, sz]),
+        "orc_lower_bound": (sz, [vp, sz, vp]),
         "orc_bench_decode_encode": (C.c_double, [sz, u32, u32, u64, i32, i32, P(u64)]),
         "orc_bench_reduce": (C.c_double, [sz, u64, i32, P(Reduce)]),
     }
@@ -404,6 +405,14 @@ def sort_records(recs):
     out = np.ascontiguousarray(recs, dtype=REC_DTYPE).copy()
     lib.orc_sort_records(_ptr(out), out.shape[0])
     return out
+
+
+def lower_bound(sorted_recs, key):
+    """First index whose record is >= key (a 1-element REC_DTYPE array or a (barcode, umi, index) tuple)."""
+    r = np.ascontiguousarray(sorted_recs, dtype=REC_DTYPE)
+    k = np.zeros(1, dtype=REC_DTYPE)
+    k[0] = tuple(int(v) for v in key) if isinstance(key, tuple) else key
+    return int(lib.orc_lower_bound(_ptr(r), r.shape[0], _ptr(k)))
 
 
 def barcode_counts(sorted_recs):

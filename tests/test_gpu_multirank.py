@@ -68,3 +68,6 @@ def test_distributed_sort_two_ranks():
     assert out["every_rank_sorted"] and out["rank_ranges_ordered"] and out["multiset_preserved"]
     assert out["count"] == 6_000_002 and sum(out["records_per_rank_out"]) == 6_000_002
     assert max(out["records_per_rank_out"]) < 0.6 * 6_000_002  # the splitter balanced the two ranges
+    # about half of every shard travels; the transport says what carried it (gloo + host staging here, RCCL in production)
+    assert all(0.3 * 3_000_001 * 24 < b < 0.7 * 3_000_001 * 24 for b in out["exchange_sent_bytes_per_rank"])
+    assert out["backend"] == "gloo" and out["exchange_seconds_max"] > 0

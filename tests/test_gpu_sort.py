@@ -66,6 +66,26 @@ def test_sort_other_tile_shapes(ia, oracle, variant):
         c.close()
 
 
+def test_lower_bound_records_matches_partition_point(ctx, oracle, ia):
+    """ibu_lower_bound_records (the splitter search of the multi-GPU sample sort) = slice::partition_point(|r| r < key)
+    on the sorted records: keys below / above everything, present keys (first of a run of duplicates), absent keys."""
+    n = 100_003
+    recs = _shuffled(oracle, n, 6, 3)                 # short fields: many exact (barcode, umi) ties
+    recs["index"] %= 7
+    srt = oracle.sort_records(recs)
+    keys = np.concatenate([srt[[0, 1, n // 3, n // 2, n - 1]], ia.records_array([(0, 0, 0), (2**64 - 1, 2**64 - 1, 2**64 - 1), (5, 0, 0),
+                                                                                 (int(srt["barcode"][n // 2]), int(srt["umi"][n // 2]) + 1, 0)])])
+    d_s, d_k, d_p = ctx.upload(srt), ctx.upload(keys), ctx.alloc(8 * len(keys))
+    ctx.lower_bound(d_s, n, d_k, len(keys), d_p)
+    got = d_p.download(np.uint64).tolist()
+    want = [oracle.lower_bound(srt, k) for k in keys]
+    assert got == want
+    assert got[0] == 0 and got[6] == n                # all-ones key: past the end
+    ctx.lower_bound(d_s, 0, d_k, len(keys), d_p)      # empty shard: every bound is 0
+    assert d_p.download(np.uint64).tolist() == [0] * len(keys)
+    ctx.lower_bound(d_s, n, d_k, 0, d_p)              # no keys: nothing to do
+
+
 def test_sort_of_a_shard_at_an_odd_record(ctx, oracle):
     """Records and scratch 8-byte but not 16-byte aligned (a shard starting at an odd record): census peels, the first
     count and every scatter take their 8-byte paths; same bytes."""

@@ -72,7 +72,7 @@ def test_global_totals_without_process_group_is_identity():
 
 # ---- distributed sample sort: control flow on CPU (numpy stand-in for the device ops) ------------------------------
 class _NumpySortOps:
-    """Test stand-in for DeviceSortOps: same interface, records in a CPU uint8 tensor, sorted by the oracle."""
+    """Test stand-in for DeviceSortOps: same interface, records in a CPU uint8 tensor, sorted / searched by the oracle."""
 
     def __init__(self, orc):
         self.orc = orc
@@ -81,17 +81,25 @@ class _NumpySortOps:
         import torch
         return torch.empty(max(int(nbytes), 24), dtype=torch.uint8)
 
+    def _recs(self, buf, n):
+        return np.frombuffer(buf[: n * 24].numpy().tobytes(), dtype=self.orc.REC_DTYPE)
+
     def local_sort(self, buf, n):
         import torch
         if n > 1:
-            recs = np.frombuffer(buf[: n * 24].numpy().tobytes(), dtype=self.orc.REC_DTYPE)
-            buf[: n * 24] = torch.from_numpy(np.frombuffer(self.orc.sort_records(recs).tobytes(), dtype=np.uint8).copy())
+            buf[: n * 24] = torch.from_numpy(np.frombuffer(self.orc.sort_records(self._recs(buf, n)).tobytes(), dtype=np.uint8).copy())
+
+    def rows(self, buf, n, idx):
+        return buf[: n * 24].view(n, 24)[idx]
+
+    def lower_bounds(self, buf, n, keys):
+        import torch
+        recs = self._recs(buf, n)
+        ks = np.frombuffer(keys.contiguous().numpy().tobytes(), dtype=self.orc.REC_DTYPE)
+        return torch.tensor([self.orc.lower_bound(recs, k) for k in ks], dtype=torch.int64)
 
     def fetch(self, buf, i):
         return bytes(buf[i * 24:(i + 1) * 24].numpy())
-
-    def sample(self, buf, n, idx):
-        return b"".join(self.fetch(buf, i) for i in idx)
 
 
 def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir):

@@ -52,7 +52,8 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    out, n_out = sharding.distributed_sort(sharding.DeviceSortOps(ctx), buf, n)
+    stats = {}
+    out, n_out = sharding.distributed_sort(sharding.DeviceSortOps(ctx), buf, n, stats=stats)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -62,15 +63,18 @@ def main():
     edge = (ops.fetch(out, 0), ops.fetch(out, n_out - 1)) if n_out else None
     edges = [None] * world
     if world > 1:
-        dist.all_gather_object(edges, (ok, n_out, edge))
+        dist.all_gather_object(edges, (ok, n_out, edge, stats.get("sent_bytes", 0), stats.get("exchange_seconds", 0.0)))  # result check only
     else:
-        edges = [(ok, n_out, edge)]
+        edges = [(ok, n_out, edge, 0, 0.0)]
     after = sharding.global_totals(ctx.reduce(out, n_out), device=coll_dev)
     if rank == 0:
         keys = [(sharding._rec_key(e[2][0]), sharding._rec_key(e[2][1])) for e in edges if e[1]]
         ordered = all(keys[i][1] <= keys[i + 1][0] for i in range(len(keys) - 1))
         print(json.dumps({"ranks": world, "records_per_rank_in": n, "records_per_rank_out": [e[1] for e in edges],
                           "seconds": round(dt, 4), "M_records_per_s": round(n * world / dt / 1e6, 1),
+                          "backend": a.backend, "transport": ("RCCL" if a.backend == "nccl" else "gloo, staged through the host (rehearsal)"),
+                          "exchange_sent_bytes_per_rank": [e[3] for e in edges], "exchange_seconds_max": round(max(e[4] for e in edges), 4),
+                          "exchange_GBps_per_rank": round(max(e[3] for e in edges) / max(max(e[4] for e in edges), 1e-9) / 1e9, 2),
                           "every_rank_sorted": all(e[0] for e in edges), "rank_ranges_ordered": ordered,
                           "multiset_preserved": before == after, "count": after["count"]}), flush=True)
     if world > 1:

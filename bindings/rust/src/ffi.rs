@@ -1,4 +1,4 @@
-//! Raw `extern "C"` declarations — one-to-one with include/ibu_hip.h (ABI revision 1).
+//! Raw `extern "C"` declarations — one-to-one with include/ibu_hip.h (ABI revision 3).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -57,6 +57,8 @@ pub struct ibu_decode_sink_t {
     pub d_bc_ascii: *mut u8,
     pub d_umi_ascii: *mut u8,
     pub d_index: *mut u64,
+    /// rows every non-NULL column can hold (ABI revision 3): a longer stream is IBU_ERR_INVALID_ARG, never an overrun
+    pub cap_records: usize,
 }
 #[repr(C)]
 pub struct ibu_processor_vtable_t {

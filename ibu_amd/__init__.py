@@ -360,9 +360,11 @@ class Reader:
 
     def process_device(self, ctx, proc=PROC_REDUCE, sink=None, ring=None):
         """Stream the rest of this reader (plain or gzip) through the pinned ring to a device
-        processor.  Returns (result, stats)."""
+        processor.  Returns (result, stats).  PROC_DECODE: sink = (d_bc, d_umi, d_index[, cap_records]); without
+        cap_records the capacity is what the DeviceBuffers hold.  A stream longer than that raises InvalidArg."""
+        h = self.header()
         return ctx._run_proc(lambda c, rg, s, st: lib.ibu_reader_process_device(self._r, c, rg, proc, s, st),
-                             proc, sink, ring)
+                             proc, sink, ring, (h.bc_len, h.umi_len))
 
     def close(self):
         if getattr(self, "_r", None):
@@ -487,9 +489,10 @@ class MmapReader:
 
     def process_device(self, ctx, proc=PROC_REDUCE, shard=0, n_shards=1, sink=None, ring=None):
         """One shard of the static split on one GPU, through the pinned ring."""
+        h = self.header()
         return ctx._run_proc(
             lambda c, rg, s, st: lib.ibu_mmap_process_device(self._m, c, rg, proc, shard, n_shards, s, st),
-            proc, sink, ring)
+            proc, sink, ring, (h.bc_len, h.umi_len))
 
     def decode_to_host(self, ctx, shard=0, n_shards=1, ring=None, want=("bc", "umi", "index")):
         """One shard -> (barcode ASCII [n, bc_len], UMI ASCII [n, umi_len], index [n]) as numpy arrays in host
@@ -693,13 +696,21 @@ class Context:
     def free(self, ptr):
         _check(lib.ibu_device_free(self._c, ptr))
 
-    def _run_proc(self, call, proc, sink, ring):
+    def _run_proc(self, call, proc, sink, ring, lens=(1, 1)):
         st = CStreamStats()
         if proc == PROC_REDUCE:
             r = CReduceResult()
             _check(call(self._c, _ring(ring), C.cast(C.byref(r), C.c_void_p), C.byref(st)))
             return {"count": r.count, "sum": list(r.sum), "xor": list(r.xor_)}, st
-        s = CDecodeSink(*(_dptr(x) for x in sink))
+        cols = list(sink[:3])
+        if len(sink) > 3:
+            cap = int(sink[3])
+        else:  # capacity = what the buffers hold (DeviceBuffer / torch tensors know their size)
+            sizes = [(c, w) for c, w in zip(cols, (lens[0], lens[1], 8)) if c is not None]
+            if not all(hasattr(c, "nbytes") or hasattr(c, "numel") for c, _ in sizes):
+                raise TypeError("a decode sink of raw pointers needs its capacity: sink=(d_bc, d_umi, d_index, cap_records)")
+            cap = min((c.nbytes if hasattr(c, "nbytes") else c.numel() * c.element_size()) // w for c, w in sizes) if sizes else 0
+        s = CDecodeSink(*(_dptr(x) for x in cols), cap)
         _check(call(self._c, _ring(ring), C.cast(C.byref(s), C.c_void_p), C.byref(st)))
         return None, st
 

@@ -40,7 +40,7 @@ class CStreamStats(C.Structure):  # ibu_stream_stats_t
 
 
 class CDecodeSink(C.Structure):  # ibu_decode_sink_t
-    _fields_ = [("d_bc_ascii", vp), ("d_umi_ascii", vp), ("d_index", vp)]
+    _fields_ = [("d_bc_ascii", vp), ("d_umi_ascii", vp), ("d_index", vp), ("cap_records", sz)]
 
 
 WRITE_FN = C.CFUNCTYPE(i32, vp, u8p, sz)

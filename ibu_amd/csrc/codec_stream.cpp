@@ -36,15 +36,12 @@ void par_memcpy(uint8_t* dst, const uint8_t* src, size_t bytes, uint32_t threads
     if (bytes) memcpy(dst, src, bytes);
     return;
   }
-  std::vector<std::thread> th;
   const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
-  for (size_t i = 0; i < parts; ++i) {
-    const size_t off = i * per;
-    if (off >= bytes) break;
-    const size_t len = off + per < bytes ? per : bytes - off;
-    th.emplace_back([=]() { memcpy(dst + off, src + off, len); });
-  }
-  for (auto& t : th) t.join();
+  run_pieces((unsigned)parts, [=](unsigned i) {  // never throws (common.hpp)
+    const size_t off = (size_t)i * per;
+    if (off >= bytes) return;
+    memcpy(dst + off, src + off, off + per < bytes ? per : bytes - off);
+  });
 }
 
 uint32_t feeders(const ibu_ring_config_t* cfg) { return cfg && cfg->feeder_threads ? cfg->feeder_threads : 4; }
@@ -181,7 +178,9 @@ extern "C" int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
   Handoff ho;
   ibu_error_detail_t collector_detail;
   memset(&collector_detail, 0, sizeof collector_detail);
-  std::thread collector([&]() {
+  std::thread collector;
+  try {
+  collector = std::thread([&]() {
     (void)hipSetDevice(ctx->device);
     size_t k;
     while (ho.next(&k)) {
@@ -190,6 +189,9 @@ extern "C" int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
       ho.done(e);
     }
   });
+  } catch (...) {  // std::system_error (EAGAIN under a pids cgroup) / bad_alloc: nothing is in flight yet
+    return caught_io("cannot start the collector thread");
+  }
   for (size_t k = 0; k < nb && rc == IBU_OK; ++k) {
     const uint32_t s = (uint32_t)(k % r.slots);
     rc = ho.wait_slot(k, r.slots);  // slot s is free: batch k - slots has been delivered
@@ -270,7 +272,9 @@ extern "C" int32_t ibu_writer_write_ascii_batch(ibu_writer_t* w, ibu_ctx_t* ctx,
   Handoff ho;
   ibu_error_detail_t collector_detail;
   memset(&collector_detail, 0, sizeof collector_detail);
-  std::thread collector([&]() {  // delivers batches to the writer while the caller's thread stages the next ones
+  std::thread collector;
+  try {
+  collector = std::thread([&]() {  // delivers batches to the writer while the caller's thread stages the next ones
     (void)hipSetDevice(ctx->device);
     size_t k;
     while (ho.next(&k)) {
@@ -279,6 +283,9 @@ extern "C" int32_t ibu_writer_write_ascii_batch(ibu_writer_t* w, ibu_ctx_t* ctx,
       ho.done(e);
     }
   });
+  } catch (...) {  // std::system_error (EAGAIN under a pids cgroup) / bad_alloc: nothing is in flight yet
+    return caught_io("cannot start the collector thread");
+  }
   for (size_t k = 0; k < nb && rc == IBU_OK; ++k) {
     const uint32_t s = (uint32_t)(k % r.slots);
     rc = ho.wait_slot(k, r.slots);

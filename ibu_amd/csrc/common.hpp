@@ -1,9 +1,15 @@
 // common.hpp — status/detail plumbing shared by the host and device halves of libibu_hip.so.
 #pragma once
+#include <errno.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <new>
+#include <system_error>
+#include <thread>
+#include <vector>
 
 #include "../../include/ibu_hip.h"
 
@@ -69,6 +75,32 @@ inline int32_t err_seq_len(uint32_t len) {
 }
 inline int32_t err_niffler(const char* what) {
   return set_error(IBU_ERR_NIFFLER, 0, 0, 0, "Niffler error: %s", what);
+}
+
+// No C++ exception may cross the C ABI (the caller is Rust, C or ctypes: an escaping exception is std::terminate).
+// Thread creation is where they come from on this path (std::system_error EAGAIN under a pids cgroup, bad_alloc):
+// run_pieces runs fn(0..n-1) on up to n threads and NEVER throws — a piece whose thread cannot be started runs on the
+// calling thread instead, so the call degrades to the single-threaded path.  fn itself must not throw.
+template <class F>
+inline void run_pieces(unsigned n, F&& fn) noexcept {
+  if (n <= 1) { if (n) fn(0u); return; }
+  std::vector<std::thread> th;
+  unsigned started = 0;
+  try {
+    th.reserve(n - 1);
+    for (; started + 1 < n; ++started) th.emplace_back(fn, started);
+  } catch (...) {
+    // `started` threads run; the rest is ours
+  }
+  for (unsigned i = started; i < n; ++i) fn(i);
+  for (auto& t : th) t.join();
+}
+// Map whatever a C++ library call threw to a status; used as `catch (...) { return caught_io("what"); }` at the ABI.
+inline int32_t caught_io(const char* what) {
+  try { throw; }
+  catch (const std::bad_alloc&) { return err_io(ENOMEM, what); }
+  catch (const std::system_error& e) { return err_io(e.code().value() ? e.code().value() : EAGAIN, what); }
+  catch (...) { return err_io(EIO, what); }
 }
 
 }  // namespace ibu

@@ -61,7 +61,9 @@ extern "C" const char* ibu_status_name(int32_t s) {
   }
 }
 extern "C" const char* ibu_version(void) { return "ibu_hip 0.1.0 (format v2, reference ibu 0.2.1, gfx950)"; }
-extern "C" uint32_t ibu_abi_revision(void) { return 2; }  // 2: + device_copy, barcode_counts, decode_to_host, write_ascii_batch, ctx_set_option
+// 2: + device_copy, barcode_counts, decode_to_host, write_ascii_batch, ctx_set_option
+// 3: ibu_decode_sink_t.cap_records (layout change), + lower_bound_records, "base_order" / "sort_variant" options
+extern "C" uint32_t ibu_abi_revision(void) { return 3; }
 extern "C" void ibu_free(void* p) { free(p); }
 
 // ------------------------------------------------------------------------------------------
@@ -559,15 +561,24 @@ struct BgzfSource : Source {
       }
       inflateEnd(&zs);
     };
-    if (nt == 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
-      for (auto& x : th) x.join();
-    }
+    run_pieces(nt, work);  // never throws: blocks of a thread that cannot be started are inflated here
     for (int r : rcs)
       if (r) return r;
     return 0;
+  }
+  // refill() grows vectors: bad_alloc must not leave as an exception (this is called under extern "C" entry points)
+  int refill_noexcept() {
+    try { return refill(next_out); }
+    catch (const std::bad_alloc&) { return ENOMEM; }
+    catch (...) { return EIO; }
+  }
+  bool start_refill() {
+    try {
+      next = std::async(std::launch::async, [this] { return refill_noexcept(); });
+      return true;
+    } catch (...) {  // std::system_error (EAGAIN) / bad_alloc from the thread start
+      return false;
+    }
   }
   int read(uint8_t* dst, size_t cap, size_t* got) override {
     *got = 0;
@@ -584,13 +595,22 @@ struct BgzfSource : Source {
       if (!next.valid()) {
         if (fallback) return fallback->read(dst, cap, got);
         if (eof) return 0;
-        next = std::async(std::launch::async, [this] { return refill(next_out); });
+        if (!start_refill()) {   // no thread to be had: inflate the batch on this one
+          const int rc = refill_noexcept();
+          if (rc) return rc;
+          out.swap(next_out);
+          out_pos = 0;
+          continue;
+        }
       }
-      const int rc = next.get();  // synchronises with everything the worker wrote (eof, fallback, next_out)
+      int rc;
+      try { rc = next.get(); }  // synchronises with everything the worker wrote (eof, fallback, next_out)
+      catch (const std::bad_alloc&) { rc = ENOMEM; }
+      catch (...) { rc = EIO; }
       if (rc) return rc;
       out.swap(next_out);
       out_pos = 0;
-      if (!eof && !fallback) next = std::async(std::launch::async, [this] { return refill(next_out); });
+      if (!eof && !fallback) (void)start_refill();  // failure: the next round inflates inline
     }
   }
 };
@@ -993,15 +1013,12 @@ extern "C" int32_t ibu_load_to_vec(const char* path, ibu_header_t* header, ibu_r
     size_t nt = hw ? (hw < 8 ? hw : 8) : 4;
     if (nt > total / kPar + 1) nt = total / kPar + 1;
     const size_t per = ((total / nt) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    std::vector<int> rcs(nt, 0);
-    for (size_t i = 0; i < nt; ++i) {
-      const size_t off = i * per;
-      if (off >= total) break;
-      const size_t len = off + per < total ? per : total - off;
-      th.emplace_back([&, i, off, len]() { rcs[i] = read_range(off, len); });
-    }
-    for (auto& t : th) t.join();
+    int rcs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    run_pieces((unsigned)nt, [&](unsigned i) {   // never throws; nt <= 8
+      const size_t off = (size_t)i * per;
+      if (off >= total) return;
+      rcs[i] = read_range(off, off + per < total ? per : total - off);
+    });
     for (int r : rcs)
       if (r && !err) err = r;
   }
@@ -1149,12 +1166,16 @@ extern "C" int32_t ibu_mmap_process_parallel(const ibu_mmap_t* m, const ibu_proc
     int32_t rc = IBU_OK;
     ibu_error_detail_t detail;
   };
-  std::vector<Worker> ws(nt);
+  std::vector<Worker> ws;
+  try { ws.resize(nt); } catch (...) { return caught_io("process_parallel: worker table"); }
+  size_t spawned = 0;
+  int32_t spawn_rc = IBU_OK;
   for (size_t i = 0; i < nt; ++i) {
     size_t start = 0, end = 0;
     ibu_shard_range(m->len, nt, i, &start, &end);
     void* clone = vt->clone ? vt->clone(user) : user;  // processor.clone()  :309
     Worker* w = &ws[i];
+    try {
     w->th = std::thread([m, vt, clone, start, end, w]() {
       size_t batch_start = start;
       while (batch_start < end && w->rc == IBU_OK) {
@@ -1175,16 +1196,23 @@ extern "C" int32_t ibu_mmap_process_parallel(const ibu_mmap_t* m, const ibu_proc
       if (w->rc) w->detail = tls_error();  // the payload lives in the worker's thread-local slot
       if (vt->clone && vt->drop) vt->drop(clone);
     });
+    } catch (...) {  // thread::spawn panics in the reference (mmap.rs:308); here: join what runs, report Io(EAGAIN)
+      if (vt->clone && vt->drop) vt->drop(clone);
+      spawn_rc = caught_io("process_parallel: cannot start a worker thread");
+      break;
+    }
+    ++spawned;
   }
   // Join in spawn order, first Err wins (Q12).  The reference drops the remaining handles and
   // lets those threads run on detached; here they are joined so `user` may be freed on return.
   int32_t rc = IBU_OK;
-  for (size_t i = 0; i < nt; ++i) {
+  for (size_t i = 0; i < spawned; ++i) {
     ws[i].th.join();
     if (rc == IBU_OK && ws[i].rc) {
       rc = ws[i].rc;
       tls_error() = ws[i].detail;
     }
   }
+  if (spawn_rc && rc == IBU_OK) return err_io(EAGAIN, "process_parallel: cannot start a worker thread");
   return rc;
 }

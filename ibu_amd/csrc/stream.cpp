@@ -35,18 +35,17 @@ int parallel_bytes(size_t total, uint32_t threads, F fn) {
   size_t parts = (total + min_chunk - 1) / min_chunk;
   if (parts > threads) parts = threads;
   if (parts <= 1) return total ? fn((size_t)0, total) : 0;
-  std::vector<std::thread> th;
-  std::vector<int> rc(parts, 0);
+  if (parts > 64) parts = 64;
+  int rc[64];
+  for (size_t i = 0; i < parts; ++i) rc[i] = 0;
   const size_t per = (total / parts + 4095) & ~(size_t)4095;
-  for (size_t i = 0; i < parts; ++i) {
-    const size_t off = i * per;
-    if (off >= total) break;
-    const size_t len = off + per < total ? per : total - off;
-    th.emplace_back([&, i, off, len]() { rc[i] = fn(off, len); });
-  }
-  for (auto& t : th) t.join();
-  for (int r : rc)
-    if (r) return r;
+  run_pieces((unsigned)parts, [&](unsigned i) {  // never throws (common.hpp): no exception crosses the C ABI
+    const size_t off = (size_t)i * per;
+    if (off >= total) return;
+    rc[i] = fn(off, off + per < total ? per : total - off);
+  });
+  for (size_t i = 0; i < parts; ++i)
+    if (rc[i]) return rc[i];
   return 0;
 }
 
@@ -104,6 +103,12 @@ struct DeviceProc {  // the device-side ParallelProcessor applied to each staged
   int32_t kind;
   uint32_t bc_len, umi_len;
   ibu_decode_sink_t sink{};
+  // the columns of a DECODE sink hold cap_records rows: a batch that does not fit is refused BEFORE anything is launched
+  int32_t fits(size_t n, size_t row0) const {
+    if (kind != IBU_PROC_DECODE || row0 + n <= sink.cap_records) return IBU_OK;
+    return set_error(IBU_ERR_INVALID_ARG, row0 + n, sink.cap_records, 0,
+                     "Invalid argument: decode sink holds %zu records, the stream has at least %zu", sink.cap_records, row0 + n);
+  }
   int32_t launch(const uint8_t* d_slot, size_t n, size_t row0) {
     if (kind == IBU_PROC_REDUCE) {
       IBU_HIP(launch_reduce(ctx->cfg, d_slot, n, ctx->d_acc, ctx->stream));
@@ -317,6 +322,8 @@ extern "C" int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
   DeviceProc dp;
   rc = make_proc(ctx, proc, h, sink, &dp);
   if (rc) return rc;
+  rc = dp.fits(end - start, 0);   // the shard's size is known up front
+  if (rc) return rc;
   rc = ring_ensure(ctx, cfg, true);
   if (rc) return rc;
   Ring& r = ctx->ring;
@@ -397,6 +404,8 @@ extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, c
     }
     if (rc) break;
     if (filled) {
+      rc = dp.fits(filled, total);  // a gzip / BGZF / xz / zstd stream does not announce its length: check every batch
+      if (rc) break;
       rc = submit_slot(ctx, kc, dp, s, filled, total, stats);
       total += filled;
       ++k;

@@ -238,7 +238,8 @@ class Reader {
   iterator end() { return iterator{this, std::nullopt}; }
   // device: stream the rest of this reader (plain or gzip) through the pinned ring
   inline std::pair<ReduceResult, StreamStats> process_device_reduce(device::Context& ctx, const RingConfig* ring = nullptr);
-  inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, const RingConfig* ring = nullptr);
+  // cap_records: rows the columns hold; a longer stream throws IbuError (InvalidArg) instead of writing past them
+  inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records, const RingConfig* ring = nullptr);
   ibu_reader_t* raw() const { return r_; }
 
  private:
@@ -325,8 +326,8 @@ class MmapReader {
   // device: ONE shard of the same static split per GPU / rank
   inline std::pair<ReduceResult, StreamStats> process_device_reduce(device::Context& ctx, size_t shard = 0, size_t n_shards = 1,
                                                                      const RingConfig* ring = nullptr) const;
-  inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t shard = 0,
-                                           size_t n_shards = 1, const RingConfig* ring = nullptr) const;
+  inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records,
+                                           size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
   // one shard -> ASCII barcodes / UMIs + index column in HOST memory, unpacked on the GPU
   struct Decoded { std::vector<uint8_t> bc, umi; std::vector<uint64_t> index; StreamStats stats; };
   inline Decoded decode_to_host(device::Context& ctx, size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
@@ -456,8 +457,8 @@ inline std::pair<ReduceResult, StreamStats> Reader::process_device_reduce(device
   check(ibu_reader_process_device(r_, ctx.raw(), ring, IBU_PROC_REDUCE, &r, &st));
   return {r, st};
 }
-inline StreamStats Reader::process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, const RingConfig* ring) {
-  ibu_decode_sink_t sink{d_bc, d_umi, d_idx}; StreamStats st{};
+inline StreamStats Reader::process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records, const RingConfig* ring) {
+  ibu_decode_sink_t sink{d_bc, d_umi, d_idx, cap_records}; StreamStats st{};
   check(ibu_reader_process_device(r_, ctx.raw(), ring, IBU_PROC_DECODE, &sink, &st));
   return st;
 }
@@ -467,9 +468,9 @@ inline std::pair<ReduceResult, StreamStats> MmapReader::process_device_reduce(de
   check(ibu_mmap_process_device(m_, ctx.raw(), ring, IBU_PROC_REDUCE, shard, n_shards, &r, &st));
   return {r, st};
 }
-inline StreamStats MmapReader::process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t shard,
+inline StreamStats MmapReader::process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records, size_t shard,
                                                      size_t n_shards, const RingConfig* ring) const {
-  ibu_decode_sink_t sink{d_bc, d_umi, d_idx}; StreamStats st{};
+  ibu_decode_sink_t sink{d_bc, d_umi, d_idx, cap_records}; StreamStats st{};
   check(ibu_mmap_process_device(m_, ctx.raw(), ring, IBU_PROC_DECODE, shard, n_shards, &sink, &st));
   return st;
 }

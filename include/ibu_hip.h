@@ -373,7 +373,10 @@ int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_conf
                            ibu_stream_stats_t* stats);
 
 /* Device analogue of Writer::write_batch (writer.rs:315-351): n device-resident AoS records
- * are copied back through the ring and appended to the writer (same buffered/direct rules). */
+ * are copied back through the ring and appended to the writer (same buffered/direct rules).
+ * Stream ordering: the copies are ordered behind ibu_ctx_stream(ctx) ONLY.  Records produced by a kernel entry point
+ * that was given another stream must be complete (hipStreamSynchronize / an event the context stream waits on) before
+ * this call.  Likewise ibu_codec_status reads ONE status word per context: encodes issued on several streams share it. */
 int32_t ibu_writer_write_batch_device(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                       const void* d_records, size_t n, ibu_stream_stats_t* stats);
 
@@ -383,9 +386,13 @@ enum {
   IBU_PROC_DECODE = 2  /* fused decode of every batch into caller-provided device columns    */
 };
 typedef struct ibu_decode_sink {
-  uint8_t* d_bc_ascii; /* shard_records * bc_len  */
+  uint8_t* d_bc_ascii; /* cap_records * bc_len bytes (NULL: skip the column) */
   uint8_t* d_umi_ascii;
   uint64_t* d_index;
+  size_t cap_records;  /* rows every non-NULL column can hold (ABI revision 3).  A compressed stream does not say how many
+                        * records it holds before it ends: the moment a batch would not fit, the call stops, drains the ring
+                        * and returns IBU_ERR_INVALID_ARG (detail.a = rows needed so far, detail.b = cap_records) — never a
+                        * write past the columns.  An mmap shard is checked before any work starts. */
 } ibu_decode_sink_t;
 
 /* Device analogue of MmapReader::process_parallel (mmap.rs:286-332) for ONE shard of the

@@ -123,7 +123,7 @@ TEST(file_streams_to_and_from_the_device) {
   CHECK_EQ(count, want.count); CHECK_EQ(sum2, want.sum[2]);
   DeviceBuffer bc(ctx(), n * 16), umi(ctx(), n * 12), idx(ctx(), n * 8);
   Reader r = Reader::from_path(path);
-  r.process_device_decode(ctx(), bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), &ring);
+  r.process_device_decode(ctx(), bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), n, &ring);
   std::vector<uint8_t> wbc(n * 16), wumi(n * 12);
   std::vector<uint64_t> widx(n);
   orc_decode_records(reinterpret_cast<const orc_record*>(recs.data()), n, 16, 12, wbc.data(), wumi.data(), widx.data());

@@ -321,3 +321,40 @@ def test_host_codec_roundtrip_large(ia, ctx, oracle, tmp_path):
     w.close()
     m.close()
     assert p.read_bytes() == q.read_bytes()
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip"])
+def test_decode_sink_too_small_is_an_error_not_an_overrun(ia, ctx, oracle, tmp_path, kind):
+    """ibu_decode_sink_t.cap_records (ABI revision 3): a compressed stream does not say how many records it holds, so a
+    sink sized for fewer must end in InvalidArg — with the rows that did fit decoded and nothing written past them."""
+    import gzip
+    n, cap = 30_000, 10_000
+    path = tmp_path / ("s.ibu" + (".gz" if kind == "gzip" else ""))
+    recs = _write_file(oracle, tmp_path / "plain.ibu", n, 16, 12)
+    raw = open(tmp_path / "plain.ibu", "rb").read()
+    with open(path, "wb") as f:
+        f.write(gzip.compress(raw, 1) if kind == "gzip" else raw)
+    guard = 4096  # bytes behind the capacity that must stay untouched
+    d_bc, d_umi, d_idx = ctx.alloc(cap * 16 + guard), ctx.alloc(cap * 12 + guard), ctx.alloc(cap * 8 + guard)
+    for d in (d_bc, d_umi, d_idx):
+        d.upload(np.full(d.nbytes, 0xEE, dtype=np.uint8))
+    r = ia.Reader.from_path(path)
+    with pytest.raises(ia.IbuError) as e:
+        r.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx, cap), ring=SMALL_RING)
+    assert e.value.kind == "InvalidArg" and e.value.b == cap and cap < e.value.a <= n
+    r.close()
+    for d, w in ((d_bc, 16), (d_umi, 12), (d_idx, 8)):
+        assert (d.download(offset=cap * w) == 0xEE).all()          # nothing past the capacity
+    bc, _, _ = oracle.decode_records(recs, 16, 12)
+    done = (cap // 4096) * 4096                                     # whole batches that fitted were decoded
+    assert d_bc.download(count=done * 16).tobytes() == bc[: done * 16].tobytes()
+    # the mmap form knows the shard size up front: refused before any work
+    m = ia.MmapReader.new(tmp_path / "plain.ibu")
+    with pytest.raises(ia.IbuError) as e:
+        m.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx, cap), ring=SMALL_RING)
+    assert e.value.kind == "InvalidArg" and (e.value.a, e.value.b) == (n, cap)
+    _, st = m.process_device(ctx, ia.PROC_DECODE, shard=0, n_shards=3, sink=(d_bc, d_umi, d_idx, cap), ring=SMALL_RING)
+    assert st.records == n // 3
+    with pytest.raises(TypeError):
+        m.process_device(ctx, ia.PROC_DECODE, sink=(d_bc.ptr, d_umi.ptr, d_idx.ptr), ring=SMALL_RING)  # raw pointers need a capacity
+    m.close()

@@ -78,15 +78,44 @@ __device__ __forceinline__ u32 logical_block() {
 #ifndef IBU_NT_STORE
 #define IBU_NT_STORE 1
 #endif
+// IBU_ST_POLICY / IBU_LD_POLICY (measurement builds, tools/kbench.py --so): the cache-policy bits of the streaming
+// accesses spelled out, through raw buffer instructions so that the compiler still counts them in vmcnt (inline-asm
+// stores are invisible to its waitcnt pass, which then waits for the stores as well).  Value = aux bits + 1:
+// bit0 sc0, bit1 nt, bit4 sc1 — e.g. 3 = "nt" (the default policy through the buffer path), 17 = "sc1", 19 = "sc1 nt",
+// 18 = "sc0 sc1", 20 = "sc0 sc1 nt", 1 = no bits.  0 = the builtin global path below (nt or plain).
+#ifndef IBU_ST_POLICY
+#define IBU_ST_POLICY 0
+#endif
+#ifndef IBU_LD_POLICY
+#define IBU_LD_POLICY 0
+#endif
+struct WaveBuf {  // a 4 GiB window below/above the first active lane's address, as a buffer resource in SGPRs
+  __amdgpu_buffer_rsrc_t r;
+  u32 voff;
+  __device__ __forceinline__ explicit WaveBuf(const void* p) {
+    const u64 a = (u64)p;
+    // readfirstlane returns int: without the casts the low half is SIGN-extended into the high half
+    const u64 first = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(a >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)a);
+    const u64 base = first - (1ull << 30);
+    r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, -1, 0x00020000);
+    voff = (u32)(a - base);
+  }
+};
 __device__ __forceinline__ u32x4 ld16(const void* p) {
-#if IBU_NT_LOAD
+#if IBU_LD_POLICY
+  const WaveBuf w(p);
+  return __builtin_amdgcn_raw_buffer_load_b128(w.r, (int)w.voff, 0, IBU_LD_POLICY - 1);
+#elif IBU_NT_LOAD
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 #else
   return *reinterpret_cast<const u32x4*>(p);
 #endif
 }
 __device__ __forceinline__ void st16(void* p, u32x4 v) {
-#if IBU_NT_STORE
+#if IBU_ST_POLICY
+  const WaveBuf w(p);
+  __builtin_amdgcn_raw_buffer_store_b128(v, w.r, (int)w.voff, 0, IBU_ST_POLICY - 1);
+#elif IBU_NT_STORE
   __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 #else
   *reinterpret_cast<u32x4*>(p) = v;

@@ -79,10 +79,11 @@ def main():
         mix = C.CDLL(mix_so)
         mix.hbm_mix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
         span = min(recs.numel(), back.numel())
-        for tag_, r_, w_ in (("mix10", 1, 0), ("mix30", 3, 0), ("mix11", 1, 1), ("mix23", 2, 3), ("mix32", 3, 2)):
-            steps = span // 16 // max(r_, w_) // 4 * 4
+        for tag_, r_, w_ in (("mix10", 1, 0), ("mix30", 3, 0), ("mix11", 1, 1), ("mix23", 2, 3), ("mix32", 3, 2),
+                               ("pipe11", 11, 1), ("pipe23", 12, 3), ("pipe32", 13, 2)):  # r_ >= 10: software-pipelined form
+            steps = span // 16 // max(r_ % 10, w_) // 4 * 4
             mix_ops[tag_] = (lambda r_=r_, w_=w_, steps=steps: mix.hbm_mix(r_, w_, recs.data_ptr(), back.data_ptr(), steps, 256 * 7, st),
-                             (r_ + w_) * 16 * steps / n)
+                             (r_ % 10 + w_) * 16 * steps / n)
 
     names = [k for k in a.kernels.split(",") if k in ops_for(lib0, ctx0)]
     runs = []  # (tag, blocks, kernel, fn, bytes_per_record, lib, ctx)

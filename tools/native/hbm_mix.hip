@@ -23,6 +23,48 @@ __global__ void __launch_bounds__(256, 8) k_mix(const u32x4* __restrict__ src, u
   }
 }
 
+// Same traffic, software-pipelined: two steps per loop iteration, the next step's loads issued before the current
+// step's stores, no exit in the middle of the body -> the compiler's vmcnt waits count the stores exactly, so a wave
+// never waits for its own stores.  (The naive loop above ends every step with vmcnt(0).)
+template <int R, int W>
+__global__ void __launch_bounds__(256, 7) k_mix_pipe(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t steps) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= steps) return;
+  const uint64_t mine = (steps - s + stride - 1) / stride, last = s + (mine - 1) * stride;
+  u32x4 a[R], b[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[r] = __builtin_nontemporal_load(src + (uint64_t)r * steps + s);
+  for (uint64_t i = 0; i < mine / 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) b[r] = __builtin_nontemporal_load(src + (uint64_t)r * steps + s + stride);
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 acc = a[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) acc ^= a[r];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { u32x4 o = acc; o.x += w; __builtin_nontemporal_store(o, dst + (uint64_t)w * steps + s); }
+    uint64_t sn = s + 2 * stride;
+    sn = sn <= last ? sn : last;
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = __builtin_nontemporal_load(src + (uint64_t)r * steps + sn);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = b[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) acc ^= b[r];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { u32x4 o = acc; o.x += w; __builtin_nontemporal_store(o, dst + (uint64_t)w * steps + s + stride); }
+    s += 2 * stride;
+  }
+  if (mine & 1) {
+    u32x4 acc = a[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) acc ^= a[r];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { u32x4 o = acc; o.x += w; __builtin_nontemporal_store(o, dst + (uint64_t)w * steps + s); }
+  }
+}
+
 // read-only: R streams folded into one value that is stored only if it matches a sentinel (keeps the loads alive)
 template <int R>
 __global__ void __launch_bounds__(256, 8) k_read(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t steps) {
@@ -47,6 +89,8 @@ extern "C" int hbm_mix(int r, int w, const void* src, void* dst, uint64_t steps,
 #define CASE(R, W) if (r == R && w == W) { hipLaunchKernelGGL((k_mix<R, W>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, steps); return (int)hipGetLastError(); }
   if (w == 0 && r == 1) { hipLaunchKernelGGL((k_read<1>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, steps); return (int)hipGetLastError(); }
   if (w == 0 && r == 3) { hipLaunchKernelGGL((k_read<3>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, steps); return (int)hipGetLastError(); }
+#define PCASE(R, W) if (r == 10 + R && w == W) { hipLaunchKernelGGL((k_mix_pipe<R, W>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, steps); return (int)hipGetLastError(); }
+  PCASE(1, 1) PCASE(2, 3) PCASE(3, 2)
   CASE(1, 1) CASE(2, 3) CASE(3, 2) CASE(1, 2) CASE(2, 1) CASE(3, 1) CASE(1, 3) CASE(4, 1)
   return -1;
 }

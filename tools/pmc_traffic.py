@@ -3,7 +3,9 @@
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc/FETCH_SIZE -- python3 tools/kbench.py --records 2e8 --rounds 2
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc/WRITE_SIZE -- python3 tools/kbench.py --records 2e8 --rounds 2
-  python tools/pmc_traffic.py gpurun_out/pmc 2e8 16,12 > profiles/pmc_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc 2e8 16,12 [round-tag] > profiles/pmc_traffic.json
+(tools/profile_round.sh runs all of it; with a sibling directory <pmc>_sort holding the same two passes over
+tools/sortbench.py the sort kernels get a "sort" section: bytes per record per launch of each kernel.)
 
 FETCH_SIZE / WRITE_SIZE are in KiB (separate passes: FETCH_SIZE costs 3 of the 4 TCC slots,
 WRITE_SIZE 2).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly
@@ -47,7 +49,7 @@ def main():
     alg = {"decode": 24 + bc_len + umi_len + 8, "encode": 24 + bc_len + umi_len + 8, "deserialize": 48, "serialize": 48,
            "reduce": 24, "unpack": 8 + bc_len, "pack": 8 + bc_len, "generate": 24, "copy": 48}
     out = {"_method": __doc__.split("FETCH_SIZE / WRITE_SIZE are", 1)[1].strip().replace("\n", " "),
-           "_records": n, "_lens": [bc_len, umi_len]}
+           "_round": sys.argv[4] if len(sys.argv) > 4 else None, "_records": n, "_lens": [bc_len, umi_len]}
     for name, f_kib in sorted(fetch.items()):
         k = short(name)
         if not k:
@@ -58,6 +60,12 @@ def main():
         out[key] = {"kernel": name.split("(")[0], "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
                     "read_bytes_per_record": round(rd, 3), "write_bytes_per_record": round(wr, 3),
                     "hbm_bytes_per_record": round(rd + wr, 3), "algorithmic_bytes_per_record": alg[k]}
+    sort_dir = pmc_dir.rstrip("/") + "_sort"
+    if os.path.isdir(sort_dir):  # every ibu_k_sort_* kernel: mean bytes per record per launch (FETCH doubled as above)
+        sf, sw = per_kernel(sort_dir, "FETCH_SIZE"), per_kernel(sort_dir, "WRITE_SIZE")
+        out["sort"] = {name.split("(")[0].replace("void ", ""): {
+            "read_bytes_per_record": round(2 * f_kib * 1024 / n, 3), "write_bytes_per_record": round(sw.get(name, 0.0) * 1024 / n, 3)}
+            for name, f_kib in sorted(sf.items()) if "ibu_k_sort" in name or "ibu_k_copy" in name}
     print(json.dumps(out, indent=1))
 
 

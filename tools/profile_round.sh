@@ -1,0 +1,46 @@
+#!/bin/bash
+# Evidence run of a round, on the GPU box (gpurun -- 'bash tools/profile_round.sh r02_b'):
+#   1. python bench.py                                        -> <tag>_bench_1e9.json
+#   2. rocprofv3 --kernel-trace --stats over the same command -> <tag>_bench_1e9_kernel_stats.csv (+ the line it printed)
+#   3. rocprofv3 --kernel-trace --stats over tools/sortbench.py at 1e9 (random index) -> <tag>_sort_1e9_kernel_stats.csv
+#   4. two --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with each other or with other trace domains) over
+#      tools/kbench.py and tools/sortbench.py -> pmc CSVs + pmc_traffic.json (round-tagged)
+# Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
+set -o pipefail
+TAG=${1:-r02}
+N=${2:-1e9}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+step() { echo "[profile_round] $(date +%T) $*"; }
+
+step "bench (unprofiled)"
+python3 bench.py > "$OUT/${TAG}_bench_1e9.json" 2> "$OUT/bench.err" || exit 1
+
+step "bench under rocprofv3 --kernel-trace --stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline \
+  > "$OUT/${TAG}_bench_1e9_under_rocprof.json" 2> "$OUT/prof_bench.err" || exit 1
+cp "$(find "$OUT/prof_bench" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
+
+step "sortbench (unprofiled)"
+python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg > "$OUT/${TAG}_sortbench_random_index.jsonl" 2> "$OUT/sort.err" || exit 1
+python3 tools/sortbench.py --records "$N" --rounds 3 --skip-agg > "$OUT/${TAG}_sortbench_read_order.jsonl" 2>> "$OUT/sort.err" || exit 1
+
+step "sortbench under rocprofv3 --kernel-trace --stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sort" -- python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg \
+  > "$OUT/${TAG}_sortbench_under_rocprof.jsonl" 2> "$OUT/prof_sort.err" || exit 1
+cp "$(find "$OUT/prof_sort" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_sort_1e9_kernel_stats.csv"
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  step "pmc $C over kbench"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc/$C" -- python3 tools/kbench.py --records "$N" --rounds 2 \
+    > "$OUT/pmc_kbench_$C.log" 2>&1 || exit 1
+  cp "$(find "$OUT/pmc/$C" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_${C}_kbench_1e9.csv"
+  step "pmc $C over sortbench"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_sort/$C" -- python3 tools/sortbench.py --records "$N" --rounds 1 --random-index --skip-agg \
+    > "$OUT/pmc_sort_$C.log" 2>&1 || exit 1
+  cp "$(find "$OUT/pmc_sort/$C" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_${C}_sort_1e9.csv"
+done
+python3 tools/pmc_traffic.py "$OUT/pmc" "$N" 16,12 "$TAG" > "$OUT/pmc_traffic.json" || exit 1
+rm -rf "$OUT/prof_bench" "$OUT/prof_sort"   # the raw traces are large; the summaries above are what is kept
+step done

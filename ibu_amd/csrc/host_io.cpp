@@ -25,6 +25,7 @@
 
 #include "common.hpp"
 #include "host_io.hpp"
+#include "pgzip.hpp"
 
 static_assert(sizeof(ibu_header_t) == IBU_HEADER_SIZE, "header.rs:248-251");
 static_assert(sizeof(ibu_record_t) == IBU_RECORD_SIZE, "record.rs:149-152");
@@ -615,6 +616,73 @@ struct BgzfSource : Source {
   }
 };
 
+
+// Ordinary (non-BGZF) gzip input, inflated on several threads: pgzip.hpp.  Same output bytes and error class as
+// GzSource (the sequential zlib path, still used with IBU_NO_PARALLEL_GZIP=1 or on a one-core host); the next batch is
+// decoded in the background while the current one is handed out.  IBU_PGZ_THREADS / IBU_PGZ_CHUNK (bytes of compressed
+// input per thread and batch) are test knobs.
+struct ParGzSource : Source {
+  std::unique_ptr<Source> inner;
+  std::unique_ptr<pgz::ParallelGunzip> dec;
+  pgz::ByteBuf out, next_out;
+  std::future<int> next;
+  size_t out_pos = 0;
+  bool eof = false, next_eof = false;
+  static unsigned env_threads() {
+    const char* e = getenv("IBU_PGZ_THREADS");
+    size_t c = e ? (size_t)atol(e) : ibu::host_cores();
+    return (unsigned)(c < 1 ? 1 : (c > 64 ? 64 : c));
+  }
+  static size_t env_chunk() {
+    const char* e = getenv("IBU_PGZ_CHUNK");
+    return e ? (size_t)atol(e) : (size_t)2 << 20;
+  }
+  explicit ParGzSource(std::unique_ptr<Source> s) : inner(std::move(s)) {
+    Source* in = inner.get();
+    dec.reset(new pgz::ParallelGunzip([in](uint8_t* d, size_t cap, size_t* got) { return in->read(d, cap, got); }, env_threads(), env_chunk()));
+  }
+  ~ParGzSource() override { if (next.valid()) (void)next.get(); }
+  int refill_noexcept() {
+    try { return dec->next_batch(next_out, &next_eof); }
+    catch (const std::bad_alloc&) { return ENOMEM; }
+    catch (...) { return EIO; }
+  }
+  bool start_refill() {
+    try {
+      next = std::async(std::launch::async, [this] { return refill_noexcept(); });
+      return true;
+    } catch (...) {
+      return false;
+    }
+  }
+  int read(uint8_t* dst, size_t cap, size_t* got) override {
+    *got = 0;
+    for (;;) {
+      if (out_pos < out.size) {
+        const size_t k = out.size - out_pos < cap ? out.size - out_pos : cap;
+        memcpy(dst, out.data + out_pos, k);
+        out_pos += k;
+        *got = k;
+        return 0;
+      }
+      if (eof) return 0;
+      int rc;
+      if (next.valid()) {
+        try { rc = next.get(); }
+        catch (const std::bad_alloc&) { rc = ENOMEM; }
+        catch (...) { rc = EIO; }
+      } else {
+        rc = refill_noexcept();                        // the first batch (or no thread to be had): decode it here
+      }
+      if (rc) return rc;
+      out.swap(next_out);
+      out_pos = 0;
+      eof = next_eof;
+      if (!eof) (void)start_refill();                  // failure: the next round decodes inline
+    }
+  }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -832,6 +900,8 @@ int32_t reader_make_sniffed(std::unique_ptr<Source> src, ibu_reader_t** out) {
     const bool bgzf = have >= 18 && m[2] == 8 && (m[3] & 4) && m[12] == 'B' && m[13] == 'C' && m[14] == 2 && m[15] == 0;
     if (bgzf && !getenv("IBU_NO_PARALLEL_BGZF"))
       return reader_make(std::unique_ptr<Source>(new BgzfSource(std::move(ps))), true, out);
+    if (!getenv("IBU_NO_PARALLEL_GZIP") && ParGzSource::env_threads() > 1)
+      return reader_make(std::unique_ptr<Source>(new ParGzSource(std::move(ps))), true, out);
     return reader_make(std::unique_ptr<Source>(new GzSource(std::move(ps))), true, out);
   }
   if (m[0] == 0x42 && m[1] == 0x5a && m[2] == 0x68) {  // "BZh"

@@ -1,0 +1,776 @@
+// pgzip.cpp — see pgzip.hpp.  Host code only (no device code in this translation unit).
+//
+// Deflate (RFC 1951) / gzip (RFC 1952) as zlib's inflate accepts them: over-subscribed code sets are errors, incomplete
+// ones too unless the set is a single 1-bit code, a literal/length set needs the end-of-block symbol, length symbols
+// 286/287 and distance symbols 30/31 are errors when used, a distance may not reach in front of the start of the output.
+// The one check this decoder cannot make in marker mode is the last one ACROSS a member boundary (a new member's back
+// reference into the previous member's bytes); the member CRC still covers the bytes that come out.
+#include "pgzip.hpp"
+
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <chrono>
+
+#include "common.hpp"
+
+namespace ibu {
+namespace pgz {
+namespace {
+
+constexpr size_t kWin = 32768;
+constexpr int kLitBits = 11, kDistBits = 8;
+constexpr size_t kLitCap = (1u << kLitBits) + 4800, kDistCap = (1u << kDistBits) + 4096;
+constexpr size_t kPad = 512;                         // zero bytes readable behind the last compressed byte (> one dynamic header)
+constexpr size_t kNone = ~(size_t)0;
+constexpr uint32_t K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4;
+
+inline uint32_t mk(uint32_t payload, uint32_t extra, uint32_t kind, uint32_t nbits) {
+  return (payload << 16) | (extra << 8) | (kind << 5) | nbits;
+}
+inline uint32_t e_kind(uint32_t e) { return (e >> 5) & 7u; }
+inline uint32_t e_bits(uint32_t e) { return e & 31u; }
+inline uint32_t e_extra(uint32_t e) { return (e >> 8) & 31u; }
+inline uint32_t e_val(uint32_t e) { return e >> 16; }
+
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+inline uint32_t rev_bits(uint32_t code, int len) {
+  uint32_t r = 0;
+  for (int i = 0; i < len; ++i) { r = (r << 1) | (code & 1u); code >>= 1; }
+  return r;
+}
+inline uint32_t lit_entry(int sym, int nb) {
+  if (sym < 256) return mk((uint32_t)sym, 0, K_LIT, (uint32_t)nb);
+  if (sym == 256) return mk(0, 0, K_EOB, (uint32_t)nb);
+  if (sym < 286) return mk(kLenBase[sym - 257], kLenExtra[sym - 257], K_BASE, (uint32_t)nb);
+  return mk(0, 0, K_BAD, (uint32_t)nb);
+}
+inline uint32_t dist_entry(int sym, int nb) {
+  if (sym < 30) return mk(kDistBase[sym], kDistExtra[sym], K_BASE, (uint32_t)nb);
+  return mk(0, 0, K_BAD, (uint32_t)nb);
+}
+
+// Two-level decode table of a canonical Huffman code read LSB first: `P` primary bits, longer codes through
+// per-prefix subtables.  false: the code set is one zlib rejects.
+bool build_table(const uint8_t* lens, int n, int P, bool is_dist, uint32_t* tab, size_t cap) {
+  int count[16] = {0};
+  for (int i = 0; i < n; ++i) count[lens[i]]++;
+  int maxlen = 15;
+  while (maxlen > 0 && count[maxlen] == 0) --maxlen;
+  const uint32_t bad = mk(0, 0, K_BAD, 1);
+  for (size_t i = 0; i < ((size_t)1 << P); ++i) tab[i] = bad;
+  if (maxlen == 0) return is_dist;                   // no codes at all: a block of literals only (zlib allows it for distances)
+  int left = 1;
+  for (int l = 1; l <= 15; ++l) {
+    left <<= 1;
+    left -= count[l];
+    if (left < 0) return false;                      // over-subscribed
+  }
+  if (left > 0 && maxlen != 1) return false;         // incomplete (allowed: a single 1-bit code)
+  uint32_t next[16];
+  uint32_t code = 0;
+  for (int l = 1; l <= 15; ++l) { code = (code + (uint32_t)count[l - 1]) << 1; next[l] = code; }
+  // pass 1: subtable width per primary prefix
+  uint8_t sub_bits[1u << kLitBits];
+  const bool any_long = maxlen > P;
+  if (any_long) {
+    memset(sub_bits, 0, (size_t)1 << P);
+    uint32_t nx[16];
+    memcpy(nx, next, sizeof nx);
+    for (int s = 0; s < n; ++s) {
+      const int l = lens[s];
+      if (l <= P) { if (l) nx[l]++; continue; }
+      const uint32_t r = rev_bits(nx[l]++, l), pre = r & (((uint32_t)1 << P) - 1);
+      if (l - P > sub_bits[pre]) sub_bits[pre] = (uint8_t)(l - P);
+    }
+    size_t off = (size_t)1 << P;
+    for (uint32_t pre = 0; pre < ((uint32_t)1 << P); ++pre) {
+      if (!sub_bits[pre]) continue;
+      const size_t sz = (size_t)1 << sub_bits[pre];
+      if (off + sz > cap || off > 0xFFFF) return false;  // cannot happen for valid code sets (cap is the worst case)
+      tab[pre] = mk((uint32_t)off, sub_bits[pre], K_SUB, (uint32_t)P);
+      for (size_t i = 0; i < sz; ++i) tab[off + i] = bad;
+      off += sz;
+    }
+  }
+  for (int s = 0; s < n; ++s) {
+    const int l = lens[s];
+    if (!l) continue;
+    const uint32_t r = rev_bits(next[l]++, l);
+    if (l <= P) {
+      const uint32_t e = is_dist ? dist_entry(s, l) : lit_entry(s, l);
+      for (uint32_t i = r; i < ((uint32_t)1 << P); i += (uint32_t)1 << l) tab[i] = e;
+    } else {
+      const uint32_t pre = r & (((uint32_t)1 << P) - 1), link = tab[pre];
+      const uint32_t off = e_val(link), sb = e_extra(link), e = is_dist ? dist_entry(s, l - P) : lit_entry(s, l - P);
+      for (uint32_t i = r >> P; i < ((uint32_t)1 << sb); i += (uint32_t)1 << (l - P)) tab[off + i] = e;
+    }
+  }
+  return true;
+}
+
+struct FixedTables {
+  uint32_t lit[kLitCap], dist[kDistCap];
+  FixedTables() {
+    uint8_t l[288];
+    for (int i = 0; i < 144; ++i) l[i] = 8;
+    for (int i = 144; i < 256; ++i) l[i] = 9;
+    for (int i = 256; i < 280; ++i) l[i] = 7;
+    for (int i = 280; i < 288; ++i) l[i] = 8;
+    (void)build_table(l, 288, kLitBits, false, lit, kLitCap);
+    uint8_t d[32];
+    for (int i = 0; i < 32; ++i) d[i] = 5;
+    (void)build_table(d, 32, kDistBits, true, dist, kDistCap);
+  }
+};
+const FixedTables& fixed_tables() {
+  static const FixedTables t;
+  return t;
+}
+
+// ---- bit reader (little-endian host; `in` has kPad readable zero bytes behind its end) ------------------------------
+// buf holds cnt valid low bits; bits above cnt are zero or the true upcoming bits (refill ORs the same bits again).
+struct Bits {
+  const uint8_t* in;
+  uint64_t buf = 0;
+  uint32_t cnt = 0;
+  size_t pos = 0;
+  Bits(const uint8_t* p, size_t bitpos) : in(p) {
+    pos = bitpos >> 3;
+    refill();
+    drop((uint32_t)(bitpos & 7));
+  }
+  inline void refill() {
+    uint64_t w;
+    memcpy(&w, in + pos, 8);
+    buf |= w << cnt;
+    pos += (63 - cnt) >> 3;
+    cnt |= 56;
+  }
+  inline void drop(uint32_t k) { buf >>= k; cnt -= k; }
+  inline uint32_t take(uint32_t k) { const uint32_t v = (uint32_t)(buf & (((uint64_t)1 << k) - 1)); drop(k); return v; }
+  inline size_t bitpos() const { return pos * 8 - cnt; }
+};
+
+struct Segment { size_t out_end; uint32_t crc, isize; };  // a gzip member ended after out_end output elements
+
+enum St { S_HEADER, S_BLOCK, S_HUFF, S_STORED, S_TRAILER, S_DONE };
+enum Stop { R_BOUNDARY, R_OUT, R_IN, R_END, R_ERR };
+
+struct Inflater {
+  std::vector<uint32_t> lit_own, dist_own;
+  const uint32_t* lit = nullptr;
+  const uint32_t* dist = nullptr;
+  St st = S_HEADER;
+  bool last_block = false;
+  uint32_t stored_left = 0;
+  size_t bp = 0;                                     // bit position in the compressed buffer where decoding resumes
+  std::vector<Segment> segs;
+  void use_own() {
+    if (lit_own.empty()) { lit_own.resize(kLitCap); dist_own.resize(kDistCap); }
+    lit = lit_own.data();
+    dist = dist_own.data();
+  }
+};
+
+// Dynamic block header behind the 3 block bits.  false: invalid.
+bool parse_dynamic(Bits& b, Inflater& s) {
+  b.refill();
+  const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  uint8_t cl[19] = {0};
+  b.refill();
+  for (uint32_t i = 0; i < hclen; ++i) {
+    if (b.cnt < 3) b.refill();
+    cl[kClOrder[i]] = (uint8_t)b.take(3);
+  }
+  uint32_t cltab[128];
+  {
+    int count[8] = {0};
+    for (int i = 0; i < 19; ++i) count[cl[i]]++;
+    int left = 1;
+    for (int l = 1; l <= 7; ++l) { left <<= 1; left -= count[l]; if (left < 0) return false; }
+    if (left > 0) return false;                      // zlib: an incomplete code-length code is always an error
+    uint32_t next[8], code = 0;
+    for (int l = 1; l <= 7; ++l) { code = (code + (uint32_t)count[l - 1]) << 1; next[l] = code; }
+    for (int sym = 0; sym < 19; ++sym) {
+      const int l = cl[sym];
+      if (!l) continue;
+      const uint32_t r = rev_bits(next[l]++, l);
+      for (uint32_t i = r; i < 128; i += (uint32_t)1 << l) cltab[i] = ((uint32_t)sym << 8) | (uint32_t)l;
+    }
+  }
+  uint8_t lens[286 + 30];
+  uint32_t i = 0;
+  const uint32_t total = hlit + hdist;
+  while (i < total) {
+    b.refill();
+    const uint32_t e = cltab[b.buf & 127];
+    b.drop(e & 0xFF);
+    const uint32_t sym = e >> 8;
+    if (sym < 16) { lens[i++] = (uint8_t)sym; continue; }
+    uint32_t rep, val = 0;
+    if (sym == 16) {
+      if (i == 0) return false;
+      val = lens[i - 1];
+      rep = 3 + b.take(2);
+    } else if (sym == 17) rep = 3 + b.take(3);
+    else rep = 11 + b.take(7);
+    if (i + rep > total) return false;
+    memset(lens + i, (int)val, rep);
+    i += rep;
+  }
+  if (lens[256] == 0) return false;                  // no end-of-block code
+  s.use_own();
+  if (!build_table(lens, (int)hlit, kLitBits, false, s.lit_own.data(), kLitCap)) return false;
+  if (!build_table(lens + hlit, (int)hdist, kDistBits, true, s.dist_own.data(), kDistCap)) return false;
+  return true;
+}
+
+// ---- output buffer: kWin elements of history in front, grows by realloc (no zero fill) -------------------------------
+template <class T>
+struct OutBuf {
+  T* mem = nullptr;
+  size_t cap = 0;                                    // elements behind the history, incl. 64 of slack
+  size_t n = 0;
+  OutBuf() {}
+  OutBuf(const OutBuf&) = delete;
+  OutBuf& operator=(const OutBuf&) = delete;
+  ~OutBuf() { free(mem); }
+  T* at0() { return mem + kWin; }
+  bool reserve(size_t want) {
+    if (want + 64 <= cap) return true;
+    size_t nc = cap ? cap : (size_t)1 << 20;
+    while (nc < want + 64) nc *= 2;
+    T* m = static_cast<T*>(realloc(mem, (kWin + nc) * sizeof(T)));
+    if (!m) return false;
+    mem = m;
+    cap = nc;
+    return true;
+  }
+};
+
+template <class T>
+inline void lz_copy(T* o, size_t dist, size_t len) {
+  const T* s = o - dist;
+  if (dist * sizeof(T) >= 16) {                      // 16-byte pieces never overlap their own source; may write <= 15 B past len
+    T* const end = o + len;
+    do { memcpy(o, s, 16); o += 16 / sizeof(T); s += 16 / sizeof(T); } while (o < end);
+  } else if (dist == 1) {
+    const T v = s[0];
+    for (size_t i = 0; i < len; ++i) o[i] = v;
+  } else {
+    for (size_t i = 0; i < len; ++i) o[i] = s[i];
+  }
+}
+
+// Runs `s` over in[0, in_len) from s.bp.  Stops
+//   R_BOUNDARY at the first block boundary (state S_BLOCK) whose bit position is >= target and != s.bp at entry,
+//   R_OUT      in the middle of anything once ob.n >= out_cap,
+//   R_IN       when the bytes read so far do not suffice (only if !final),
+//   R_END      at the clean end of the input (final, behind a member trailer),
+//   R_ERR      on invalid data (or a truncated stream when final).
+// wlen: history elements in front of output element 0 that exist (distance check; kWin in marker mode).
+template <class T>
+Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, OutBuf<T>& ob, size_t out_cap, size_t wlen,
+         int* oom) {
+  const size_t entry_bp = s.bp;
+  // positions at which the hot loop gives up: never touch bytes behind in_len + kPad; when more input may come, stop 64 B early
+  const size_t pos_lim = final ? in_len + 16 : (in_len > 64 ? in_len - 64 : 0);
+  for (;;) {
+    switch (s.st) {
+      case S_DONE:
+        return R_END;
+      case S_HEADER: {
+        size_t p = (s.bp + 7) >> 3;
+        if (p >= in_len) {
+          if (!final) return R_IN;
+          s.st = S_DONE;
+          return R_END;
+        }
+        const size_t avail = in_len - p;
+        auto short_of = [&]() { return final ? R_ERR : R_IN; };
+        if (avail < 10) return short_of();
+        if (in[p] != 0x1f || in[p + 1] != 0x8b || in[p + 2] != 8 || (in[p + 3] & 0xE0)) return R_ERR;
+        const uint8_t flg = in[p + 3];
+        size_t q = p + 10;
+        if (flg & 4) {                               // FEXTRA
+          if (q + 2 > in_len) return short_of();
+          const size_t xl = (size_t)in[q] | ((size_t)in[q + 1] << 8);
+          q += 2;
+          if (q + xl > in_len) return short_of();
+          q += xl;
+        }
+        for (int f = 8; f <= 16; f <<= 1)            // FNAME, FCOMMENT: zero-terminated
+          if (flg & f) {
+            while (q < in_len && in[q]) ++q;
+            if (q >= in_len) return short_of();
+            ++q;
+          }
+        if (flg & 2) {                               // FHCRC
+          if (q + 2 > in_len) return short_of();
+          q += 2;
+        }
+        s.bp = q * 8;
+        s.st = S_BLOCK;
+        s.last_block = false;
+        break;
+      }
+      case S_TRAILER: {
+        const size_t p = (s.bp + 7) >> 3;
+        if (p + 8 > in_len) return final ? R_ERR : R_IN;
+        Segment g;
+        g.out_end = ob.n;
+        g.crc = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+        g.isize = (uint32_t)in[p + 4] | ((uint32_t)in[p + 5] << 8) | ((uint32_t)in[p + 6] << 16) | ((uint32_t)in[p + 7] << 24);
+        s.segs.push_back(g);
+        s.bp = (p + 8) * 8;
+        s.st = S_HEADER;
+        break;
+      }
+      case S_BLOCK: {
+        if (s.bp >= target && s.bp != entry_bp) return R_BOUNDARY;
+        if (ob.n >= out_cap) return R_OUT;
+        // a dynamic header is < 400 bytes; when more input may come, do not start one that may not be whole
+        if (!final && (s.bp >> 3) + 400 > in_len) return R_IN;
+        if ((s.bp >> 3) >= in_len) return R_ERR;     // final and nothing left: truncated
+        Bits b(in, s.bp);
+        s.last_block = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 0) {
+          const size_t p = (b.bitpos() + 7) >> 3;
+          if (p + 4 > in_len) return final ? R_ERR : R_IN;
+          const uint32_t len = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8), nlen = (uint32_t)in[p + 2] | ((uint32_t)in[p + 3] << 8);
+          if ((len ^ 0xFFFFu) != nlen) return R_ERR;
+          s.stored_left = len;
+          s.bp = (p + 4) * 8;
+          s.st = S_STORED;
+        } else if (type == 1) {
+          s.lit = fixed_tables().lit;
+          s.dist = fixed_tables().dist;
+          s.bp = b.bitpos();
+          s.st = S_HUFF;
+        } else if (type == 2) {
+          if (!parse_dynamic(b, s)) return R_ERR;
+          s.bp = b.bitpos();
+          if (s.bp > in_len * 8) return R_ERR;       // the header ran into the padding: truncated
+          s.st = S_HUFF;
+        } else {
+          return R_ERR;
+        }
+        break;
+      }
+      case S_STORED: {
+        if (s.stored_left == 0) { s.st = s.last_block ? S_TRAILER : S_BLOCK; break; }
+        if (ob.n >= out_cap) return R_OUT;
+        const size_t p = s.bp >> 3;
+        size_t k = s.stored_left;
+        if (k > out_cap - ob.n) k = out_cap - ob.n;
+        const size_t avail = in_len > p ? in_len - p : 0;
+        if (k > avail) k = avail;
+        if (k == 0) return final ? R_ERR : R_IN;       // the stored bytes are not there (yet)
+        if (!ob.reserve(ob.n + k)) { *oom = 1; return R_ERR; }
+        T* o = ob.at0() + ob.n;
+        for (size_t i = 0; i < k; ++i) o[i] = (T)in[p + i];
+        ob.n += k;
+        s.bp += k * 8;
+        s.stored_left -= (uint32_t)k;
+        break;
+      }
+      case S_HUFF: {
+        Bits b(in, s.bp);
+        const uint32_t* const lit = s.lit;
+        const uint32_t* const dist = s.dist;
+        const uint32_t lmask = (1u << kLitBits) - 1, dmask = (1u << kDistBits) - 1;
+        if (!ob.reserve(ob.n + (1u << 16))) { *oom = 1; return R_ERR; }
+        T* base = ob.at0();
+        size_t o = ob.n;
+        size_t o_lim = ob.cap - 64 - 600;            // room for three literals + one match + copy overshoot
+        if (o_lim > out_cap) o_lim = out_cap;
+        Stop why = R_BOUNDARY;
+        bool block_done = false;
+        for (;;) {
+          if (o >= o_lim) {
+            if (o >= out_cap) { why = R_OUT; break; }
+            ob.n = o;
+            if (!ob.reserve(o + (o >> 1) + (1u << 16))) { *oom = 1; return R_ERR; }
+            base = ob.at0();
+            o_lim = ob.cap - 64 - 600;
+            if (o_lim > out_cap) o_lim = out_cap;
+            if (o >= o_lim) { why = R_OUT; break; }
+          }
+          if (b.pos > pos_lim) {
+            if (!final) { why = R_IN; break; }
+            return R_ERR;                            // ran far into the padding: truncated
+          }
+          b.refill();
+          uint32_t e = lit[b.buf & lmask];
+          if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
+          b.drop(e_bits(e));
+          if (e_kind(e) == K_LIT) {                    // >= 56 bits after a refill: three symbols of <= 15 bits + 5 extra bits fit
+            base[o++] = (T)e_val(e);
+            e = lit[b.buf & lmask];
+            if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
+            b.drop(e_bits(e));
+            if (e_kind(e) == K_LIT) {
+              base[o++] = (T)e_val(e);
+              e = lit[b.buf & lmask];
+              if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
+              b.drop(e_bits(e));
+              if (e_kind(e) == K_LIT) { base[o++] = (T)e_val(e); continue; }
+            }
+          }
+          if (e_kind(e) == K_BASE) {
+            const size_t len = e_val(e) + b.take(e_extra(e));
+            b.refill();
+            uint32_t d = dist[b.buf & dmask];
+            if (e_kind(d) == K_SUB) { b.drop(kDistBits); d = dist[e_val(d) + (b.buf & ((1u << e_extra(d)) - 1))]; }
+            b.drop(e_bits(d));
+            if (e_kind(d) != K_BASE) return R_ERR;
+            const size_t dd = e_val(d) + b.take(e_extra(d));
+            if (dd > o + wlen) return R_ERR;         // reaches in front of the history
+            lz_copy(base + o, dd, len);
+            o += len;
+            continue;
+          }
+          if (e_kind(e) == K_EOB) { block_done = true; break; }
+          return R_ERR;
+        }
+        ob.n = o;
+        s.bp = b.bitpos();
+        if (block_done) {
+          if (s.bp > in_len * 8) return R_ERR;       // the block's last bits came from the padding: truncated
+          s.st = s.last_block ? S_TRAILER : S_BLOCK;
+          break;
+        }
+        return why;
+      }
+    }
+  }
+}
+
+// First bit position in [from, to) that parses as the header of a non-final dynamic block (complete code sets, an
+// end-of-block code).  Reads at most ~400 bytes behind `to`; the caller keeps that inside the buffer + padding.
+size_t find_dynamic_block(const uint8_t* in, size_t in_len, size_t from, size_t to, Inflater& scratch) {
+  constexpr uint32_t kMaxParses = 1u << 14;
+  uint32_t parses = 0;
+  for (size_t bit = from; bit < to; ++bit) {
+    uint64_t w;
+    memcpy(&w, in + (bit >> 3), 8);
+    const uint64_t x = w >> (bit & 7);
+    if ((x & 7) != 4) continue;                      // BFINAL = 0, BTYPE = 2 (bits 0 1 from the LSB: 0, then 01 -> value 0b100)
+    if (((x >> 3) & 31) > 29 || ((x >> 8) & 31) > 29) continue;
+    const uint32_t ncl = (uint32_t)((x >> 13) & 15) + 4;
+    memcpy(&w, in + ((bit + 17) >> 3), 8);
+    const uint64_t y = w >> ((bit + 17) & 7);        // 57 bits = 19 code-length-code lengths
+    uint32_t kraft = 0;
+    for (uint32_t i = 0; i < ncl; ++i) {
+      const uint32_t l = (uint32_t)(y >> (3 * i)) & 7;
+      if (l) kraft += 128u >> l;
+    }
+    if (kraft != 128) continue;
+    // Highly repetitive compressed data (a long run of one byte) passes the cheap tests at every period of its bit
+    // pattern and fails only in the full parse: bound that work; the chunk then has no candidate and the chunk in front
+    // of it decodes through.
+    if (++parses > kMaxParses) return kNone;
+    Bits b(in, bit + 3);
+    if (!parse_dynamic(b, scratch)) continue;
+    if (b.bitpos() > in_len * 8) continue;
+    return bit;
+  }
+  return kNone;
+}
+
+// 16-bit symbols -> bytes.  win: the 32 KiB in front of the chunk.  false: a symbol that is neither a byte nor a marker.
+bool resolve(const uint16_t* src, size_t n, const uint8_t* win, uint8_t* dst, uint64_t* markers) {
+  size_t i = 0;
+  uint64_t m = 0;
+  uint32_t bad = 0;
+  for (; i + 4 <= n; i += 4) {
+    uint64_t v;
+    memcpy(&v, src + i, 8);
+    if ((v & 0xFF00FF00FF00FF00ull) == 0) {
+      dst[i] = (uint8_t)v; dst[i + 1] = (uint8_t)(v >> 16); dst[i + 2] = (uint8_t)(v >> 32); dst[i + 3] = (uint8_t)(v >> 48);
+      continue;
+    }
+    for (int k = 0; k < 4; ++k) {
+      const uint16_t s = src[i + k];
+      if (s < 256) dst[i + k] = (uint8_t)s;
+      else if (s >= 0x8000) { dst[i + k] = win[s - 0x8000]; ++m; }
+      else bad = 1;
+    }
+  }
+  for (; i < n; ++i) {
+    const uint16_t s = src[i];
+    if (s < 256) dst[i] = (uint8_t)s;
+    else if (s >= 0x8000) { dst[i] = win[s - 0x8000]; ++m; }
+    else bad = 1;
+  }
+  *markers += m;
+  return !bad;
+}
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Chunk {
+  size_t start = kNone;                              // candidate bit position (chunk 0: the true position)
+  size_t target = kNone;
+  Inflater inf;
+  OutBuf<uint8_t> o8;                                // chunk 0
+  OutBuf<uint16_t> o16;                              // the others
+  Stop stop = R_ERR;
+  int oom = 0;
+  size_t n_out() const { return o8.mem ? o8.n : o16.n; }   // chunk 0 of a batch decodes to bytes, the others to symbols
+  // after acceptance
+  size_t out_off = 0;
+  std::vector<uint8_t> win_tmp;
+  const uint8_t* win = nullptr;
+  std::vector<uint32_t> piece_crc;                   // one per segment + one for the open tail
+  bool bad_symbol = false;
+};
+
+}  // namespace
+
+ByteBuf::~ByteBuf() { free(data); }
+bool ByteBuf::resize_uninit(size_t n) {
+  if (n > cap) {
+    uint8_t* d = static_cast<uint8_t*>(realloc(data, n ? n : 1));
+    if (!d) return false;
+    data = d;
+    cap = n;
+  }
+  size = n;
+  return true;
+}
+
+struct ParallelGunzip::Impl {
+  ReadFn inner;
+  unsigned threads;
+  size_t chunk;
+  std::vector<uint8_t> comp;                         // compressed bytes not yet consumed + kPad zeros
+  size_t comp_len = 0;
+  bool inner_eof = false, done = false, failed = false;
+  Inflater cur;                                      // the true decoder state; cur.bp is relative to comp[0]
+  std::vector<uint8_t> window;                       // last <= 32 KiB of output
+  uint32_t run_crc = 0;                              // CRC-32 / length of the open member so far
+  uint64_t run_len = 0;
+  size_t out_cap;
+  std::vector<Chunk> pool;                           // per-chunk buffers and tables, reused from batch to batch
+};
+
+ParallelGunzip::ParallelGunzip(ReadFn inner, unsigned threads, size_t chunk_bytes) : p_(new Impl) {
+  p_->inner = std::move(inner);
+  p_->threads = threads < 1 ? 1 : threads;
+  p_->chunk = chunk_bytes < 4096 ? 4096 : chunk_bytes;
+  p_->out_cap = p_->chunk * 24 < ((size_t)1 << 20) ? (size_t)1 << 20 : p_->chunk * 24;  // elements per chunk and batch
+  p_->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+}
+ParallelGunzip::~ParallelGunzip() {}
+
+int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
+  Impl& P = *p_;
+  out.size = 0;
+  *eof = false;
+  if (P.failed) return EPROTO;
+  const size_t kSlack = (size_t)256 << 10;
+  while (out.size == 0) {
+    if (P.done) { *eof = true; return 0; }
+    // ---- 0. top up the compressed buffer ---------------------------------------------------------------------------
+    double t0 = now_s(), t1;
+    const size_t base_byte = P.cur.bp >> 3;
+    const size_t want = base_byte + (size_t)P.threads * P.chunk + kSlack;
+    if (P.comp.size() < want + kPad) P.comp.resize(want + kPad);
+    while (P.comp_len < want && !P.inner_eof) {
+      size_t got = 0;
+      const int rc = P.inner(P.comp.data() + P.comp_len, want - P.comp_len, &got);
+      if (rc) { P.failed = true; return rc; }
+      if (got == 0) P.inner_eof = true;
+      P.comp_len += got;
+      st_.bytes_in += got;
+    }
+    memset(P.comp.data() + P.comp_len, 0, kPad);
+    const uint8_t* in = P.comp.data();
+    const size_t in_len = P.comp_len;
+    const bool final = P.inner_eof;
+
+    t1 = now_s(); st_.s_read += t1 - t0; t0 = t1;
+    // ---- 1. candidates ---------------------------------------------------------------------------------------------
+    size_t n = P.threads;
+    while (n > 1 && base_byte + (n - 1) * P.chunk + 1024 >= in_len) --n;   // chunks that have at least some bytes
+    if (P.pool.size() < P.threads) P.pool = std::vector<Chunk>(P.threads);
+    std::vector<Chunk>& ch = P.pool;
+    for (size_t j = 0; j < n; ++j) {
+      Chunk& c = ch[j];
+      c.start = c.target = kNone;
+      c.stop = R_ERR;
+      c.oom = 0;
+      c.o8.n = c.o16.n = 0;
+      c.inf.segs.clear();
+      c.out_off = 0;
+      c.win = nullptr;
+      c.piece_crc.clear();
+      c.bad_symbol = false;
+    }
+    ch[0].start = P.cur.bp;
+    if (n > 1)
+      run_pieces((unsigned)(n - 1), [&](unsigned i) {
+        const size_t j = i + 1;
+        size_t from = (base_byte + j * P.chunk) * 8, to = (base_byte + (j + 1) * P.chunk) * 8;
+        const size_t last = in_len > 8 ? (in_len - 8) * 8 : 0;   // a header needs some bytes; keep the loads inside the padding
+        if (to > last) to = last;
+        if (from <= P.cur.bp) from = P.cur.bp + 1;
+        Inflater scratch;
+        ch[j].start = from < to ? find_dynamic_block(in, in_len, from, to, scratch) : kNone;
+      });
+    std::vector<size_t> act;                           // chunks that will be decoded
+    act.push_back(0);
+    for (size_t j = 1; j < n; ++j) {
+      if (ch[j].start != kNone) act.push_back(j);
+      else st_.candidates_missing++;
+    }
+    const size_t nominal_end = (base_byte + n * P.chunk) * 8;
+    for (size_t a = 0; a < act.size(); ++a)
+      ch[act[a]].target = a + 1 < act.size() ? ch[act[a + 1]].start : (final && nominal_end >= in_len * 8 ? kNone : nominal_end);
+
+    t1 = now_s(); st_.s_find += t1 - t0; t0 = t1;
+    // ---- 2. decode -------------------------------------------------------------------------------------------------
+    {
+      Chunk& c0 = ch[0];
+      c0.inf = std::move(P.cur);
+      if (!c0.o8.reserve(P.chunk * 4)) { P.failed = true; return ENOMEM; }
+      memset(c0.o8.mem, 0, kWin - P.window.size());
+      if (!P.window.empty()) memcpy(c0.o8.mem + kWin - P.window.size(), P.window.data(), P.window.size());
+    }
+    const size_t wlen0 = P.window.size();
+    run_pieces((unsigned)act.size(), [&](unsigned a) {
+      Chunk& c = ch[act[a]];
+      if (a == 0) {
+        c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.o8, P.out_cap, wlen0, &c.oom);
+        return;
+      }
+      c.inf.st = S_BLOCK;
+      c.inf.bp = c.start;
+      if (!c.o16.reserve(P.chunk * 4)) { c.oom = 1; c.stop = R_ERR; return; }
+      for (size_t i = 0; i < kWin; ++i) c.o16.mem[i] = (uint16_t)(0x8000u + i);
+      c.stop = run<uint16_t>(c.inf, in, in_len, final, c.target, c.o16, P.out_cap, kWin, &c.oom);
+    });
+
+    t1 = now_s(); st_.s_decode += t1 - t0; t0 = t1;
+    // ---- 3. chain --------------------------------------------------------------------------------------------------
+    std::vector<size_t> ok;
+    ok.push_back(0);
+    for (size_t a = 1; a < act.size(); ++a) {
+      const Chunk& prev = ch[ok.back()];
+      const Chunk& c = ch[act[a]];
+      if (prev.stop != R_BOUNDARY || prev.inf.bp != c.start) break;
+      ok.push_back(act[a]);
+    }
+    st_.chunks_accepted += ok.size();
+    st_.chunks_discarded += act.size() - ok.size();
+    for (size_t k : ok) {
+      if (ch[k].oom) { P.failed = true; return ENOMEM; }
+      if (ch[k].stop == R_ERR) { P.failed = true; return EPROTO; }   // an accepted chunk decodes the true stream
+    }
+
+    // ---- 4. windows, patching, CRC ----------------------------------------------------------------------------------
+    size_t total = 0;
+    for (size_t k : ok) { ch[k].out_off = total; total += ch[k].n_out(); }
+    if (!out.resize_uninit(total)) { P.failed = true; return ENOMEM; }
+    uint8_t* const dst = out.data;
+    auto tail_of = [](size_t nn) { return nn < kWin ? nn : kWin; };
+    // chunk 0's bytes are final: copy its tail now (a window source), its body in the parallel step
+    {
+      Chunk& c0 = ch[0];
+      const size_t t = tail_of(c0.o8.n);
+      if (t) memcpy(dst + c0.o8.n - t, c0.o8.at0() + c0.o8.n - t, t);
+    }
+    for (size_t a = 1; a < ok.size(); ++a) {           // sequential: 32 KiB per chunk
+      Chunk& c = ch[ok[a]];
+      if (c.out_off >= kWin) c.win = dst + c.out_off - kWin;
+      else {                                           // the window reaches back into the previous batch
+        c.win_tmp.assign(kWin, 0);
+        const size_t from_old = kWin - c.out_off, have = P.window.size() < from_old ? P.window.size() : from_old;
+        if (have) memcpy(c.win_tmp.data() + from_old - have, P.window.data() + P.window.size() - have, have);
+        if (c.out_off) memcpy(c.win_tmp.data() + from_old, dst, c.out_off);
+        c.win = c.win_tmp.data();
+      }
+      const size_t t = tail_of(c.o16.n);
+      uint64_t m = 0;
+      if (!resolve(c.o16.at0() + c.o16.n - t, t, c.win, dst + c.out_off + c.o16.n - t, &m)) c.bad_symbol = true;
+      st_.marker_symbols += m;
+    }
+    t1 = now_s(); st_.s_windows += t1 - t0; t0 = t1;
+    std::vector<uint64_t> markers(ok.size(), 0);
+    run_pieces((unsigned)ok.size(), [&](unsigned a) {
+      Chunk& c = ch[ok[a]];
+      const size_t nn = c.n_out(), body = nn - tail_of(nn);
+      if (a == 0) { if (body) memcpy(dst, c.o8.at0(), body); }
+      else if (!resolve(c.o16.at0(), body, c.win, dst + c.out_off, &markers[a])) c.bad_symbol = true;
+      size_t from = 0;
+      for (size_t g = 0; g <= c.inf.segs.size(); ++g) {
+        const size_t to = g < c.inf.segs.size() ? c.inf.segs[g].out_end : nn;
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t p = from; p < to;) {               // crc32 takes a uInt length
+          const size_t k = to - p > ((size_t)1 << 30) ? (size_t)1 << 30 : to - p;
+          crc = (uint32_t)crc32(crc, dst + c.out_off + p, (uInt)k);
+          p += k;
+        }
+        c.piece_crc.push_back(crc);
+        from = to;
+      }
+    });
+    for (size_t a = 0; a < ok.size(); ++a) st_.marker_symbols += markers[a];
+    for (size_t k : ok) {
+      Chunk& c = ch[k];
+      if (c.bad_symbol) { P.failed = true; return EPROTO; }
+      size_t from = 0;
+      for (size_t g = 0; g <= c.inf.segs.size(); ++g) {
+        const size_t to = g < c.inf.segs.size() ? c.inf.segs[g].out_end : c.n_out();
+        P.run_crc = (uint32_t)crc32_combine(P.run_crc, c.piece_crc[g], (z_off_t)(to - from));
+        P.run_len += to - from;
+        if (g < c.inf.segs.size()) {                   // a member ended here
+          if (P.run_crc != c.inf.segs[g].crc || (uint32_t)P.run_len != c.inf.segs[g].isize) { P.failed = true; return EPROTO; }
+          P.run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+          P.run_len = 0;
+        }
+        from = to;
+      }
+    }
+
+    t1 = now_s(); st_.s_patch_crc += t1 - t0; t0 = t1;
+    // ---- 5. carry over ---------------------------------------------------------------------------------------------
+    Chunk& lastc = ch[ok.back()];
+    if (lastc.stop == R_END) P.done = true;
+    if (lastc.stop == R_IN && final) { P.failed = true; return EPROTO; }
+    if (total >= kWin) P.window.assign(dst + total - kWin, dst + total);
+    else {
+      if (total) P.window.insert(P.window.end(), dst, dst + total);
+      if (P.window.size() > kWin) P.window.erase(P.window.begin(), P.window.begin() + (P.window.size() - kWin));
+    }
+    P.cur = std::move(lastc.inf);
+    P.cur.segs.clear();
+    const size_t shift = P.cur.bp >> 3;
+    if (shift) {
+      const size_t keep = shift < P.comp_len ? P.comp_len - shift : 0;
+      memmove(P.comp.data(), P.comp.data() + (shift < P.comp_len ? shift : P.comp_len), keep);
+      P.comp_len = keep;
+      P.cur.bp -= shift * 8;
+    }
+    st_.batches++;
+    st_.bytes_out += total;
+    st_.s_carry += now_s() - t0;
+    if (total == 0 && !P.done && lastc.stop == R_IN && !final) continue;  // needs more input: the top-up reads it
+    if (total == 0 && !P.done && shift == 0 && lastc.stop != R_IN) { P.failed = true; return EPROTO; }  // no progress: cannot happen
+  }
+  return 0;
+}
+
+}  // namespace pgz
+}  // namespace ibu

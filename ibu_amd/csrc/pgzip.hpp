@@ -1,0 +1,73 @@
+// pgzip.hpp — parallel inflate of an ORDINARY gzip stream (one or many members, no index, no BGZF framing).
+//
+// Why: BASELINE configs[4] is "1e9 records gzip-compressed input (niffler path): host inflate -> pinned ring -> GPU
+// decode".  niffler / flate2 (reference: src/io/reader.rs:345-352) inflate one stream on one thread, ~0.45 GB/s of
+// records, 2 400x below the HBM-resident rate; the GPU and PCIe idle.  A deflate stream has no entry points, but its
+// blocks can be FOUND (a dynamic-Huffman block header is self-checking) and decoded before the 32 KiB of history in
+// front of them is known, if unresolved back-references are kept as markers and patched afterwards:
+//
+//   batch = `threads` chunks of `chunk_bytes` compressed bytes
+//   1. find   (parallel)   chunk j >= 1: first bit position in its range that parses as a non-final dynamic block header
+//                          with complete code-length / literal-length / distance codes
+//   2. decode (parallel)   chunk 0 from the TRUE position with the true window, to bytes;
+//                          chunk j >= 1 from its candidate to 16-bit symbols: < 256 a byte, >= 0x8000 "byte (v - 0x8000)
+//                          of the 32 KiB window in front of this chunk"; each chunk stops at the block boundary that is
+//                          the next chunk's candidate (or overshoots it)
+//   3. chain  (sequential) chunk j+1 is accepted only if chunk j ended EXACTLY at its candidate: chunk 0 decodes the
+//                          true stream, so by induction every accepted chunk started at a true block boundary.  The batch
+//                          ends at the first break; the next batch starts there (progress is guaranteed by chunk 0).
+//   4. patch  (seq + par)  last 32 KiB of every accepted chunk in order (the windows), then all bodies in parallel,
+//                          CRC-32 per (chunk, member) piece, combined with crc32_combine and checked against every
+//                          member trailer together with ISIZE.
+//
+// Output bytes and error class are those of the sequential zlib path (GzSource in host_io.cpp): same bytes, EPROTO for a
+// corrupt / truncated stream.  The decoder is suspendable in the middle of a block (output cap per chunk, end of the
+// bytes read so far), so memory stays bounded for any input.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <functional>
+#include <memory>
+#include <vector>
+
+namespace ibu {
+namespace pgz {
+
+typedef std::function<int(uint8_t* dst, size_t cap, size_t* got)> ReadFn;  // 0 or errno; *got == 0 at EOF
+
+struct Stats {
+  uint64_t batches = 0, chunks_accepted = 0, chunks_discarded = 0, candidates_missing = 0;
+  uint64_t bytes_in = 0, bytes_out = 0, marker_symbols = 0;
+  double s_read = 0, s_find = 0, s_decode = 0, s_windows = 0, s_patch_crc = 0, s_carry = 0;  // wall seconds per phase
+};
+
+struct ByteBuf {  // grows by realloc, never zero-fills
+  uint8_t* data = nullptr;
+  size_t size = 0, cap = 0;
+  ByteBuf() {}
+  ByteBuf(const ByteBuf&) = delete;
+  ByteBuf& operator=(const ByteBuf&) = delete;
+  ~ByteBuf();
+  bool resize_uninit(size_t n);
+  void swap(ByteBuf& o) { uint8_t* d = data; data = o.data; o.data = d; size_t t = size; size = o.size; o.size = t; t = cap; cap = o.cap; o.cap = t; }
+};
+
+class ParallelGunzip {
+ public:
+  // threads: chunks decoded at once (>= 1); chunk_bytes: compressed bytes per chunk
+  ParallelGunzip(ReadFn inner, unsigned threads, size_t chunk_bytes);
+  ~ParallelGunzip();
+  // Decodes the next batch into `out` (replaced).  Returns 0 or errno (EPROTO: corrupt / truncated stream).
+  // An empty `out` with *eof set is the clean end of the stream.
+  int next_batch(ByteBuf& out, bool* eof);
+  const Stats& stats() const { return st_; }
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> p_;
+  Stats st_;
+};
+
+}  // namespace pgz
+}  // namespace ibu

@@ -1,0 +1,185 @@
+"""Parallel inflate of ordinary gzip input (ibu_amd/csrc/pgzip.cpp; BASELINE configs[4], reference path
+src/io/reader.rs:345-352 = niffler's single-stream gzip decoder).
+
+The checker here is zlib itself (Python's gzip / zlib modules, the same library niffler's flate2 wraps): the bytes a
+Reader over `x.gz` delivers must be the bytes zlib inflates, for every way a deflate stream can be put together, with
+the compressed input cut into many small chunks (IBU_PGZ_CHUNK) on several threads (IBU_PGZ_THREADS) so that every
+batch exercises the candidate search, marker decoding, chain validation and window patching.  The sequential zlib
+path (IBU_NO_PARALLEL_GZIP=1) is the second witness: same outcome class on damaged input."""
+import gzip
+import hashlib
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import ibu_amd as ia
+
+
+def _header(bc=16, umi=12):
+    return ia.Header(bc, umi).as_bytes()
+
+
+def _zc(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _payloads():
+    rng = np.random.default_rng(0x1B0)
+    n = 150_000
+    recs = np.zeros((n, 3), dtype=np.uint64)
+    recs[:, 0] = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    recs[:, 1] = rng.integers(0, 1 << 24, n, dtype=np.uint64)
+    recs[:, 2] = np.arange(n, dtype=np.uint64)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 9))).astype(np.uint8)) for _ in range(500)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 500, 400_000))
+    text = text[: len(text) // 24 * 24]
+    return {
+        "records": recs.tobytes(),                              # what an .ibu file holds: half-random 24-byte records
+        "text": text,                                           # many matches, long-lived back references
+        "zeros": bytes(24 * 600_000),                           # 1000:1: the per-chunk output cap suspends mid-block
+        "random": rng.integers(0, 256, 24 * 40_000, dtype=np.uint8).tobytes(),  # incompressible: stored blocks
+    }
+
+
+_P = None
+
+
+def payloads():
+    global _P
+    if _P is None:
+        _P = _payloads()
+    return _P
+
+
+def _read_all(path):
+    r = ia.Reader.from_path(path)
+    out = []
+    try:
+        while r.read_batch():
+            b = r.buffered()
+            out.append(np.array(b, copy=True).tobytes())
+            r.consume(len(b))
+    finally:
+        r.close()
+    return b"".join(out)
+
+
+def _knobs(monkeypatch, threads, chunk):
+    monkeypatch.delenv("IBU_NO_PARALLEL_GZIP", raising=False)
+    monkeypatch.setenv("IBU_PGZ_THREADS", str(threads))
+    monkeypatch.setenv("IBU_PGZ_CHUNK", str(chunk))
+
+
+CASES = [
+    ("records", dict(level=1)), ("records", dict(level=6)), ("records", dict(level=9)), ("records", dict(level=6, memlevel=1)),
+    ("text", dict(level=1)), ("text", dict(level=9)), ("text", dict(level=6, strategy=zlib.Z_FIXED)),
+    ("text", dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY)), ("text", dict(level=6, strategy=zlib.Z_RLE)),
+    ("text", dict(level=6, strategy=zlib.Z_FILTERED)), ("zeros", dict(level=6)), ("zeros", dict(level=1)),
+    ("random", dict(level=6)), ("random", dict(level=0)),
+]
+
+
+@pytest.mark.parametrize("threads,chunk", [(4, 4096), (7, 30_000), (3, 1 << 20)])
+@pytest.mark.parametrize("name,kw", CASES, ids=[f"{n}-{'-'.join(f'{k}{v}' for k, v in kw.items())}" for n, kw in CASES])
+def test_every_kind_of_deflate_stream(tmp_path, monkeypatch, name, kw, threads, chunk):
+    body = payloads()[name]
+    p = tmp_path / "x.ibu.gz"
+    p.write_bytes(_zc(_header() + body, **kw))
+    _knobs(monkeypatch, threads, chunk)
+    got = _read_all(p)
+    assert len(got) == len(body) and hashlib.md5(got).digest() == hashlib.md5(body).digest()
+
+
+def test_members_header_fields_and_mixed_content(tmp_path, monkeypatch):
+    P = payloads()
+    raw = _header() + P["text"][:240_000] + P["random"][:24 * 3000] + P["zeros"][:24 * 100_000] + P["records"][:24 * 60_000] + P["text"][240_000:480_000]
+    cuts = [0, 1, 33, 40_000, 40_000, 700_001, 700_002, len(raw) - 5, len(raw)]          # empty members, members cut inside records
+    multi = b"".join(_zc(raw[a:b], 1 + i % 9) for i, (a, b) in enumerate(zip(cuts, cuts[1:])))
+    # one member with every optional gzip header field (FEXTRA, FNAME, FCOMMENT, FHCRC)
+    head = b"\x1f\x8b\x08\x1e" + bytes(6) + struct.pack("<H", 7) + b"AB\x03\x00xyz" + b"name.ibu\0" + b"made by a test\0"
+    head += struct.pack("<H", zlib.crc32(head) & 0xFFFF)
+    fields = head + _zc(raw, 6, wbits=-15) + struct.pack("<II", zlib.crc32(raw), len(raw) & 0xFFFFFFFF)
+    for blob in (multi, fields, _zc(raw, 6), gzip.compress(raw, 9)):
+        p = tmp_path / "m.ibu.gz"
+        p.write_bytes(blob)
+        for threads, chunk in ((5, 4096), (2, 65536), (16, 5000)):
+            _knobs(monkeypatch, threads, chunk)
+            assert _read_all(p) == raw[32:]
+
+
+def test_tiny_and_empty_streams(tmp_path, monkeypatch):
+    _knobs(monkeypatch, 4, 4096)
+    p = tmp_path / "t.ibu.gz"
+    p.write_bytes(_zc(_header()))                                  # header only: zero records
+    assert _read_all(p) == b""
+    p.write_bytes(_zc(_header() + bytes(range(24))))
+    assert _read_all(p) == bytes(range(24))
+    p.write_bytes(_zc(_header()) + _zc(b"") + _zc(b""))           # trailing empty members
+    assert _read_all(p) == b""
+    p.write_bytes(_zc(b""))                                        # valid gzip, no IBU header inside
+    with pytest.raises(ia.IbuError) as e:
+        ia.Reader.from_path(p)
+    assert e.value.kind == "Io"                                    # UnexpectedEof while reading the header, like the plain path
+
+
+def _outcome(path):
+    try:
+        b = _read_all(path)
+        return ("ok", len(b), hashlib.md5(b).hexdigest())
+    except ia.IbuError as e:
+        return ("error", "Niffler" if e.kind in ("Niffler", "Io") else e.kind)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_damaged_streams_fail_like_the_sequential_path(tmp_path, monkeypatch, seed):
+    """Flips, cuts and garbage tails: the parallel decoder must agree with zlib on WHETHER the stream is good, and on the
+    bytes when it is.  (A damaged stream may deliver fewer records before the error than the sequential path does: the
+    parallel path works in batches.)"""
+    rng = np.random.default_rng(seed)
+    P = payloads()
+    raw = _header() + P["records"][:24 * 20_000] + P["text"][:120_000] + P["zeros"][:24 * 5000]
+    blob = _zc(raw[:300_000], 6) + _zc(raw[300_000:], 1)
+    p = tmp_path / "d.ibu.gz"
+    for trial in range(40):
+        b = bytearray(blob)
+        kind = trial % 4
+        pos = int(rng.integers(12, len(b)))
+        if kind == 0:
+            b[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            del b[pos:]
+        elif kind == 2:
+            b[pos:pos + 40] = bytes(min(40, len(b) - pos))
+        else:
+            b += bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+        p.write_bytes(bytes(b))
+        monkeypatch.setenv("IBU_NO_PARALLEL_GZIP", "1")
+        want = _outcome(p)
+        _knobs(monkeypatch, 4, 4096)
+        got = _outcome(p)
+        if want[0] == "ok":
+            assert got == want, (trial, kind, pos)
+        else:
+            assert got[0] == "error", (trial, kind, pos, want, got)
+
+
+def test_large_file_default_settings_and_process_equivalence(tmp_path, monkeypatch):
+    """Default chunking (2 MiB per thread) on a file of several batches; multi-member with members larger than a batch."""
+    monkeypatch.delenv("IBU_NO_PARALLEL_GZIP", raising=False)
+    monkeypatch.delenv("IBU_PGZ_CHUNK", raising=False)
+    monkeypatch.setenv("IBU_PGZ_THREADS", "4")
+    rng = np.random.default_rng(5)
+    n = 1_500_000
+    recs = np.zeros((n, 3), dtype=np.uint64)
+    recs[:, 0] = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    recs[:, 1] = rng.integers(0, 1 << 24, n, dtype=np.uint64)
+    recs[:, 2] = np.arange(n, dtype=np.uint64)
+    raw = _header() + recs.tobytes()
+    p = tmp_path / "big.ibu.gz"
+    half = 32 + 24 * 700_001 + 11
+    p.write_bytes(_zc(raw[:half], 1) + _zc(raw[half:], 6))
+    got = _read_all(p)
+    assert hashlib.md5(got).digest() == hashlib.md5(raw[32:]).digest()

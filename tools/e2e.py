@@ -33,6 +33,69 @@ def _gz_member(args):
     return c.compress(data) + c.flush()
 
 
+def _deflate_piece(args):
+    path, off, length, level, last = args
+    with open(path, "rb") as f:
+        f.seek(off)
+        data = f.read(length)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)  # raw deflate; every piece starts with an empty window
+    return c.compress(data) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(data), len(data)
+
+
+def gzip_single_member(src, dst, level=1, piece_bytes=64 << 20, workers=16):
+    """ONE gzip member (what `gzip` / `pigz` write: one header, one deflate stream, one trailer), compressed in parallel
+    the way pigz does it: pieces end in a sync flush (byte-aligned, not final), the last one finishes the stream."""
+    import struct
+    size = os.path.getsize(src)
+    offs = list(range(0, size, piece_bytes))
+    jobs = [(src, off, min(piece_bytes, size - off), level, off == offs[-1]) for off in offs]
+    crc, total = 0, 0
+    with ProcessPoolExecutor(max_workers=workers) as ex, open(dst, "wb") as out:
+        out.write(b"\x1f\x8b\x08\x00\0\0\0\0\x00\xff")
+        for blob, c, k in ex.map(_deflate_piece, jobs):
+            out.write(blob)
+            crc = _crc32_combine(crc, c, k)
+            total += k
+        out.write(struct.pack("<II", crc, total & 0xFFFFFFFF))
+    return os.path.getsize(dst)
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (GF(2) matrix method), which the Python module does not export."""
+    if len2 == 0:
+        return crc1
+
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+
+    odd = [0xEDB88320] + [1 << n for n in range(31)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
 def _bgzf_range(args):
     import struct
     path, off, length, level = args
@@ -181,19 +244,42 @@ def main():
 
         # 4. gzip stream
         if a.gzip:
+            def gz_leg(label, gzpath, gz_bytes, tc, **env):
+                saved = {k: os.environ.get(k) for k in env}
+                for k, v in env.items():
+                    os.environ[k] = str(v)          # read by the library when the reader is opened
+                try:
+                    r = ia.Reader.from_path(gzpath)
+                    t0 = time.perf_counter()
+                    _, st = r.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
+                    dt = time.perf_counter() - t0
+                    r.close()
+                finally:
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                same = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()] == plain
+                emit(label, dt, st, gz_bytes=gz_bytes, gz_ratio=round(gz_bytes / file_bytes, 3), compress_seconds=round(tc, 2),
+                     equals_plain_path=same, **{k.lower(): v for k, v in env.items()})
+                assert same
+
             gz = path + ".gz"
             t0 = time.perf_counter()
             gz_bytes = gzip_parallel(path, gz)
             tc = time.perf_counter() - t0
-            r = ia.Reader.from_path(gz)
+            gz_leg("gzip (64 MiB members) Reader process_device DECODE, sequential zlib", gz, gz_bytes, tc, IBU_NO_PARALLEL_GZIP=1)
+            gz_leg("gzip (64 MiB members) Reader process_device DECODE, parallel inflate", gz, gz_bytes, tc)
+            os.unlink(gz)
+            # configs[4] literally: ONE gzip member (one deflate stream) — nothing in the container says where to start
             t0 = time.perf_counter()
-            _, st = r.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
-            dt = time.perf_counter() - t0
-            r.close()
-            same = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()] == plain
-            emit("gzip Reader process_device DECODE", dt, st, gz_bytes=gz_bytes, gz_ratio=round(gz_bytes / file_bytes, 3),
-                 compress_seconds=round(tc, 2), equals_plain_path=same)
-            assert same
+            gz_bytes = gzip_single_member(path, gz)
+            tc = time.perf_counter() - t0
+            gz_leg("gzip (one member) Reader process_device DECODE, sequential zlib", gz, gz_bytes, tc, IBU_NO_PARALLEL_GZIP=1)
+            for th in (2, 4, 8, 16, 32):
+                gz_leg("gzip (one member) Reader process_device DECODE, parallel inflate", gz, gz_bytes, tc, IBU_PGZ_THREADS=th)
+            gz_leg("gzip (one member) Reader process_device DECODE, parallel inflate", gz, gz_bytes, tc)
             os.unlink(gz)
             # the same records bgzip'd: block boundaries are known without inflating -> parallel inflate on the host
             bgz = path + ".bgz"

@@ -641,7 +641,17 @@ struct ParGzSource : Source {
     Source* in = inner.get();
     dec.reset(new pgz::ParallelGunzip([in](uint8_t* d, size_t cap, size_t* got) { return in->read(d, cap, got); }, env_threads(), env_chunk()));
   }
-  ~ParGzSource() override { if (next.valid()) (void)next.get(); }
+  ~ParGzSource() override {
+    if (next.valid()) (void)next.get();
+    if (getenv("IBU_PGZ_TRACE")) {                     // where the time of the parallel inflate went (wall seconds per phase)
+      const pgz::Stats& t = dec->stats();
+      fprintf(stderr, "[pgzip] in %llu B out %llu B batches %llu chunks accepted %llu discarded %llu no-candidate %llu markers %llu | "
+              "read %.3f find %.3f decode %.3f windows %.3f patch+crc %.3f carry %.3f s\n",
+              (unsigned long long)t.bytes_in, (unsigned long long)t.bytes_out, (unsigned long long)t.batches,
+              (unsigned long long)t.chunks_accepted, (unsigned long long)t.chunks_discarded, (unsigned long long)t.candidates_missing,
+              (unsigned long long)t.marker_symbols, t.s_read, t.s_find, t.s_decode, t.s_windows, t.s_patch_crc, t.s_carry);
+    }
+  }
   int refill_noexcept() {
     try { return dec->next_batch(next_out, &next_eof); }
     catch (const std::bad_alloc&) { return ENOMEM; }

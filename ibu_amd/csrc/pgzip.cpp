@@ -8,11 +8,13 @@
 #include "pgzip.hpp"
 
 #include <errno.h>
+#include <immintrin.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
 #include <chrono>
+#include <future>
 
 #include "common.hpp"
 
@@ -162,7 +164,7 @@ struct Bits {
 struct Segment { size_t out_end; uint32_t crc, isize; };  // a gzip member ended after out_end output elements
 
 enum St { S_HEADER, S_BLOCK, S_HUFF, S_STORED, S_TRAILER, S_DONE };
-enum Stop { R_BOUNDARY, R_OUT, R_IN, R_END, R_ERR };
+enum Stop { R_BOUNDARY, R_OUT, R_IN, R_END, R_ERR, R_SWITCH };
 
 struct Inflater {
   std::vector<uint32_t> lit_own, dist_own;
@@ -172,6 +174,7 @@ struct Inflater {
   bool last_block = false;
   uint32_t stored_left = 0;
   size_t bp = 0;                                     // bit position in the compressed buffer where decoding resumes
+  size_t clean_from = 0;                             // marker mode: every symbol from this output index on is a plain byte
   std::vector<Segment> segs;
   void use_own() {
     if (lit_own.empty()) { lit_own.resize(kLitCap); dist_own.resize(kDistCap); }
@@ -276,7 +279,9 @@ inline void lz_copy(T* o, size_t dist, size_t len) {
 //   R_OUT      in the middle of anything once ob.n >= out_cap,
 //   R_IN       when the bytes read so far do not suffice (only if !final),
 //   R_END      at the clean end of the input (final, behind a member trailer),
-//   R_ERR      on invalid data (or a truncated stream when final).
+//   R_ERR      on invalid data (or a truncated stream when final),
+//   R_SWITCH   (marker mode only) at a block boundary once the last 32 KiB of output hold no marker: nothing decoded
+//              from here on can refer to the unknown window, the caller continues in byte mode.
 // wlen: history elements in front of output element 0 that exist (distance check; kWin in marker mode).
 template <class T>
 Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, OutBuf<T>& ob, size_t out_cap, size_t wlen,
@@ -338,6 +343,7 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
       case S_BLOCK: {
         if (s.bp >= target && s.bp != entry_bp) return R_BOUNDARY;
         if (ob.n >= out_cap) return R_OUT;
+        if (sizeof(T) == 2 && ob.n >= s.clean_from + kWin) return R_SWITCH;
         // a dynamic header is < 400 bytes; when more input may come, do not start one that may not be whole
         if (!final && (s.bp >> 3) + 400 > in_len) return R_IN;
         if ((s.bp >> 3) >= in_len) return R_ERR;     // final and nothing left: truncated
@@ -411,22 +417,27 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
             return R_ERR;                            // ran far into the padding: truncated
           }
           b.refill();
+          // >= 56 bits after a refill: three symbols of <= 15 bits and 5 extra length bits fit.  Literals first: the
+          // subtable link is tested only on the way out of the literal path.
           uint32_t e = lit[b.buf & lmask];
-          if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
-          b.drop(e_bits(e));
-          if (e_kind(e) == K_LIT) {                    // >= 56 bits after a refill: three symbols of <= 15 bits + 5 extra bits fit
+          if (e_kind(e) == K_LIT) {
+            b.drop(e_bits(e));
             base[o++] = (T)e_val(e);
             e = lit[b.buf & lmask];
-            if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
-            b.drop(e_bits(e));
             if (e_kind(e) == K_LIT) {
+              b.drop(e_bits(e));
               base[o++] = (T)e_val(e);
               e = lit[b.buf & lmask];
-              if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
-              b.drop(e_bits(e));
-              if (e_kind(e) == K_LIT) { base[o++] = (T)e_val(e); continue; }
+              if (e_kind(e) == K_LIT) {
+                b.drop(e_bits(e));
+                base[o++] = (T)e_val(e);
+                continue;
+              }
             }
           }
+          if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
+          b.drop(e_bits(e));
+          if (e_kind(e) == K_LIT) { base[o++] = (T)e_val(e); continue; }
           if (e_kind(e) == K_BASE) {
             const size_t len = e_val(e) + b.take(e_extra(e));
             b.refill();
@@ -436,6 +447,7 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
             if (e_kind(d) != K_BASE) return R_ERR;
             const size_t dd = e_val(d) + b.take(e_extra(d));
             if (dd > o + wlen) return R_ERR;         // reaches in front of the history
+            if (sizeof(T) == 2 && (dd > o || o - dd < s.clean_from)) s.clean_from = o + len;   // may have copied markers
             lz_copy(base + o, dd, len);
             o += len;
             continue;
@@ -519,21 +531,126 @@ bool resolve(const uint16_t* src, size_t n, const uint8_t* win, uint8_t* dst, ui
 
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// CRC-32 (the gzip polynomial) by carry-less multiplication: four 128-bit lanes folded over 64 bytes per step, then
+// folded together and Barrett-reduced (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ",
+// Intel 2009; constants for the bit-reflected polynomial 0xEDB88320).  `crc` in and out are zlib's crc32() values.
+// zlib 1.2.11's table-driven crc32 runs at ~0.8 GB/s here, a quarter of the whole parallel decode; this one at memory speed.
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t crc, const uint8_t* buf, size_t len) {  // len >= 64, len % 16 == 0
+  alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+  alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+  alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0};
+  alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+  __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+  x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
+  x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+  x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
+  x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)~crc));
+  x0 = _mm_load_si128((const __m128i*)k1k2);
+  buf += 64;
+  len -= 64;
+  while (len >= 64) {
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+    x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+    x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    y5 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
+    y6 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+    y7 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
+    y8 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+    buf += 64;
+    len -= 64;
+  }
+  x0 = _mm_load_si128((const __m128i*)k3k4);          // four lanes -> one
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+  while (len >= 16) {                                  // remaining whole 16-byte blocks
+    x2 = _mm_loadu_si128((const __m128i*)buf);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    buf += 16;
+    len -= 16;
+  }
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);             // 128 -> 64 bits
+  x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x1 = _mm_srli_si128(x1, 8);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+  x2 = _mm_srli_si128(x1, 4);
+  x1 = _mm_and_si128(x1, x3);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_load_si128((const __m128i*)poly);           // Barrett reduction to 32 bits
+  x2 = _mm_and_si128(x1, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+  x2 = _mm_and_si128(x2, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  return ~(uint32_t)_mm_extract_epi32(x1, 1);
+}
+bool have_clmul() {
+  static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+  return ok;
+}
+uint32_t crc32_bytes(uint32_t crc, const uint8_t* buf, size_t len) {
+  if (len >= 64 && have_clmul()) {
+    const size_t k = len & ~(size_t)15;
+    crc = crc32_clmul(crc, buf, k);
+    buf += k;
+    len -= k;
+  }
+  while (len) {                                        // zlib's crc32 takes a uInt length
+    const size_t k = len > ((size_t)1 << 30) ? (size_t)1 << 30 : len;
+    crc = (uint32_t)crc32(crc, buf, (uInt)k);
+    buf += k;
+    len -= k;
+  }
+  return crc;
+}
+
 struct Chunk {
   size_t start = kNone;                              // candidate bit position (chunk 0: the true position)
   size_t target = kNone;
   Inflater inf;
-  OutBuf<uint8_t> o8;                                // chunk 0
-  OutBuf<uint16_t> o16;                              // the others
+  OutBuf<uint16_t> o16;                              // head of a chunk >= 1: symbols (bytes and markers)
+  OutBuf<uint8_t> o8;                                // chunk 0, and the tail of a chunk >= 1 once it is marker-free
   Stop stop = R_ERR;
   int oom = 0;
-  size_t n_out() const { return o8.mem ? o8.n : o16.n; }   // chunk 0 of a batch decodes to bytes, the others to symbols
+  size_t n_out() const { return o16.n + o8.n; }
   // after acceptance
   size_t out_off = 0;
   std::vector<uint8_t> win_tmp;
   const uint8_t* win = nullptr;
   std::vector<uint32_t> piece_crc;                   // one per segment + one for the open tail
   bool bad_symbol = false;
+  // final bytes of output elements [a, b) of this chunk -> dst (dst[0] = element a)
+  bool finalize(size_t a, size_t b, uint8_t* dst, uint64_t* markers) {
+    bool good = true;
+    if (a < o16.n) {
+      const size_t e = b < o16.n ? b : o16.n;
+      good = resolve(o16.at0() + a, e - a, win, dst, markers);
+      dst += e - a;
+      a = e;
+    }
+    if (a < b) memcpy(dst, o8.at0() + (a - o16.n), b - a);
+    return good;
+  }
 };
 
 }  // namespace
@@ -563,6 +680,41 @@ struct ParallelGunzip::Impl {
   uint64_t run_len = 0;
   size_t out_cap;
   std::vector<Chunk> pool;                           // per-chunk buffers and tables, reused from batch to batch
+  // read-ahead: while a batch is searched / decoded / patched, one helper thread reads the next batch's compressed bytes
+  // (the read is otherwise 1/7 of the wall time: a single thread copying 12 GB out of the page cache)
+  std::vector<uint8_t> ahead;
+  size_t ahead_len = 0;
+  bool ahead_eof = false;
+  std::future<int> ahead_f;
+  int join_ahead() {                                 // appends what the helper read to comp
+    if (!ahead_f.valid()) return 0;
+    int rc;
+    try { rc = ahead_f.get(); } catch (...) { rc = EIO; }
+    if (rc) return rc;
+    if (comp.size() < comp_len + ahead_len + kPad) comp.resize(comp_len + ahead_len + kPad);
+    if (ahead_len) memcpy(comp.data() + comp_len, ahead.data(), ahead_len);
+    comp_len += ahead_len;
+    ahead_len = 0;
+    if (ahead_eof) inner_eof = true;
+    return 0;
+  }
+  void start_ahead(size_t bytes) {
+    if (inner_eof || bytes == 0) return;
+    try {
+      if (ahead.size() < bytes) ahead.resize(bytes);
+      ahead_f = std::async(std::launch::async, [this, bytes]() -> int {
+        while (ahead_len < bytes) {
+          size_t got = 0;
+          const int rc = inner(ahead.data() + ahead_len, bytes - ahead_len, &got);
+          if (rc) return rc;
+          if (got == 0) { ahead_eof = true; break; }
+          ahead_len += got;
+        }
+        return 0;
+      });
+    } catch (...) {                                    // no thread / no memory: the next top-up reads synchronously
+    }
+  }
 };
 
 ParallelGunzip::ParallelGunzip(ReadFn inner, unsigned threads, size_t chunk_bytes) : p_(new Impl) {
@@ -572,7 +724,9 @@ ParallelGunzip::ParallelGunzip(ReadFn inner, unsigned threads, size_t chunk_byte
   p_->out_cap = p_->chunk * 24 < ((size_t)1 << 20) ? (size_t)1 << 20 : p_->chunk * 24;  // elements per chunk and batch
   p_->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
 }
-ParallelGunzip::~ParallelGunzip() {}
+ParallelGunzip::~ParallelGunzip() {
+  if (p_ && p_->ahead_f.valid()) { try { (void)p_->ahead_f.get(); } catch (...) {} }
+}
 
 int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
   Impl& P = *p_;
@@ -586,6 +740,12 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     double t0 = now_s(), t1;
     const size_t base_byte = P.cur.bp >> 3;
     const size_t want = base_byte + (size_t)P.threads * P.chunk + kSlack;
+    {
+      const size_t before = P.comp_len;
+      const int rc = P.join_ahead();
+      if (rc) { P.failed = true; return rc; }
+      st_.bytes_in += P.comp_len - before;
+    }
     if (P.comp.size() < want + kPad) P.comp.resize(want + kPad);
     while (P.comp_len < want && !P.inner_eof) {
       size_t got = 0;
@@ -596,6 +756,7 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
       st_.bytes_in += got;
     }
     memset(P.comp.data() + P.comp_len, 0, kPad);
+    P.start_ahead((size_t)P.threads * P.chunk);       // uses `inner` until joined at the next top-up; nothing else touches it meanwhile
     const uint8_t* in = P.comp.data();
     const size_t in_len = P.comp_len;
     const bool final = P.inner_eof;
@@ -659,7 +820,16 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
       c.inf.bp = c.start;
       if (!c.o16.reserve(P.chunk * 4)) { c.oom = 1; c.stop = R_ERR; return; }
       for (size_t i = 0; i < kWin; ++i) c.o16.mem[i] = (uint16_t)(0x8000u + i);
+      c.inf.clean_from = 0;
       c.stop = run<uint16_t>(c.inf, in, in_len, final, c.target, c.o16, P.out_cap, kWin, &c.oom);
+      if (c.stop != R_SWITCH) return;
+      // the last 32 KiB are plain bytes: they are the window of everything that follows -> byte mode (faster, no patching)
+      if (!c.o8.reserve(P.chunk * 4)) { c.oom = 1; c.stop = R_ERR; return; }
+      const uint16_t* tail = c.o16.at0() + c.o16.n - kWin;
+      for (size_t i = 0; i < kWin; ++i) c.o8.mem[i] = (uint8_t)tail[i];
+      const size_t nseg = c.inf.segs.size(), cap8 = P.out_cap > c.o16.n ? P.out_cap - c.o16.n : 0;
+      c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.o8, cap8, kWin, &c.oom);
+      for (size_t g = nseg; g < c.inf.segs.size(); ++g) c.inf.segs[g].out_end += c.o16.n;   // member ends count from the chunk's start
     });
 
     t1 = now_s(); st_.s_decode += t1 - t0; t0 = t1;
@@ -685,25 +855,22 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     if (!out.resize_uninit(total)) { P.failed = true; return ENOMEM; }
     uint8_t* const dst = out.data;
     auto tail_of = [](size_t nn) { return nn < kWin ? nn : kWin; };
-    // chunk 0's bytes are final: copy its tail now (a window source), its body in the parallel step
-    {
-      Chunk& c0 = ch[0];
-      const size_t t = tail_of(c0.o8.n);
-      if (t) memcpy(dst + c0.o8.n - t, c0.o8.at0() + c0.o8.n - t, t);
-    }
-    for (size_t a = 1; a < ok.size(); ++a) {           // sequential: 32 KiB per chunk
+    // sequential: the last 32 KiB of every chunk in order (each is the window of the next chunk)
+    for (size_t a = 0; a < ok.size(); ++a) {
       Chunk& c = ch[ok[a]];
-      if (c.out_off >= kWin) c.win = dst + c.out_off - kWin;
-      else {                                           // the window reaches back into the previous batch
-        c.win_tmp.assign(kWin, 0);
-        const size_t from_old = kWin - c.out_off, have = P.window.size() < from_old ? P.window.size() : from_old;
-        if (have) memcpy(c.win_tmp.data() + from_old - have, P.window.data() + P.window.size() - have, have);
-        if (c.out_off) memcpy(c.win_tmp.data() + from_old, dst, c.out_off);
-        c.win = c.win_tmp.data();
+      if (a > 0) {
+        if (c.out_off >= kWin) c.win = dst + c.out_off - kWin;
+        else {                                         // the window reaches back into the previous batch
+          c.win_tmp.assign(kWin, 0);
+          const size_t from_old = kWin - c.out_off, have = P.window.size() < from_old ? P.window.size() : from_old;
+          if (have) memcpy(c.win_tmp.data() + from_old - have, P.window.data() + P.window.size() - have, have);
+          if (c.out_off) memcpy(c.win_tmp.data() + from_old, dst, c.out_off);
+          c.win = c.win_tmp.data();
+        }
       }
-      const size_t t = tail_of(c.o16.n);
+      const size_t nn = c.n_out(), t = tail_of(nn);
       uint64_t m = 0;
-      if (!resolve(c.o16.at0() + c.o16.n - t, t, c.win, dst + c.out_off + c.o16.n - t, &m)) c.bad_symbol = true;
+      if (t && !c.finalize(nn - t, nn, dst + c.out_off + nn - t, &m)) c.bad_symbol = true;
       st_.marker_symbols += m;
     }
     t1 = now_s(); st_.s_windows += t1 - t0; t0 = t1;
@@ -711,17 +878,11 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     run_pieces((unsigned)ok.size(), [&](unsigned a) {
       Chunk& c = ch[ok[a]];
       const size_t nn = c.n_out(), body = nn - tail_of(nn);
-      if (a == 0) { if (body) memcpy(dst, c.o8.at0(), body); }
-      else if (!resolve(c.o16.at0(), body, c.win, dst + c.out_off, &markers[a])) c.bad_symbol = true;
+      if (body && !c.finalize(0, body, dst + c.out_off, &markers[a])) c.bad_symbol = true;
       size_t from = 0;
       for (size_t g = 0; g <= c.inf.segs.size(); ++g) {
         const size_t to = g < c.inf.segs.size() ? c.inf.segs[g].out_end : nn;
-        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-        for (size_t p = from; p < to;) {               // crc32 takes a uInt length
-          const size_t k = to - p > ((size_t)1 << 30) ? (size_t)1 << 30 : to - p;
-          crc = (uint32_t)crc32(crc, dst + c.out_off + p, (uInt)k);
-          p += k;
-        }
+        const uint32_t crc = crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), dst + c.out_off + from, to - from);
         c.piece_crc.push_back(crc);
         from = to;
       }

@@ -55,6 +55,9 @@ def parse():
     # rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never used by the driver):
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: collectives on CPU tensors")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise the process group and run every collective even with one rank (a one-GPU box can then "
+                        "execute the RCCL code path of the N > 1 runs: init, barrier, all_reduce, all_gather)")
     return p.parse_args()
 
 
@@ -228,8 +231,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
         local_rank = 0
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":  # "nccl" IS RCCL on ROCm
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -255,13 +260,13 @@ def main():
     assert st != 0
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     leg = Leg(ctx, torch, dev, st, args.seed, first, n, bc_len, umi_len)
     elapsed, dec_ms, enc_ms = leg.timed(args.steps, args.warmup, barrier)
     per_rank = [[float(n), dec_ms, enc_ms, elapsed]]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         mine = torch.tensor(per_rank[0], dtype=torch.float64, device=coll_dev)
@@ -274,11 +279,11 @@ def main():
     red, verified = leg.verify(not args.no_verify)
     # the one cross-GPU exchange: global count + wrapping field sums (4 x i64 over RCCL); timed on its second call
     # (the first pays the communicator's lazy set-up)
-    g = sharding.global_totals(red, device=coll_dev)
+    g = sharding.global_totals(red, device=coll_dev, force=args.force_dist)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    g = sharding.global_totals(red, device=coll_dev)
+    g = sharding.global_totals(red, device=coll_dev, force=args.force_dist)
     torch.cuda.synchronize()
     allreduce_ms = (time.perf_counter() - t0) * 1e3
     tot = [g["count"]] + g["sum"]
@@ -356,7 +361,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

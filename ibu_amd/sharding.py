@@ -25,15 +25,16 @@ def _to_i64(v):
     return v - (1 << 64) if v >= (1 << 63) else v
 
 
-def global_totals(local, device=None, group=None):
+def global_totals(local, device=None, group=None, force=False):
     """Combine per-rank `{"count", "sum"[3], "xor"[3]}` (Context.reduce) into the global one.
 
     Wrapping u64 adds are two's-complement i64 adds, so SUM over int64 is bit-exact.  Without an
-    initialised process group (single GPU) the local value is returned unchanged."""
+    initialised process group (single GPU) the local value is returned unchanged; so it is with a group of one rank
+    unless `force` (a one-GPU box rehearsing the collectives of the N > 1 runs)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return {"count": local["count"], "sum": list(local["sum"]), "xor": list(local["xor"])}
     world = dist.get_world_size(group)
     t = torch.tensor([_to_i64(local["count"])] + [_to_i64(v) for v in local["sum"]], dtype=torch.int64, device=device)
@@ -126,15 +127,16 @@ def _collective(t, group):
     return t.cpu() if dist.get_backend(group) == "gloo" and t.device.type != "cpu" else t
 
 
-def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None):
+def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None, force=False):
     """Sort the records of all ranks globally.  `buf`: this rank's n records (24 n bytes, uint8 tensor).  Returns
     (out_buf, n_out): rank r holds the r-th contiguous range of the global order; sum of n_out == sum of n.
-    `stats` (dict, optional) receives the exchange's byte counts."""
+    `stats` (dict, optional) receives the exchange's byte counts.  `force`: run every collective even in a group of
+    one rank (a one-GPU box rehearsing the RCCL calls of the N > 1 runs)."""
     import torch
     import torch.distributed as dist
 
     ops.local_sort(buf, n)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return buf, n
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = buf.device

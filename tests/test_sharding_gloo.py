@@ -102,7 +102,7 @@ class _NumpySortOps:
         return bytes(buf[i * 24:(i + 1) * 24].numpy())
 
 
-def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir):
+def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir, force=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -119,7 +119,9 @@ def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir):
             recs["barcode"] %= 3
             recs["umi"] %= 2
         buf = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()) if counts[rank] else torch.empty(24, dtype=torch.uint8)
-        out, n_out = sharding.distributed_sort(_NumpySortOps(orc), buf, counts[rank], samples_per_rank=16)
+        out, n_out = sharding.distributed_sort(_NumpySortOps(orc), buf, counts[rank], samples_per_rank=16, force=force)
+        tot = sharding.global_totals(orc.reduce_records(recs), force=force)
+        assert tot["count"] >= counts[rank]
         np.save(os.path.join(out_dir, f"s{rank}.npy"), out[: n_out * 24].numpy())
     finally:
         dist.destroy_process_group()
@@ -141,3 +143,15 @@ def test_distributed_sort_control_flow(tmp_path, oracle, counts, lens, skew):
     assert b"".join(parts) == want  # rank order IS the global order; nothing lost, nothing duplicated
     if not skew and sum(counts) > 1000:  # samples balance the ranges roughly (no rank ends up with everything)
         assert max(len(p) for p in parts) < 0.8 * len(want)
+
+
+def test_group_of_one_rank_runs_every_collective_when_forced(tmp_path, oracle):
+    """`force=True` (bench.py / tools/sharded_sort.py --force-dist): a single rank still goes through the sample
+    gather, the count exchange and the record all-to-all (zero splitters) — what a one-GPU box runs to put the RCCL
+    calls of the N > 1 path on real hardware before an 8-GPU node ever does."""
+    import torch.multiprocessing as mp
+
+    counts, lens, seed = [6007], (16, 12), 0x1B00006
+    mp.spawn(_sort_worker, args=(1, _free_port(), counts, seed, lens, False, str(tmp_path), True), nprocs=1, join=True)
+    want = oracle.sort_records(oracle.generate(seed, 0, counts[0], *lens)).tobytes()
+    assert np.load(tmp_path / "s0.npy").tobytes() == want

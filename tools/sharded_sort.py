@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--records", type=float, default=1e8, help="records per rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="one rank, but every collective runs (RCCL rehearsal on a one-GPU box)")
     ap.add_argument("--lens", default="16,12")
     a = ap.parse_args()
     import torch
@@ -33,8 +34,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29532")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -48,25 +51,25 @@ def main():
     first, end = sharding.rank_shard(n * world, world, rank)
     buf = torch.empty(n * 24, dtype=torch.uint8, device=dev)
     ctx.generate(0x1B00007, first, n, bc_len, umi_len, buf)
-    before = sharding.global_totals(ctx.reduce(buf, n), device=coll_dev)
-    if world > 1:
+    before = sharding.global_totals(ctx.reduce(buf, n), device=coll_dev, force=a.force_dist)
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     stats = {}
-    out, n_out = sharding.distributed_sort(sharding.DeviceSortOps(ctx), buf, n, stats=stats)
+    out, n_out = sharding.distributed_sort(sharding.DeviceSortOps(ctx), buf, n, stats=stats, force=a.force_dist)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     ok = ctx.is_sorted(out, n_out) if n_out else True
     ops = sharding.DeviceSortOps(ctx)
     edge = (ops.fetch(out, 0), ops.fetch(out, n_out - 1)) if n_out else None
     edges = [None] * world
-    if world > 1:
+    if use_dist:
         dist.all_gather_object(edges, (ok, n_out, edge, stats.get("sent_bytes", 0), stats.get("exchange_seconds", 0.0)))  # result check only
     else:
         edges = [(ok, n_out, edge, 0, 0.0)]
-    after = sharding.global_totals(ctx.reduce(out, n_out), device=coll_dev)
+    after = sharding.global_totals(ctx.reduce(out, n_out), device=coll_dev, force=a.force_dist)
     if rank == 0:
         keys = [(sharding._rec_key(e[2][0]), sharding._rec_key(e[2][1])) for e in edges if e[1]]
         ordered = all(keys[i][1] <= keys[i + 1][0] for i in range(len(keys) - 1))
@@ -77,7 +80,7 @@ def main():
                           "exchange_GBps_per_rank": round(max(e[3] for e in edges) / max(max(e[4] for e in edges), 1e-9) / 1e9, 2),
                           "every_rank_sorted": all(e[0] for e in edges), "rank_ranges_ordered": ordered,
                           "multiset_preserved": before == after, "count": after["count"]}), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

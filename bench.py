@@ -142,7 +142,7 @@ def traffic_from_profile(bc_len, umi_len, n):
         return None, None
 
 
-def place_leg(make, tries, set_bytes, torch, dev):
+def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     """Placement probing.  On this part the rate of a read+write streaming kernel depends on WHERE the driver put the
     arrays' physical pages: the same kernel on the same GPU runs 9.4 ... 11.3 ms from one allocation to the next
     (profiles/README.md: pool survey, r02_placement_pmc — L2 tag-pipeline stalls, not translation), and an
@@ -152,7 +152,7 @@ def place_leg(make, tries, set_bytes, torch, dev):
     few hundred ms once, and every probe is reported in the line (`placement`), the first one being what a job that
     does not probe would have got."""
     free_b, _ = torch.cuda.mem_get_info(dev)
-    tries = max(1, min(tries, int(free_b * 0.94 // max(set_bytes, 1))))
+    tries = max(1, min(tries, int(free_b * 0.94 / max(sharers, 1) // max(set_bytes, 1))))   # sharers: ranks on this GPU (rehearsals)
     legs, probes = [], []
     for _ in range(tries):
         leg = make()
@@ -302,7 +302,7 @@ def main():
             dist.barrier()
 
     leg, placement = place_leg(lambda: Leg(ctx, torch, dev, st, args.seed, first, n, bc_len, umi_len), args.placement_tries,
-                               n * (48 + bc_len + umi_len + 8), torch, dev)
+                               n * (48 + bc_len + umi_len + 8), torch, dev, sharers=world if args.share_gpu else 1)
     elapsed, dec_ms, enc_ms = leg.timed(args.steps, args.warmup, barrier)
     per_rank = [[float(n), dec_ms, enc_ms, elapsed]]
     if use_dist:

@@ -68,7 +68,7 @@ def test_cpp_mirror_under_asan_ubsan(tmp_path, oracle):
     fx = tmp_path / "compressed"
     fx.mkdir()
     _compressed_fixture(fx, oracle)
-    env = {**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx),
+    env = {**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx), "IBU_PGZ_THREADS": "4", "IBU_PGZ_CHUNK": "4096",
            "ASAN_OPTIONS": "detect_leaks=1:halt_on_error=1", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"}
     r = _run([os.path.join(BIN, "asan", "test_host")], env=env)
     assert r.returncode == 0 and "0 failed" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -82,12 +82,14 @@ def test_plain_c_client_of_the_abi(built):
 
 @pytest.mark.skipif(not os.environ.get("IBU_RUN_ASAN"), reason="set IBU_RUN_ASAN=1: builds a sanitized library (~1 min)")
 def test_cpp_mirror_under_tsan(tmp_path, oracle):
-    """ThreadSanitizer over process_parallel's workers, the parallel loaders and the BGZF inflate threads."""
+    """ThreadSanitizer over process_parallel's workers, the parallel loaders, the BGZF inflate threads and the parallel
+    gzip inflate (many small chunks per batch: IBU_PGZ_CHUNK)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "tsan"])
     fx = tmp_path / "compressed"
     fx.mkdir()
     _compressed_fixture(fx, oracle)
-    env = {**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx), "TSAN_OPTIONS": "halt_on_error=1"}
+    env = {**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx), "IBU_PGZ_THREADS": "4", "IBU_PGZ_CHUNK": "4096",
+           "TSAN_OPTIONS": "halt_on_error=1"}
     r = _run([os.path.join(BIN, "tsan", "test_host")], env=env)
     assert r.returncode == 0 and "0 failed" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout[-2000:] + r.stderr[-4000:]
 

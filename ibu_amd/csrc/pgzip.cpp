@@ -260,17 +260,31 @@ struct OutBuf {
   }
 };
 
+// Copy of a match.  May write up to 16 elements past `len` (the buffers keep 64 elements of slack); most matches of a
+// fast-level gzip stream are 3-6 long, so the first piece is stored unconditionally and the loop is the exception.
 template <class T>
 inline void lz_copy(T* o, size_t dist, size_t len) {
   const T* s = o - dist;
-  if (dist * sizeof(T) >= 16) {                      // 16-byte pieces never overlap their own source; may write <= 15 B past len
-    T* const end = o + len;
-    do { memcpy(o, s, 16); o += 16 / sizeof(T); s += 16 / sizeof(T); } while (o < end);
-  } else if (dist == 1) {
-    const T v = s[0];
-    for (size_t i = 0; i < len; ++i) o[i] = v;
-  } else {
-    for (size_t i = 0; i < len; ++i) o[i] = s[i];
+  constexpr size_t W = 16 / sizeof(T);               // elements per 16-byte piece
+  if (dist >= W) {                                   // a piece never overlaps its own source
+    memcpy(o, s, 16);
+    if (len > W) {
+      T* const end = o + len;
+      o += W; s += W;
+      do { memcpy(o, s, 16); o += W; s += W; } while (o < end);
+    }
+  } else if (dist == 1) {                            // run of one value
+    uint64_t v = (uint64_t)s[0];
+    v *= sizeof(T) == 1 ? 0x0101010101010101ull : 0x0001000100010001ull;
+    memcpy(o, &v, 8);
+    memcpy(reinterpret_cast<uint8_t*>(o) + 8, &v, 8);
+    if (len > W) {
+      T* const end = o + len;
+      for (o += W; o < end; o += W) { memcpy(o, &v, 8); memcpy(reinterpret_cast<uint8_t*>(o) + 8, &v, 8); }
+    }
+  } else {                                           // 2 <= dist < W: the pattern repeats inside a piece
+    for (size_t i = 0; i < W; ++i) o[i] = s[i];
+    for (size_t i = W; i < len; ++i) o[i] = s[i];
   }
 }
 
@@ -417,8 +431,8 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
             return R_ERR;                            // ran far into the padding: truncated
           }
           b.refill();
-          // >= 56 bits after a refill: three symbols of <= 15 bits and 5 extra length bits fit.  Literals first: the
-          // subtable link is tested only on the way out of the literal path.
+          // >= 56 bits after a refill: three symbols of <= 15 bits fit.  Literals first; the subtable link is tested only
+          // on the way out of the literal path.
           uint32_t e = lit[b.buf & lmask];
           if (e_kind(e) == K_LIT) {
             b.drop(e_bits(e));
@@ -436,11 +450,11 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
             }
           }
           if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
-          b.drop(e_bits(e));
+          b.drop(e_bits(e));                           // >= 11 bits left in the worst case (two 15-bit literals in front)
           if (e_kind(e) == K_LIT) { base[o++] = (T)e_val(e); continue; }
           if (e_kind(e) == K_BASE) {
             const size_t len = e_val(e) + b.take(e_extra(e));
-            b.refill();
+            if (b.cnt < 32) b.refill();                // a distance needs <= 15 + 13 bits
             uint32_t d = dist[b.buf & dmask];
             if (e_kind(d) == K_SUB) { b.drop(kDistBits); d = dist[e_val(d) + (b.buf & ((1u << e_extra(d)) - 1))]; }
             b.drop(e_bits(d));

@@ -685,8 +685,8 @@ struct ParallelGunzip::Impl {
   ReadFn inner;
   unsigned threads;
   size_t chunk;
-  std::vector<uint8_t> comp;                         // compressed bytes not yet consumed + kPad zeros
-  size_t comp_len = 0;
+  std::vector<uint8_t> comp;                         // compressed bytes not yet consumed live at comp[comp_off, comp_off + comp_len), kPad zeros behind
+  size_t comp_off = 0, comp_len = 0;
   bool inner_eof = false, done = false, failed = false;
   Inflater cur;                                      // the true decoder state; cur.bp is relative to comp[0]
   std::vector<uint8_t> window;                       // last <= 32 KiB of output
@@ -695,18 +695,22 @@ struct ParallelGunzip::Impl {
   size_t out_cap;
   std::vector<Chunk> pool;                           // per-chunk buffers and tables, reused from batch to batch
   // read-ahead: while a batch is searched / decoded / patched, one helper thread reads the next batch's compressed bytes
-  // (the read is otherwise 1/7 of the wall time: a single thread copying 12 GB out of the page cache)
+  // (otherwise 1/7 of the wall time: one thread copying 12 GB out of the page cache) — into the SECOND buffer, behind a
+  // gap that is large enough for whatever the current batch leaves unconsumed; at the next top-up the leftover (small)
+  // is copied in front of the new bytes and the two buffers swap roles: the bulk of the input is never copied again.
   std::vector<uint8_t> ahead;
-  size_t ahead_len = 0;
+  size_t ahead_gap = 0, ahead_len = 0;
   bool ahead_eof = false;
   std::future<int> ahead_f;
-  int join_ahead() {                                 // appends what the helper read to comp
+  int join_ahead() {
     if (!ahead_f.valid()) return 0;
     int rc;
     try { rc = ahead_f.get(); } catch (...) { rc = EIO; }
     if (rc) return rc;
-    if (comp.size() < comp_len + ahead_len + kPad) comp.resize(comp_len + ahead_len + kPad);
-    if (ahead_len) memcpy(comp.data() + comp_len, ahead.data(), ahead_len);
+    // leftover <= the comp_len the gap was sized for (bytes are only consumed in between)
+    if (comp_len) memcpy(ahead.data() + ahead_gap - comp_len, comp.data() + comp_off, comp_len);
+    comp.swap(ahead);
+    comp_off = ahead_gap - comp_len;
     comp_len += ahead_len;
     ahead_len = 0;
     if (ahead_eof) inner_eof = true;
@@ -715,11 +719,14 @@ struct ParallelGunzip::Impl {
   void start_ahead(size_t bytes) {
     if (inner_eof || bytes == 0) return;
     try {
-      if (ahead.size() < bytes) ahead.resize(bytes);
+      ahead_gap = comp_len;
+      if (ahead.size() < ahead_gap + bytes + kPad) ahead.resize(ahead_gap + bytes + kPad);
+      ahead_len = 0;
       ahead_f = std::async(std::launch::async, [this, bytes]() -> int {
+        uint8_t* const dst = ahead.data() + ahead_gap;
         while (ahead_len < bytes) {
           size_t got = 0;
-          const int rc = inner(ahead.data() + ahead_len, bytes - ahead_len, &got);
+          const int rc = inner(dst + ahead_len, bytes - ahead_len, &got);
           if (rc) return rc;
           if (got == 0) { ahead_eof = true; break; }
           ahead_len += got;
@@ -760,18 +767,24 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
       if (rc) { P.failed = true; return rc; }
       st_.bytes_in += P.comp_len - before;
     }
-    if (P.comp.size() < want + kPad) P.comp.resize(want + kPad);
-    while (P.comp_len < want && !P.inner_eof) {
-      size_t got = 0;
-      const int rc = P.inner(P.comp.data() + P.comp_len, want - P.comp_len, &got);
-      if (rc) { P.failed = true; return rc; }
-      if (got == 0) P.inner_eof = true;
-      P.comp_len += got;
-      st_.bytes_in += got;
+    if (P.comp_len < want && !P.inner_eof) {
+      if (P.comp.size() < P.comp_off + want + kPad) {
+        if (P.comp_off) { memmove(P.comp.data(), P.comp.data() + P.comp_off, P.comp_len); P.comp_off = 0; }
+        if (P.comp.size() < want + kPad) P.comp.resize(want + kPad);
+      }
+      while (P.comp_len < want && !P.inner_eof) {
+        size_t got = 0;
+        const int rc = P.inner(P.comp.data() + P.comp_off + P.comp_len, want - P.comp_len, &got);
+        if (rc) { P.failed = true; return rc; }
+        if (got == 0) P.inner_eof = true;
+        P.comp_len += got;
+        st_.bytes_in += got;
+      }
     }
-    memset(P.comp.data() + P.comp_len, 0, kPad);
+    if (P.comp.size() < P.comp_off + P.comp_len + kPad) P.comp.resize(P.comp_off + P.comp_len + kPad);
+    memset(P.comp.data() + P.comp_off + P.comp_len, 0, kPad);
     P.start_ahead((size_t)P.threads * P.chunk);       // uses `inner` until joined at the next top-up; nothing else touches it meanwhile
-    const uint8_t* in = P.comp.data();
+    const uint8_t* in = P.comp.data() + P.comp_off;
     const size_t in_len = P.comp_len;
     const bool final = P.inner_eof;
 
@@ -932,10 +945,10 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     P.cur = std::move(lastc.inf);
     P.cur.segs.clear();
     const size_t shift = P.cur.bp >> 3;
-    if (shift) {
-      const size_t keep = shift < P.comp_len ? P.comp_len - shift : 0;
-      memmove(P.comp.data(), P.comp.data() + (shift < P.comp_len ? shift : P.comp_len), keep);
-      P.comp_len = keep;
+    if (shift) {                                       // consumed bytes are dropped by moving the start, not the bytes
+      const size_t drop = shift < P.comp_len ? shift : P.comp_len;
+      P.comp_off += drop;
+      P.comp_len -= drop;
       P.cur.bp -= shift * 8;
     }
     st_.batches++;

@@ -183,3 +183,21 @@ def test_large_file_default_settings_and_process_equivalence(tmp_path, monkeypat
     p.write_bytes(_zc(raw[:half], 1) + _zc(raw[half:], 6))
     got = _read_all(p)
     assert hashlib.md5(got).digest() == hashlib.md5(raw[32:]).digest()
+
+
+@pytest.mark.parametrize("level", ["-1", "-6", "-9"])
+def test_streams_written_by_the_gzip_program(tmp_path, monkeypatch, level):
+    """GNU gzip has its own deflate implementation (block splitting and match finding differ from zlib's): its output
+    must inflate to the same bytes, too.  Skipped where the program is missing."""
+    import shutil
+    import subprocess
+    if not shutil.which("gzip"):
+        pytest.skip("no gzip program on this host")
+    P = payloads()
+    raw = _header() + P["records"][:24 * 100_000] + P["text"][:600_000] + P["zeros"][:24 * 20_000] + P["random"][:24 * 5000]
+    p = tmp_path / "cli.ibu"
+    p.write_bytes(raw)
+    subprocess.check_call(["gzip", level, "-k", "-n", str(p)])
+    for threads, chunk in ((4, 4096), (6, 50_000)):
+        _knobs(monkeypatch, threads, chunk)
+        assert _read_all(str(p) + ".gz") == raw[32:]

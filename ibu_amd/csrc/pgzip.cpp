@@ -163,7 +163,7 @@ struct Bits {
 
 struct Segment { size_t out_end; uint32_t crc, isize; };  // a gzip member ended after out_end output elements
 
-enum St { S_HEADER, S_BLOCK, S_HUFF, S_STORED, S_TRAILER, S_DONE };
+enum St { S_HEADER, S_BLOCK, S_HUFF, S_STORED_LEN, S_STORED, S_TRAILER, S_DONE };
 enum Stop { R_BOUNDARY, R_OUT, R_IN, R_END, R_ERR, R_SWITCH };
 
 struct Inflater {
@@ -289,7 +289,9 @@ inline void lz_copy(T* o, size_t dist, size_t len) {
 }
 
 // Runs `s` over in[0, in_len) from s.bp.  Stops
-//   R_BOUNDARY at the first block boundary (state S_BLOCK) whose bit position is >= target and != s.bp at entry,
+//   R_BOUNDARY at the first block boundary (state S_BLOCK) whose bit position is >= target and != s.bp at entry; with
+//              target_stored also in state S_STORED_LEN (behind a stored block's 3 header bits and padding, in front of
+//              its LEN field) when that byte position is exactly the target and the block is not the final one,
 //   R_OUT      in the middle of anything once ob.n >= out_cap,
 //   R_IN       when the bytes read so far do not suffice (only if !final),
 //   R_END      at the clean end of the input (final, behind a member trailer),
@@ -298,8 +300,8 @@ inline void lz_copy(T* o, size_t dist, size_t len) {
 //              from here on can refer to the unknown window, the caller continues in byte mode.
 // wlen: history elements in front of output element 0 that exist (distance check; kWin in marker mode).
 template <class T>
-Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, OutBuf<T>& ob, size_t out_cap, size_t wlen,
-         int* oom) {
+Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, bool target_stored, OutBuf<T>& ob,
+         size_t out_cap, size_t wlen, int* oom) {
   const size_t entry_bp = s.bp;
   // positions at which the hot loop gives up: never touch bytes behind in_len + kPad; when more input may come, stop 64 B early
   const size_t pos_lim = final ? in_len + 16 : (in_len > 64 ? in_len - 64 : 0);
@@ -365,13 +367,8 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
         s.last_block = b.take(1) != 0;
         const uint32_t type = b.take(2);
         if (type == 0) {
-          const size_t p = (b.bitpos() + 7) >> 3;
-          if (p + 4 > in_len) return final ? R_ERR : R_IN;
-          const uint32_t len = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8), nlen = (uint32_t)in[p + 2] | ((uint32_t)in[p + 3] << 8);
-          if ((len ^ 0xFFFFu) != nlen) return R_ERR;
-          s.stored_left = len;
-          s.bp = (p + 4) * 8;
-          s.st = S_STORED;
+          s.bp = ((b.bitpos() + 7) >> 3) * 8;        // header bits, then padding to the byte boundary
+          s.st = S_STORED_LEN;
         } else if (type == 1) {
           s.lit = fixed_tables().lit;
           s.dist = fixed_tables().dist;
@@ -385,6 +382,17 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
         } else {
           return R_ERR;
         }
+        break;
+      }
+      case S_STORED_LEN: {
+        if (target_stored && s.bp == target && !s.last_block && s.bp != entry_bp) return R_BOUNDARY;
+        const size_t p = s.bp >> 3;
+        if (p + 4 > in_len) return final ? R_ERR : R_IN;
+        const uint32_t len = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8), nlen = (uint32_t)in[p + 2] | ((uint32_t)in[p + 3] << 8);
+        if ((len ^ 0xFFFFu) != nlen) return R_ERR;
+        s.stored_left = len;
+        s.bp = (p + 4) * 8;
+        s.st = S_STORED;
         break;
       }
       case S_STORED: {
@@ -482,14 +490,42 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
   }
 }
 
-// First bit position in [from, to) that parses as the header of a non-final dynamic block (complete code sets, an
-// end-of-block code).  Reads at most ~400 bytes behind `to`; the caller keeps that inside the buffer + padding.
-size_t find_dynamic_block(const uint8_t* in, size_t in_len, size_t from, size_t to, Inflater& scratch) {
+// A stored block whose LEN field sits at byte P: LEN / NLEN agree, the byte in front ends in BFINAL = 0, BTYPE = 00 and
+// zero padding (what zlib, gzip and pigz write), and — LEN ^ NLEN alone is only a 2^-16 test — the block BEHIND it starts
+// with a valid stored or dynamic header as well.  (A sync flush, the seam between pigz's pieces, is an empty stored block.)
+bool stored_candidate(const uint8_t* in, size_t in_len, size_t P, Inflater& scratch) {
+  if (P < 1 || P + 4 > in_len) return false;
+  const uint32_t len = (uint32_t)in[P] | ((uint32_t)in[P + 1] << 8), nlen = (uint32_t)in[P + 2] | ((uint32_t)in[P + 3] << 8);
+  if ((len ^ 0xFFFFu) != nlen || (in[P - 1] & 0xE0)) return false;
+  const size_t Q = P + 4 + len;
+  if (Q + 5 > in_len) return false;                  // cannot be confirmed inside this buffer: not a candidate
+  const uint32_t type = (in[Q] >> 1) & 3;
+  if (type == 0) {
+    if (in[Q] >> 3) return false;                    // padding
+    const uint32_t l2 = (uint32_t)in[Q + 1] | ((uint32_t)in[Q + 2] << 8), n2 = (uint32_t)in[Q + 3] | ((uint32_t)in[Q + 4] << 8);
+    return (l2 ^ 0xFFFFu) == n2;
+  }
+  if (type == 2) {
+    Bits b(in, Q * 8 + 3);
+    return parse_dynamic(b, scratch) && b.bitpos() <= in_len * 8;
+  }
+  return false;
+}
+
+// First candidate in [from, to): the bit position of a non-final dynamic block header (complete code sets, an
+// end-of-block code), or — *stored set — the bit position of the LEN field of a stored block (see stored_candidate).
+// Reads at most ~400 bytes behind `to`; the caller keeps that inside the buffer + padding.
+size_t find_block(const uint8_t* in, size_t in_len, size_t from, size_t to, Inflater& scratch, bool* stored) {
   constexpr uint32_t kMaxParses = 1u << 14;
   uint32_t parses = 0;
+  *stored = false;
   for (size_t bit = from; bit < to; ++bit) {
     uint64_t w;
     memcpy(&w, in + (bit >> 3), 8);
+    if ((bit & 7) == 0 && ((((uint32_t)w ^ (uint32_t)(w >> 16)) & 0xFFFFu) == 0xFFFFu) && stored_candidate(in, in_len, bit >> 3, scratch)) {
+      *stored = true;
+      return bit;
+    }
     const uint64_t x = w >> (bit & 7);
     if ((x & 7) != 4) continue;                      // BFINAL = 0, BTYPE = 2 (bits 0 1 from the LSB: 0, then 01 -> value 0b100)
     if (((x >> 3) & 31) > 29 || ((x >> 8) & 31) > 29) continue;
@@ -641,6 +677,7 @@ uint32_t crc32_bytes(uint32_t crc, const uint8_t* buf, size_t len) {
 struct Chunk {
   size_t start = kNone;                              // candidate bit position (chunk 0: the true position)
   size_t target = kNone;
+  bool start_stored = false, target_stored = false;  // the candidate / the target is a stored block's LEN field
   Inflater inf;
   OutBuf<uint16_t> o16;                              // head of a chunk >= 1: symbols (bytes and markers)
   OutBuf<uint8_t> o8;                                // chunk 0, and the tail of a chunk >= 1 once it is marker-free
@@ -694,6 +731,10 @@ struct ParallelGunzip::Impl {
   uint64_t run_len = 0;
   size_t out_cap;
   std::vector<Chunk> pool;                           // per-chunk buffers and tables, reused from batch to batch
+  // A stream in which the search finds nothing (only fixed-Huffman blocks, say) would pay for a futile search in every
+  // batch: after a batch without any candidate the next `find_skip` batches are decoded by one thread without searching
+  // (1, 2, 4 ... 16 batches), then the search is tried again.
+  unsigned find_fail_streak = 0, find_skip = 0;
   // read-ahead: while a batch is searched / decoded / patched, one helper thread reads the next batch's compressed bytes
   // (otherwise 1/7 of the wall time: one thread copying 12 GB out of the page cache) — into the SECOND buffer, behind a
   // gap that is large enough for whatever the current batch leaves unconsumed; at the next top-up the leftover (small)
@@ -792,11 +833,14 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     // ---- 1. candidates ---------------------------------------------------------------------------------------------
     size_t n = P.threads;
     while (n > 1 && base_byte + (n - 1) * P.chunk + 1024 >= in_len) --n;   // chunks that have at least some bytes
+    const bool searching = n > 1 && P.find_skip == 0;
+    if (!searching && n > 1) { --P.find_skip; n = 1; }
     if (P.pool.size() < P.threads) P.pool = std::vector<Chunk>(P.threads);
     std::vector<Chunk>& ch = P.pool;
     for (size_t j = 0; j < n; ++j) {
       Chunk& c = ch[j];
       c.start = c.target = kNone;
+      c.start_stored = c.target_stored = false;
       c.stop = R_ERR;
       c.oom = 0;
       c.o8.n = c.o16.n = 0;
@@ -815,7 +859,7 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
         if (to > last) to = last;
         if (from <= P.cur.bp) from = P.cur.bp + 1;
         Inflater scratch;
-        ch[j].start = from < to ? find_dynamic_block(in, in_len, from, to, scratch) : kNone;
+        ch[j].start = from < to ? find_block(in, in_len, from, to, scratch, &ch[j].start_stored) : kNone;
       });
     std::vector<size_t> act;                           // chunks that will be decoded
     act.push_back(0);
@@ -823,9 +867,20 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
       if (ch[j].start != kNone) act.push_back(j);
       else st_.candidates_missing++;
     }
+    if (searching) {
+      if (act.size() == 1) {
+        P.find_fail_streak = P.find_fail_streak < 4 ? P.find_fail_streak + 1 : 4;
+        P.find_skip = 1u << P.find_fail_streak;
+      } else {
+        P.find_fail_streak = 0;
+      }
+    }
     const size_t nominal_end = (base_byte + n * P.chunk) * 8;
-    for (size_t a = 0; a < act.size(); ++a)
-      ch[act[a]].target = a + 1 < act.size() ? ch[act[a + 1]].start : (final && nominal_end >= in_len * 8 ? kNone : nominal_end);
+    for (size_t a = 0; a < act.size(); ++a) {
+      Chunk& c = ch[act[a]];
+      c.target = a + 1 < act.size() ? ch[act[a + 1]].start : (final && nominal_end >= in_len * 8 ? kNone : nominal_end);
+      c.target_stored = a + 1 < act.size() && ch[act[a + 1]].start_stored;
+    }
 
     t1 = now_s(); st_.s_find += t1 - t0; t0 = t1;
     // ---- 2. decode -------------------------------------------------------------------------------------------------
@@ -840,22 +895,23 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     run_pieces((unsigned)act.size(), [&](unsigned a) {
       Chunk& c = ch[act[a]];
       if (a == 0) {
-        c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.o8, P.out_cap, wlen0, &c.oom);
+        c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.target_stored, c.o8, P.out_cap, wlen0, &c.oom);
         return;
       }
-      c.inf.st = S_BLOCK;
+      c.inf.st = c.start_stored ? S_STORED_LEN : S_BLOCK;
+      c.inf.last_block = false;
       c.inf.bp = c.start;
       if (!c.o16.reserve(P.chunk * 4)) { c.oom = 1; c.stop = R_ERR; return; }
       for (size_t i = 0; i < kWin; ++i) c.o16.mem[i] = (uint16_t)(0x8000u + i);
       c.inf.clean_from = 0;
-      c.stop = run<uint16_t>(c.inf, in, in_len, final, c.target, c.o16, P.out_cap, kWin, &c.oom);
+      c.stop = run<uint16_t>(c.inf, in, in_len, final, c.target, c.target_stored, c.o16, P.out_cap, kWin, &c.oom);
       if (c.stop != R_SWITCH) return;
       // the last 32 KiB are plain bytes: they are the window of everything that follows -> byte mode (faster, no patching)
       if (!c.o8.reserve(P.chunk * 4)) { c.oom = 1; c.stop = R_ERR; return; }
       const uint16_t* tail = c.o16.at0() + c.o16.n - kWin;
       for (size_t i = 0; i < kWin; ++i) c.o8.mem[i] = (uint8_t)tail[i];
       const size_t nseg = c.inf.segs.size(), cap8 = P.out_cap > c.o16.n ? P.out_cap - c.o16.n : 0;
-      c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.o8, cap8, kWin, &c.oom);
+      c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.target_stored, c.o8, cap8, kWin, &c.oom);
       for (size_t g = nseg; g < c.inf.segs.size(); ++g) c.inf.segs[g].out_end += c.o16.n;   // member ends count from the chunk's start
     });
 
@@ -866,7 +922,7 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     for (size_t a = 1; a < act.size(); ++a) {
       const Chunk& prev = ch[ok.back()];
       const Chunk& c = ch[act[a]];
-      if (prev.stop != R_BOUNDARY || prev.inf.bp != c.start) break;
+      if (prev.stop != R_BOUNDARY || prev.inf.bp != c.start || prev.inf.st != (c.start_stored ? S_STORED_LEN : S_BLOCK)) break;
       ok.push_back(act[a]);
     }
     st_.chunks_accepted += ok.size();

@@ -7,12 +7,15 @@
 // front of them is known, if unresolved back-references are kept as markers and patched afterwards:
 //
 //   batch = `threads` chunks of `chunk_bytes` compressed bytes
-//   1. find   (parallel)   chunk j >= 1: first bit position in its range that parses as a non-final dynamic block header
-//                          with complete code-length / literal-length / distance codes
+//   1. find   (parallel)   chunk j >= 1: first position in its range that is the header of a non-final dynamic block
+//                          (complete code-length / literal-length / distance codes, an end-of-block code) or the LEN
+//                          field of a non-final stored block that is followed by another valid block header (incompressible
+//                          input, sync-flush seams); fixed-Huffman blocks are not searched for (nothing to check)
 //   2. decode (parallel)   chunk 0 from the TRUE position with the true window, to bytes;
 //                          chunk j >= 1 from its candidate to 16-bit symbols: < 256 a byte, >= 0x8000 "byte (v - 0x8000)
-//                          of the 32 KiB window in front of this chunk"; each chunk stops at the block boundary that is
-//                          the next chunk's candidate (or overshoots it)
+//                          of the 32 KiB window in front of this chunk" — until 32 KiB in a row hold no marker, from
+//                          there on to bytes; each chunk stops at the block boundary that is the next chunk's candidate
+//                          (or overshoots it)
 //   3. chain  (sequential) chunk j+1 is accepted only if chunk j ended EXACTLY at its candidate: chunk 0 decodes the
 //                          true stream, so by induction every accepted chunk started at a true block boundary.  The batch
 //                          ends at the first break; the next batch starts there (progress is guaranteed by chunk 0).

@@ -18,7 +18,8 @@ step "bench (unprofiled)"
 python3 bench.py > "$OUT/${TAG}_bench_1e9.json" 2> "$OUT/bench.err" || exit 1
 
 step "bench under rocprofv3 --kernel-trace --stats"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline \
+# (--placement-tries 1: the probes of placement probing would be averaged into the per-kernel statistics)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline --placement-tries 1 \
   > "$OUT/${TAG}_bench_1e9_under_rocprof.json" 2> "$OUT/prof_bench.err" || exit 1
 cp "$(find "$OUT/prof_bench" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
 

@@ -69,10 +69,17 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
     vi = ld16(idx_src + (size_t)tp * idx_tile);
     wave_lds_fence();
     bool okb0 = true, oku0 = true, okb1 = true, oku1 = true;
+#if IBU_PROBE == 1      // measurement build (WRONG output): the LDS row reads stay, the packing ALU goes
+    u64 b0 = *reinterpret_cast<const u32*>(asc_bc + (2 * lane) * bc_len), u0 = *reinterpret_cast<const u32*>(asc_umi + (2 * lane) * umi_len);
+    u64 b1 = *reinterpret_cast<const u32*>(asc_bc + (2 * lane + 1) * bc_len), u1 = *reinterpret_cast<const u32*>(asc_umi + (2 * lane + 1) * umi_len);
+#elif IBU_PROBE == 2    // measurement build (WRONG output): no LDS row reads either
+    u64 b0 = row0 + lane, u0 = b0 * 3, b1 = b0 + 7, u1 = b0 ^ 5;
+#else
     u64 b0 = pack_row<BC>(asc_bc + (2 * lane) * bc_len, bc_len, okb0);
     u64 u0 = pack_row<UM>(asc_umi + (2 * lane) * umi_len, umi_len, oku0);
     u64 b1 = pack_row<BC>(asc_bc + (2 * lane + 1) * bc_len, bc_len, okb1);
     u64 u1 = pack_row<UM>(asc_umi + (2 * lane + 1) * umi_len, umi_len, oku1);
+#endif
     if (!okb0) b0 = 0;
     if (!oku0) u0 = 0;
     if (!okb1) b1 = 0;

@@ -646,10 +646,10 @@ struct ParGzSource : Source {
     if (getenv("IBU_PGZ_TRACE")) {                     // where the time of the parallel inflate went (wall seconds per phase)
       const pgz::Stats& t = dec->stats();
       fprintf(stderr, "[pgzip] in %llu B out %llu B batches %llu chunks accepted %llu discarded %llu no-candidate %llu markers %llu | "
-              "read %.3f find %.3f decode %.3f windows %.3f patch+crc %.3f carry %.3f s\n",
+              "read %.3f (join %.3f, helper busy %.3f) find %.3f decode %.3f windows %.3f patch+crc %.3f carry %.3f s\n",
               (unsigned long long)t.bytes_in, (unsigned long long)t.bytes_out, (unsigned long long)t.batches,
               (unsigned long long)t.chunks_accepted, (unsigned long long)t.chunks_discarded, (unsigned long long)t.candidates_missing,
-              (unsigned long long)t.marker_symbols, t.s_read, t.s_find, t.s_decode, t.s_windows, t.s_patch_crc, t.s_carry);
+              (unsigned long long)t.marker_symbols, t.s_read, t.s_join_wait, t.s_helper_read, t.s_find, t.s_decode, t.s_windows, t.s_patch_crc, t.s_carry);
     }
   }
   int refill_noexcept() {

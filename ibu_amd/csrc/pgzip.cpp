@@ -742,6 +742,7 @@ struct ParallelGunzip::Impl {
   std::vector<uint8_t> ahead;
   size_t ahead_gap = 0, ahead_len = 0;
   bool ahead_eof = false;
+  double ahead_seconds = 0;
   std::future<int> ahead_f;
   int join_ahead() {
     if (!ahead_f.valid()) return 0;
@@ -765,6 +766,8 @@ struct ParallelGunzip::Impl {
       ahead_len = 0;
       ahead_f = std::async(std::launch::async, [this, bytes]() -> int {
         uint8_t* const dst = ahead.data() + ahead_gap;
+        const double h0 = now_s();
+        struct Acc { double* d; double t; ~Acc() { *d += now_s() - t; } } acc{&ahead_seconds, h0};
         while (ahead_len < bytes) {
           size_t got = 0;
           const int rc = inner(dst + ahead_len, bytes - ahead_len, &got);
@@ -807,6 +810,8 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
       const int rc = P.join_ahead();
       if (rc) { P.failed = true; return rc; }
       st_.bytes_in += P.comp_len - before;
+      st_.s_join_wait += now_s() - t0;
+      st_.s_helper_read = P.ahead_seconds;
     }
     if (P.comp_len < want && !P.inner_eof) {
       if (P.comp.size() < P.comp_off + want + kPad) {

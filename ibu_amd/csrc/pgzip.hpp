@@ -43,6 +43,7 @@ struct Stats {
   uint64_t batches = 0, chunks_accepted = 0, chunks_discarded = 0, candidates_missing = 0;
   uint64_t bytes_in = 0, bytes_out = 0, marker_symbols = 0;
   double s_read = 0, s_find = 0, s_decode = 0, s_windows = 0, s_patch_crc = 0, s_carry = 0;  // wall seconds per phase
+  double s_join_wait = 0, s_helper_read = 0;         // of s_read: waiting for the read-ahead helper; the helper's own read time
 };
 
 struct ByteBuf {  // grows by realloc, never zero-fills

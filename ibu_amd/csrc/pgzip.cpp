@@ -762,7 +762,8 @@ struct ParallelGunzip::Impl {
     if (inner_eof || bytes == 0) return;
     try {
       ahead_gap = comp_len;
-      if (ahead.size() < ahead_gap + bytes + kPad) ahead.resize(ahead_gap + bytes + kPad);
+      // + 1 MiB: the synchronous top-up behind the swap (the slack the last chunk ran into) must fit without compaction
+      if (ahead.size() < ahead_gap + bytes + ((size_t)1 << 20) + kPad) ahead.resize(ahead_gap + bytes + ((size_t)1 << 20) + kPad);
       ahead_len = 0;
       ahead_f = std::async(std::launch::async, [this, bytes]() -> int {
         uint8_t* const dst = ahead.data() + ahead_gap;

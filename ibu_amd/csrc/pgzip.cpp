@@ -967,11 +967,21 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     run_pieces((unsigned)ok.size(), [&](unsigned a) {
       Chunk& c = ch[ok[a]];
       const size_t nn = c.n_out(), body = nn - tail_of(nn);
-      if (body && !c.finalize(0, body, dst + c.out_off, &markers[a])) c.bad_symbol = true;
+      // bytes are made final (copied / patched) and CRC'd block by block, so the CRC reads them from the cache
+      constexpr size_t kBlock = (size_t)256 << 10;
       size_t from = 0;
       for (size_t g = 0; g <= c.inf.segs.size(); ++g) {
         const size_t to = g < c.inf.segs.size() ? c.inf.segs[g].out_end : nn;
-        const uint32_t crc = crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), dst + c.out_off + from, to - from);
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t p = from; p < to;) {
+          const size_t q = to - p > kBlock ? p + kBlock : to;
+          if (p < body) {
+            const size_t e = q < body ? q : body;
+            if (!c.finalize(p, e, dst + c.out_off + p, &markers[a])) c.bad_symbol = true;
+          }
+          crc = crc32_bytes(crc, dst + c.out_off + p, q - p);
+          p = q;
+        }
         c.piece_crc.push_back(crc);
         from = to;
       }

@@ -29,12 +29,16 @@ constexpr size_t kPad = 512;                         // zero bytes readable behi
 constexpr size_t kNone = ~(size_t)0;
 constexpr uint32_t K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4;
 
-inline uint32_t mk(uint32_t payload, uint32_t extra, uint32_t kind, uint32_t nbits) {
-  return (payload << 16) | (extra << 8) | (kind << 5) | nbits;
+// Decode-table entry: bits 0-7 the number of stream bits this step consumes (code length, for a length / distance
+// symbol PLUS its extra bits, so that one shift consumes both; for a subtable link the primary width), bits 8-11 the
+// code length alone (where the extra bits start; for a link: the subtable's width), bits 12-14 the kind, bits 16-31 the
+// payload (literal, base length, base distance, subtable offset).
+inline uint32_t mk(uint32_t payload, uint32_t f, uint32_t kind, uint32_t nbits) {
+  return (payload << 16) | (kind << 12) | (f << 8) | nbits;
 }
-inline uint32_t e_kind(uint32_t e) { return (e >> 5) & 7u; }
-inline uint32_t e_bits(uint32_t e) { return e & 31u; }
-inline uint32_t e_extra(uint32_t e) { return (e >> 8) & 31u; }
+inline uint32_t e_kind(uint32_t e) { return (e >> 12) & 7u; }
+inline uint32_t e_bits(uint32_t e) { return e & 0xFFu; }
+inline uint32_t e_f(uint32_t e) { return (e >> 8) & 15u; }
 inline uint32_t e_val(uint32_t e) { return e >> 16; }
 
 const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -51,11 +55,11 @@ inline uint32_t rev_bits(uint32_t code, int len) {
 inline uint32_t lit_entry(int sym, int nb) {
   if (sym < 256) return mk((uint32_t)sym, 0, K_LIT, (uint32_t)nb);
   if (sym == 256) return mk(0, 0, K_EOB, (uint32_t)nb);
-  if (sym < 286) return mk(kLenBase[sym - 257], kLenExtra[sym - 257], K_BASE, (uint32_t)nb);
+  if (sym < 286) return mk(kLenBase[sym - 257], (uint32_t)nb, K_BASE, (uint32_t)nb + kLenExtra[sym - 257]);
   return mk(0, 0, K_BAD, (uint32_t)nb);
 }
 inline uint32_t dist_entry(int sym, int nb) {
-  if (sym < 30) return mk(kDistBase[sym], kDistExtra[sym], K_BASE, (uint32_t)nb);
+  if (sym < 30) return mk(kDistBase[sym], (uint32_t)nb, K_BASE, (uint32_t)nb + kDistExtra[sym]);
   return mk(0, 0, K_BAD, (uint32_t)nb);
 }
 
@@ -111,7 +115,7 @@ bool build_table(const uint8_t* lens, int n, int P, bool is_dist, uint32_t* tab,
       for (uint32_t i = r; i < ((uint32_t)1 << P); i += (uint32_t)1 << l) tab[i] = e;
     } else {
       const uint32_t pre = r & (((uint32_t)1 << P) - 1), link = tab[pre];
-      const uint32_t off = e_val(link), sb = e_extra(link), e = is_dist ? dist_entry(s, l - P) : lit_entry(s, l - P);
+      const uint32_t off = e_val(link), sb = e_f(link), e = is_dist ? dist_entry(s, l - P) : lit_entry(s, l - P);
       for (uint32_t i = r >> P; i < ((uint32_t)1 << sb); i += (uint32_t)1 << (l - P)) tab[off + i] = e;
     }
   }
@@ -457,17 +461,19 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
               }
             }
           }
-          if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_extra(e)) - 1))]; }
-          b.drop(e_bits(e));                           // >= 11 bits left in the worst case (two 15-bit literals in front)
+          if (e_kind(e) == K_SUB) { b.drop(kLitBits); e = lit[e_val(e) + (b.buf & ((1u << e_f(e)) - 1))]; }
+          uint64_t saved = b.buf;
+          b.drop(e_bits(e));                           // code + extra bits in one shift; >= 6 bits left in the worst case
           if (e_kind(e) == K_LIT) { base[o++] = (T)e_val(e); continue; }
           if (e_kind(e) == K_BASE) {
-            const size_t len = e_val(e) + b.take(e_extra(e));
+            const size_t len = e_val(e) + ((uint32_t)(saved >> e_f(e)) & ((1u << (e_bits(e) - e_f(e))) - 1));
             if (b.cnt < 32) b.refill();                // a distance needs <= 15 + 13 bits
             uint32_t d = dist[b.buf & dmask];
-            if (e_kind(d) == K_SUB) { b.drop(kDistBits); d = dist[e_val(d) + (b.buf & ((1u << e_extra(d)) - 1))]; }
+            if (e_kind(d) == K_SUB) { b.drop(kDistBits); d = dist[e_val(d) + (b.buf & ((1u << e_f(d)) - 1))]; }
+            saved = b.buf;
             b.drop(e_bits(d));
             if (e_kind(d) != K_BASE) return R_ERR;
-            const size_t dd = e_val(d) + b.take(e_extra(d));
+            const size_t dd = e_val(d) + ((uint32_t)(saved >> e_f(d)) & ((1u << (e_bits(d) - e_f(d))) - 1));
             if (dd > o + wlen) return R_ERR;         // reaches in front of the history
             if (sizeof(T) == 2 && (dd > o || o - dd < s.clean_from)) s.clean_from = o + len;   // may have copied markers
             lz_copy(base + o, dd, len);

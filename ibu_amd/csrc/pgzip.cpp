@@ -304,8 +304,8 @@ inline void lz_copy(T* o, size_t dist, size_t len) {
 //              from here on can refer to the unknown window, the caller continues in byte mode.
 // wlen: history elements in front of output element 0 that exist (distance check; kWin in marker mode).
 template <class T>
-Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, bool target_stored, OutBuf<T>& ob,
-         size_t out_cap, size_t wlen, int* oom) {
+__attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target,
+                                                    bool target_stored, OutBuf<T>& ob, size_t out_cap, size_t wlen, int* oom) {
   const size_t entry_bp = s.bp;
   // positions at which the hot loop gives up: never touch bytes behind in_len + kPad; when more input may come, stop 64 B early
   const size_t pos_lim = final ? in_len + 16 : (in_len > 64 ? in_len - 64 : 0);
@@ -494,6 +494,26 @@ Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t targe
       }
     }
   }
+}
+
+// The same body compiled twice: for any x86-64, and with BMI2 (shrx / bzhi: the variable shifts and masks of the symbol
+// loop stop going through CL and the flags), picked once at run time.
+template <class T>
+Stop run_generic(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, bool target_stored, OutBuf<T>& ob,
+                 size_t out_cap, size_t wlen, int* oom) {
+  return run_body<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
+}
+template <class T>
+__attribute__((target("bmi2,bmi,lzcnt"))) Stop run_bmi2(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target,
+                                                        bool target_stored, OutBuf<T>& ob, size_t out_cap, size_t wlen, int* oom) {
+  return run_body<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
+}
+template <class T>
+Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, bool target_stored, OutBuf<T>& ob,
+         size_t out_cap, size_t wlen, int* oom) {
+  static const bool bmi2 = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi") && !getenv("IBU_PGZ_NO_BMI2");
+  return bmi2 ? run_bmi2<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom)
+              : run_generic<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
 }
 
 // A stored block whose LEN field sits at byte P: LEN / NLEN agree, the byte in front ends in BFINAL = 0, BTYPE = 00 and

@@ -466,8 +466,9 @@ struct BgzfSource : Source {
   unsigned threads;
   struct Block { size_t coff, clen, ooff, isize; uint32_t crc; };
   explicit BgzfSource(std::unique_ptr<Source> s) : inner(std::move(s)) {
-    size_t c = ibu::host_cores();
-    threads = (unsigned)(c < 1 ? 1 : (c > 16 ? 16 : c));
+    const char* e = getenv("IBU_BGZF_THREADS");
+    size_t c = e ? (size_t)atol(e) : ibu::inflate_threads();
+    threads = (unsigned)(c < 1 ? 1 : (c > 64 ? 64 : c));
   }
   int read_exact(uint8_t* dst, size_t n, size_t* got_total) {
     size_t have = 0;
@@ -630,7 +631,7 @@ struct ParGzSource : Source {
   bool eof = false, next_eof = false;
   static unsigned env_threads() {
     const char* e = getenv("IBU_PGZ_THREADS");
-    size_t c = e ? (size_t)atol(e) : ibu::host_cores();
+    size_t c = e ? (size_t)atol(e) : ibu::inflate_threads();
     return (unsigned)(c < 1 ? 1 : (c > 64 ? 64 : c));
   }
   static size_t env_chunk() {
@@ -1243,6 +1244,21 @@ size_t ibu::host_cores() {
   const size_t q = cgroup_cpu_quota();
   if (q && q < n) n = q;
   return n;
+}
+size_t ibu::inflate_threads() {
+  size_t n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) {
+    int c = CPU_COUNT(&set);
+    if (c > 0) n = (size_t)c;
+  }
+  if (!n) {
+    unsigned h = std::thread::hardware_concurrency();
+    n = h ? h : 1;
+  }
+  const size_t q = cgroup_cpu_quota();
+  if (q && 2 * q < n) n = 2 * q;
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
 }
 
 extern "C" int32_t ibu_mmap_process_parallel(const ibu_mmap_t* m, const ibu_processor_vtable_t* vt, void* user,

@@ -92,11 +92,18 @@ def cpu_baseline(args):
     1Mi-record batches, scalar 2-bit codec) timed on this box's host cores on a bounded sample."""
     from oracle import oracle as orc  # the checker, used here only as the reported baseline
 
-    threads = usable_cores()
+    quota = usable_cores()
     n = int(args.cpu_sample) or 100_000_000
-    t1, chk = orc.bench_decode_encode(min(n, 4_000_000), args.bc_len, args.umi_len, args.seed, threads)  # warm-up + rate probe
-    rate = min(n, 4_000_000) / max(t1, 1e-6)
-    # about 1.5 s of wall time on every usable core (16 cores -> ~25 CPU-seconds): repeat the pass over the sample
+    # the strongest baseline this box gives: the CPU quota's worth of threads, or twice that (under a cgroup quota the
+    # second thread per CPU still pays: the box's 16-CPU quota gives 650 M records/s at 16 threads, 810 at 32, less at 64)
+    best = None
+    for threads in sorted({quota, min(2 * quota, len(os.sched_getaffinity(0)))}):
+        t1, chk = orc.bench_decode_encode(min(n, 8_000_000), args.bc_len, args.umi_len, args.seed, threads)  # warm-up + rate probe
+        rate = min(n, 8_000_000) / max(t1, 1e-6)
+        if best is None or rate > best[1]:
+            best = (threads, rate)
+    threads, rate = best
+    # about 1.5 s of wall time (16 CPUs -> ~25 CPU-seconds): repeat the pass over the sample
     reps = max(1, int(rate * 1.5 / n))
     t, chk = orc.bench_decode_encode(n, args.bc_len, args.umi_len, args.seed, threads, reps)
     assert chk != 2**64 - 1, "oracle round trip failed"
@@ -106,7 +113,7 @@ def cpu_baseline(args):
         "sample": f"{reps} pass(es) over {n} records bc_len={args.bc_len} umi_len={args.umi_len}, decode+encode, static split over "
                   f"{threads} OS threads (C restatement of the reference's std::thread path; the reference is Rust "
                   f"and cannot be built here)",
-        "seconds": t, "cpu_seconds": t * threads,
+        "seconds": t, "cpu_seconds": t * min(threads, quota), "cpu_quota": quota,
     }
 
 

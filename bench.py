@@ -250,10 +250,13 @@ class Leg:
         ok = None
         if full:
             red_back = self.ctx.reduce(self.back, n, stream=self.st)
-            chunk = 1 << 30  # compare in 1 GiB pieces: torch.equal materialises a mask as large as its inputs
+            # whole-buffer equality twice: the library's own slice comparison (ibu_records_first_mismatch) and torch.equal
+            # in 1 GiB pieces (torch.equal materialises a mask as large as its inputs)
+            first_diff = self.ctx.first_mismatch(self.recs, self.back, n, stream=self.st)
+            chunk = 1 << 30
             nb = n * 24
             same = all(bool(torch.equal(self.recs[o:min(o + chunk, nb)], self.back[o:min(o + chunk, nb)])) for o in range(0, nb, chunk))
-            ok = same and red == red_back and red["count"] == n
+            ok = same and first_diff == n and red == red_back and red["count"] == n
             if not ok:
                 raise SystemExit("round trip encode(decode(x)) != x")
         return red, ok

@@ -176,6 +176,8 @@ extern "C" {
                             stream: *mut c_void) -> i32;
     pub fn ibu_lower_bound_records(ctx: *mut ibu_ctx_t, d_sorted_records: *const c_void, n: usize, d_keys: *const c_void, k: usize,
                                    d_pos: *mut u64, stream: *mut c_void) -> i32;
+    pub fn ibu_records_first_mismatch(ctx: *mut ibu_ctx_t, d_a: *const c_void, d_b: *const c_void, n: usize, first: *mut u64,
+                                      stream: *mut c_void) -> i32;
     pub fn ibu_is_sorted(ctx: *mut ibu_ctx_t, d_records: *const c_void, n: usize, stream: *mut c_void,
                          sorted: *mut i32) -> i32;
     pub fn ibu_load_to_device(ctx: *mut ibu_ctx_t, path: *const c_char, cfg: *const ibu_ring_config_t,

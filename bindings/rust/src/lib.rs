@@ -479,6 +479,13 @@ pub mod device {
         pub fn sort_records(&self, recs: &DeviceBuf, tmp: &DeviceBuf, n: usize) -> Result<()> {
             check(unsafe { ffi::ibu_sort_records(self.raw, recs.ptr, tmp.ptr, n, std::ptr::null_mut()) })
         }
+        /// `a[..n] == b[..n]` on device-resident records (`Record: PartialEq`), with the position: the index of the
+        /// first record that differs, `n` if none does.
+        pub fn first_mismatch(&self, a: &DeviceBuf, b: &DeviceBuf, n: usize) -> Result<usize> {
+            let mut f = 0u64;
+            check(unsafe { ffi::ibu_records_first_mismatch(self.raw, a.ptr, b.ptr, n, &mut f, std::ptr::null_mut()) })?;
+            Ok(f as usize)
+        }
         pub fn is_sorted(&self, recs: &DeviceBuf, n: usize) -> Result<bool> {
             let mut s = 0i32;
             check(unsafe { ffi::ibu_is_sorted(self.raw, recs.ptr, n, std::ptr::null_mut(), &mut s) })?;

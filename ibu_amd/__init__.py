@@ -679,6 +679,16 @@ class Context:
         """d_pos[j] (u64, device) = first position whose record is >= key j (24-byte records in d_keys); asynchronous."""
         _check(lib.ibu_lower_bound_records(self._c, _dptr(d_sorted_records), n, _dptr(d_keys), k, _dptr(d_pos), stream))
 
+    def first_mismatch(self, d_a, d_b, n, stream=None):
+        """Index of the first of n records in which the two device slices differ; n if they are equal
+        (`a == b` on record slices: Record derives PartialEq / Eq, record.rs:58)."""
+        f = C.c_uint64()
+        _check(lib.ibu_records_first_mismatch(self._c, _dptr(d_a), _dptr(d_b), n, C.byref(f), stream))
+        return int(f.value)
+
+    def records_equal(self, d_a, d_b, n, stream=None):
+        return self.first_mismatch(d_a, d_b, n, stream) == n
+
     def is_sorted(self, d_records, n, stream=None):
         s = C.c_int32()
         _check(lib.ibu_is_sorted(self._c, _dptr(d_records), n, stream, C.byref(s)))

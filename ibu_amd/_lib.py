@@ -138,6 +138,7 @@ SIGNATURES = {
     "ibu_sort_records": (i32, [vp, vp, vp, sz, vp]),
     "ibu_lower_bound_records": (i32, [vp, vp, sz, vp, sz, vp, vp]),
     "ibu_is_sorted": (i32, [vp, vp, sz, vp, P(i32)]),
+    "ibu_records_first_mismatch": (i32, [vp, vp, vp, sz, P(u64), vp]),
     "ibu_load_to_device": (i32, [vp, C.c_char_p, P(CRingConfig), P(CHeader), P(vp), sz, P(sz), P(CStreamStats)]),
     "ibu_writer_write_batch_device": (i32, [vp, vp, P(CRingConfig), vp, sz, P(CStreamStats)]),
     "ibu_mmap_process_device": (i32, [vp, vp, P(CRingConfig), i32, sz, sz, vp, P(CStreamStats)]),

@@ -316,6 +316,26 @@ extern "C" int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n
   *sorted = (*reinterpret_cast<uint32_t*>(ctx->h_pinned + 8)) == 0;
   return IBU_OK;
 }
+// `a == b` on two device-resident record slices, with the position (Record: PartialEq / Eq, record.rs:58).
+extern "C" int32_t ibu_records_first_mismatch(ibu_ctx_t* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first,
+                                              void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!first) return err_arg("first is NULL");
+  *first = n;
+  if (n == 0) return IBU_OK;
+  if (!d_a || !d_b || !aligned8(d_a) || !aligned8(d_b)) return err_arg("d_a / d_b must be non-NULL and 8-byte aligned");
+  if (n > (~(size_t)0) / 3) return err_arg("n too large");
+  hipStream_t st = pick_stream(ctx, stream);
+  uint64_t* slot = reinterpret_cast<uint64_t*>(ctx->d_flag) + 1;   // d_flag: 16 bytes; [0] is the sortedness flag
+  IBU_HIP(hipMemsetAsync(slot, 0xFF, 8, st));
+  IBU_HIP(launch_mismatch(ctx->cfg, d_a, d_b, 3 * n, slot, st));
+  IBU_HIP(hipMemcpyAsync(ctx->h_pinned + 10, slot, 8, hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipStreamSynchronize(st));
+  const uint64_t w = ctx->h_pinned[10];
+  if (w != ~0ull) *first = w / 3;
+  return IBU_OK;
+}
 static int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   if (need > ctx->sort_scratch_bytes) {  // grows only; the one allocation a launch path may make
     if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));

@@ -236,6 +236,38 @@ ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchun
   }
   for (; c < nchunks; c += stride) st16(dst + 16 * c, ld16(src + 16 * c));
 }
+// First differing 8-byte word of two word arrays, or ~0: `a == b` on two record slices (Record derives PartialEq / Eq,
+// src/constructs/record.rs:58) with the position a test wants.  VEC 2: both 16-B aligned, dwordx4 loads, four chunks of
+// each array in flight; VEC 1: 8-B aligned inputs.  One atomicMin per wave, and only where something differs.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock, 8)
+ibu_k_mismatch(const u64* __restrict__ a, const u64* __restrict__ b, u64 nwords, u64* __restrict__ first) {
+  const u64 stride = (u64)gridDim.x * kBlock;
+  u64 c = (u64)logical_block() * kBlock + threadIdx.x;
+  u64 best = ~0ull;
+  if constexpr (VEC == 2) {
+    const uint8_t* pa = reinterpret_cast<const uint8_t*>(a);
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(b);
+    const u64 nch = nwords >> 1;
+    auto cmp = [&](u32x4 x, u32x4 y, u64 chunk) {
+      const bool lo = x.x == y.x && x.y == y.y, hi = x.z == y.z && x.w == y.w;
+      if (!(lo && hi)) { const u64 w = 2 * chunk + (lo ? 1 : 0); best = w < best ? w : best; }
+    };
+    for (; c + 3 * stride < nch; c += 4 * stride) {
+      const u32x4 x0 = ld16(pa + 16 * c), x1 = ld16(pa + 16 * (c + stride)), x2 = ld16(pa + 16 * (c + 2 * stride)), x3 = ld16(pa + 16 * (c + 3 * stride));
+      const u32x4 y0 = ld16(pb + 16 * c), y1 = ld16(pb + 16 * (c + stride)), y2 = ld16(pb + 16 * (c + 2 * stride)), y3 = ld16(pb + 16 * (c + 3 * stride));
+      cmp(x0, y0, c); cmp(x1, y1, c + stride); cmp(x2, y2, c + 2 * stride); cmp(x3, y3, c + 3 * stride);
+    }
+    for (; c < nch; c += stride) cmp(ld16(pa + 16 * c), ld16(pb + 16 * c), c);
+    if ((nwords & 1) && blockIdx.x == 0 && threadIdx.x == 0 && a[nwords - 1] != b[nwords - 1]) best = nwords - 1 < best ? nwords - 1 : best;
+  } else {
+    for (; c < nwords; c += stride)
+      if (a[c] != b[c]) best = c < best ? c : best;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const u64 o = shfl_xor_u64(best, m); best = o < best ? o : best; }
+  if ((threadIdx.x & (kWave - 1)) == 0 && best != ~0ull) atomicMin(first, best);
+}
 extern "C" __global__ void ibu_k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 off, u64 n) {
   const u64 i = off + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -397,6 +429,25 @@ hipError_t launch_copy(const LaunchCfg& cfg, const void* src, void* dst, size_t 
 hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipLaunchKernelGGL(ibu_k_fill_u64, dim3(1), dim3(1), 0, st, (u64*)p, (u64)v0, (u64)v1);
+  return hipGetLastError();
+}
+
+hipError_t launch_mismatch(const LaunchCfg& cfg, const void* a, const void* b, size_t nwords, uint64_t* first, hipStream_t st) {
+  (void)hipGetLastError();
+  if (nwords == 0) return hipSuccess;
+  const bool vec = aligned16(a) && aligned16(b);
+  const u64 units = vec ? (nwords >> 1) + 1 : nwords;
+  u64 blocks = (units + kBlock - 1) / kBlock;
+  static std::atomic<int> occ[2];
+  if (vec) {
+    const u64 cap = (u64)cfg.cus * resident_blocks<kBlock>(cfg, ibu_k_mismatch<2>, 0, &occ[1]);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ibu_k_mismatch<2>, dim3((u32)blocks), dim3(kBlock), 0, st, (const u64*)a, (const u64*)b, (u64)nwords, (u64*)first);
+  } else {
+    const u64 cap = (u64)cfg.cus * resident_blocks<kBlock>(cfg, ibu_k_mismatch<1>, 0, &occ[0]);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ibu_k_mismatch<1>, dim3((u32)blocks), dim3(kBlock), 0, st, (const u64*)a, (const u64*)b, (u64)nwords, (u64*)first);
+  }
   return hipGetLastError();
 }
 

@@ -53,6 +53,7 @@ hipError_t launch_generate(const LaunchCfg&, uint64_t seed, uint64_t first, size
                            uint32_t umi_len, void* recs, hipStream_t st);
 hipError_t launch_copy(const LaunchCfg&, const void* src, void* dst, size_t bytes, hipStream_t st);
 hipError_t launch_sorted_check(const LaunchCfg&, const void* recs, size_t n, uint32_t* flag, hipStream_t st);
+hipError_t launch_mismatch(const LaunchCfg&, const void* a, const void* b, size_t nwords, uint64_t* first, hipStream_t st);
 hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
 
 // sort.hip

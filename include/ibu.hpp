@@ -381,6 +381,8 @@ class Context {
   void copy(void* d_dst, const void* d_src, size_t bytes, void* st = nullptr) { check(ibu_device_copy(c_, d_dst, d_src, bytes, st)); }
   void sort_records(void* d_recs, void* d_tmp, size_t n, void* st = nullptr) { check(ibu_sort_records(c_, d_recs, d_tmp, n, st)); }
   void lower_bound(const void* d_sorted, size_t n, const void* d_keys, size_t k, uint64_t* d_pos, void* st = nullptr) { check(ibu_lower_bound_records(c_, d_sorted, n, d_keys, k, d_pos, st)); }
+  // index of the first record that differs, n if the slices are equal (Record: PartialEq, record.rs:58)
+  size_t first_mismatch(const void* d_a, const void* d_b, size_t n, void* st = nullptr) { uint64_t f = 0; check(ibu_records_first_mismatch(c_, d_a, d_b, n, &f, st)); return (size_t)f; }
   bool is_sorted(const void* d_recs, size_t n, void* st = nullptr) { int32_t s = 0; check(ibu_is_sorted(c_, d_recs, n, st, &s)); return s != 0; }
   // BarcodeAnalyzer (parallel.rs:72-98) on sorted device records: (barcode, records, distinct UMIs), ascending barcode
   inline std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> barcode_counts(const void* d_sorted, size_t n);

@@ -342,6 +342,9 @@ int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t 
  * multi-GPU sample sort (ibu_amd/sharding.py): one launch for all splitters instead of a host binary search. */
 int32_t ibu_lower_bound_records(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, const void* d_keys, size_t k,
                                 uint64_t* d_pos, void* stream);
+/* `a == b` on two device-resident slices of n records each (Record derives PartialEq / Eq, record.rs:58): *first = the
+ * index of the first record that differs, n if none does.  8-byte aligned inputs (16-byte: the fast path).  Synchronises. */
+int32_t ibu_records_first_mismatch(ibu_ctx_t* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first, void* stream);
 /* 1 if the n records are non-decreasing under ibu_record_cmp. Synchronises. */
 int32_t ibu_is_sorted(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream,
                       int32_t* sorted);

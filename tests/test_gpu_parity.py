@@ -508,9 +508,11 @@ def test_full_size_roundtrip_properties_1e9(ia, ctx, lens):
     ctx.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back)
     ctx.codec_status()  # every decoded byte was a valid base
     assert ctx.reduce(back, n) == red
-    # byte-for-byte equality of the round trip over the WHOLE buffers (24 GB each), 480 MB of host memory at a time
+    # byte-for-byte equality of the round trip over the WHOLE buffers (24 GB each): on the device, and — the device
+    # comparison is itself under test — on the host for every 10th piece of 20 M records
+    assert ctx.first_mismatch(recs, back, n) == n
     step = 20_000_000
-    for lo in range(0, n, step):
+    for lo in range(0, n, 10 * step):
         k = min(step, n - lo)
         a = ia.DeviceBuffer.wrap(ctx, recs.ptr + lo * 24, k * 24).download()
         b = ia.DeviceBuffer.wrap(ctx, back.ptr + lo * 24, k * 24).download()
@@ -590,3 +592,38 @@ def test_hip_runtime_errors_surface_as_status(ia, ctx):
     d = ctx.alloc(24 * 256)
     ctx.generate(1, 0, 256, 16, 12, d)
     assert ctx.reduce(d, 256)["count"] == 256
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 1000, 4097, 1_000_003])
+def test_first_mismatch_is_slice_equality_with_a_position(ia, ctx, oracle, n):
+    """ibu_records_first_mismatch = `a == b` on record slices (Record: PartialEq / Eq, record.rs:58) with the position:
+    checked against numpy on equal slices, a difference in every field of the first / middle / last record, several
+    differences (the FIRST one counts), and inputs that are only 8-byte aligned (the word kernel)."""
+    recs = oracle.generate(SEED, 0, max(n, 1), 16, 12)[:n]
+    raw = np.frombuffer(recs.tobytes(), dtype=np.uint64).copy()
+    a, b = ctx.alloc(max(24 * n, 16) + 32), ctx.alloc(max(24 * n, 16) + 32)
+    for shift in (0, 8):                                   # 16-B aligned / 8-B aligned device pointers
+        da = ia.DeviceBuffer.wrap(ctx, a.ptr + shift, max(24 * n, 16))
+        db = ia.DeviceBuffer.wrap(ctx, b.ptr + shift, max(24 * n, 16))
+        if n:
+            da.upload(raw.view(np.uint8))
+            db.upload(raw.view(np.uint8))
+        assert ctx.first_mismatch(da, db, n) == n and ctx.records_equal(da, db, n)
+        if n == 0:
+            continue
+        for rec in sorted({0, n // 2, n - 1}):
+            for field in range(3):
+                other = raw.copy()
+                other[3 * rec + field] ^= np.uint64(1) << np.uint64(17 * field + 3)
+                db.upload(other.view(np.uint8))
+                assert ctx.first_mismatch(da, db, n) == rec, (shift, rec, field)
+                assert ctx.first_mismatch(da, db, rec) == rec        # a prefix that ends in front of the difference is equal
+        if n > 10:
+            other = raw.copy()
+            for rec in (n - 1, n // 3, n // 2):
+                other[3 * rec + 1] += np.uint64(1)
+            db.upload(other.view(np.uint8))
+            assert ctx.first_mismatch(da, db, n) == n // 3
+    with pytest.raises(ia.IbuError) as e:
+        ctx.first_mismatch(a.ptr + 4, b, 1)
+    assert e.value.kind == "InvalidArg"

@@ -64,6 +64,7 @@ def main():
             "pack": (lambda: lib.ibu_pack_2bit(ctx, p(bc), n, bc_len, p(c1), st), 8 + bc_len),
             "generate": (lambda: lib.ibu_generate(ctx, 1, 0, n, bc_len, umi_len, p(back), st), 24),
             "copy": (lambda: lib.ibu_device_copy(ctx, p(back), p(recs), 24 * n, st), 48),
+            "mismatch": (lambda: lib.ibu_records_first_mismatch(ctx, p(recs), p(back), n, C.byref(C.c_uint64()), st), 48),
         }
 
     tag0, lib0, ctx0 = cfgs[0]

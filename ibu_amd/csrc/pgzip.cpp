@@ -175,6 +175,7 @@ struct Inflater {
   const uint32_t* lit = nullptr;
   const uint32_t* dist = nullptr;
   St st = S_HEADER;
+  bool raw = false;                                  // a bare deflate stream (no gzip header / trailer): ends behind its final block
   bool last_block = false;
   uint32_t stored_left = 0;
   size_t bp = 0;                                     // bit position in the compressed buffer where decoding resumes
@@ -400,7 +401,7 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
         break;
       }
       case S_STORED: {
-        if (s.stored_left == 0) { s.st = s.last_block ? S_TRAILER : S_BLOCK; break; }
+        if (s.stored_left == 0) { s.st = s.last_block ? (s.raw ? S_DONE : S_TRAILER) : S_BLOCK; break; }
         if (ob.n >= out_cap) return R_OUT;
         const size_t p = s.bp >> 3;
         size_t k = s.stored_left;
@@ -487,7 +488,7 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
         s.bp = b.bitpos();
         if (block_done) {
           if (s.bp > in_len * 8) return R_ERR;       // the block's last bits came from the padding: truncated
-          s.st = s.last_block ? S_TRAILER : S_BLOCK;
+          s.st = s.last_block ? (s.raw ? S_DONE : S_TRAILER) : S_BLOCK;
           break;
         }
         return why;
@@ -731,6 +732,30 @@ struct Chunk {
 };
 
 }  // namespace
+
+struct RawInflater::Impl {
+  Inflater inf;
+  OutBuf<uint8_t> ob;
+};
+RawInflater::RawInflater() : p_(new Impl) {}
+RawInflater::~RawInflater() {}
+int RawInflater::inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, uint32_t* crc) {
+  Impl& P = *p_;
+  P.inf.st = S_BLOCK;
+  P.inf.raw = true;
+  P.inf.last_block = false;
+  P.inf.bp = 0;
+  P.inf.segs.clear();
+  P.ob.n = 0;
+  if (!P.ob.reserve(out_len + 1)) return ENOMEM;
+  int oom = 0;
+  const Stop st = run<uint8_t>(P.inf, in, in_len, true, kNone, false, P.ob, out_len + 1, 0, &oom);
+  if (oom) return ENOMEM;
+  if (st != R_END || P.ob.n != out_len || ((P.inf.bp + 7) >> 3) != in_len) return EPROTO;
+  if (out_len) memcpy(out, P.ob.at0(), out_len);
+  if (crc) *crc = crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), out, out_len);
+  return 0;
+}
 
 ByteBuf::~ByteBuf() { free(data); }
 bool ByteBuf::resize_uninit(size_t n) {

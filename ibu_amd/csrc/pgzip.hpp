@@ -57,6 +57,21 @@ struct ByteBuf {  // grows by realloc, never zero-fills
   void swap(ByteBuf& o) { uint8_t* d = data; data = o.data; o.data = d; size_t t = size; size = o.size; o.size = t; t = cap; cap = o.cap; o.cap = t; }
 };
 
+// One bare deflate stream with nothing in front of it (a BGZF block: <= 64 KiB, its sizes known from the container)
+// -> `out_len` bytes, with the same symbol loop and CRC as the parallel decoder (about twice zlib's inflate, and the CRC
+// by carry-less multiplication).  `in` must be readable for in_len + 512 bytes.  0, ENOMEM, or EPROTO when the stream is
+// invalid, does not end exactly at in_len, or does not produce exactly out_len bytes.  One instance per thread.
+class RawInflater {
+ public:
+  RawInflater();
+  ~RawInflater();
+  int inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, uint32_t* crc);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> p_;
+};
+
 class ParallelGunzip {
  public:
   // threads: chunks decoded at once (>= 1); chunk_bytes: compressed bytes per chunk

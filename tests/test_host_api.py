@@ -368,6 +368,11 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
     monkeypatch.setenv("IBU_NO_PARALLEL_BGZF", "1")
     assert records_array(list(Reader.from_path(tmp_path / "bgzf.ibu.gz"))).tobytes() == recs.tobytes()
     monkeypatch.delenv("IBU_NO_PARALLEL_BGZF")
+    # ... and so does the block-parallel path with zlib's inflate + crc32 per block instead of the library's own decoder
+    monkeypatch.setenv("IBU_BGZF_ZLIB", "1")
+    for name in ("bgzf.ibu.gz", "bgzf_small_blocks.ibu.gz"):
+        assert records_array(list(Reader.from_path(tmp_path / name))).tobytes() == recs.tobytes(), name
+    monkeypatch.delenv("IBU_BGZF_ZLIB")
     # damage: a flipped payload byte fails the block CRC, a cut inside a block is a truncated stream -> Niffler
     blob = bytearray(cases["bgzf.ibu.gz"])
     blob[len(blob) // 2] ^= 0x55

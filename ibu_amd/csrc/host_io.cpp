@@ -494,64 +494,74 @@ struct BgzfSource : Source {
     return 0;
   }
   ~BgzfSource() override { if (next.valid()) (void)next.get(); }  // never leave the worker running over freed members
+  // Input is read in large pieces and the block headers are parsed from memory (one read(2) per 16 MiB instead of three
+  // per block: at 1e9 records that was 1.4 M system calls on the thread every batch waits for); blocks are inflated
+  // straight out of `comp`, a block that is not whole yet stays for the next batch.
+  size_t comp_pos = 0, comp_len = 0;                  // unparsed bytes: comp[comp_pos, comp_len)
+  bool inner_eof = false;
   int refill(std::vector<uint8_t>& out) {
-    comp.clear();
     out.clear();
     std::vector<Block> blocks;
     size_t total_out = 0;
-    const size_t kBatchComp = (size_t)16 << 20;
-    while (comp.size() < kBatchComp && !eof) {
-      uint8_t hd[12];
+    const size_t kBatchComp = (size_t)16 << 20, kPadBytes = 512;
+    if (comp_pos) {                                   // leftover of the previous batch to the front
+      memmove(comp.data(), comp.data() + comp_pos, comp_len - comp_pos);
+      comp_len -= comp_pos;
+      comp_pos = 0;
+    }
+    if (comp.size() < kBatchComp + (128u << 10) + kPadBytes) comp.resize(kBatchComp + (128u << 10) + kPadBytes);
+    while (!inner_eof && comp_len < kBatchComp + (128u << 10)) {
       size_t got = 0;
-      int rc = read_exact(hd, 12, &got);
+      int rc = inner->read(comp.data() + comp_len, kBatchComp + (128u << 10) - comp_len, &got);
       if (rc) return rc;
-      if (got == 0) { eof = true; break; }
-      if (got < 12) return EPROTO;
+      if (got == 0) inner_eof = true;
+      comp_len += got;
+    }
+    memset(comp.data() + comp_len, 0, kPadBytes);     // the symbol loop may read (not use) a few bytes behind a block
+    while (comp_pos < comp_len || inner_eof) {
+      const size_t avail = comp_len - comp_pos;
+      if (avail == 0) { eof = true; break; }
+      const uint8_t* hd = comp.data() + comp_pos;
+      if (avail < 12) { if (inner_eof) return EPROTO; break; }
       const bool bgzf_like = hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8 && (hd[3] & 4);
-      uint16_t xlen = (uint16_t)(hd[10] | (hd[11] << 8));
-      std::vector<uint8_t> extra(bgzf_like ? xlen : 0);
+      const size_t xlen = bgzf_like ? (size_t)(hd[10] | (hd[11] << 8)) : 0;
       size_t bsize = 0;
       if (bgzf_like) {
-        rc = read_exact(extra.data(), xlen, &got);
-        if (rc) return rc;
-        if (got < xlen) return EPROTO;
-        for (size_t p = 0; p + 4 <= extra.size();) {
+        if (avail < 12 + xlen) { if (inner_eof) return EPROTO; break; }
+        const uint8_t* extra = hd + 12;
+        for (size_t p = 0; p + 4 <= xlen;) {
           const size_t slen = (size_t)(extra[p + 2] | (extra[p + 3] << 8));
-          if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= extra.size()) bsize = (size_t)(extra[p + 4] | (extra[p + 5] << 8)) + 1;
+          if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = (size_t)(extra[p + 4] | (extra[p + 5] << 8)) + 1;
           p += 4 + slen;
         }
       }
-      if (!bgzf_like || bsize < 12 + 2 + (size_t)xlen + 8) {
-        // not a BGZF block: push what was consumed back and let the sequential decoder take over from here
+      if (!bgzf_like || bsize < 12 + 2 + xlen + 8) {
+        // not a BGZF block: everything not yet parsed goes back in front of the inner source and the sequential
+        // decoder takes over from here
         std::unique_ptr<PrefixSource> ps(new PrefixSource);
-        ps->pre.assign(hd, hd + 12);
-        ps->pre.insert(ps->pre.end(), extra.begin(), extra.end());
+        ps->pre.assign(hd, hd + avail);
         ps->inner = std::move(inner);
         fallback.reset(new GzSource(std::move(ps)));
+        comp_pos = comp_len;
         break;
       }
-      const size_t rest = bsize - 12 - xlen;  // deflate data + CRC32 + ISIZE
-      const size_t off = comp.size();
-      comp.resize(off + rest);
-      rc = read_exact(comp.data() + off, rest, &got);
-      if (rc) return rc;
-      if (got < rest) return EPROTO;  // stream ends inside a block
-      const uint8_t* tr = comp.data() + off + rest - 8;
+      if (avail < bsize) { if (inner_eof) return EPROTO; break; }  // the block is not whole yet / the stream ends inside it
+      const uint8_t* tr = hd + bsize - 8;
       Block b;
-      b.coff = off;
-      b.clen = rest - 8;
+      b.coff = comp_pos + 12 + xlen;
+      b.clen = bsize - 12 - xlen - 8;
       b.crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
       b.isize = (size_t)tr[4] | ((size_t)tr[5] << 8) | ((size_t)tr[6] << 16) | ((size_t)tr[7] << 24);
       if (b.isize > 65536) return EPROTO;
       b.ooff = total_out;
       total_out += b.isize;
       blocks.push_back(b);
+      comp_pos += bsize;
     }
     out.resize(total_out);
     if (blocks.empty()) return 0;
     const unsigned nt = blocks.size() < threads ? (unsigned)blocks.size() : threads;
     std::vector<int> rcs(nt, 0);
-    comp.resize(comp.size() + 512);                    // the symbol loop may read (not use) a few bytes behind a block
     auto work = [&](unsigned t) {
       const bool use_zlib = getenv("IBU_BGZF_ZLIB") != nullptr;   // A/B and second witness: zlib's inflate + crc32
       z_stream zs;

@@ -373,6 +373,19 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
     for name in ("bgzf.ibu.gz", "bgzf_small_blocks.ibu.gz"):
         assert records_array(list(Reader.from_path(tmp_path / name))).tobytes() == recs.tobytes(), name
     monkeypatch.delenv("IBU_BGZF_ZLIB")
+    # more compressed bytes than one batch buffer holds (16 MiB): blocks that straddle the buffer edge wait for the next batch
+    big = oracle.generate(7, 0, 1_600_000, 16, 12)
+    bigp = tmp_path / "big_bgzf.ibu.gz"
+    bigp.write_bytes(bgzf_compress(create_test_data(big)))
+    assert bigp.stat().st_size > (17 << 20)
+    r = Reader.from_path(bigp)
+    parts = []
+    while r.read_batch():
+        v = r.buffered()
+        parts.append(np.array(v, copy=True))
+        r.consume(len(v))
+    r.close()
+    assert np.concatenate(parts).tobytes() == big.tobytes()
     # damage: a flipped payload byte fails the block CRC, a cut inside a block is a truncated stream -> Niffler
     blob = bytearray(cases["bgzf.ibu.gz"])
     blob[len(blob) // 2] ^= 0x55

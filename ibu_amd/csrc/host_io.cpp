@@ -644,9 +644,9 @@ struct BgzfSource : Source {
 struct ParGzSource : Source {
   std::unique_ptr<Source> inner;
   std::unique_ptr<pgz::ParallelGunzip> dec;
-  pgz::ByteBuf out, next_out;
+  std::vector<pgz::Span> out, next_out;              // pieces of the decoder's chunk buffers (valid while the NEXT batch decodes)
   std::future<int> next;
-  size_t out_pos = 0;
+  size_t span_i = 0, span_off = 0;
   bool eof = false, next_eof = false;
   static unsigned env_threads() {
     const char* e = getenv("IBU_PGZ_THREADS");
@@ -688,20 +688,27 @@ struct ParGzSource : Source {
   int read(uint8_t* dst, size_t cap, size_t* got) override {
     *got = 0;
     for (;;) {
-      if (out_pos < out.size) {
-        const size_t k = out.size - out_pos < cap ? out.size - out_pos : cap;
-        if (k >= ((size_t)16 << 20)) {                 // a ring slot's worth: one thread copies ~8 GB/s, the inflate delivers 4-6
-          const uint8_t* src = out.data + out_pos;
-          const size_t per = ((k / 4) + 4095) & ~(size_t)4095;
-          run_pieces(4, [=](unsigned i) {
-            const size_t off = (size_t)i * per;
-            if (off < k) memcpy(dst + off, src + off, off + per < k ? per : k - off);
-          });
-        } else {
-          memcpy(dst, out.data + out_pos, k);
+      if (span_i < out.size()) {                       // hand out pieces until `cap` is full or the batch is used up
+        size_t done = 0;
+        while (span_i < out.size() && done < cap) {
+          const pgz::Span& sp = out[span_i];
+          const size_t k = sp.n - span_off < cap - done ? sp.n - span_off : cap - done;
+          const uint8_t* src = sp.p + span_off;
+          uint8_t* d = dst + done;
+          if (k >= ((size_t)4 << 20)) {                // one thread copies ~8 GB/s, the inflate delivers 5-6
+            const size_t per = ((k / 4) + 4095) & ~(size_t)4095;
+            run_pieces(4, [=](unsigned i) {
+              const size_t off = (size_t)i * per;
+              if (off < k) memcpy(d + off, src + off, off + per < k ? per : k - off);
+            });
+          } else if (k) {
+            memcpy(d, src, k);
+          }
+          done += k;
+          span_off += k;
+          if (span_off == sp.n) { ++span_i; span_off = 0; }
         }
-        out_pos += k;
-        *got = k;
+        *got = done;
         return 0;
       }
       if (eof) return 0;
@@ -714,8 +721,8 @@ struct ParGzSource : Source {
         rc = refill_noexcept();                        // the first batch (or no thread to be had): decode it here
       }
       if (rc) return rc;
-      out.swap(next_out);
-      out_pos = 0;
+      out.swap(next_out);                              // the batch just consumed is dead: its buffers are the ones the refill
+      span_i = span_off = 0;                           // started below decodes into
       eof = next_eof;
       if (!eof) (void)start_refill();                  // failure: the next round decodes inline
     }

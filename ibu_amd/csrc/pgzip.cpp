@@ -179,7 +179,7 @@ struct Inflater {
   bool last_block = false;
   uint32_t stored_left = 0;
   size_t bp = 0;                                     // bit position in the compressed buffer where decoding resumes
-  size_t clean_from = 0;                             // marker mode: every symbol from this output index on is a plain byte
+  size_t scanned = 0, last_marker = 0;               // marker mode: symbols [0, scanned) were searched; the last marker sits in front of last_marker
   std::vector<Segment> segs;
   void use_own() {
     if (lit_own.empty()) { lit_own.resize(kLitCap); dist_own.resize(kDistCap); }
@@ -364,7 +364,24 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
       case S_BLOCK: {
         if (s.bp >= target && s.bp != entry_bp) return R_BOUNDARY;
         if (ob.n >= out_cap) return R_OUT;
-        if (sizeof(T) == 2 && ob.n >= s.clean_from + kWin) return R_SWITCH;
+        if (sizeof(T) == 2) {
+          // Markers die out quickly (0.7 % of the symbols of a records file) but not monotonically: a long-distance match
+          // can copy one forward.  So the symbols written since the last boundary are searched — backwards, stopping at the
+          // first marker, four at a time — and byte mode starts once 32 KiB in a row hold none.
+          const uint16_t* p = reinterpret_cast<const uint16_t*>(ob.at0());
+          size_t i = ob.n;
+          while (i > s.scanned) {
+            if (i - s.scanned >= 4) {
+              uint64_t v;
+              memcpy(&v, p + i - 4, 8);
+              if (!(v & 0x8000800080008000ull)) { i -= 4; continue; }
+            }
+            --i;
+            if (p[i] & 0x8000u) { s.last_marker = i + 1; break; }
+          }
+          s.scanned = ob.n;
+          if (ob.n >= s.last_marker + kWin) return R_SWITCH;
+        }
         // a dynamic header is < 400 bytes; when more input may come, do not start one that may not be whole
         if (!final && (s.bp >> 3) + 400 > in_len) return R_IN;
         if ((s.bp >> 3) >= in_len) return R_ERR;     // final and nothing left: truncated
@@ -476,7 +493,6 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
             if (e_kind(d) != K_BASE) return R_ERR;
             const size_t dd = e_val(d) + ((uint32_t)(saved >> e_f(d)) & ((1u << (e_bits(d) - e_f(d))) - 1));
             if (dd > o + wlen) return R_ERR;         // reaches in front of the history
-            if (sizeof(T) == 2 && (dd > o || o - dd < s.clean_from)) s.clean_from = o + len;   // may have copied markers
             lz_copy(base + o, dd, len);
             o += len;
             continue;
@@ -717,17 +733,20 @@ struct Chunk {
   const uint8_t* win = nullptr;
   std::vector<uint32_t> piece_crc;                   // one per segment + one for the open tail
   bool bad_symbol = false;
-  // final bytes of output elements [a, b) of this chunk -> dst (dst[0] = element a)
-  bool finalize(size_t a, size_t b, uint8_t* dst, uint64_t* markers) {
-    bool good = true;
+  std::vector<uint8_t> head8;                        // the symbols of o16 as bytes once the window is known
+  // the chunk's bytes are head8[0, o16.n) followed by o8[0, o8.n)
+  bool resolve_head(size_t a, size_t b, uint64_t* markers) {   // symbols [a, b) of the head -> bytes
+    return a >= b || resolve(o16.at0() + a, b - a, win, head8.data() + a, markers);
+  }
+  uint32_t crc_range(size_t a, size_t b) {                     // CRC-32 of output bytes [a, b) of this chunk
+    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
     if (a < o16.n) {
       const size_t e = b < o16.n ? b : o16.n;
-      good = resolve(o16.at0() + a, e - a, win, dst, markers);
-      dst += e - a;
+      crc = crc32_bytes(crc, head8.data() + a, e - a);
       a = e;
     }
-    if (a < b) memcpy(dst, o8.at0() + (a - o16.n), b - a);
-    return good;
+    if (a < b) crc = crc32_bytes(crc, o8.at0() + (a - o16.n), b - a);
+    return crc;
   }
 };
 
@@ -757,18 +776,6 @@ int RawInflater::inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t 
   return 0;
 }
 
-ByteBuf::~ByteBuf() { free(data); }
-bool ByteBuf::resize_uninit(size_t n) {
-  if (n > cap) {
-    uint8_t* d = static_cast<uint8_t*>(realloc(data, n ? n : 1));
-    if (!d) return false;
-    data = d;
-    cap = n;
-  }
-  size = n;
-  return true;
-}
-
 struct ParallelGunzip::Impl {
   ReadFn inner;
   unsigned threads;
@@ -781,7 +788,8 @@ struct ParallelGunzip::Impl {
   uint32_t run_crc = 0;                              // CRC-32 / length of the open member so far
   uint64_t run_len = 0;
   size_t out_cap;
-  std::vector<Chunk> pool;                           // per-chunk buffers and tables, reused from batch to batch
+  std::vector<Chunk> pool[2];                        // per-chunk buffers and tables; the two sets take turns (see next_batch)
+  unsigned flip = 0;
   // A stream in which the search finds nothing (only fixed-Huffman blocks, say) would pay for a futile search in every
   // batch: after a batch without any candidate the next `find_skip` batches are decoded by one thread without searching
   // (1, 2, 4 ... 16 batches), then the search is tried again.
@@ -845,13 +853,13 @@ ParallelGunzip::~ParallelGunzip() {
   if (p_ && p_->ahead_f.valid()) { try { (void)p_->ahead_f.get(); } catch (...) {} }
 }
 
-int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
+int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
   Impl& P = *p_;
-  out.size = 0;
+  out.clear();
   *eof = false;
   if (P.failed) return EPROTO;
   const size_t kSlack = (size_t)256 << 10;
-  while (out.size == 0) {
+  while (out.empty()) {
     if (P.done) { *eof = true; return 0; }
     // ---- 0. top up the compressed buffer ---------------------------------------------------------------------------
     double t0 = now_s(), t1;
@@ -892,8 +900,8 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     while (n > 1 && base_byte + (n - 1) * P.chunk + 1024 >= in_len) --n;   // chunks that have at least some bytes
     const bool searching = n > 1 && P.find_skip == 0;
     if (!searching && n > 1) { --P.find_skip; n = 1; }
-    if (P.pool.size() < P.threads) P.pool = std::vector<Chunk>(P.threads);
-    std::vector<Chunk>& ch = P.pool;
+    if (P.pool[P.flip].size() < P.threads) P.pool[P.flip] = std::vector<Chunk>(P.threads);
+    std::vector<Chunk>& ch = P.pool[P.flip];
     for (size_t j = 0; j < n; ++j) {
       Chunk& c = ch[j];
       c.start = c.target = kNone;
@@ -960,7 +968,7 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
       c.inf.bp = c.start;
       if (!c.o16.reserve(P.chunk * 4)) { c.oom = 1; c.stop = R_ERR; return; }
       for (size_t i = 0; i < kWin; ++i) c.o16.mem[i] = (uint16_t)(0x8000u + i);
-      c.inf.clean_from = 0;
+      c.inf.scanned = c.inf.last_marker = 0;
       c.stop = run<uint16_t>(c.inf, in, in_len, final, c.target, c.target_stored, c.o16, P.out_cap, kWin, &c.oom);
       if (c.stop != R_SWITCH) return;
       // the last 32 KiB are plain bytes: they are the window of everything that follows -> byte mode (faster, no patching)
@@ -990,50 +998,47 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     }
 
     // ---- 4. windows, patching, CRC ----------------------------------------------------------------------------------
+    // Nothing is copied into one output buffer: a chunk's bytes stay where they were decoded (o8) or are patched into a
+    // byte buffer of their own (head8, the symbols in front of the byte-mode switch) and are handed out as pieces.
     size_t total = 0;
     for (size_t k : ok) { ch[k].out_off = total; total += ch[k].n_out(); }
-    if (!out.resize_uninit(total)) { P.failed = true; return ENOMEM; }
-    uint8_t* const dst = out.data;
-    auto tail_of = [](size_t nn) { return nn < kWin ? nn : kWin; };
-    // sequential: the last 32 KiB of every chunk in order (each is the window of the next chunk)
+    auto push_window = [](std::vector<uint8_t>& w, const uint8_t* p, size_t n) {   // w = last <= 32 KiB of (w ++ p[0, n))
+      if (n >= kWin) { w.assign(p + n - kWin, p + n); return; }
+      if (n) w.insert(w.end(), p, p + n);
+      if (w.size() > kWin) w.erase(w.begin(), w.begin() + (w.size() - kWin));
+    };
+    // sequential, 32 KiB per chunk: the window in front of every chunk, then that chunk's own last 32 KiB
+    std::vector<uint8_t> runwin = P.window;
     for (size_t a = 0; a < ok.size(); ++a) {
       Chunk& c = ch[ok[a]];
-      if (a > 0) {
-        if (c.out_off >= kWin) c.win = dst + c.out_off - kWin;
-        else {                                         // the window reaches back into the previous batch
-          c.win_tmp.assign(kWin, 0);
-          const size_t from_old = kWin - c.out_off, have = P.window.size() < from_old ? P.window.size() : from_old;
-          if (have) memcpy(c.win_tmp.data() + from_old - have, P.window.data() + P.window.size() - have, have);
-          if (c.out_off) memcpy(c.win_tmp.data() + from_old, dst, c.out_off);
-          c.win = c.win_tmp.data();
+      uint64_t m = 0;
+      if (c.o16.n) {
+        c.win_tmp.assign(kWin, 0);
+        if (!runwin.empty()) memcpy(c.win_tmp.data() + kWin - runwin.size(), runwin.data(), runwin.size());
+        c.win = c.win_tmp.data();
+        if (c.head8.size() < c.o16.n) c.head8.resize(c.o16.n);
+        if (c.o8.n < kWin) {                           // the chunk's last 32 KiB reach into its head: patch that part now
+          const size_t need = kWin - c.o8.n, from = c.o16.n > need ? c.o16.n - need : 0;
+          if (!c.resolve_head(from, c.o16.n, &m)) c.bad_symbol = true;
+          push_window(runwin, c.head8.data() + from, c.o16.n - from);
         }
       }
-      const size_t nn = c.n_out(), t = tail_of(nn);
-      uint64_t m = 0;
-      if (t && !c.finalize(nn - t, nn, dst + c.out_off + nn - t, &m)) c.bad_symbol = true;
+      if (c.o8.n) push_window(runwin, c.o8.at0(), c.o8.n);
       st_.marker_symbols += m;
     }
     t1 = now_s(); st_.s_windows += t1 - t0; t0 = t1;
     std::vector<uint64_t> markers(ok.size(), 0);
     run_pieces((unsigned)ok.size(), [&](unsigned a) {
       Chunk& c = ch[ok[a]];
-      const size_t nn = c.n_out(), body = nn - tail_of(nn);
-      // bytes are made final (copied / patched) and CRC'd block by block, so the CRC reads them from the cache
-      constexpr size_t kBlock = (size_t)256 << 10;
+      const size_t nn = c.n_out();
+      if (c.o16.n) {                                   // the rest of the head (its tail is done if the windows pass needed it)
+        const size_t need = c.o8.n < kWin ? kWin - c.o8.n : 0, upto = c.o16.n > need ? c.o16.n - need : 0;
+        if (!c.resolve_head(0, upto, &markers[a])) c.bad_symbol = true;
+      }
       size_t from = 0;
       for (size_t g = 0; g <= c.inf.segs.size(); ++g) {
         const size_t to = g < c.inf.segs.size() ? c.inf.segs[g].out_end : nn;
-        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-        for (size_t p = from; p < to;) {
-          const size_t q = to - p > kBlock ? p + kBlock : to;
-          if (p < body) {
-            const size_t e = q < body ? q : body;
-            if (!c.finalize(p, e, dst + c.out_off + p, &markers[a])) c.bad_symbol = true;
-          }
-          crc = crc32_bytes(crc, dst + c.out_off + p, q - p);
-          p = q;
-        }
-        c.piece_crc.push_back(crc);
+        c.piece_crc.push_back(c.crc_range(from, to));
         from = to;
       }
     });
@@ -1060,11 +1065,13 @@ int ParallelGunzip::next_batch(ByteBuf& out, bool* eof) {
     Chunk& lastc = ch[ok.back()];
     if (lastc.stop == R_END) P.done = true;
     if (lastc.stop == R_IN && final) { P.failed = true; return EPROTO; }
-    if (total >= kWin) P.window.assign(dst + total - kWin, dst + total);
-    else {
-      if (total) P.window.insert(P.window.end(), dst, dst + total);
-      if (P.window.size() > kWin) P.window.erase(P.window.begin(), P.window.begin() + (P.window.size() - kWin));
+    P.window.swap(runwin);
+    for (size_t k : ok) {
+      Chunk& c = ch[k];
+      if (c.o16.n) out.push_back(Span{c.head8.data(), c.o16.n});
+      if (c.o8.n) out.push_back(Span{c.o8.at0(), c.o8.n});
     }
+    P.flip ^= 1;                                       // the next batch decodes into the other set of buffers
     P.cur = std::move(lastc.inf);
     P.cur.segs.clear();
     const size_t shift = P.cur.bp >> 3;

@@ -46,16 +46,7 @@ struct Stats {
   double s_join_wait = 0, s_helper_read = 0;         // of s_read: waiting for the read-ahead helper; the helper's own read time
 };
 
-struct ByteBuf {  // grows by realloc, never zero-fills
-  uint8_t* data = nullptr;
-  size_t size = 0, cap = 0;
-  ByteBuf() {}
-  ByteBuf(const ByteBuf&) = delete;
-  ByteBuf& operator=(const ByteBuf&) = delete;
-  ~ByteBuf();
-  bool resize_uninit(size_t n);
-  void swap(ByteBuf& o) { uint8_t* d = data; data = o.data; o.data = d; size_t t = size; size = o.size; o.size = t; t = cap; cap = o.cap; o.cap = t; }
-};
+struct Span { const uint8_t* p; size_t n; };  // a piece of a batch's output (the decoder's own chunk buffers: no copy into one buffer)
 
 // One bare deflate stream with nothing in front of it (a BGZF block: <= 64 KiB, its sizes known from the container)
 // -> `out_len` bytes, with the same symbol loop and CRC as the parallel decoder (about twice zlib's inflate, and the CRC
@@ -77,9 +68,11 @@ class ParallelGunzip {
   // threads: chunks decoded at once (>= 1); chunk_bytes: compressed bytes per chunk
   ParallelGunzip(ReadFn inner, unsigned threads, size_t chunk_bytes);
   ~ParallelGunzip();
-  // Decodes the next batch into `out` (replaced).  Returns 0 or errno (EPROTO: corrupt / truncated stream).
-  // An empty `out` with *eof set is the clean end of the stream.
-  int next_batch(ByteBuf& out, bool* eof);
+  // Decodes the next batch; `out` (replaced) lists its bytes in order as pieces of the decoder's chunk buffers.  The pieces
+  // stay valid until the call AFTER the next one (two sets of chunk buffers take turns), so a caller may consume batch k
+  // while batch k + 1 is being decoded.  Returns 0 or errno (EPROTO: corrupt / truncated stream).  An empty `out` with
+  // *eof set is the clean end of the stream.
+  int next_batch(std::vector<Span>& out, bool* eof);
   const Stats& stats() const { return st_; }
 
  private:

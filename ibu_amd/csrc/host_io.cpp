@@ -567,6 +567,7 @@ struct BgzfSource : Source {
       z_stream zs;
       memset(&zs, 0, sizeof zs);
       if (use_zlib && inflateInit2(&zs, -15) != Z_OK) { rcs[t] = EPROTO; return; }
+      try {                                            // a worker thread must not throw
       pgz::RawInflater raw;
       for (size_t i = t; i < blocks.size(); i += nt) {
         const Block& b = blocks[i];
@@ -579,6 +580,9 @@ struct BgzfSource : Source {
           if (rc == 0 && crc != b.crc) rc = EPROTO;
         }
         if (rc) { rcs[t] = rc; break; }
+      }
+      } catch (...) {
+        rcs[t] = ENOMEM;
       }
       if (use_zlib) inflateEnd(&zs);
     };

@@ -923,8 +923,12 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
         const size_t last = in_len > 8 ? (in_len - 8) * 8 : 0;   // a header needs some bytes; keep the loads inside the padding
         if (to > last) to = last;
         if (from <= P.cur.bp) from = P.cur.bp + 1;
-        Inflater scratch;
-        ch[j].start = from < to ? find_block(in, in_len, from, to, scratch, &ch[j].start_stored) : kNone;
+        try {                                          // a worker thread must not throw (bad_alloc of the scratch tables)
+          Inflater scratch;
+          ch[j].start = from < to ? find_block(in, in_len, from, to, scratch, &ch[j].start_stored) : kNone;
+        } catch (...) {
+          ch[j].start = kNone;                         // no candidate: the chunk in front decodes through
+        }
       });
     std::vector<size_t> act;                           // chunks that will be decoded
     act.push_back(0);
@@ -959,6 +963,7 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     const size_t wlen0 = P.window.size();
     run_pieces((unsigned)act.size(), [&](unsigned a) {
       Chunk& c = ch[act[a]];
+      try {
       if (a == 0) {
         c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.target_stored, c.o8, P.out_cap, wlen0, &c.oom);
         return;
@@ -978,6 +983,10 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
       const size_t nseg = c.inf.segs.size(), cap8 = P.out_cap > c.o16.n ? P.out_cap - c.o16.n : 0;
       c.stop = run<uint8_t>(c.inf, in, in_len, final, c.target, c.target_stored, c.o8, cap8, kWin, &c.oom);
       for (size_t g = nseg; g < c.inf.segs.size(); ++g) c.inf.segs[g].out_end += c.o16.n;   // member ends count from the chunk's start
+      } catch (...) {                                  // bad_alloc in a table / segment vector: a worker thread must not throw
+        c.oom = 1;
+        c.stop = R_ERR;
+      }
     });
 
     t1 = now_s(); st_.s_decode += t1 - t0; t0 = t1;
@@ -1030,6 +1039,7 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     std::vector<uint64_t> markers(ok.size(), 0);
     run_pieces((unsigned)ok.size(), [&](unsigned a) {
       Chunk& c = ch[ok[a]];
+      try {
       const size_t nn = c.n_out();
       if (c.o16.n) {                                   // the rest of the head (its tail is done if the windows pass needed it)
         const size_t need = c.o8.n < kWin ? kWin - c.o8.n : 0, upto = c.o16.n > need ? c.o16.n - need : 0;
@@ -1041,7 +1051,12 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
         c.piece_crc.push_back(c.crc_range(from, to));
         from = to;
       }
+      } catch (...) {
+        c.oom = 1;
+      }
     });
+    for (size_t k : ok)
+      if (ch[k].oom) { P.failed = true; return ENOMEM; }
     for (size_t a = 0; a < ok.size(); ++a) st_.marker_symbols += markers[a];
     for (size_t k : ok) {
       Chunk& c = ch[k];

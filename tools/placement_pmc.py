@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--lens", default="16,12")
     ap.add_argument("--analyse", default="")
+    ap.add_argument("--blocks", default="", help="comma list of blocks_per_cu caps: time decode / encode at each one in every cycle")
     a = ap.parse_args()
     if a.analyse:
         return analyse(a.analyse)
@@ -115,6 +116,14 @@ def main():
                 "copy_ms": timed(lambda: ctx.copy(bufs["back"], bufs["recs"], 24 * n)),
                 "reduce_ms": timed(lambda: ctx.reduce(bufs["recs"], n)),
                 "ptrs": {k: hex(v.ptr) for k, v in bufs.items()}}
+        if a.blocks:   # does a slow placement prefer fewer resident waves?
+            sweep = {}
+            for bpc in (int(x) for x in a.blocks.split(",")):
+                ctx.set_option("blocks_per_cu", bpc)
+                sweep[bpc] = [timed(lambda: ctx.decode_ascii(bufs["recs"], n, bc_len, umi_len, bufs["bc"], bufs["umi"], bufs["idx"])),
+                              timed(lambda: ctx.encode_ascii(bufs["bc"], bufs["umi"], bufs["idx"], n, bc_len, umi_len, bufs["back"]))]
+            ctx.set_option("blocks_per_cu", 7)   # the library default
+            line["blocks_sweep_decode_encode_ms"] = sweep
         print(json.dumps(line), flush=True)
         for b in bufs.values():
             b.free()

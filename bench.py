@@ -162,9 +162,18 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     tries = max(1, min(tries, int(free_b * 0.94 / max(sharers, 1) // max(set_bytes, 1))))   # sharers: ranks on this GPU (rehearsals)
     legs, probes = [], []
     for _ in range(tries):
-        leg = make()
+        try:
+            leg = make()
+        except RuntimeError:           # out of memory on a later set (fragmentation, another process on the card):
+            if not legs:               # the sets that exist are the candidates
+                raise
+            torch.cuda.empty_cache()
+            break
         legs.append(leg)
         probes.append(leg.probe() if tries > 1 else None)
+    tries = len(legs)
+    if tries > 1 and probes[0] is None:
+        probes[0] = legs[0].probe()
     best = min(range(tries), key=lambda i: sum(probes[i])) if tries > 1 else 0
     for i, leg in enumerate(legs):
         if i != best:

@@ -21,6 +21,7 @@
 #include <memory>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -455,16 +456,42 @@ struct ZstdSource : InflatingSource {
 // inflates them on several threads.  Same output bytes, same error class (EPROTO -> IBU_ERR_NIFFLER); CRC32 and
 // ISIZE of every block are verified.  A member that is not a BGZF block hands the rest of the stream to the
 // sequential GzSource (mixed files stay correct).
+// Bytes without value-initialisation: std::vector<uint8_t>::resize memsets what the inflate threads are about to
+// overwrite (24 GB of memset on the thread every batch waits for, at 1e9 records).
+struct RawBytes {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  RawBytes() {}
+  RawBytes(const RawBytes&) = delete;
+  RawBytes& operator=(const RawBytes&) = delete;
+  ~RawBytes() { free(p); }
+  bool resize_uninit(size_t want) {
+    if (want > cap) {
+      uint8_t* q = static_cast<uint8_t*>(realloc(p, want ? want : 1));
+      if (!q) return false;
+      p = q;
+      cap = want;
+    }
+    n = want;
+    return true;
+  }
+  uint8_t* data() { return p; }
+  size_t size() const { return n; }
+  void swap(RawBytes& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+};
 struct BgzfSource : Source {
   std::unique_ptr<Source> inner;
   std::unique_ptr<Source> fallback;   // sequential inflate once a non-BGZF member shows up
-  std::vector<uint8_t> comp, out;     // out: the batch being handed out by read()
-  std::vector<uint8_t> next_out;      // the batch being inflated in the background while `out` is consumed
+  std::vector<uint8_t> comp;
+  RawBytes out;                       // the batch being handed out by read()
+  RawBytes next_out;                  // the batch being inflated in the background while `out` is consumed
   std::future<int> next;              // pending background refill (at most one; it alone touches inner/comp/eof/fallback)
   size_t out_pos = 0;
   bool eof = false;
   unsigned threads;
   struct Block { size_t coff, clen, ooff, isize; uint32_t crc; };
+  std::unique_ptr<pgz::WorkerPool> pool;                       // threads - 1 workers, started with the first batch
+  std::vector<std::unique_ptr<pgz::RawInflater>> raws;         // one decoder (tables, 64 KiB buffer) per thread, kept
   explicit BgzfSource(std::unique_ptr<Source> s) : inner(std::move(s)) {
     const char* e = getenv("IBU_BGZF_THREADS");
     size_t c = e ? (size_t)atol(e) : ibu::inflate_threads();
@@ -499,8 +526,8 @@ struct BgzfSource : Source {
   // straight out of `comp`, a block that is not whole yet stays for the next batch.
   size_t comp_pos = 0, comp_len = 0;                  // unparsed bytes: comp[comp_pos, comp_len)
   bool inner_eof = false;
-  int refill(std::vector<uint8_t>& out) {
-    out.clear();
+  int refill(RawBytes& out) {
+    out.n = 0;
     std::vector<Block> blocks;
     size_t total_out = 0;
     const size_t kBatchComp = (size_t)16 << 20, kPadBytes = 512;
@@ -558,7 +585,7 @@ struct BgzfSource : Source {
       blocks.push_back(b);
       comp_pos += bsize;
     }
-    out.resize(total_out);
+    if (!out.resize_uninit(total_out)) return ENOMEM;
     if (blocks.empty()) return 0;
     const unsigned nt = blocks.size() < threads ? (unsigned)blocks.size() : threads;
     std::vector<int> rcs(nt, 0);
@@ -568,7 +595,8 @@ struct BgzfSource : Source {
       memset(&zs, 0, sizeof zs);
       if (use_zlib && inflateInit2(&zs, -15) != Z_OK) { rcs[t] = EPROTO; return; }
       try {                                            // a worker thread must not throw
-      pgz::RawInflater raw;
+      if (!raws[t]) raws[t].reset(new pgz::RawInflater);
+      pgz::RawInflater& raw = *raws[t];
       for (size_t i = t; i < blocks.size(); i += nt) {
         const Block& b = blocks[i];
         if (b.isize == 0 && b.clen <= 2) continue;  // empty block (the EOF marker)
@@ -586,7 +614,9 @@ struct BgzfSource : Source {
       }
       if (use_zlib) inflateEnd(&zs);
     };
-    run_pieces(nt, work);  // never throws: blocks of a thread that cannot be started are inflated here
+    if (raws.size() < threads) raws.resize(threads);
+    if (!pool) pool.reset(new pgz::WorkerPool(threads - 1));
+    pool->run(nt, work);   // never throws: the share of a worker that could not be started is inflated by the others
     for (int r : rcs)
       if (r) return r;
     return 0;

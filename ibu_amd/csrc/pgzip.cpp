@@ -831,6 +831,11 @@ struct Chunk {
 
 }  // namespace
 
+struct WorkerPool::Impl { Pool pool; explicit Impl(unsigned w) : pool(w) {} };
+WorkerPool::WorkerPool(unsigned workers) : p_(new Impl(workers)) {}
+WorkerPool::~WorkerPool() {}
+void WorkerPool::run(unsigned n, const std::function<void(unsigned)>& fn) { p_->pool.run(n, fn); }
+
 struct RawInflater::Impl {
   Inflater inf;
   OutBuf<uint8_t> ob;

@@ -63,6 +63,20 @@ class RawInflater {
   std::unique_ptr<Impl> p_;
 };
 
+// Worker threads that live as long as their owner (the pool the parallel decoder runs its phases on; BgzfSource uses one
+// too).  run(n, fn) calls fn(0) ... fn(n-1) on the workers and the calling thread and returns when all are done; fn must
+// not throw.  Workers that cannot be started do not exist: the caller runs their share.
+class WorkerPool {
+ public:
+  explicit WorkerPool(unsigned workers);
+  ~WorkerPool();
+  void run(unsigned n, const std::function<void(unsigned)>& fn);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> p_;
+};
+
 class ParallelGunzip {
  public:
   // threads: chunks decoded at once (>= 1); chunk_bytes: compressed bytes per chunk

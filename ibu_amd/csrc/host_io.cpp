@@ -530,7 +530,8 @@ struct BgzfSource : Source {
     out.n = 0;
     std::vector<Block> blocks;
     size_t total_out = 0;
-    const size_t kBatchComp = (size_t)16 << 20, kPadBytes = 512;
+    static const size_t kBatchComp = [] { const char* e = getenv("IBU_BGZF_BATCH"); return e ? (size_t)atol(e) : (size_t)32 << 20; }();   // 16 ... 128 MiB: 382 ... 409 M records/s, flat
+    const size_t kPadBytes = 512;
     if (comp_pos) {                                   // leftover of the previous batch to the front
       memmove(comp.data(), comp.data() + comp_pos, comp_len - comp_pos);
       comp_len -= comp_pos;

@@ -378,6 +378,7 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
     bigp = tmp_path / "big_bgzf.ibu.gz"
     bigp.write_bytes(bgzf_compress(create_test_data(big)))
     assert bigp.stat().st_size > (17 << 20)
+    monkeypatch.setenv("IBU_BGZF_BATCH", str(5 << 20))   # several batches, block edges off the batch edges
     r = Reader.from_path(bigp)
     parts = []
     while r.read_batch():
@@ -386,6 +387,7 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
         r.consume(len(v))
     r.close()
     assert np.concatenate(parts).tobytes() == big.tobytes()
+    monkeypatch.delenv("IBU_BGZF_BATCH")
     # damage: a flipped payload byte fails the block CRC, a cut inside a block is a truncated stream -> Niffler
     blob = bytearray(cases["bgzf.ibu.gz"])
     blob[len(blob) // 2] ^= 0x55

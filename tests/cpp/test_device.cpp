@@ -46,6 +46,14 @@ TEST(generate_decode_encode_reduce_match_the_oracle) {
       ctx().encode_ascii(bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), n, h, back.ptr());
       ctx().codec_status();
       CHECK(back.download<Record>(n) == want);
+      CHECK_EQ(ctx().first_mismatch(recs.ptr(), back.ptr(), n), n);   // `recs == back` on the device (Record: PartialEq)
+      if (n > 2) {                                                     // ... and a difference is found where it is
+        auto other = want;
+        other[n / 2].umi ^= 1;
+        other[n - 1].index += 1;
+        back.upload(other);
+        CHECK_EQ(ctx().first_mismatch(recs.ptr(), back.ptr(), n), n / 2);
+      }
       orc_reduce r;
       orc_reduce_records(reinterpret_cast<const orc_record*>(want.data()), n, &r);
       auto got = ctx().reduce(recs.ptr(), n);

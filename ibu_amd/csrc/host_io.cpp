@@ -189,17 +189,61 @@ struct MemSource : Source {
 struct FdSource : Source {
   int fd;
   bool owned;
-  FdSource(int f, bool o) : fd(f), owned(o) {}
+  // A regular file is read with several preads at once when the caller asks for a lot (a ring slot, a batch of compressed
+  // input): one read(2) copies ~10 GB/s out of the page cache, the pinned ring and PCIe take 50.
+  bool regular = false;
+  off_t pos = 0;
+  FdSource(int f, bool o) : fd(f), owned(o) {
+    struct stat st;
+    if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !getenv("IBU_NO_PARALLEL_READ")) {
+      const off_t cur = lseek(fd, 0, SEEK_CUR);
+      if (cur >= 0) { regular = true; pos = cur; }
+    }
+  }
   ~FdSource() override {
     if (owned && fd >= 0) close(fd);
   }
   int read(uint8_t* dst, size_t cap, size_t* got) override {
+    constexpr size_t kParMin = (size_t)8 << 20;
+    if (regular && cap >= kParMin) {
+      constexpr unsigned kPieces = 4;
+      const size_t per = ((cap / kPieces) + 4095) & ~(size_t)4095;
+      size_t done[kPieces] = {0, 0, 0, 0};
+      int err[kPieces] = {0, 0, 0, 0};
+      const off_t base = pos;
+      const int f = fd;
+      run_pieces(kPieces, [&, base, f](unsigned i) {    // never throws
+        const size_t off = (size_t)i * per;
+        if (off >= cap) return;
+        const size_t len = off + per < cap ? per : cap - off;
+        while (done[i] < len) {
+          const ssize_t k = pread(f, dst + off + done[i], len - done[i], base + (off_t)(off + done[i]));
+          if (k < 0) { if (errno == EINTR) continue; err[i] = errno; return; }
+          if (k == 0) return;                           // end of file inside this piece
+          done[i] += (size_t)k;
+        }
+      });
+      size_t total = 0;
+      for (unsigned i = 0; i < kPieces; ++i) {           // the contiguous prefix that was read
+        const size_t off = (size_t)i * per;
+        if (off >= cap) break;
+        const size_t len = off + per < cap ? per : cap - off;
+        if (err[i] && done[i] == 0 && total == 0) return err[i];
+        total += done[i];
+        if (done[i] < len) break;
+      }
+      pos = base + (off_t)total;
+      (void)lseek(fd, pos, SEEK_SET);                  // keep the descriptor's own offset where a plain read would leave it
+      *got = total;
+      return 0;
+    }
     for (;;) {
       ssize_t k = ::read(fd, dst, cap);
       if (k < 0) {
         if (errno == EINTR) continue;
         return errno;
       }
+      if (regular) pos += k;
       *got = (size_t)k;
       return 0;
     }

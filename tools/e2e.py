@@ -243,6 +243,16 @@ def main():
             assert ok, "device decode differs from the host load_to_vec + numpy unpack"
             del recs
 
+        # 3b. the same plain file through the STREAMING reader (Reader::from_path -> read(2) / pread into the ring)
+        r = ia.Reader.from_path(path)
+        t0 = time.perf_counter()
+        _, st = r.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
+        dt = time.perf_counter() - t0
+        r.close()
+        same = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()] == plain
+        emit("plain file, streaming Reader process_device DECODE", dt, st, equals_plain_path=same)
+        assert same
+
         # 4. gzip stream
         if a.gzip:
             def gz_leg(label, gzpath, gz_bytes, tc, **env):

@@ -189,7 +189,7 @@ struct MemSource : Source {
 struct FdSource : Source {
   int fd;
   bool owned;
-  // A regular file is read with several preads at once when the caller asks for a lot (a ring slot, a batch of compressed
+  // A regular file is read with eight preads at once when the caller asks for a lot (a ring slot, a batch of compressed
   // input): one read(2) copies ~10 GB/s out of the page cache, the pinned ring and PCIe take 50.
   bool regular = false;
   off_t pos = 0;
@@ -206,10 +206,10 @@ struct FdSource : Source {
   int read(uint8_t* dst, size_t cap, size_t* got) override {
     constexpr size_t kParMin = (size_t)8 << 20;
     if (regular && cap >= kParMin) {
-      constexpr unsigned kPieces = 4;
+      constexpr unsigned kPieces = 8;
       const size_t per = ((cap / kPieces) + 4095) & ~(size_t)4095;
-      size_t done[kPieces] = {0, 0, 0, 0};
-      int err[kPieces] = {0, 0, 0, 0};
+      size_t done[kPieces] = {0};
+      int err[kPieces] = {0};
       const off_t base = pos;
       const int f = fd;
       run_pieces(kPieces, [&, base, f](unsigned i) {    // never throws
@@ -1119,6 +1119,25 @@ extern "C" int32_t ibu_reader_buffered(ibu_reader_t* r, const ibu_record_t** rec
 extern "C" int32_t ibu_reader_consume(ibu_reader_t* r, size_t n) {
   if (!r || n > r->cap - r->pos) return err_arg("consume beyond the buffered records");
   r->pos += n;
+  return IBU_OK;
+}
+int32_t ibu::reader_read_direct(ibu_reader_t* r, uint8_t* dst, size_t cap_bytes, size_t* got_bytes, bool* eof) {
+  *got_bytes = 0;
+  *eof = false;
+  if (!r || r->pos < r->cap) return err_arg("reader_read_direct: the reader's own buffer still holds records");
+  cap_bytes -= cap_bytes % IBU_RECORD_SIZE;
+  size_t read = 0;
+  while (read < cap_bytes) {
+    size_t got = 0;
+    int e = r->inner->read(dst + read, cap_bytes - read, &got);
+    if (e) return src_error(r, e, "read");
+    if (got == 0) { *eof = true; break; }
+    read += got;
+  }
+  if (read % IBU_RECORD_SIZE != 0)                     // only at the end of the stream: it ends inside a record
+    return err_truncated(r->bytes_read + (read - read % IBU_RECORD_SIZE));
+  r->bytes_read += read;
+  *got_bytes = read;
   return IBU_OK;
 }
 extern "C" uint64_t ibu_reader_bytes_read(const ibu_reader_t* r) { return r ? r->bytes_read : 0; }

@@ -10,6 +10,11 @@ namespace ibu {
 int32_t writer_write_bytes(ibu_writer_t* w, const uint8_t* bytes, size_t len);
 // Front half of load_to_vec (reader.rs:511-526): open, header, validate, size check.
 int32_t open_plain_file(const char* path, int* fd_out, ibu_header_t* header, size_t* n_records);
+// The device streaming path's refill: reads straight from the reader's source into `dst` (a pinned ring slot) until
+// `cap_bytes` are there or the stream ends, without the detour through the reader's own 1.18 MB buffer (which must be
+// empty: ibu_reader_buffered == 0).  Whole records only: a stream that ends inside a record is TruncatedRecord with the
+// position read_batch would report (reader.rs:232-237).  *eof: the stream ended (possibly with *got_bytes > 0).
+int32_t reader_read_direct(ibu_reader_t* r, uint8_t* dst, size_t cap_bytes, size_t* got_bytes, bool* eof);
 // num_cpus::get()
 size_t host_cores();
 // Threads for the inflate workers (BGZF blocks, pgzip chunks): the CPUs this process may run on, but at most twice its

@@ -387,16 +387,21 @@ extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, c
     if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
     kc.harvest(s);
     size_t filled = 0;
-    while (filled < slot_records) {  // inflate / read straight into the pinned slot's refill-sized pieces
+    while (filled < slot_records) {
       const ibu_record_t* recs;
       size_t have = 0;
       ibu_reader_buffered(rd, &recs, &have);
       if (have == 0) {
-        int32_t has = 0;
-        rc = ibu_reader_read_batch(rd, &has);  // reader.rs:218-242 incl. the truncation rule
-        if (rc || !has) { eof = true; break; }
+        // the source fills the pinned slot directly (parallel preads of a plain file, the inflate threads' own copies):
+        // no detour through the reader's 1.18 MB buffer; the truncation rule of reader.rs:232-237 applies to the slot
+        size_t got = 0;
+        rc = reader_read_direct(rd, r.pinned[s] + filled * IBU_RECORD_SIZE, (slot_records - filled) * IBU_RECORD_SIZE, &got, &eof);
+        if (rc) { eof = true; break; }
+        filled += got / IBU_RECORD_SIZE;
+        if (eof) break;
         continue;
       }
+      // records the caller had already pulled into the reader's buffer (read_batch / next before this call) go first
       const size_t take = have < slot_records - filled ? have : slot_records - filled;
       memcpy(r.pinned[s] + filled * IBU_RECORD_SIZE, recs, take * IBU_RECORD_SIZE);
       ibu_reader_consume(rd, take);

@@ -225,7 +225,8 @@ static constexpr int kTilesPerBlock = 1024;                   // tiles per scan 
 // three dwordx4 loads always belongs to field (2 (64 k + lane) + h) % 3; only the slots of the pass's field count.
 template <int T>
 __global__ void __launch_bounds__(kSortThreads, 8)
-ibu_k_sort_tilecounts_recs(const uint8_t* __restrict__ recs, u32 nfull, u32 field, u32 shift, uint16_t* __restrict__ counts) {
+ibu_k_sort_tilecounts_recs(const uint8_t* __restrict__ recs, u32 nfull, u32 field, u32 shift, uint16_t* __restrict__ counts,
+                           uint8_t* __restrict__ copy_dst) {   // copy_dst != nullptr: the records are copied there on the way
   __shared__ u32 h[kBins];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
   constexpr int kSub = T / kTileRecs;                         // 128-record sub-tiles per tile
@@ -245,6 +246,11 @@ ibu_k_sort_tilecounts_recs(const uint8_t* __restrict__ recs, u32 nfull, u32 fiel
       u32x4 a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) a[k] = ld16(p + 1024 * k);
+      if (copy_dst) {                                          // block-uniform
+        uint8_t* q = copy_dst + (p - recs);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st16(q + 1024 * k, a[k]);
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const u64 v0 = ((u64)a[k].y << 32) | a[k].x, v1 = ((u64)a[k].w << 32) | a[k].z;
@@ -261,14 +267,19 @@ ibu_k_sort_tilecounts_recs(const uint8_t* __restrict__ recs, u32 nfull, u32 fiel
 // tile of an input that is only 8-byte aligned)
 template <int T>
 __global__ void __launch_bounds__(kSortThreads)
-ibu_k_sort_tilecounts_recs_tail(const u64* __restrict__ recs, u64 n, u32 tile0, u32 field, u32 shift, uint16_t* __restrict__ counts) {
+ibu_k_sort_tilecounts_recs_tail(const u64* __restrict__ recs, u64 n, u32 tile0, u32 field, u32 shift, uint16_t* __restrict__ counts,
+                                u64* __restrict__ copy_dst) {
   __shared__ u32 h[kBins];
   const u32 tile = tile0 + blockIdx.x;
   h[threadIdx.x] = 0;
   __syncthreads();
   const u64 tbase = (u64)tile * T;
   const u32 cnt = n - tbase < (u64)T ? (u32)(n - tbase) : (u32)T;
-  for (u32 i = threadIdx.x; i < cnt; i += kSortThreads) atomicAdd(&h[(u32)(recs[3 * (tbase + i) + field] >> shift) & 255u], 1u);
+  for (u32 i = threadIdx.x; i < cnt; i += kSortThreads) {
+    const u64* r = recs + 3 * (tbase + i);
+    atomicAdd(&h[(u32)(r[field] >> shift) & 255u], 1u);
+    if (copy_dst) { u64* w = copy_dst + 3 * (tbase + i); w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; }
+  }
   __syncthreads();
   counts[(size_t)tile * kBins + threadIdx.x] = (uint16_t)h[threadIdx.x];
 }
@@ -550,8 +561,8 @@ struct SweepVariant {
   size_t lds;
   const void* scatter32;
   const void* scatter64;
-  void (*counts_recs)(const uint8_t*, u32, u32, u32, uint16_t*);
-  void (*counts_tail)(const u64*, u64, u32, u32, u32, uint16_t*);
+  void (*counts_recs)(const uint8_t*, u32, u32, u32, uint16_t*, uint8_t*);
+  void (*counts_tail)(const u64*, u64, u32, u32, u32, uint16_t*, u64*);
   void (*counts_bytes)(const uint8_t*, u64, u32, uint16_t*);
 };
 #ifdef IBU_SORT_PROBE
@@ -640,20 +651,25 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
 
   u64* src = static_cast<u64*>(recs);
   u64* dst = static_cast<u64*>(tmp);
+  // An odd number of passes would leave the result in `tmp` (a 48 B/record copy back).  The first pass's counting kernel
+  // reads every record anyway: with an odd count it also writes them to `tmp` (24 B/record) and the passes run
+  // tmp -> recs -> tmp ... -> recs.
+  const bool stage = (npass & 1) && npass > 0;
   const u32 nfull = (u32)(n / sv.tile);          // tiles with all T records
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
   for (int p = 0; p < npass; ++p) {
     // counts of every tile: from the records for the first pass, from the digit side stream afterwards
     if (p == 0) {
-      const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+      const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (stage ? reinterpret_cast<uintptr_t>(dst) : 0)) & 15u) == 0;
       const u32 fast = aligned ? nfull : 0;
       if (fast)
         hipLaunchKernelGGL(sv.counts_recs, dim3(fast < cap ? fast : cap), dim3(kSortThreads), 0, st, (const uint8_t*)src, fast,
-                           passes[p].field, passes[p].shift, counts);
+                           passes[p].field, passes[p].shift, counts, stage ? reinterpret_cast<uint8_t*>(dst) : (uint8_t*)nullptr);
       if (fast < L.ntiles)
         hipLaunchKernelGGL(sv.counts_tail, dim3(L.ntiles - fast), dim3(kSortThreads), 0, st, (const u64*)src, (u64)n, fast,
-                           passes[p].field, passes[p].shift, counts);
+                           passes[p].field, passes[p].shift, counts, stage ? dst : (u64*)nullptr);
+      if (stage) { u64* t = src; src = dst; dst = t; }   // the records now sit in tmp: scatter tmp -> recs
     } else {
       hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits,
                          (u64)n, L.ntiles, counts);

@@ -313,7 +313,8 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
                                                     bool target_stored, OutBuf<T>& ob, size_t out_cap, size_t wlen, int* oom) {
   const size_t entry_bp = s.bp;
   // positions at which the hot loop gives up: never touch bytes behind in_len + kPad; when more input may come, stop 64 B early
-  const size_t pos_lim = final ? in_len + 16 : (in_len > 64 ? in_len - 64 : 0);
+  // (final: from in_len on the exact bit position is compared with the end of the input every iteration)
+  const size_t pos_lim = final ? in_len : (in_len > 64 ? in_len - 64 : 0);
   for (;;) {
     switch (s.st) {
       case S_DONE:
@@ -450,6 +451,7 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
         if (o_lim > out_cap) o_lim = out_cap;
         Stop why = R_BOUNDARY;
         bool block_done = false;
+        size_t o_prev = o;                             // output position in front of the previous iteration's symbols
         for (;;) {
           if (o >= o_lim) {
             if (o >= out_cap) { why = R_OUT; break; }
@@ -462,8 +464,13 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
           }
           if (b.pos > pos_lim) {
             if (!final) { why = R_IN; break; }
-            return R_ERR;                            // ran far into the padding: truncated
+            if (b.bitpos() > in_len * 8) {           // the previous iteration decoded padding: the stream is truncated;
+              o = o_prev;                            // what it produced is not part of it
+              why = R_ERR;
+              break;
+            }
           }
+          o_prev = o;
           b.refill();
           // >= 56 bits after a refill: three symbols of <= 15 bits fit.  Literals first; the subtable link is tested only
           // on the way out of the literal path.
@@ -494,20 +501,21 @@ __attribute__((always_inline)) inline Stop run_body(Inflater& s, const uint8_t* 
             if (e_kind(d) == K_SUB) { b.drop(kDistBits); d = dist[e_val(d) + (b.buf & ((1u << e_f(d)) - 1))]; }
             saved = b.buf;
             b.drop(e_bits(d));
-            if (e_kind(d) != K_BASE) return R_ERR;
+            if (e_kind(d) != K_BASE) { why = R_ERR; break; }
             const size_t dd = e_val(d) + ((uint32_t)(saved >> e_f(d)) & ((1u << (e_bits(d) - e_f(d))) - 1));
-            if (dd > o + wlen) return R_ERR;         // reaches in front of the history
+            if (dd > o + wlen) { why = R_ERR; break; }   // reaches in front of the history
             lz_copy(base + o, dd, len);
             o += len;
             continue;
           }
           if (e_kind(e) == K_EOB) { block_done = true; break; }
-          return R_ERR;
+          why = R_ERR;                                 // an unused code / a length symbol that does not exist
+          break;
         }
-        ob.n = o;
+        ob.n = o;                                      // on an error: everything in front of the bad spot stays
         s.bp = b.bitpos();
         if (block_done) {
-          if (s.bp > in_len * 8) return R_ERR;       // the block's last bits came from the padding: truncated
+          if (s.bp > in_len * 8) { ob.n = o_prev; return R_ERR; }   // the block's last bits came from the padding: truncated
           s.st = s.last_block ? (s.raw ? S_DONE : S_TRAILER) : S_BLOCK;
           break;
         }
@@ -1087,10 +1095,12 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     }
     st_.chunks_accepted += ok.size();
     st_.chunks_discarded += act.size() - ok.size();
-    for (size_t k : ok) {
+    for (size_t k : ok)
       if (ch[k].oom) { P.failed = true; return ENOMEM; }
-      if (ch[k].stop == R_ERR) { P.failed = true; return EPROTO; }   // an accepted chunk decodes the true stream
-    }
+    // An accepted chunk decodes the true stream, so an error in it (only the LAST accepted chunk can carry one: nothing
+    // chains behind it) is the stream's: what was decoded in front of the bad spot is delivered like any other batch —
+    // a sequential inflate hands those bytes out, too — and the NEXT call reports the error.
+    const bool stream_bad = ch[ok.back()].stop == R_ERR;
 
     // ---- 4. windows, patching, CRC ----------------------------------------------------------------------------------
     // Nothing is copied into one output buffer: a chunk's bytes stay where they were decoded (o8) or are patched into a
@@ -1166,6 +1176,10 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     Chunk& lastc = ch[ok.back()];
     if (lastc.stop == R_END) P.done = true;
     if (lastc.stop == R_IN && final) { P.failed = true; return EPROTO; }
+    if (stream_bad) {
+      P.failed = true;                                 // sticky: every later call returns EPROTO
+      if (total == 0) return EPROTO;
+    }
     P.window.swap(runwin);
     for (size_t k : ok) {
       Chunk& c = ch[k];
@@ -1185,6 +1199,7 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     st_.batches++;
     st_.bytes_out += total;
     st_.s_carry += now_s() - t0;
+    if (stream_bad) return 0;                          // the bytes in front of the bad spot; the error comes with the next call
     if (total == 0 && !P.done && lastc.stop == R_IN && !final) continue;  // needs more input: the top-up reads it
     if (total == 0 && !P.done && shift == 0 && lastc.stop != R_IN) { P.failed = true; return EPROTO; }  // no progress: cannot happen
   }

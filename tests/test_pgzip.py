@@ -201,3 +201,40 @@ def test_streams_written_by_the_gzip_program(tmp_path, monkeypatch, level):
     for threads, chunk in ((4, 4096), (6, 50_000)):
         _knobs(monkeypatch, threads, chunk)
         assert _read_all(str(p) + ".gz") == raw[32:]
+
+
+def _records_before_error(path):
+    """(records delivered through read_batch before the error, error kind or None)."""
+    r = ia.Reader.from_path(path)
+    n = 0
+    try:
+        while r.read_batch():
+            k = len(r.buffered())
+            n += k
+            r.consume(k)
+        return n, None
+    except ia.IbuError as e:
+        return n, e.kind
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("where", [0.13, 0.5, 0.77, 0.999])
+def test_a_truncated_stream_delivers_what_the_sequential_path_delivers(tmp_path, monkeypatch, where):
+    """The bytes in front of the bad spot are handed out, the error comes afterwards — like a sequential inflate (flate2
+    under niffler): a stream cut anywhere gives the same number of records before the same error.  (The reader rejects
+    the refill the error falls into, reader.rs:232-237, so whole 49 152-record refills are what arrives.)"""
+    P = payloads()
+    raw = _header() + P["records"] + P["text"][:24 * 20_000]
+    blob = _zc(raw, 6)
+    p = tmp_path / "cut.ibu.gz"
+    p.write_bytes(blob[: int(len(blob) * where)])
+    monkeypatch.setenv("IBU_NO_PARALLEL_GZIP", "1")
+    want = _records_before_error(p)
+    assert want[1] == "Niffler"
+    for threads, chunk in ((4, 4096), (3, 200_000), (8, 1 << 20)):
+        _knobs(monkeypatch, threads, chunk)
+        got = _records_before_error(p)
+        assert got[1] == "Niffler"
+        assert abs(got[0] - want[0]) <= 49_152, (threads, chunk, got, want)   # the cut may fall next to a refill edge
+        assert got[0] >= want[0] - 49_152 and (where < 0.2 or got[0] > 0)

@@ -532,6 +532,7 @@ struct BgzfSource : Source {
   std::future<int> next;              // pending background refill (at most one; it alone touches inner/comp/eof/fallback)
   size_t out_pos = 0;
   bool eof = false;
+  int pending_err = 0;                // a bad spot was met: reported once what lies in front of it has been handed out
   unsigned threads;
   struct Block { size_t coff, clen, ooff, isize; uint32_t crc; };
   std::unique_ptr<pgz::WorkerPool> pool;                       // threads - 1 workers, started with the first batch
@@ -594,16 +595,19 @@ struct BgzfSource : Source {
       comp_len += got;
     }
     memset(comp.data() + comp_len, 0, kPadBytes);     // the symbol loop may read (not use) a few bytes behind a block
-    while (comp_pos < comp_len || inner_eof) {
+    // A bad spot (a block that is cut off, a size that cannot be) does not take the blocks in front of it with it: they
+    // are inflated and handed out like any batch — a sequential inflate delivers them, too — and the error (pending_err)
+    // comes with the read() behind them.
+    while ((comp_pos < comp_len || inner_eof) && !pending_err) {
       const size_t avail = comp_len - comp_pos;
       if (avail == 0) { eof = true; break; }
       const uint8_t* hd = comp.data() + comp_pos;
-      if (avail < 12) { if (inner_eof) return EPROTO; break; }
+      if (avail < 12) { if (inner_eof) pending_err = EPROTO; break; }
       const bool bgzf_like = hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8 && (hd[3] & 4);
       const size_t xlen = bgzf_like ? (size_t)(hd[10] | (hd[11] << 8)) : 0;
       size_t bsize = 0;
       if (bgzf_like) {
-        if (avail < 12 + xlen) { if (inner_eof) return EPROTO; break; }
+        if (avail < 12 + xlen) { if (inner_eof) pending_err = EPROTO; break; }
         const uint8_t* extra = hd + 12;
         for (size_t p = 0; p + 4 <= xlen;) {
           const size_t slen = (size_t)(extra[p + 2] | (extra[p + 3] << 8));
@@ -621,23 +625,25 @@ struct BgzfSource : Source {
         comp_pos = comp_len;
         break;
       }
-      if (avail < bsize) { if (inner_eof) return EPROTO; break; }  // the block is not whole yet / the stream ends inside it
+      if (avail < bsize) { if (inner_eof) pending_err = EPROTO; break; }  // the block is not whole yet / the stream ends inside it
       const uint8_t* tr = hd + bsize - 8;
       Block b;
       b.coff = comp_pos + 12 + xlen;
       b.clen = bsize - 12 - xlen - 8;
       b.crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
       b.isize = (size_t)tr[4] | ((size_t)tr[5] << 8) | ((size_t)tr[6] << 16) | ((size_t)tr[7] << 24);
-      if (b.isize > 65536) return EPROTO;
+      if (b.isize > 65536) { pending_err = EPROTO; break; }
       b.ooff = total_out;
       total_out += b.isize;
       blocks.push_back(b);
       comp_pos += bsize;
     }
+    if (pending_err) eof = true;                       // nothing is read behind a bad spot
     if (!out.resize_uninit(total_out)) return ENOMEM;
     if (blocks.empty()) return 0;
     const unsigned nt = blocks.size() < threads ? (unsigned)blocks.size() : threads;
     std::vector<int> rcs(nt, 0);
+    std::vector<size_t> bad_at(nt, ~(size_t)0);        // per task: the first block that did not inflate
     auto work = [&](unsigned t) {
       const bool use_zlib = getenv("IBU_BGZF_ZLIB") != nullptr;   // A/B and second witness: zlib's inflate + crc32
       z_stream zs;
@@ -656,7 +662,7 @@ struct BgzfSource : Source {
           rc = raw.inflate(comp.data() + b.coff, b.clen, out.data() + b.ooff, b.isize, &crc);
           if (rc == 0 && crc != b.crc) rc = EPROTO;
         }
-        if (rc) { rcs[t] = rc; break; }
+        if (rc) { rcs[t] = rc; bad_at[t] = i; break; }
       }
       } catch (...) {
         rcs[t] = ENOMEM;
@@ -666,8 +672,16 @@ struct BgzfSource : Source {
     if (raws.size() < threads) raws.resize(threads);
     if (!pool) pool.reset(new pgz::WorkerPool(threads - 1));
     pool->run(nt, work);   // never throws: the share of a worker that could not be started is inflated by the others
-    for (int r : rcs)
-      if (r) return r;
+    size_t first_bad = ~(size_t)0;
+    for (unsigned t = 0; t < nt; ++t) {
+      if (rcs[t] && bad_at[t] == ~(size_t)0) return rcs[t];          // not a block's fault (no memory, no zlib state)
+      if (bad_at[t] < first_bad) first_bad = bad_at[t];
+    }
+    if (first_bad != ~(size_t)0) {                       // blocks in front of the first bad one are good and go out
+      out.n = blocks[first_bad].ooff;
+      pending_err = EPROTO;
+      eof = true;                                      // nothing is read behind the bad spot
+    }
     return 0;
   }
   // refill() grows vectors: bad_alloc must not leave as an exception (this is called under extern "C" entry points)
@@ -697,6 +711,7 @@ struct BgzfSource : Source {
       // current batch drained: take the one inflated in the background (or start the first), then immediately start
       // the next so that reading + inflating batch k+1 overlaps the caller's consumption of batch k
       if (!next.valid()) {
+        if (pending_err) return pending_err;   // everything in front of the bad spot has been handed out
         if (fallback) return fallback->read(dst, cap, got);
         if (eof) return 0;
         if (!start_refill()) {   // no thread to be had: inflate the batch on this one

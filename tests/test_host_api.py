@@ -401,6 +401,23 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
     with pytest.raises(IbuError) as ei:
         list(Reader.from_path(cut))
     assert ei.value.kind == "Niffler"
+    # ... and what lies in front of the bad spot arrives first, as with the sequential decoder: same records, same error
+    def until_error(path):
+        got = []
+        try:
+            for r in Reader.from_path(path):
+                got.append(r)
+        except IbuError as e:
+            return len(got), e.kind
+        return len(got), None
+    for damaged in (bad, cut):
+        monkeypatch.setenv("IBU_NO_PARALLEL_BGZF", "1")
+        want = until_error(damaged)
+        monkeypatch.delenv("IBU_NO_PARALLEL_BGZF")
+        have = until_error(damaged)
+        # (the block-parallel path works in whole blocks: the decodable front of the damaged block itself, < 64 KiB, is
+        #  the one thing it does not hand out — at most one refill of 49 152 records fewer)
+        assert have[1] == want[1] == "Niffler" and want[0] - 49_152 <= have[0] <= want[0], (have, want)
 
 
 def _zstd_compress(data, level=1):

@@ -1154,21 +1154,29 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     for (size_t k : ok)
       if (ch[k].oom) { P.failed = true; return ENOMEM; }
     for (size_t a = 0; a < ok.size(); ++a) st_.marker_symbols += markers[a];
+    // A member whose CRC-32 / ISIZE does not match: a sequential inflate has handed its bytes out before it sees the
+    // trailer, so they go out here as well — everything up to the end of that member — and the error follows.
+    size_t deliver = total;
+    bool crc_bad = false;
     for (size_t k : ok) {
       Chunk& c = ch[k];
       if (c.bad_symbol) { P.failed = true; return EPROTO; }
       size_t from = 0;
-      for (size_t g = 0; g <= c.inf.segs.size(); ++g) {
+      for (size_t g = 0; g <= c.inf.segs.size() && !crc_bad; ++g) {
         const size_t to = g < c.inf.segs.size() ? c.inf.segs[g].out_end : c.n_out();
         P.run_crc = (uint32_t)crc32_combine(P.run_crc, c.piece_crc[g], (z_off_t)(to - from));
         P.run_len += to - from;
         if (g < c.inf.segs.size()) {                   // a member ended here
-          if (P.run_crc != c.inf.segs[g].crc || (uint32_t)P.run_len != c.inf.segs[g].isize) { P.failed = true; return EPROTO; }
+          if (P.run_crc != c.inf.segs[g].crc || (uint32_t)P.run_len != c.inf.segs[g].isize) {
+            crc_bad = true;
+            deliver = c.out_off + to;
+          }
           P.run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
           P.run_len = 0;
         }
         from = to;
       }
+      if (crc_bad) break;
     }
 
     t1 = now_s(); st_.s_patch_crc += t1 - t0; t0 = t1;
@@ -1176,15 +1184,20 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     Chunk& lastc = ch[ok.back()];
     if (lastc.stop == R_END) P.done = true;
     if (lastc.stop == R_IN && final) { P.failed = true; return EPROTO; }
-    if (stream_bad) {
+    if (stream_bad || crc_bad) {
       P.failed = true;                                 // sticky: every later call returns EPROTO
-      if (total == 0) return EPROTO;
+      if (deliver == 0) return EPROTO;
     }
     P.window.swap(runwin);
+    size_t left = deliver;                             // == total unless a member failed its CRC
     for (size_t k : ok) {
       Chunk& c = ch[k];
-      if (c.o16.n) out.push_back(Span{c.head8.data(), c.o16.n});
-      if (c.o8.n) out.push_back(Span{c.o8.at0(), c.o8.n});
+      const size_t h = c.o16.n < left ? c.o16.n : left;
+      if (h) out.push_back(Span{c.head8.data(), h});
+      left -= h;
+      const size_t t = c.o8.n < left ? c.o8.n : left;
+      if (t) out.push_back(Span{c.o8.at0(), t});
+      left -= t;
     }
     P.flip ^= 1;                                       // the next batch decodes into the other set of buffers
     P.cur = std::move(lastc.inf);
@@ -1199,7 +1212,7 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
     st_.batches++;
     st_.bytes_out += total;
     st_.s_carry += now_s() - t0;
-    if (stream_bad) return 0;                          // the bytes in front of the bad spot; the error comes with the next call
+    if (stream_bad || crc_bad) return 0;               // the bytes in front of the bad spot; the error comes with the next call
     if (total == 0 && !P.done && lastc.stop == R_IN && !final) continue;  // needs more input: the top-up reads it
     if (total == 0 && !P.done && shift == 0 && lastc.stop != R_IN) { P.failed = true; return EPROTO; }  // no progress: cannot happen
   }

@@ -411,13 +411,17 @@ def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
             return len(got), e.kind
         return len(got), None
     for damaged in (bad, cut):
-        monkeypatch.setenv("IBU_NO_PARALLEL_BGZF", "1")
+        monkeypatch.setenv("IBU_NO_PARALLEL_BGZF", "1")     # -> the gzip path ...
+        monkeypatch.setenv("IBU_NO_PARALLEL_GZIP", "1")     # ... with one zlib stream: what niffler does
         want = until_error(damaged)
+        monkeypatch.delenv("IBU_NO_PARALLEL_GZIP")
+        mid = until_error(damaged)                          # the parallel gzip decoder on the same multi-member stream
         monkeypatch.delenv("IBU_NO_PARALLEL_BGZF")
         have = until_error(damaged)
+        assert mid[1] == "Niffler" and want[0] - 49_152 <= mid[0] <= want[0] + 49_152, (mid, want)
         # (the block-parallel path works in whole blocks: the decodable front of the damaged block itself, < 64 KiB, is
         #  the one thing it does not hand out — at most one refill of 49 152 records fewer)
-        assert have[1] == want[1] == "Niffler" and want[0] - 49_152 <= have[0] <= want[0], (have, want)
+        assert have[1] == want[1] == "Niffler" and want[0] - 49_152 <= have[0] <= want[0] + 49_152, (have, want)
 
 
 def _zstd_compress(data, level=1):

@@ -8,7 +8,12 @@
 #include "pgzip.hpp"
 
 #include <errno.h>
+#if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
+#define IBU_PGZ_X86 1
+#else
+#define IBU_PGZ_X86 0
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
@@ -532,17 +537,21 @@ Stop run_generic(Inflater& s, const uint8_t* in, size_t in_len, bool final, size
                  size_t out_cap, size_t wlen, int* oom) {
   return run_body<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
 }
+#if IBU_PGZ_X86
 template <class T>
 __attribute__((target("bmi2,bmi,lzcnt"))) Stop run_bmi2(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target,
                                                         bool target_stored, OutBuf<T>& ob, size_t out_cap, size_t wlen, int* oom) {
   return run_body<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
 }
+#endif
 template <class T>
 Stop run(Inflater& s, const uint8_t* in, size_t in_len, bool final, size_t target, bool target_stored, OutBuf<T>& ob,
          size_t out_cap, size_t wlen, int* oom) {
+#if IBU_PGZ_X86
   static const bool bmi2 = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi") && !getenv("IBU_PGZ_NO_BMI2");
-  return bmi2 ? run_bmi2<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom)
-              : run_generic<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
+  if (bmi2) return run_bmi2<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
+#endif
+  return run_generic<T>(s, in, in_len, final, target, target_stored, ob, out_cap, wlen, oom);
 }
 
 // A stored block whose LEN field sits at byte P: LEN / NLEN agree, the byte in front ends in BFINAL = 0, BTYPE = 00 and
@@ -715,6 +724,7 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // folded together and Barrett-reduced (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ",
 // Intel 2009; constants for the bit-reflected polynomial 0xEDB88320).  `crc` in and out are zlib's crc32() values.
 // zlib 1.2.11's table-driven crc32 runs at ~0.8 GB/s here, a quarter of the whole parallel decode; this one at memory speed.
+#if IBU_PGZ_X86
 __attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t crc, const uint8_t* buf, size_t len) {  // len >= 64, len % 16 == 0
   alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
   alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
@@ -784,17 +794,24 @@ __attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t crc, cons
   x1 = _mm_xor_si128(x1, x2);
   return ~(uint32_t)_mm_extract_epi32(x1, 1);
 }
+#endif
 bool have_clmul() {
+#if IBU_PGZ_X86
   static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
   return ok;
+#else
+  return false;
+#endif
 }
 uint32_t crc32_bytes(uint32_t crc, const uint8_t* buf, size_t len) {
+#if IBU_PGZ_X86
   if (len >= 64 && have_clmul()) {
     const size_t k = len & ~(size_t)15;
     crc = crc32_clmul(crc, buf, k);
     buf += k;
     len -= k;
   }
+#endif
   while (len) {                                        // zlib's crc32 takes a uInt length
     const size_t k = len > ((size_t)1 << 30) ? (size_t)1 << 30 : len;
     crc = (uint32_t)crc32(crc, buf, (uInt)k);

@@ -956,7 +956,10 @@ ParallelGunzip::ParallelGunzip(ReadFn inner, unsigned threads, size_t chunk_byte
   p_->inner = std::move(inner);
   p_->threads = threads < 1 ? 1 : threads;
   p_->chunk = chunk_bytes < 4096 ? 4096 : chunk_bytes;
-  p_->out_cap = p_->chunk * 24 < ((size_t)1 << 20) ? (size_t)1 << 20 : p_->chunk * 24;  // elements per chunk and batch
+  // Output elements per chunk and batch: ten times the compressed bytes.  A chunk that inflates further (long runs: up to
+  // 1000 : 1) stops there, in the middle of a block if need be, the chain ends with it and the next batch resumes at that
+  // spot — so the buffers of 32 threads stay bounded (<= 20 B per compressed byte and thread) whatever the input is.
+  p_->out_cap = p_->chunk * 10 < ((size_t)1 << 20) ? (size_t)1 << 20 : p_->chunk * 10;
   p_->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
 }
 ParallelGunzip::~ParallelGunzip() {

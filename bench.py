@@ -180,6 +180,10 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
             leg.free()
     torch.cuda.empty_cache()
     info = {"tries": tries, "kept": best, "probe_ms_decode_encode": [[round(v, 3) for v in p] for p in probes] if tries > 1 else None}
+    if tries > 1:   # what the first allocation alone would have given (the number a job that does not probe sees)
+        leg0 = legs[best]
+        bytes_per_launch = leg0.n * (24 + leg0.bc_len + leg0.umi_len + 8)
+        info["first_placement_decode_frac"] = round(bytes_per_launch / (probes[0][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
     return legs[best], info
 
 

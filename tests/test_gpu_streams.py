@@ -164,9 +164,12 @@ def test_mmap_process_device_decode_shards_concatenate(ia, ctx, oracle, tmp_path
     m.close()
 
 
-@pytest.mark.parametrize("compressed", [False, True, "bgzf"])
+@pytest.mark.parametrize("compressed", [False, True, "bgzf", "gzip-many-chunks"])
 @pytest.mark.parametrize("n", [0, 1, 49_152, 100_000, 500_003])
-def test_reader_process_device_plain_and_gzip(ia, ctx, oracle, tmp_path, compressed, n):
+def test_reader_process_device_plain_and_gzip(ia, ctx, oracle, tmp_path, compressed, n, monkeypatch):
+    if compressed == "gzip-many-chunks":   # the parallel inflate with dozens of chunks per batch feeding the pinned slots
+        monkeypatch.setenv("IBU_PGZ_THREADS", "6")
+        monkeypatch.setenv("IBU_PGZ_CHUNK", "16384")
     p = tmp_path / "r.ibu"
     recs = _write_file(oracle, p, n)
     path = p

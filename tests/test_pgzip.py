@@ -238,3 +238,29 @@ def test_a_truncated_stream_delivers_what_the_sequential_path_delivers(tmp_path,
         assert got[1] == "Niffler"
         assert abs(got[0] - want[0]) <= 49_152, (threads, chunk, got, want)   # the cut may fall next to a refill edge
         assert got[0] >= want[0] - 49_152 and (where < 0.2 or got[0] > 0)
+
+
+def test_gzip_through_a_pipe(tmp_path):
+    """Reader::from_stdin (reader.rs:389-396) on a pipe: nothing to seek or pread, the read-ahead helper and the
+    decoder work from whatever read(2) hands over."""
+    import os
+    import subprocess
+    import sys
+    P = payloads()
+    raw = _header() + P["records"]
+    gz = tmp_path / "pipe.ibu.gz"
+    gz.write_bytes(_zc(raw, 1))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import numpy as np; import ibu_amd as ia; r = ia.Reader.from_stdin(); "
+            "h = hashlib.md5(); k = 0\n"
+            "while r.read_batch():\n"
+            "    b = r.buffered(); h.update(np.array(b, copy=True).tobytes()); k += len(b); r.consume(len(b))\n"
+            "print(k, h.hexdigest())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, IBU_PGZ_THREADS="4", IBU_PGZ_CHUNK="32768")
+    env.pop("IBU_NO_PARALLEL_GZIP", None)
+    with open(gz, "rb") as f:
+        cat = subprocess.Popen(["cat"], stdin=f, stdout=subprocess.PIPE)
+        out = subprocess.run([sys.executable, "-c", code], stdin=cat.stdout, capture_output=True, env=env, timeout=120)
+        cat.wait()
+    assert out.returncode == 0, out.stderr.decode()[-500:]
+    k, digest = out.stdout.decode().split()
+    assert int(k) == len(P["records"]) // 24 and digest == hashlib.md5(P["records"]).hexdigest()

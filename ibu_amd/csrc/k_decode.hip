@@ -13,6 +13,7 @@ namespace ibu {
 #define IBU_DECODE_NT 1
 #endif
 static constexpr int kDecodeNT = IBU_DECODE_NT;
+
 static constexpr int kDecRecs = kTileRecs * kDecodeNT;
 static constexpr int kDecBytes = kTileBytes * kDecodeNT;
 static constexpr int kDecLoads = 3 * kDecodeNT;      // dwordx4 loads per lane per iteration
@@ -71,8 +72,10 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kDecBytes;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
+  const TileRange tr = tile_range(ntiles, wib);
+  const u32 nwaves = tr.stride;
+  u32 t = tr.t;
+  ntiles = tr.end;
   if (t >= ntiles) return;
   if (BC > 0) bc_len = BC;
   if (UM > 0) umi_len = UM;
@@ -103,8 +106,10 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __rest
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * 1024;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
+  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
+  const u32 nwaves = tr.stride;
+  u32 t = tr.t;
+  ntiles = tr.end;
   if (t >= ntiles) return;
   if (LEN > 0) len = LEN;
   const uint8_t* base = reinterpret_cast<const uint8_t*>(codes) + 16 * lane;

@@ -40,8 +40,10 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   uint8_t* area = dyn_lds + wib * wave_lds_bytes;
   uint8_t* asc_bc = area;
   uint8_t* asc_umi = area + kTileRecs * bc_len;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
+  const TileRange tr = tile_range(ntiles, wib);
+  const u32 nwaves = tr.stride;
+  u32 t = tr.t;
+  ntiles = tr.end;
   if (t >= ntiles) return;
   // idx_in == NULL: the loads below read the (valid, 16-B aligned) barcode column instead and
   // the result is ignored, so the instruction stream has no branch around a load.
@@ -114,9 +116,11 @@ ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles, u32 len, u6
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
   uint8_t* asc = lds + wib * kTileRecs * 32;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
+  const u32 nwaves = tr.stride;
+  u32 t = tr.t;
+  ntiles = tr.end;
   if (LEN > 0) len = LEN;
-  u32 t = logical_block() * kWavesPerBlock + wib;
   if (t >= ntiles) return;
   AsciiStage<LEN> sv;
   sv.issue(in + (size_t)t * kTileRecs * len, len, lane);

@@ -35,8 +35,10 @@ ibu_k_deserialize(const uint8_t* __restrict__ recs, u32 ntiles, u64* __restrict_
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
+  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
+  const u32 nwaves = tr.stride;
+  u32 t = tr.t;
+  ntiles = tr.end;
   if (t >= ntiles) return;
   const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
   u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
@@ -65,8 +67,10 @@ ibu_k_serialize(const u64* __restrict__ bc, const u64* __restrict__ umi, const u
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
+  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
+  const u32 nwaves = tr.stride;
+  u32 t = tr.t;
+  ntiles = tr.end;
   if (t >= ntiles) return;
   size_t off = (size_t)t * 1024 + 16 * lane;   // records 2*lane, 2*lane+1 of each column
   u32x4 c0 = ld16(reinterpret_cast<const uint8_t*>(bc) + off);

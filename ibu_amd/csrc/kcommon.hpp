@@ -72,6 +72,24 @@ __device__ __forceinline__ u32 logical_block() {
 #endif
 }
 
+// Which tiles a wave sweeps.  IBU_XCD_STATIC 0: wave w of the (XCD-remapped) grid takes tiles w, w + nwaves, ... — every XCD
+// owns an eighth of the MOVING FRONT.  1: every XCD owns one fixed eighth of the arrays (tiles [x N/8, (x+1) N/8)) and
+// its workgroups sweep that range: the eight fronts sit an eighth of each array apart instead of side by side.
+#ifndef IBU_XCD_STATIC
+#define IBU_XCD_STATIC 1
+#endif
+struct TileRange { u32 t, stride, end; };
+__device__ __forceinline__ TileRange tile_range(u32 ntiles, u32 wib) {
+#if IBU_XCD_STATIC
+  if ((gridDim.x & 7u) == 0 && gridDim.x >= 8u) {
+    const u32 tpx = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u, t0 = xcd * tpx;
+    const u32 t1 = t0 + tpx < ntiles ? t0 + tpx : ntiles;
+    return {t0 + (blockIdx.x >> 3) * (u32)kWavesPerBlock + wib, (gridDim.x >> 3) * (u32)kWavesPerBlock, t0 < ntiles ? t1 : 0u};
+  }
+#endif
+  return {logical_block() * (u32)kWavesPerBlock + wib, gridDim.x * (u32)kWavesPerBlock, ntiles};
+}
+
 #ifndef IBU_NT_LOAD
 #define IBU_NT_LOAD 1
 #endif

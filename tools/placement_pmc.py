@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--lens", default="16,12")
     ap.add_argument("--analyse", default="")
     ap.add_argument("--blocks", default="", help="comma list of blocks_per_cu caps: time decode / encode at each one in every cycle")
+    ap.add_argument("--so", action="append", default=[], help="tag=path of another build: its decode / encode timed on the same arrays in every cycle")
     a = ap.parse_args()
     if a.analyse:
         return analyse(a.analyse)
@@ -97,6 +98,16 @@ def main():
             ts.append((time.perf_counter() - t0) * 1e3)
         return round(min(ts), 3)
 
+    variants = []
+    if a.so:
+        import ctypes as C
+        from ibu_amd import _lib
+        for spec in a.so:
+            tag, path = spec.split("=", 1)
+            vl = _lib.load(path)
+            vc = C.c_void_p()
+            assert vl.ibu_ctx_create(0, C.byref(vc)) == 0
+            variants.append((tag, vl, vc))
     held = []  # filler blocks that stay allocated across cycles: they fragment what later cycles get
     for cyc in range(a.cycles):
         order = orders[cyc % len(orders)]
@@ -124,6 +135,15 @@ def main():
                               timed(lambda: ctx.encode_ascii(bufs["bc"], bufs["umi"], bufs["idx"], n, bc_len, umi_len, bufs["back"]))]
             ctx.set_option("blocks_per_cu", 7)   # the library default
             line["blocks_sweep_decode_encode_ms"] = sweep
+        for tag, vl, vc in variants:
+            P = lambda k: C.c_void_p(bufs[k].ptr)
+            def vdec():
+                assert vl.ibu_decode_ascii(vc, P("recs"), n, bc_len, umi_len, P("bc"), P("umi"), P("idx"), None) == 0
+                assert vl.ibu_ctx_synchronize(vc, None) == 0
+            def venc():
+                assert vl.ibu_encode_ascii(vc, P("bc"), P("umi"), P("idx"), 0, n, bc_len, umi_len, P("back"), None) == 0
+                assert vl.ibu_ctx_synchronize(vc, None) == 0
+            line[f"{tag}_decode_encode_ms"] = [timed(vdec), timed(venc)]
         print(json.dumps(line), flush=True)
         for b in bufs.values():
             b.free()

@@ -79,12 +79,21 @@ __device__ __forceinline__ u32 logical_block() {
 #define IBU_XCD_STATIC 1
 #endif
 struct TileRange { u32 t, stride, end; };
+// IBU_XCD_SUB (measurement builds): every XCD's eighth is cut into this many sub-ranges, each swept by its own share of the
+// XCD's workgroups (8 x SUB fronts instead of 8).
+#ifndef IBU_XCD_SUB
+#define IBU_XCD_SUB 1
+#endif
 __device__ __forceinline__ TileRange tile_range(u32 ntiles, u32 wib) {
 #if IBU_XCD_STATIC
-  if ((gridDim.x & 7u) == 0 && gridDim.x >= 8u) {
-    const u32 tpx = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u, t0 = xcd * tpx;
-    const u32 t1 = t0 + tpx < ntiles ? t0 + tpx : ntiles;
-    return {t0 + (blockIdx.x >> 3) * (u32)kWavesPerBlock + wib, (gridDim.x >> 3) * (u32)kWavesPerBlock, t0 < ntiles ? t1 : 0u};
+  if ((gridDim.x & 7u) == 0 && gridDim.x >= 8u * IBU_XCD_SUB) {
+    const u32 parts = 8u * IBU_XCD_SUB;
+    const u32 tpp = (ntiles + parts - 1) / parts;                 // tiles per part
+    const u32 xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const u32 sub = lb % IBU_XCD_SUB, part = xcd * IBU_XCD_SUB + sub;
+    const u32 nb_sub = (nbx - sub + IBU_XCD_SUB - 1) / IBU_XCD_SUB;   // workgroups of this XCD on this sub-range
+    const u32 t0 = part * tpp, t1 = t0 + tpp < ntiles ? t0 + tpp : ntiles;
+    return {t0 + (lb / IBU_XCD_SUB) * (u32)kWavesPerBlock + wib, nb_sub * (u32)kWavesPerBlock, t0 < ntiles ? t1 : 0u};
   }
 #endif
   return {logical_block() * (u32)kWavesPerBlock + wib, gridDim.x * (u32)kWavesPerBlock, ntiles};

@@ -7,29 +7,35 @@
 
 namespace ibu {
 
-// Records per wave iteration = 128 * kDecodeNT.  With NT = 2 every ASCII column whose length is a
-// multiple of 4 is a whole number of 64-lane store rounds (16*len chunks), so no round is partial.
-#ifndef IBU_DECODE_NT
-#define IBU_DECODE_NT 1
+// Records per wave iteration = 128 * NT.  With NT = 2 every ASCII column whose length is a multiple of 4 is a whole
+// number of 64-lane store rounds (16*len chunks), so no round is partial, and a wave keeps twice the bytes in flight:
+// 1.0-1.7 % faster for the dword-path specialisations with at least 20 bases per record ((16,12) in every one of ten
+// placements, (32,32), (12,8), (32,12)); slower for (8,8) by 1 %, and the byte-path length 10 spills (2.7x slower), so
+// NT is a property of the instantiation: dec_nt<BC, UM>().  -DIBU_DECODE_NT=1|2 forces one value everywhere (A/B builds).
+constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
+template <int BC, int UM>
+constexpr int dec_nt() {
+#ifdef IBU_DECODE_NT
+  return IBU_DECODE_NT;
+#else
+  return (dword_len(BC) && dword_len(UM) && BC + UM >= 20) ? 2 : 1;
 #endif
-static constexpr int kDecodeNT = IBU_DECODE_NT;
+}
 
-static constexpr int kDecRecs = kTileRecs * kDecodeNT;
-static constexpr int kDecBytes = kTileBytes * kDecodeNT;
-static constexpr int kDecLoads = 3 * kDecodeNT;      // dwordx4 loads per lane per iteration
-
+template <int NT>
 struct DecRegs {
-  u32x4 v[kDecLoads];
+  u32x4 v[3 * NT];                                   // dwordx4 loads per lane per iteration
   __device__ __forceinline__ void load(const uint8_t* src) {
 #pragma unroll
-    for (int k = 0; k < kDecLoads; ++k) v[k] = ld16(src + 1024 * k);
+    for (int k = 0; k < 3 * NT; ++k) v[k] = ld16(src + 1024 * k);
   }
 };
 
 // Stage one AoS tile held in registers into the wave's LDS slice and expand it.
 template <int BC, int UM, bool MSB>
-__device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs& a, u32 t, u32 bc_len, u32 umi_len,
+__device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs<dec_nt<BC, UM>()>& a, u32 t, u32 bc_len, u32 umi_len,
                                             uint8_t* bc_out, uint8_t* umi_out, u64* idx_out, u32 lane) {
+  constexpr int kDecodeNT = dec_nt<BC, UM>(), kDecLoads = 3 * kDecodeNT, kDecRecs = kTileRecs * kDecodeNT;
   wave_lds_fence();                            // previous tile's LDS reads precede these writes
 #pragma unroll
   for (int k = 0; k < kDecLoads; ++k) *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = a.v[k];
@@ -60,14 +66,12 @@ __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs& a, u32
 // Register budget: the dword-path specialisations fit 72 VGPRs (7 waves/SIMD); the byte-path
 // (len % 4 != 0) and generic kernels would spill there, so they get 168 (3 waves/SIMD).  72 VGPRs
 // (7 waves/SIMD) measured as fast as 64 (8) for the streaming kernels (profiles/r01_b sweep).
-constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
-#ifndef IBU_DECODE_MINWAVES
-#define IBU_DECODE_MINWAVES (IBU_DECODE_NT > 1 ? 5 : 7)
-#endif
+// (NT = 2 holds twice the tile registers: 5 waves/SIMD.)
 template <int BC, int UM, bool MSB>
-__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? IBU_DECODE_MINWAVES - (MSB ? 1 : 0) : 3)
+__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? (dec_nt<BC, UM>() > 1 ? 5 : 7) - (MSB ? 1 : 0) : 3)
 ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
              uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
+  constexpr int kDecBytes = kTileBytes * dec_nt<BC, UM>();
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kDecBytes];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
@@ -80,7 +84,7 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
   if (BC > 0) bc_len = BC;
   if (UM > 0) umi_len = UM;
 
-  DecRegs a, b;
+  DecRegs<dec_nt<BC, UM>()> a, b;
   a.load(recs + (size_t)t * kDecBytes + 16 * lane);
   for (;;) {
     u32 tn = t + nwaves;
@@ -165,12 +169,19 @@ static constexpr DecFn dec_entry() { return ibu_k_decode<len_of_mode(B), len_of_
 #define IBU_DEC_ROW(B, M) {dec_entry<B, 0, M>(), dec_entry<B, 1, M>(), dec_entry<B, 2, M>(), dec_entry<B, 3, M>(), dec_entry<B, 4, M>(), dec_entry<B, 5, M>()}
 #define IBU_DEC_TABLE(M) {IBU_DEC_ROW(0, M), IBU_DEC_ROW(1, M), IBU_DEC_ROW(2, M), IBU_DEC_ROW(3, M), IBU_DEC_ROW(4, M), IBU_DEC_ROW(5, M)}
 static const DecFn kDecTable[2][kNumLenModes][kNumLenModes] = {IBU_DEC_TABLE(false), IBU_DEC_TABLE(true)};  // [base_order][bc][umi]
+// records per wave iteration of each instantiation (the same for both base orders)
+template <int B, int U>
+static constexpr int dec_recs() { return kTileRecs * dec_nt<len_of_mode(B), len_of_mode(U)>(); }
+#define IBU_DEC_RECS_ROW(B) {dec_recs<B, 0>(), dec_recs<B, 1>(), dec_recs<B, 2>(), dec_recs<B, 3>(), dec_recs<B, 4>(), dec_recs<B, 5>()}
+static const int kDecRecsTable[kNumLenModes][kNumLenModes] = {IBU_DEC_RECS_ROW(0), IBU_DEC_RECS_ROW(1), IBU_DEC_RECS_ROW(2),
+                                                              IBU_DEC_RECS_ROW(3), IBU_DEC_RECS_ROW(4), IBU_DEC_RECS_ROW(5)};
 
 hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t bc_len, uint32_t umi_len,
                          uint8_t* bc, uint8_t* umi, uint64_t* idx, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, bc_len}, {umi, umi_len}, {idx, 8}};
+  const size_t kDecRecs = (size_t)kDecRecsTable[mode_of_len(bc_len)][mode_of_len(umi_len)];
   const RowSplit rs = split_rows(sp, 4, n, kDecRecs);   // peel rows until every array is 16-B aligned
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_decode_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0,

@@ -155,9 +155,9 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     (profiles/README.md: pool survey, r02_placement_pmc — L2 tag-pipeline stalls, not translation), and an
     allocation keeps its speed for as long as it lives.  A job that keeps its shard resident can therefore choose:
     allocate the set a few times (holding the earlier sets, so that the allocator has to hand out other pages), time
-    one decode+encode on each, keep the fastest, free the rest.  All of it happens before the timed region, costs a
-    few hundred ms once, and every probe is reported in the line (`placement`), the first one being what a job that
-    does not probe would have got."""
+    the kernels on them, keep the fastest arrays, free the rest.  All of it happens before the timed region, costs
+    well under a second once, and every probe is reported in the line (`placement`), the first one being what a job
+    that does not probe would have got."""
     free_b, _ = torch.cuda.mem_get_info(dev)
     tries = max(1, min(tries, int(free_b * 0.94 / max(sharers, 1) // max(set_bytes, 1))))   # sharers: ranks on this GPU (rehearsals)
     legs, probes = [], []
@@ -174,17 +174,35 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     tries = len(legs)
     if tries > 1 and probes[0] is None:
         probes[0] = legs[0].probe()
-    best = min(range(tries), key=lambda i: sum(probes[i])) if tries > 1 else 0
-    for i, leg in enumerate(legs):
-        if i != best:
-            leg.free()
+    info = {"tries": tries, "kept": 0, "probe_ms_decode_encode": [[round(v, 3) for v in p] for p in probes] if tries > 1 else None}
+    if tries == 1:
+        return legs[0], info
+    # The arrays of the sets can be mixed: decode touches (records, columns), encode (columns, re-encoded records), and
+    # the slow placements of the two are not the same allocations.  So every (records i, columns j) pair is timed with
+    # one decode and every (columns j, output k) pair with one encode, and the combination with the smallest decode +
+    # encode is kept — 2 T^2 launches of ~10 ms, once; the matrices are part of the line.
+    T = tries
+    dec = [[0.0] * T for _ in range(T)]
+    enc = [[0.0] * T for _ in range(T)]
+    for j in range(T):
+        for i in range(T):
+            dec[i][j] = legs[i].probe_decode(legs[j])
+        for k in range(T):
+            enc[j][k] = legs[j].probe_encode(legs[k])   # the columns of set j hold decoded data (identical in every set)
+    i, j, k = min(((i, j, k) for i in range(T) for j in range(T) for k in range(T)), key=lambda c: dec[c[0]][c[1]] + enc[c[1]][c[2]])
+    leg = legs[i]
+    keep = (legs[i].recs, legs[j].bc, legs[j].umi, legs[j].idx, legs[k].back)
+    for other in legs:                                   # drop every array, then hand the chosen ones to the kept leg
+        other.recs = other.bc = other.umi = other.idx = other.back = None
+    leg.recs, leg.bc, leg.umi, leg.idx, leg.back = keep
+    keep = legs = None
     torch.cuda.empty_cache()
-    info = {"tries": tries, "kept": best, "probe_ms_decode_encode": [[round(v, 3) for v in p] for p in probes] if tries > 1 else None}
-    if tries > 1:   # what the first allocation alone would have given (the number a job that does not probe sees)
-        leg0 = legs[best]
-        bytes_per_launch = leg0.n * (24 + leg0.bc_len + leg0.umi_len + 8)
-        info["first_placement_decode_frac"] = round(bytes_per_launch / (probes[0][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-    return legs[best], info
+    bytes_per_launch = leg.n * (24 + leg.bc_len + leg.umi_len + 8)
+    info.update(kept={"records": i, "columns": j, "output": k},
+                decode_ms_records_x_columns=[[round(v, 3) for v in row] for row in dec],
+                encode_ms_columns_x_output=[[round(v, 3) for v in row] for row in enc],
+                first_placement_decode_frac=round(bytes_per_launch / (probes[0][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+    return leg, info
 
 
 class Leg:
@@ -212,6 +230,26 @@ class Leg:
         c.encode_ascii(self.bc, self.umi, self.idx, n, self.bc_len, self.umi_len, self.back, stream=st)
         if ev:
             ev[2].record()
+
+    def _timed_once(self, fn):
+        torch = self.torch
+        fn()                                            # untimed first touch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    def probe_decode(self, cols):
+        """ms of one decode of THIS set's records into the columns of `cols` (placement probing)."""
+        return self._timed_once(lambda: self.ctx.decode_ascii(self.recs, self.n, self.bc_len, self.umi_len, cols.bc, cols.umi, cols.idx,
+                                                              stream=self.st))
+
+    def probe_encode(self, out):
+        """ms of one encode of THIS set's columns into the output array of `out` (placement probing)."""
+        return self._timed_once(lambda: self.ctx.encode_ascii(self.bc, self.umi, self.idx, self.n, self.bc_len, self.umi_len, out.back,
+                                                              stream=self.st))
 
     def probe(self):
         """(decode ms, encode ms) of one step after one untimed step (placement probing, outside every timed region)."""

@@ -52,10 +52,11 @@ def parse():
     p.add_argument("--cpu-sample", type=float, default=0, help="records for the CPU baseline (0 = auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
-    p.add_argument("--placement-tries", type=int, default=3,
+    p.add_argument("--placement-tries", type=int, default=0,
                    help="allocate the resident arrays this many times (all sets held at once, memory permitting), probe each "
-                        "with one decode+encode, keep the fastest set and free the others BEFORE the timed region; every "
-                        "probe is printed.  1 = take the first allocation (round-1 behaviour).  See place_leg()")
+                        "with one decode+encode, keep the fastest arrays and free the others BEFORE the timed region; every "
+                        "probe is printed.  0 (default) = as many as fit, at most 12: 3 for 1e9 records on one GPU, 12 for the "
+                        "shards of an 8-GPU run.  1 = take the first allocation (round-1 behaviour).  See place_leg()")
     # rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never used by the driver):
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: collectives on CPU tensors")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
@@ -152,14 +153,17 @@ def traffic_from_profile(bc_len, umi_len, n):
 def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     """Placement probing.  On this part the rate of a read+write streaming kernel depends on WHERE the driver put the
     arrays' physical pages: the same kernel on the same GPU runs 9.4 ... 11.3 ms from one allocation to the next
-    (profiles/README.md: pool survey, r02_placement_pmc — L2 tag-pipeline stalls, not translation), and an
-    allocation keeps its speed for as long as it lives.  A job that keeps its shard resident can therefore choose:
-    allocate the set a few times (holding the earlier sets, so that the allocator has to hand out other pages), time
-    the kernels on them, keep the fastest arrays, free the rest.  All of it happens before the timed region, costs
-    well under a second once, and every probe is reported in the line (`placement`), the first one being what a job
-    that does not probe would have got."""
+    (profiles/README.md: pool survey, r02_placement_pmc, r02_ag — physical regions in buddy-block runs, L2 tag-pipeline
+    stalls, not translation), and an allocation keeps its speed for as long as it lives.  A job that keeps its shard
+    resident can therefore choose: allocate the set a few times (holding the earlier sets, so that the allocator has to
+    hand out other pages), time the kernels on them, keep the fastest ARRAYS, free the rest.  All of it happens before the
+    timed region, costs well under a second once, and every probe is reported in the line (`placement`), the first one
+    being what a job that does not probe would have got."""
     free_b, _ = torch.cuda.mem_get_info(dev)
-    tries = max(1, min(tries, int(free_b * 0.94 / max(sharers, 1) // max(set_bytes, 1))))   # sharers: ranks on this GPU (rehearsals)
+    # 0 = auto.  Small shards get more tries: at the shard size of an 8-GPU run the rate is two-valued and only about one
+    # set in four to twelve draws the fast value (profiles/experiments/r02_ag_pl_125e6.json), and the job's time is the
+    # slowest rank's.
+    tries = max(1, min(tries or 16, int(free_b * 0.94 / max(sharers, 1) // max(set_bytes, 1))))   # sharers: ranks on this GPU (rehearsals)
     legs, probes = [], []
     for _ in range(tries):
         try:
@@ -177,30 +181,42 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     info = {"tries": tries, "kept": 0, "probe_ms_decode_encode": [[round(v, 3) for v in p] for p in probes] if tries > 1 else None}
     if tries == 1:
         return legs[0], info
-    # The arrays of the sets can be mixed: decode touches (records, columns), encode (columns, re-encoded records), and
-    # the slow placements of the two are not the same allocations.  So every (records i, columns j) pair is timed with
-    # one decode and every (columns j, output k) pair with one encode, and the combination with the smallest decode +
-    # encode is kept — 2 T^2 launches of ~10 ms, once; the matrices are part of the line.
+    # The arrays of the sets hold the same data and can be mixed freely, and a kernel's time follows mostly the arrays it
+    # WRITES — one slow array spoils its set.  So the choice is made per array, one coordinate at a time, starting from the
+    # best whole set: each of the three decode outputs (decode timed with that one array taken from every set in turn),
+    # then the records decode reads, then the array encode writes.  5 T launches of ~10 ms, once; all of them in the line.
     T = tries
-    dec = [[0.0] * T for _ in range(T)]
-    enc = [[0.0] * T for _ in range(T)]
-    for j in range(T):
-        for i in range(T):
-            dec[i][j] = legs[i].probe_decode(legs[j])
-        for k in range(T):
-            enc[j][k] = legs[j].probe_encode(legs[k])   # the columns of set j hold decoded data (identical in every set)
-    i, j, k = min(((i, j, k) for i in range(T) for j in range(T) for k in range(T)), key=lambda c: dec[c[0]][c[1]] + enc[c[1]][c[2]])
-    leg = legs[i]
-    keep = (legs[i].recs, legs[j].bc, legs[j].umi, legs[j].idx, legs[k].back)
+    names = ("recs", "bc", "umi", "idx", "back")
+    base = min(range(T), key=lambda t: probes[t][0] + probes[t][1])
+    cur = {k: base for k in names}
+    leg = legs[base]
+
+    def arrays(c):
+        return {k: getattr(legs[c[k]], k) for k in names}
+
+    per_array = {}
+    for name in ("bc", "umi", "idx", "recs"):
+        ms = [leg.probe_decode_arrays(arrays({**cur, name: t})) for t in range(T)]
+        cur[name] = min(range(T), key=ms.__getitem__)
+        per_array[name] = [round(v, 3) for v in ms]
+    ms = [leg.probe_encode_arrays(arrays({**cur, "back": t})) for t in range(T)]
+    cur["back"] = min(range(T), key=ms.__getitem__)
+    per_array["back"] = [round(v, 3) for v in ms]
+    final = (leg.probe_decode_arrays(arrays(cur)), leg.probe_encode_arrays(arrays(cur)))
+    if final[0] + final[1] > probes[base][0] + probes[base][1]:      # the coordinates did not add up: the best whole set it is
+        cur = {k: base for k in names}
+        final = probes[base]
+    keep = arrays(cur)
     for other in legs:                                   # drop every array, then hand the chosen ones to the kept leg
         other.recs = other.bc = other.umi = other.idx = other.back = None
-    leg.recs, leg.bc, leg.umi, leg.idx, leg.back = keep
+    for k in names:
+        setattr(leg, k, keep[k])
     keep = legs = None
     torch.cuda.empty_cache()
     bytes_per_launch = leg.n * (24 + leg.bc_len + leg.umi_len + 8)
-    info.update(kept={"records": i, "columns": j, "output": k},
-                decode_ms_records_x_columns=[[round(v, 3) for v in row] for row in dec],
-                encode_ms_columns_x_output=[[round(v, 3) for v in row] for row in enc],
+    info.update(kept={"records": cur["recs"], "bc": cur["bc"], "umi": cur["umi"], "idx": cur["idx"], "output": cur["back"]}, best_whole_set=base,
+                decode_ms_by_set_of_one_array={"bc": per_array["bc"], "umi": per_array["umi"], "idx": per_array["idx"], "records": per_array["recs"]},
+                encode_ms_by_set_of_output=per_array["back"], kept_probe_ms_decode_encode=[round(v, 3) for v in final],
                 first_placement_decode_frac=round(bytes_per_launch / (probes[0][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
     return leg, info
 
@@ -241,14 +257,14 @@ class Leg:
         e1.synchronize()
         return e0.elapsed_time(e1)
 
-    def probe_decode(self, cols):
-        """ms of one decode of THIS set's records into the columns of `cols` (placement probing)."""
-        return self._timed_once(lambda: self.ctx.decode_ascii(self.recs, self.n, self.bc_len, self.umi_len, cols.bc, cols.umi, cols.idx,
+    def probe_decode_arrays(self, a):
+        """ms of one decode over the arrays in `a` (recs -> bc, umi, idx), whichever sets they come from (placement probing)."""
+        return self._timed_once(lambda: self.ctx.decode_ascii(a["recs"], self.n, self.bc_len, self.umi_len, a["bc"], a["umi"], a["idx"],
                                                               stream=self.st))
 
-    def probe_encode(self, out):
-        """ms of one encode of THIS set's columns into the output array of `out` (placement probing)."""
-        return self._timed_once(lambda: self.ctx.encode_ascii(self.bc, self.umi, self.idx, self.n, self.bc_len, self.umi_len, out.back,
+    def probe_encode_arrays(self, a):
+        """ms of one encode over the arrays in `a` (bc, umi, idx -> back; the columns hold decoded data in every set)."""
+        return self._timed_once(lambda: self.ctx.encode_ascii(a["bc"], a["umi"], a["idx"], self.n, self.bc_len, self.umi_len, a["back"],
                                                               stream=self.st))
 
     def probe(self):
@@ -395,7 +411,7 @@ def main():
         # BASELINE configs[2]: maximum width, encode+decode on one GPU — a short leg outside the headline's timed region
         leg.free()
         nw = int(args.wide_records) or n
-        wl, w_placement = place_leg(lambda: Leg(ctx, torch, dev, st, 0x1B00002, 0, nw, 32, 32), min(args.placement_tries, 2),
+        wl, w_placement = place_leg(lambda: Leg(ctx, torch, dev, st, 0x1B00002, 0, nw, 32, 32), min(args.placement_tries or 2, 2),
                                     nw * (48 + 72), torch, dev)
         w_steps = max(1, min(args.steps, 5))
         w_el, w_dec, w_enc = wl.timed(w_steps, 1, barrier)

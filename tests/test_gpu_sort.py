@@ -226,6 +226,23 @@ def test_barcode_counts(ctx, oracle, ia, n, n_barcodes, n_umis):
     assert u2 is None and b2.tobytes() == wb.tobytes() and c2.tobytes() == wc.tobytes()
 
 
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 255, 8192 + 1, 8192 + 128 + 5, 3 * 8192 + 129, 100_001])
+@pytest.mark.parametrize("n_barcodes,n_umis", [(1, 1), (5, 2), (1 << 40, 1 << 20)])
+def test_barcode_counts_of_a_shard_at_an_odd_record(ctx, oracle, ia, n, n_barcodes, n_umis):
+    """Sorted records that start at an odd record of a larger buffer (8- but not 16-byte aligned): one row is peeled in
+    front of the tiled segments, the n % 128 rest follows them; the runs that straddle the three parts are counted once."""
+    rng = np.random.default_rng(3 * n + n_barcodes)
+    recs = np.empty(n + 1, dtype=ia.REC_DTYPE)
+    recs["barcode"] = rng.integers(0, n_barcodes, n + 1, dtype=np.uint64)
+    recs["umi"] = rng.integers(0, n_umis, n + 1, dtype=np.uint64)
+    recs["index"] = np.arange(n + 1, dtype=np.uint64)
+    srt = oracle.sort_records(recs)
+    d = ctx.upload(srt)
+    b, c, u = ctx.barcode_counts(d.ptr + 24, n)
+    wb, wc, wu = oracle.barcode_counts(srt[1:])
+    assert (b.tobytes(), c.tobytes(), u.tobytes()) == (wb.tobytes(), wc.tobytes(), wu.tobytes())
+
+
 def test_barcode_counts_after_device_sort_and_capacity_error(ctx, oracle, ia):
     import ctypes as C
     n = 300_000

@@ -105,6 +105,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->cfg.sort_variant = (int)value;
     return IBU_OK;
   }
+  if (strcmp(key, "sort_compact") == 0) {
+    if (value < 0 || value > sort_num_compact_variants()) return err_arg("sort_compact out of range");
+    ctx->cfg.sort_compact = (int)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "base_order") == 0) {
     if (value != IBU_BASE_ORDER_LSB_FIRST && value != IBU_BASE_ORDER_MSB_FIRST) return err_arg("base_order must be 0 (LSB first) or 1 (MSB first)");
     ctx->cfg.base_order = (uint32_t)value;

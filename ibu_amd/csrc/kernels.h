@@ -12,6 +12,7 @@ struct LaunchCfg {
   int cus = 256;           // hipDeviceProp_t::multiProcessorCount
   int blocks_per_cu = 7;   // persistent grid = cus * blocks_per_cu workgroups of 256 threads (7 beats 8: profiles/r01_c)
   int sort_variant = 0;    // tile shape / write-out mode of the radix passes (sort.hip kSweep; A/B knob)
+  int sort_compact = 1;    // compact-key passes (12-byte elements when at most 12 key bytes vary): 0 = never, k = tile shape kCompact[k-1]
   uint32_t base_order = 0; // bit order of the 2-bit codec: 0 = base i at bits [2i,2i+1] (default), 1 = first base most significant
 };
 
@@ -61,6 +62,7 @@ hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n
                                size_t scratch_bytes, hipStream_t st);
 size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
 int sort_num_variants();
+int sort_num_compact_variants();
 hipError_t launch_lower_bound(const void* recs, size_t n, const void* keys, size_t k, uint64_t* pos, hipStream_t st);
 // per-barcode run-length aggregation of sorted records (sort.hip)
 size_t runs_scratch_bytes(size_t n);

@@ -530,6 +530,254 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
 }
 
 // =====================================================================================================
+// COMPACT-KEY passes.  A record is 24 bytes, but the census usually finds few of them varying: 16-base barcodes, 12-base
+// UMIs and indices below 2^32 vary in 4 + 3 + 4 = 11 bytes, and every other byte is the same in all records.  When at
+// most 12 bytes vary (and n < 2^32) the sort runs on 12-BYTE ELEMENTS instead of records:
+//
+//   compress   records -> elements: element byte j = the j-th least significant varying byte of the key (index bytes
+//              lowest, barcode bytes highest), so the element read as a 96-bit little-endian integer orders like the
+//              record; also the 1-byte digit side stream of the first pass.                      24 R + 13 W per record
+//   passes     LSD over the element bytes that must be sorted (not the index bytes when the input is in index
+//              order), counts from the side stream, scan, scatter as above — on half the bytes.  ~26.6 B per record
+//   expand     elements -> records (constant bytes from the census' AND words).                   12 R + 24 W per record
+//
+// 16/12 with a random index: 24 (census) + 37 + 11 x 26.6 + 36 = 390 B/record against 24 + 48 + 11 x 51.9 = 643.
+// Both element buffers live in the caller's `tmp` (12 n bytes each), so the second one starts at a 4-byte boundary: every
+// element access is a per-lane dwordx3 (64 lanes x 12 B = 768 contiguous bytes), which needs no more than that — and a
+// lane that loads whole elements needs no LDS staging in front of the ranking.  The result is the same permutation as the
+// 24-byte passes give (stable LSD over the same digits; constant bytes never decide a comparison).
+// =====================================================================================================
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+struct __attribute__((packed, aligned(4))) Elem { u32 w[3]; };
+static_assert(sizeof(Elem) == 12, "12-byte elements");
+__device__ __forceinline__ u32x3 ld_elem(const Elem* p) {
+  u32x3 v;
+  __builtin_memcpy(&v, p, 12);                                 // 4-byte aligned: one global_load_dwordx3
+  return v;
+}
+__device__ __forceinline__ void st_elem(Elem* p, u32x3 v) { __builtin_memcpy(p, &v, 12); }
+
+struct CompactPlan {
+  uint8_t sel[12];   // element byte j <- record byte sel[j] (0..23 = 8 * field + byte of the field); j >= k unused
+  u32 k;             // bytes carried
+  u64 base[3];       // each field with its varying bytes cleared (the census' AND words)
+};
+__device__ __forceinline__ u32x3 compress_rec(const uint8_t* r /*LDS or global, 24 bytes*/, const CompactPlan& pl) {
+  u32 e[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+    if ((u32)j < pl.k) e[j >> 2] |= (u32)r[pl.sel[j]] << (8 * (j & 3));
+  return u32x3{e[0], e[1], e[2]};
+}
+__device__ __forceinline__ void expand_elem(u32x3 v, const CompactPlan& pl, u64& f0, u64& f1, u64& f2) {
+  f0 = pl.base[0]; f1 = pl.base[1]; f2 = pl.base[2];
+  const u32 e[3] = {v.x, v.y, v.z};
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+    if ((u32)j < pl.k) {
+      const u32 s = pl.sel[j];                               // uniform
+      const u64 b = (u64)((e[j >> 2] >> (8 * (j & 3))) & 255u) << (8 * (s & 7u));
+      if ((s >> 3) == 0) f0 |= b; else if ((s >> 3) == 1) f1 |= b; else f2 |= b;
+    }
+}
+// records [0, 128 ntiles) -> elements + first digit; tiled like the census (recs 16-B aligned)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, Elem* __restrict__ out,
+                    uint8_t* __restrict__ digits) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * kTileBytes;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u32 t = logical_block() * kWavesPerBlock + wib;
+  if (t >= ntiles) return;
+  const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
+  u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
+  for (;;) {
+    const u32 tn = t + nwaves;
+    const bool more = tn < ntiles;                           // wave-uniform; the prefetch is unconditional (kcommon.hpp)
+    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
+    const u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
+    wave_lds_fence();
+    *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
+    *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
+    *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
+    wave_lds_fence();
+    const uint8_t* r = tile + (2 * lane) * 24;               // records 2L, 2L+1
+    const u32x3 e0 = compress_rec(r, pl), e1 = compress_rec(r + 24, pl);
+    const size_t row = (size_t)t * kTileRecs + 2 * lane;
+    st_elem(out + row, e0);
+    st_elem(out + row + 1, e1);
+    const u32 w = first_byte >> 2, sh = 8 * (first_byte & 3);
+    const u32 d0 = ((w == 0 ? e0.x : w == 1 ? e0.y : e0.z) >> sh) & 255u, d1 = ((w == 0 ? e1.x : w == 1 ? e1.y : e1.z) >> sh) & 255u;
+    *reinterpret_cast<uint16_t*>(digits + row) = (uint16_t)(d0 | (d1 << 8));
+    if (!more) break;
+    t = tn;
+    a0 = b0; a1 = b1; a2 = b2;
+  }
+}
+extern "C" __global__ void ibu_k_sort_compress_tail(const uint8_t* __restrict__ recs, u64 row0, u64 n, CompactPlan pl, u32 first_byte,
+                                                    Elem* __restrict__ out, uint8_t* __restrict__ digits) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32x3 e = compress_rec(recs + 24 * i, pl);
+  st_elem(out + i, e);
+  const u32 w = first_byte >> 2;
+  digits[i] = (uint8_t)((w == 0 ? e.x : w == 1 ? e.y : e.z) >> (8 * (first_byte & 3)));
+}
+// elements -> records [0, 128 ntiles) (recs 16-B aligned)
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_sort_expand(const Elem* __restrict__ in, u32 ntiles, CompactPlan pl, uint8_t* __restrict__ recs) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * kTileBytes;
+  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  u32 t = logical_block() * kWavesPerBlock + wib;
+  if (t >= ntiles) return;
+  u32x3 a0 = ld_elem(in + (size_t)t * kTileRecs + 2 * lane), a1 = ld_elem(in + (size_t)t * kTileRecs + 2 * lane + 1);
+  for (;;) {
+    const u32 tn = t + nwaves;
+    const bool more = tn < ntiles;
+    const size_t nrow = (size_t)(more ? tn : t) * kTileRecs + 2 * lane;
+    const u32x3 b0 = ld_elem(in + nrow), b1 = ld_elem(in + nrow + 1);
+    u64 f[6];
+    expand_elem(a0, pl, f[0], f[1], f[2]);
+    expand_elem(a1, pl, f[3], f[4], f[5]);
+    wave_lds_fence();                                        // the previous tile's reads precede these writes
+    u64* r = reinterpret_cast<u64*>(tile + lane * 48);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = f[k];
+    wave_lds_fence();
+    uint8_t* dst = recs + (size_t)t * kTileBytes + 16 * lane;
+    st16(dst, *reinterpret_cast<const u32x4*>(tile + 16 * lane));
+    st16(dst + 1024, *reinterpret_cast<const u32x4*>(tile + 1024 + 16 * lane));
+    st16(dst + 2048, *reinterpret_cast<const u32x4*>(tile + 2048 + 16 * lane));
+    if (!more) break;
+    t = tn;
+    a0 = b0; a1 = b1;
+  }
+}
+extern "C" __global__ void ibu_k_sort_expand_tail(const Elem* __restrict__ in, u64 row0, u64 n, CompactPlan pl, u64* __restrict__ recs) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 f0, f1, f2;
+  expand_elem(ld_elem(in + i), pl, f0, f1, f2);
+  recs[3 * i] = f0; recs[3 * i + 1] = f1; recs[3 * i + 2] = f2;
+}
+
+template <int THREADS, int ROUNDS>
+struct CompactShape {
+  static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
+  // LDS: stage 12 T | gdelta 256 x u32 | whist NW x 256 x u32 | misc 16 x u32 | sbin T bytes
+  static constexpr size_t lds = 12 * (size_t)T + 4 * kBins + 4 * (size_t)NW * kBins + 64 + (size_t)T;
+};
+// One pass over element byte `byte`; nbyte: the next pass's byte (>= 12: there is none, no side stream).
+template <int THREADS, int ROUNDS>
+__global__ void __launch_bounds__(THREADS)
+ibu_k_sort_scatter12(const Elem* __restrict__ src, Elem* __restrict__ dst, u32 n, u32 byte, u32 nbyte, const u32* __restrict__ pos,
+                     uint8_t* __restrict__ digits) {
+  typedef CompactShape<THREADS, ROUNDS> S;
+  constexpr int T = S::T, NW = S::NW, PER_WAVE = S::PER_WAVE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  u32* stage = reinterpret_cast<u32*>(smem);                 // the tile in digit order
+  u32* gdelta = stage + 3 * T;                               // global element index of slot p of bin d = gdelta[d] + p
+  u32* whist = gdelta + kBins;
+  u32* misc = whist + NW * kBins;
+  uint8_t* sbin = reinterpret_cast<uint8_t*>(misc + 16);
+  const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wib = tid >> 6;
+  const u64 lt_mask = (1ull << lane) - 1;
+#if IBU_SORT_XCD
+  const u32 tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware tile order, as above
+#else
+  const u32 tile = blockIdx.x;
+#endif
+  const u64 tbase64 = (u64)tile * T;
+  if (tbase64 >= n) return;                                   // block-uniform: padding of the grid
+  const u32 tbase = (u32)tbase64;
+  const u32 cnt = n - tbase < (u32)T ? n - tbase : (u32)T;
+  const u32 mypos = tid < (u32)kBins ? pos[(size_t)tile * kBins + tid] : 0;
+
+  // 1. every lane loads its elements (unconditional, clamped) and the per-wave counters are cleared
+  u32x3 v[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const u32 slot = wib * PER_WAVE + r * kWave + lane;
+    v[r] = ld_elem(src + tbase + (slot < cnt ? slot : cnt - 1));
+  }
+#pragma unroll
+  for (int k = 0; k < kBins / kWave; ++k) whist[wib * kBins + lane + kWave * k] = 0;
+  wave_lds_fence();                                          // a wave's counters are its own
+
+  // 2. rank every element among the elements of its wave with the same digit (stable: slot order)
+  const u32 wsel = byte >> 2, wsh = 8 * (byte & 3);
+  u32 dig[ROUNDS], rk[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const u32 slot = wib * PER_WAVE + r * kWave + lane;
+    const bool valid = slot < cnt;
+    const u32 d = ((wsel == 0 ? v[r].x : wsel == 1 ? v[r].y : v[r].z) >> wsh) & 255u;
+    u64 m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const u64 bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const u32 before = (u32)__popcll(m & lt_mask);
+    const u32 prev = valid ? whist[wib * kBins + d] : 0;
+    wave_lds_fence();                                        // every lane has read before the leaders write
+    if (valid && before == 0) whist[wib * kBins + d] = prev + (u32)__popcll(m);
+    wave_lds_fence();
+    dig[r] = d;
+    rk[r] = prev + before;
+  }
+  __syncthreads();
+
+  // 3. bin totals of the tile -> slot bases per (wave, bin)
+  {
+    u32 c[NW], tot = 0;
+    if (tid < (u32)kBins) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { c[w] = whist[w * kBins + tid]; tot += c[w]; }
+    }
+    u32 all;
+    const u32 tb = block_exclusive_scan(tid < (u32)kBins ? tot : 0u, misc, &all);
+    if (tid < (u32)kBins) {
+      u32 run = tb;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { whist[w * kBins + tid] = run; run += c[w]; }
+      gdelta[tid] = mypos - tb;                               // wraps harmlessly: slot >= tb for this bin
+    }
+  }
+  __syncthreads();
+
+  // 4. permute into digit order inside LDS
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const u32 slot = wib * PER_WAVE + r * kWave + lane;
+    if (slot < cnt) {
+      const u32 p = whist[wib * kBins + dig[r]] + rk[r];
+      stage[3 * p] = v[r].x; stage[3 * p + 1] = v[r].y; stage[3 * p + 2] = v[r].z;
+      sbin[p] = (uint8_t)dig[r];
+    }
+  }
+  __syncthreads();
+
+  // 5. write out: lane = element, consecutive lanes write the consecutive elements of a run (dwordx3 each; plain stores:
+  //    the L2 merges the pieces of a run that neighbouring tiles write); 6. the next pass's digit at the new position
+  const u32 nsel = (nbyte >> 2) < 3 ? (nbyte >> 2) : 0, nsh = 8 * (nbyte & 3);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const u32 p = tid + THREADS * r;
+    if (p < cnt) {
+      const u32 g = gdelta[sbin[p]] + p;
+      const u32x3 e{stage[3 * p], stage[3 * p + 1], stage[3 * p + 2]};
+      st_elem(dst + g, e);
+      if (nbyte < 12) digits[g] = (uint8_t)((nsel == 0 ? e.x : nsel == 1 ? e.y : e.z) >> nsh);
+    }
+  }
+}
+
+// =====================================================================================================
 // Host side.  Scratch layout (bytes), all offsets 256-byte aligned:
 //   census u64[8] | binbase u64[256] | blocksum u32[nblocks][256] | blockoff u64[nblocks][256] | counts u16[ntiles][256]
 //   | pos IDX[ntiles][256] | digits u8[ntiles * T]
@@ -596,7 +844,105 @@ static const SweepVariant& pick_variant(const LaunchCfg& cfg) {
   return kSweep[cfg.sort_variant >= 0 && cfg.sort_variant < kNumSweep ? cfg.sort_variant : 0];
 }
 
-size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) { return sort_layout(n, pick_variant(cfg).tile).total; }
+
+// compact-key passes: tile shapes (cfg.sort_compact = 1 + index; 0 = never take the compact path)
+struct CompactVariant {
+  int threads, tile;
+  size_t lds;
+  const void* scatter;
+  void (*counts_bytes)(const uint8_t*, u64, u32, uint16_t*);
+};
+template <int TH, int R>
+static CompactVariant compact_variant() {
+  typedef CompactShape<TH, R> S;
+  return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter12<TH, R>), ibu_k_sort_tilecounts_bytes<S::T>};
+}
+static const CompactVariant kCompact[] = {
+    compact_variant<256, 16>(),   // 1 (default): 4096-element tiles (48 KiB, the bytes of a 2048-record tile), 4 waves
+    compact_variant<256, 8>(),    // 2: 2048-element tiles
+    compact_variant<512, 8>(),    // 3: 4096-element tiles, 8 waves
+    compact_variant<512, 16>(),   // 4: 8192-element tiles, 8 waves, one workgroup per CU
+    compact_variant<1024, 8>(),   // 5: 8192-element tiles, 16 waves
+    compact_variant<1024, 4>(),   // 6: 4096-element tiles, 16 waves
+};
+static constexpr int kNumCompact = sizeof(kCompact) / sizeof(kCompact[0]);
+int sort_num_compact_variants() { return kNumCompact; }
+static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
+  return cfg.sort_compact >= 1 && cfg.sort_compact <= kNumCompact ? &kCompact[cfg.sort_compact - 1] : nullptr;
+}
+
+size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) {
+  size_t need = sort_layout(n, pick_variant(cfg).tile).total;
+  if (const CompactVariant* cv = pick_compact(cfg)) {
+    const size_t c = sort_layout(n, cv->tile).total;
+    if (c > need) need = c;
+  }
+  return need;
+}
+
+// The compact-key path of launch_sort_records (see "COMPACT-KEY passes" above).  first_elem_byte: the first element byte
+// that is sorted (the index bytes below it are carried only).
+static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
+                                        const CompactPlan& pl, u32 first_elem_byte, hipStream_t st) {
+  const SortLayout L = sort_layout(n, cv.tile);
+  u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
+  u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
+  u64* blockoff = reinterpret_cast<u64*>(sc + L.blockoff);
+  uint16_t* counts = reinterpret_cast<uint16_t*>(sc + L.counts);
+  u32* pos = reinterpret_cast<u32*>(sc + L.pos);
+  uint8_t* digits = sc + L.digits;
+  Elem* src = static_cast<Elem*>(tmp);
+  Elem* dst = reinterpret_cast<Elem*>(static_cast<uint8_t*>(tmp) + 12 * n);
+
+  const int vi = (int)(&cv - kCompact);
+  static std::atomic<bool> lds_set[kNumCompact];
+  hipError_t e;
+  if (cv.lds > 48 * 1024 && !lds_set[vi].load(std::memory_order_relaxed)) {
+    e = hipFuncSetAttribute(cv.scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
+    if (e != hipSuccess) return e;
+    lds_set[vi].store(true, std::memory_order_relaxed);
+  }
+  // compress
+  const size_t main_rows = (n / kTileRecs) * kTileRecs;
+  if (main_rows) {
+    static std::atomic<int> occ;
+    const u32 nt = (u32)(main_rows / kTileRecs);
+    hipLaunchKernelGGL(ibu_k_sort_compress, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress, 0, &occ))),
+                       dim3(kBlock), 0, st, (const uint8_t*)recs, nt, pl, first_elem_byte, src, digits);
+  }
+  if (main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const uint8_t*)recs, (u64)main_rows,
+                       (u64)n, pl, first_elem_byte, src, digits);
+  // passes
+  const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
+  const u32 cap = (u32)cfg.cus * 8;
+  for (u32 b = first_elem_byte; b < pl.k; ++b) {
+    hipLaunchKernelGGL(cv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n,
+                       L.ntiles, counts);
+    hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
+    hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
+    hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+                       (const u64*)blockoff, (const u64*)binbase, pos);
+    u32 n_arg = (u32)n, b_arg = b, nb_arg = b + 1 < pl.k ? b + 1 : 12u;
+    const Elem* src_arg = src;
+    const u32* pos_arg = pos;
+    void* args[] = {&src_arg, &dst, &n_arg, &b_arg, &nb_arg, &pos_arg, &digits};
+    e = hipLaunchKernel(cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
+    if (e != hipSuccess) return e;
+    Elem* t = src; src = dst; dst = t;
+  }
+  // expand
+  if (main_rows) {
+    static std::atomic<int> occ;
+    const u32 nt = (u32)(main_rows / kTileRecs);
+    hipLaunchKernelGGL(ibu_k_sort_expand, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_expand, 0, &occ))), dim3(kBlock),
+                       0, st, (const Elem*)src, nt, pl, (uint8_t*)recs);
+  }
+  if (main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const Elem*)src, (u64)main_rows, (u64)n,
+                       pl, (u64*)recs);
+  return hipGetLastError();
+}
 
 // Not purely asynchronous: the census result comes back to the host (one 64-byte read) to pick the passes; everything
 // after that is queued on `st`.
@@ -638,6 +984,29 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     const u64 varying = c[f] ^ c[3 + f];        // bits that differ between some two records
     for (u32 b = 0; b < 8; ++b)
       if ((varying >> (8 * b)) & 255u) passes[npass++] = {(u32)f, 8 * b};   // constant digits: the pass would be the identity
+  }
+
+  // compact-key path: at most 12 varying bytes (the index bytes are carried even when they are not sorted), n < 2^32,
+  // records 16-byte aligned (the tiled compress / expand kernels), tmp at least 4-byte aligned
+  if (const CompactVariant* cv = pick_compact(cfg)) {
+    CompactPlan pl{};
+    u32 k = 0, first_sorted = 0;
+    for (int fo = 0; fo < 3; ++fo) {
+      const int f = kFieldOrder[fo];
+      const u64 varying = c[f] ^ c[3 + f];
+      pl.base[f] = c[3 + f];
+      for (u32 b = 0; b < 8; ++b)
+        if ((varying >> (8 * b)) & 255u) {
+          if (k < 12) pl.sel[k] = (uint8_t)(8 * f + b);
+          ++k;
+          pl.base[f] &= ~(255ull << (8 * b));
+        }
+      if (f == 2 && c[6] == 0) first_sorted = k;          // input in index order: the index bytes ride along unsorted
+    }
+    pl.k = k;
+    const bool ok = npass > 0 && k <= 12 && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total;
+    if (ok) return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, first_sorted, st);
   }
 
   static std::atomic<bool> lds_set[kNumSweep][2];

@@ -42,12 +42,58 @@ def _shuffled(oracle, n, bc_len, umi_len, seed=SEED):
     return recs
 
 
+@pytest.fixture(scope="module")
+def ctx24(ia):
+    """A context that never takes the compact-key path (sort_compact = 0): the 24-byte passes stay covered."""
+    c = ia.Context(0)
+    c.set_option("sort_compact", 0)
+    yield c
+    c.close()
+
+
 @pytest.mark.parametrize("n", SIZES)
-def test_sort_random_16_12(ctx, oracle, n):
+def test_sort_random_16_12(ctx, ctx24, oracle, n):
     recs = _shuffled(oracle, n, 16, 12)
-    got, d = _sort_on_device(ctx, recs)
-    assert got == oracle.sort_records(recs).tobytes()
+    want = oracle.sort_records(recs).tobytes()
+    got, d = _sort_on_device(ctx, recs)          # 11 varying bytes: 12-byte elements (compact-key passes)
+    assert got == want
     assert ctx.is_sorted(d, n)
+    assert _sort_on_device(ctx24, recs)[0] == want
+    idx_order = recs.copy()
+    idx_order["index"] = np.arange(n, dtype=np.uint64)   # input in index order: the index bytes ride along unsorted
+    want = oracle.sort_records(idx_order).tobytes()
+    assert _sort_on_device(ctx, idx_order)[0] == want
+    assert _sort_on_device(ctx24, idx_order)[0] == want
+
+
+@pytest.mark.parametrize("compact", [2, 3, 4, 5, 6])
+def test_sort_compact_tile_shapes(ia, oracle, compact):
+    """The tile shapes of the compact-key passes (ibu_ctx_set_option "sort_compact") are the same algorithm: same bytes."""
+    c = ia.Context(0)
+    try:
+        c.set_option("sort_compact", compact)
+        for n in (1, 4097, 8193, 70_001, 3_000_001):
+            recs = _shuffled(oracle, n, 16, 12)
+            recs["index"] = np.random.default_rng(n).integers(0, 2**30, n, dtype=np.uint64)
+            assert _sort_on_device(c, recs)[0] == oracle.sort_records(recs).tobytes(), (compact, n)
+        with pytest.raises(ia.IbuError):
+            c.set_option("sort_compact", 99)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n", [2, 129, 5000, 300_007])
+@pytest.mark.parametrize("nbytes", [1, 5, 11, 12, 13, 24])
+def test_sort_with_scattered_varying_bytes(ctx, oracle, ia, n, nbytes):
+    """The compact-key path gathers whichever bytes vary — not only the low bytes of each field — and carries the constant
+    ones through the census' AND words; 12 varying bytes still fit an element, 13 take the 24-byte passes."""
+    rng = np.random.default_rng(nbytes * 1000 + n)
+    which = np.sort(rng.permutation(24)[:nbytes])          # byte positions of the record that vary
+    raw = np.tile(rng.integers(0, 256, 24, dtype=np.uint8), (n, 1))   # every other byte: the same value in all records
+    raw[:, which] = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
+    raw[0, which], raw[1, which] = 0, 255                   # every chosen byte really varies
+    recs = raw.reshape(-1).view(ia.REC_DTYPE)
+    assert _sort_on_device(ctx, recs)[0] == oracle.sort_records(recs).tobytes()
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
@@ -56,6 +102,7 @@ def test_sort_other_tile_shapes(ia, oracle, variant):
     c = ia.Context(0)
     try:
         c.set_option("sort_variant", variant)
+        c.set_option("sort_compact", 0)                  # the 24-byte passes are what these shapes belong to
         for n in (1, 4097, 70_001, 3_000_001):
             recs = _shuffled(oracle, n, 16, 12)
             recs["index"] = np.random.default_rng(n).integers(0, 2**30, n, dtype=np.uint64)

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--random-index", action="store_true",
                     help="index column in random order (default: increasing = records in read order, whose index passes are skipped)")
     ap.add_argument("--variants", default="0", help="comma list of sort_variant values to time (A/B in one process)")
+    ap.add_argument("--compact", default="", help="comma list of sort_compact values to time (0 = 24-byte passes only, k = compact tile shape k; "
+                                                  "default: the library's default)")
     ap.add_argument("--skip-agg", action="store_true")
     a = ap.parse_args()
     import ibu_amd as ia
@@ -29,8 +31,10 @@ def main():
     for n in (int(float(x)) for x in a.records.split(",")):
         d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)
         cols = [ctx.alloc(8 * n) for _ in range(4)] if a.random_index else None
-        for variant in (int(v) for v in a.variants.split(",")):
+        for variant, compact in ((int(v), c) for v in a.variants.split(",") for c in (a.compact.split(",") if a.compact else [None])):
             ctx.set_option("sort_variant", variant)
+            if compact is not None:
+                ctx.set_option("sort_compact", int(compact))
             ts = []
             for _ in range(a.rounds + 1):
                 ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)  # random barcode/UMI, increasing index: unsorted
@@ -57,7 +61,7 @@ def main():
             passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
             # algorithmic traffic: census 24 + histogram 24 once, 48 per pass, 48 for the copy back after an odd number of passes
             alg = n * (48 + 48 * passes + (48 if passes & 1 else 0))
-            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "index": "random" if a.random_index else "increasing (read order)",
+            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "index": "random" if a.random_index else "increasing (read order)",
                               "seconds": round(sec, 4), "best": round(min(ts[1:]), 4), "M_records_per_s": round(n / sec / 1e6, 1),
                               "passes": passes, "barcode_counts_seconds": agg, "distinct_barcodes": nb,
                               "algorithmic_GB": round(alg / 1e9, 1), "GBps_algorithmic": round(alg / sec / 1e9)}), flush=True)

@@ -369,12 +369,13 @@ ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, const u64* _
   const u32 bin = threadIdx.x;
   const u32 t0 = blockIdx.x * kTilesPerBlock, t1 = t0 + kTilesPerBlock < ntiles ? t0 + kTilesPerBlock : ntiles;
   u64 running = binbase[bin] + blockoff[(size_t)blockIdx.x * kBins + bin];
-  for (u32 t = t0; t < t1; t += 8) {
-    u32 v[8];
+  constexpr int kFly = 32;                                    // loads in flight per thread: the walk is latency-bound
+  for (u32 t = t0; t < t1; t += kFly) {
+    u32 v[kFly];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = t + j < t1 ? counts[(size_t)(t + j) * kBins + bin] : 0;
+    for (int j = 0; j < kFly; ++j) v[j] = t + j < t1 ? counts[(size_t)(t + j) * kBins + bin] : 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < kFly; ++j) {
       if (t + j < t1) pos[(size_t)(t + j) * kBins + bin] = (IDX)running;
       running += v[j];
     }
@@ -539,9 +540,10 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
 //              record; also the 1-byte digit side stream of the first pass.                      24 R + 13 W per record
 //   passes     LSD over the element bytes that must be sorted (not the index bytes when the input is in index
 //              order), counts from the side stream, scan, scatter as above — on half the bytes.  ~26.6 B per record
-//   expand     elements -> records (constant bytes from the census' AND words).                   12 R + 24 W per record
+//   expand     fused into the LAST pass: its scatter writes every element as the 24-byte record it stands for (constant
+//              bytes from the census' AND words) straight into the caller's array.            12 R + 24 W per record
 //
-// 16/12 with a random index: 24 (census) + 37 + 11 x 26.6 + 36 = 390 B/record against 24 + 48 + 11 x 51.9 = 643.
+// 16/12 with a random index: 24 (census) + 37 + 10 x 26.6 + 38 = 365 B/record against 24 + 48 + 11 x 51.9 = 643.
 // Both element buffers live in the caller's `tmp` (12 n bytes each), so the second one starts at a 4-byte boundary: every
 // element access is a per-lane dwordx3 (64 lanes x 12 B = 768 contiguous bytes), which needs no more than that — and a
 // lane that loads whole elements needs no LDS staging in front of the ranking.  The result is the same permutation as the
@@ -550,51 +552,55 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
 struct __attribute__((packed, aligned(4))) Elem { u32 w[3]; };
 static_assert(sizeof(Elem) == 12, "12-byte elements");
-__device__ __forceinline__ u32x3 ld_elem(const Elem* p) {
-  u32x3 v;
-  __builtin_memcpy(&v, p, 12);                                 // 4-byte aligned: one global_load_dwordx3
-  return v;
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+__device__ __forceinline__ u32x3 ld_elem(const Elem* p) {      // 4-byte aligned: one global_load_dwordx3, read once (nt)
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(p));
 }
 __device__ __forceinline__ void st_elem(Elem* p, u32x3 v) { __builtin_memcpy(p, &v, 12); }
 
+// Byte gathers as v_perm_b32: a selector byte 0..7 picks a byte of the (hi, lo) register pair, 0x0C gives zero.
 struct CompactPlan {
-  uint8_t sel[12];   // element byte j <- record byte sel[j] (0..23 = 8 * field + byte of the field); j >= k unused
-  u32 k;             // bytes carried
+  u32 csel[3][3];    // compress: element word w = OR over the fields f of perm(f.hi, f.lo, csel[w][f])
+  u32 xsel[6][2];    // expand: record dword d (= 2 f + half) = base | perm(e.w1, e.w0, xsel[d][0]) | perm(0, e.w2, xsel[d][1])
+  u32 k;             // bytes carried (element bytes k .. 11 are zero)
   u64 base[3];       // each field with its varying bytes cleared (the census' AND words)
 };
-__device__ __forceinline__ u32x3 compress_rec(const uint8_t* r /*LDS or global, 24 bytes*/, const CompactPlan& pl) {
-  u32 e[3] = {0, 0, 0};
+__device__ __forceinline__ u32x3 compress_rec(u64 f0, u64 f1, u64 f2, const CompactPlan& pl) {
+  u32 e[3];
 #pragma unroll
-  for (int j = 0; j < 12; ++j)
-    if ((u32)j < pl.k) e[j >> 2] |= (u32)r[pl.sel[j]] << (8 * (j & 3));
+  for (int w = 0; w < 3; ++w)
+    e[w] = __builtin_amdgcn_perm((u32)(f0 >> 32), (u32)f0, pl.csel[w][0]) | __builtin_amdgcn_perm((u32)(f1 >> 32), (u32)f1, pl.csel[w][1]) |
+           __builtin_amdgcn_perm((u32)(f2 >> 32), (u32)f2, pl.csel[w][2]);
   return u32x3{e[0], e[1], e[2]};
 }
 __device__ __forceinline__ void expand_elem(u32x3 v, const CompactPlan& pl, u64& f0, u64& f1, u64& f2) {
-  f0 = pl.base[0]; f1 = pl.base[1]; f2 = pl.base[2];
-  const u32 e[3] = {v.x, v.y, v.z};
+  u32 d[6];
 #pragma unroll
-  for (int j = 0; j < 12; ++j)
-    if ((u32)j < pl.k) {
-      const u32 s = pl.sel[j];                               // uniform
-      const u64 b = (u64)((e[j >> 2] >> (8 * (j & 3))) & 255u) << (8 * (s & 7u));
-      if ((s >> 3) == 0) f0 |= b; else if ((s >> 3) == 1) f1 |= b; else f2 |= b;
-    }
+  for (int k = 0; k < 6; ++k) d[k] = __builtin_amdgcn_perm(v.y, v.x, pl.xsel[k][0]) | __builtin_amdgcn_perm(0u, v.z, pl.xsel[k][1]);
+  f0 = pl.base[0] | ((u64)d[1] << 32) | d[0];
+  f1 = pl.base[1] | ((u64)d[3] << 32) | d[2];
+  f2 = pl.base[2] | ((u64)d[5] << 32) | d[4];
 }
-// records [0, 128 ntiles) -> elements + first digit; tiled like the census (recs 16-B aligned)
+__device__ __forceinline__ u32 elem_byte(u32x3 e, u32 byte) {   // byte: uniform
+  const u32 w = byte >> 2;
+  return ((w == 0 ? e.x : w == 1 ? e.y : e.z) >> (8 * (byte & 3))) & 255u;
+}
+// records [0, 128 ntiles) -> elements + first digit; tiled like the census (recs 16-B aligned).  Lane L owns records L and
+// L + 64 of the tile: stride-24 ds_read_b64 is conflict-free and each of its two element stores is 768 contiguous bytes.
 extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, Elem* __restrict__ out,
                     uint8_t* __restrict__ digits) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
-  if (t >= ntiles) return;
+  const TileRange tr = tile_range(ntiles, wib);             // which tiles this wave sweeps (kcommon.hpp)
+  u32 t = tr.t;
+  if (t >= tr.end) return;
   const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
   u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
   for (;;) {
-    const u32 tn = t + nwaves;
-    const bool more = tn < ntiles;                           // wave-uniform; the prefetch is unconditional (kcommon.hpp)
+    const u32 tn = t + tr.stride;
+    const bool more = tn < tr.end;                           // wave-uniform; the prefetch is unconditional (kcommon.hpp)
     src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
     const u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
     wave_lds_fence();
@@ -602,79 +608,40 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
     *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
     wave_lds_fence();
-    const uint8_t* r = tile + (2 * lane) * 24;               // records 2L, 2L+1
-    const u32x3 e0 = compress_rec(r, pl), e1 = compress_rec(r + 24, pl);
-    const size_t row = (size_t)t * kTileRecs + 2 * lane;
+    const u64* r = reinterpret_cast<const u64*>(tile + lane * 24);
+    const u64* q = reinterpret_cast<const u64*>(tile + (lane + kWave) * 24);
+    const u32x3 e0 = compress_rec(r[0], r[1], r[2], pl), e1 = compress_rec(q[0], q[1], q[2], pl);
+    const size_t row = (size_t)t * kTileRecs + lane;
     st_elem(out + row, e0);
-    st_elem(out + row + 1, e1);
-    const u32 w = first_byte >> 2, sh = 8 * (first_byte & 3);
-    const u32 d0 = ((w == 0 ? e0.x : w == 1 ? e0.y : e0.z) >> sh) & 255u, d1 = ((w == 0 ? e1.x : w == 1 ? e1.y : e1.z) >> sh) & 255u;
-    *reinterpret_cast<uint16_t*>(digits + row) = (uint16_t)(d0 | (d1 << 8));
+    st_elem(out + row + kWave, e1);
+    digits[row] = (uint8_t)elem_byte(e0, first_byte);
+    digits[row + kWave] = (uint8_t)elem_byte(e1, first_byte);
     if (!more) break;
     t = tn;
     a0 = b0; a1 = b1; a2 = b2;
   }
 }
-extern "C" __global__ void ibu_k_sort_compress_tail(const uint8_t* __restrict__ recs, u64 row0, u64 n, CompactPlan pl, u32 first_byte,
+extern "C" __global__ void ibu_k_sort_compress_tail(const u64* __restrict__ recs, u64 row0, u64 n, CompactPlan pl, u32 first_byte,
                                                     Elem* __restrict__ out, uint8_t* __restrict__ digits) {
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u32x3 e = compress_rec(recs + 24 * i, pl);
+  const u32x3 e = compress_rec(recs[3 * i], recs[3 * i + 1], recs[3 * i + 2], pl);
   st_elem(out + i, e);
-  const u32 w = first_byte >> 2;
-  digits[i] = (uint8_t)((w == 0 ? e.x : w == 1 ? e.y : e.z) >> (8 * (first_byte & 3)));
+  digits[i] = (uint8_t)elem_byte(e, first_byte);
 }
-// elements -> records [0, 128 ntiles) (recs 16-B aligned)
-extern "C" __global__ void __launch_bounds__(kBlock, 8)
-ibu_k_sort_expand(const Elem* __restrict__ in, u32 ntiles, CompactPlan pl, uint8_t* __restrict__ recs) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
-  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kTileBytes;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
-  u32 t = logical_block() * kWavesPerBlock + wib;
-  if (t >= ntiles) return;
-  u32x3 a0 = ld_elem(in + (size_t)t * kTileRecs + 2 * lane), a1 = ld_elem(in + (size_t)t * kTileRecs + 2 * lane + 1);
-  for (;;) {
-    const u32 tn = t + nwaves;
-    const bool more = tn < ntiles;
-    const size_t nrow = (size_t)(more ? tn : t) * kTileRecs + 2 * lane;
-    const u32x3 b0 = ld_elem(in + nrow), b1 = ld_elem(in + nrow + 1);
-    u64 f[6];
-    expand_elem(a0, pl, f[0], f[1], f[2]);
-    expand_elem(a1, pl, f[3], f[4], f[5]);
-    wave_lds_fence();                                        // the previous tile's reads precede these writes
-    u64* r = reinterpret_cast<u64*>(tile + lane * 48);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) r[k] = f[k];
-    wave_lds_fence();
-    uint8_t* dst = recs + (size_t)t * kTileBytes + 16 * lane;
-    st16(dst, *reinterpret_cast<const u32x4*>(tile + 16 * lane));
-    st16(dst + 1024, *reinterpret_cast<const u32x4*>(tile + 1024 + 16 * lane));
-    st16(dst + 2048, *reinterpret_cast<const u32x4*>(tile + 2048 + 16 * lane));
-    if (!more) break;
-    t = tn;
-    a0 = b0; a1 = b1;
-  }
-}
-extern "C" __global__ void ibu_k_sort_expand_tail(const Elem* __restrict__ in, u64 row0, u64 n, CompactPlan pl, u64* __restrict__ recs) {
-  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u64 f0, f1, f2;
-  expand_elem(ld_elem(in + i), pl, f0, f1, f2);
-  recs[3 * i] = f0; recs[3 * i + 1] = f1; recs[3 * i + 2] = f2;
-}
-
 template <int THREADS, int ROUNDS>
 struct CompactShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
   // LDS: stage 12 T | gdelta 256 x u32 | whist NW x 256 x u32 | misc 16 x u32 | sbin T bytes
   static constexpr size_t lds = 12 * (size_t)T + 4 * kBins + 4 * (size_t)NW * kBins + 64 + (size_t)T;
 };
-// One pass over element byte `byte`; nbyte: the next pass's byte (>= 12: there is none, no side stream).
-template <int THREADS, int ROUNDS>
+// One pass over element byte `byte`; nbyte: the next pass's byte (the digit side stream it leaves behind).
+// LAST: the last pass — every element leaves as the 24-byte record it stands for, straight into the caller's array
+// (`dst` = the records, `pl` = the expansion; no side stream): the expand kernel and one element round trip are saved.
+template <int THREADS, int ROUNDS, bool LAST>
 __global__ void __launch_bounds__(THREADS)
-ibu_k_sort_scatter12(const Elem* __restrict__ src, Elem* __restrict__ dst, u32 n, u32 byte, u32 nbyte, const u32* __restrict__ pos,
-                     uint8_t* __restrict__ digits) {
+ibu_k_sort_scatter12(const Elem* __restrict__ src, void* __restrict__ dst_v, u32 n, u32 byte, u32 nbyte, const u32* __restrict__ pos,
+                     uint8_t* __restrict__ digits, CompactPlan pl) {
   typedef CompactShape<THREADS, ROUNDS> S;
   constexpr int T = S::T, NW = S::NW, PER_WAVE = S::PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -708,13 +675,12 @@ ibu_k_sort_scatter12(const Elem* __restrict__ src, Elem* __restrict__ dst, u32 n
   wave_lds_fence();                                          // a wave's counters are its own
 
   // 2. rank every element among the elements of its wave with the same digit (stable: slot order)
-  const u32 wsel = byte >> 2, wsh = 8 * (byte & 3);
   u32 dig[ROUNDS], rk[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const u32 slot = wib * PER_WAVE + r * kWave + lane;
     const bool valid = slot < cnt;
-    const u32 d = ((wsel == 0 ? v[r].x : wsel == 1 ? v[r].y : v[r].z) >> wsh) & 255u;
+    const u32 d = elem_byte(v[r], byte);
     u64 m = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -764,15 +730,21 @@ ibu_k_sort_scatter12(const Elem* __restrict__ src, Elem* __restrict__ dst, u32 n
 
   // 5. write out: lane = element, consecutive lanes write the consecutive elements of a run (dwordx3 each; plain stores:
   //    the L2 merges the pieces of a run that neighbouring tiles write); 6. the next pass's digit at the new position
-  const u32 nsel = (nbyte >> 2) < 3 ? (nbyte >> 2) : 0, nsh = 8 * (nbyte & 3);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const u32 p = tid + THREADS * r;
     if (p < cnt) {
       const u32 g = gdelta[sbin[p]] + p;
       const u32x3 e{stage[3 * p], stage[3 * p + 1], stage[3 * p + 2]};
-      st_elem(dst + g, e);
-      if (nbyte < 12) digits[g] = (uint8_t)((nsel == 0 ? e.x : nsel == 1 ? e.y : e.z) >> nsh);
+      if constexpr (LAST) {
+        u64 f0, f1, f2;
+        expand_elem(e, pl, f0, f1, f2);
+        u64* o = static_cast<u64*>(dst_v) + 3 * (size_t)g;
+        o[0] = f0; o[1] = f1; o[2] = f2;
+      } else {
+        st_elem(static_cast<Elem*>(dst_v) + g, e);
+        digits[g] = (uint8_t)elem_byte(e, nbyte);
+      }
     }
   }
 }
@@ -845,25 +817,30 @@ static const SweepVariant& pick_variant(const LaunchCfg& cfg) {
 }
 
 
-// compact-key passes: tile shapes (cfg.sort_compact = 1 + index; 0 = never take the compact path)
+// compact-key passes: tile shapes (cfg.sort_compact = 1 + index; 0 = never take the compact path); times: the whole sort,
+// 1e9 records 16/12 with a random 30-bit index (profiles/r02_aj_*)
 struct CompactVariant {
   int threads, tile;
   size_t lds;
   const void* scatter;
+  const void* scatter_last;
   void (*counts_bytes)(const uint8_t*, u64, u32, uint16_t*);
 };
 template <int TH, int R>
 static CompactVariant compact_variant() {
   typedef CompactShape<TH, R> S;
-  return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter12<TH, R>), ibu_k_sort_tilecounts_bytes<S::T>};
+  return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter12<TH, R, false>),
+          reinterpret_cast<const void*>(ibu_k_sort_scatter12<TH, R, true>), ibu_k_sort_tilecounts_bytes<S::T>};
 }
 static const CompactVariant kCompact[] = {
-    compact_variant<256, 16>(),   // 1 (default): 4096-element tiles (48 KiB, the bytes of a 2048-record tile), 4 waves
-    compact_variant<256, 8>(),    // 2: 2048-element tiles
-    compact_variant<512, 8>(),    // 3: 4096-element tiles, 8 waves
-    compact_variant<512, 16>(),   // 4: 8192-element tiles, 8 waves, one workgroup per CU
-    compact_variant<1024, 8>(),   // 5: 8192-element tiles, 16 waves
-    compact_variant<1024, 4>(),   // 6: 4096-element tiles, 16 waves
+    compact_variant<256, 20>(),   // 1 (default): 5120-element tiles (60 KiB), 4 waves, two workgroups per CU (1e9 records: 73.7 ms)
+    compact_variant<256, 16>(),   // 2: 4096-element tiles (75.2 ms)
+    compact_variant<256, 8>(),    // 3: 2048-element tiles (94 ms: runs of 8 elements = 96 bytes)
+    compact_variant<512, 8>(),    // 4: 4096-element tiles, 8 waves (79-83 ms)
+    compact_variant<512, 16>(),   // 5: 8192-element tiles, 8 waves, one workgroup per CU (99 ms)
+    compact_variant<1024, 8>(),   // 6: 8192-element tiles, 16 waves (97 ms)
+    compact_variant<1024, 4>(),   // 7: 4096-element tiles, 16 waves (79-83 ms)
+    compact_variant<256, 12>(),   // 8: 3072-element tiles, three workgroups per CU (86 ms)
 };
 static constexpr int kNumCompact = sizeof(kCompact) / sizeof(kCompact[0]);
 int sort_num_compact_variants() { return kNumCompact; }
@@ -900,6 +877,8 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
   if (cv.lds > 48 * 1024 && !lds_set[vi].load(std::memory_order_relaxed)) {
     e = hipFuncSetAttribute(cv.scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(cv.scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
+    if (e != hipSuccess) return e;
     lds_set[vi].store(true, std::memory_order_relaxed);
   }
   // compress
@@ -911,9 +890,9 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
                        dim3(kBlock), 0, st, (const uint8_t*)recs, nt, pl, first_elem_byte, src, digits);
   }
   if (main_rows < n)
-    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const uint8_t*)recs, (u64)main_rows,
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const u64*)recs, (u64)main_rows,
                        (u64)n, pl, first_elem_byte, src, digits);
-  // passes
+  // passes; the last one writes the records themselves
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
   for (u32 b = first_elem_byte; b < pl.k; ++b) {
@@ -923,24 +902,17 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
     hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
                        (const u64*)blockoff, (const u64*)binbase, pos);
-    u32 n_arg = (u32)n, b_arg = b, nb_arg = b + 1 < pl.k ? b + 1 : 12u;
+    const bool last = b + 1 == pl.k;
+    u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? b : b + 1;
     const Elem* src_arg = src;
+    void* dst_arg = last ? recs : static_cast<void*>(dst);
     const u32* pos_arg = pos;
-    void* args[] = {&src_arg, &dst, &n_arg, &b_arg, &nb_arg, &pos_arg, &digits};
-    e = hipLaunchKernel(cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
+    CompactPlan pl_arg = pl;
+    void* args[] = {&src_arg, &dst_arg, &n_arg, &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
+    e = hipLaunchKernel(last ? cv.scatter_last : cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
     if (e != hipSuccess) return e;
     Elem* t = src; src = dst; dst = t;
   }
-  // expand
-  if (main_rows) {
-    static std::atomic<int> occ;
-    const u32 nt = (u32)(main_rows / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_sort_expand, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_expand, 0, &occ))), dim3(kBlock),
-                       0, st, (const Elem*)src, nt, pl, (uint8_t*)recs);
-  }
-  if (main_rows < n)
-    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const Elem*)src, (u64)main_rows, (u64)n,
-                       pl, (u64*)recs);
   return hipGetLastError();
 }
 
@@ -990,6 +962,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   // records 16-byte aligned (the tiled compress / expand kernels), tmp at least 4-byte aligned
   if (const CompactVariant* cv = pick_compact(cfg)) {
     CompactPlan pl{};
+    for (auto& row : pl.csel) for (u32& v : row) v = 0x0C0C0C0Cu;   // selector 0x0C: a zero byte
+    for (auto& row : pl.xsel) for (u32& v : row) v = 0x0C0C0C0Cu;
     u32 k = 0, first_sorted = 0;
     for (int fo = 0; fo < 3; ++fo) {
       const int f = kFieldOrder[fo];
@@ -997,7 +971,12 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       pl.base[f] = c[3 + f];
       for (u32 b = 0; b < 8; ++b)
         if ((varying >> (8 * b)) & 255u) {
-          if (k < 12) pl.sel[k] = (uint8_t)(8 * f + b);
+          if (k < 12) {                                     // element byte k <- byte b of field f, and back
+            u32& cs = pl.csel[k >> 2][f];
+            cs = (cs & ~(255u << (8 * (k & 3)))) | (b << (8 * (k & 3)));
+            u32& xs = pl.xsel[2 * f + (b >> 2)][k < 8 ? 0 : 1];
+            xs = (xs & ~(255u << (8 * (b & 3)))) | ((k < 8 ? k : k - 8) << (8 * (b & 3)));
+          }
           ++k;
           pl.base[f] &= ~(255ull << (8 * b));
         }

@@ -236,6 +236,10 @@ int32_t ibu_device_count(int32_t* n);
  *   "blocks_per_cu"  1..8   cap on resident 256-thread workgroups per CU for the persistent grids
  *   "sort_variant"   0..7   tile shape / write-out mode of the radix passes (0 = default; the rest are A/B builds of the
  *                           same algorithm kept for measurement: ibu_amd/csrc/sort.hip, kSweep)
+ *   "sort_compact"   0..8   compact-key passes of the sort: when at most 12 bytes of the 24-byte key vary (16/12 records
+ *                           with indices below 2^32: 11) the passes move 12-byte elements instead of records.  0 = never
+ *                           (24-byte passes only), 1 = default tile shape, 2..8 = A/B tile shapes (sort.hip, kCompact).
+ *                           Same result either way, byte for byte.
  *   "base_order"     0 | 1  bit order of the 2-bit codec for every pack / unpack / decode / encode issued through
  *                           this context (device kernels and the stream entry points alike):
  *                             0 = IBU_BASE_ORDER_LSB_FIRST (default): base i at bits [2i, 2i+1], "ACGT" -> 0b11100100
@@ -322,7 +326,9 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
 /* Device-side sort by (barcode, umi, index) — the order `derive(Ord)` defines (record.rs:58)
  * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch.  The context
  * additionally keeps (and grows on demand) about 1.75 B per record of its own scratch.  Any n the
- * device can hold (n < 2^40); synchronises `stream` once (a 64-byte census read-back picks the passes). */
+ * device can hold (n < 2^40); synchronises `stream` once (a 64-byte census read-back picks the passes).
+ * Stable LSD radix sort over the key bytes that vary; when at most 12 of them do (and n < 2^32, d_records 16-byte
+ * aligned) the passes run on 12-byte compacted keys held in d_tmp (option "sort_compact"). */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
 /* Per-barcode aggregation of SORTED device records: the device form of the reference's BarcodeAnalyzer
  * processor (src/parallel.rs:72-98 — HashMap<barcode, count> merged in on_batch_complete).  Writes, in

@@ -66,7 +66,7 @@ def test_sort_random_16_12(ctx, ctx24, oracle, n):
     assert _sort_on_device(ctx24, idx_order)[0] == want
 
 
-@pytest.mark.parametrize("compact", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("compact", [2, 3, 4, 5, 6, 7, 8])
 def test_sort_compact_tile_shapes(ia, oracle, compact):
     """The tile shapes of the compact-key passes (ibu_ctx_set_option "sort_compact") are the same algorithm: same bytes."""
     c = ia.Context(0)

@@ -8,6 +8,7 @@ package binds it and nothing else (no numpy/torch arithmetic stands in for a ker
 """
 import copy
 import ctypes as C
+import weakref
 from collections import namedtuple
 
 import numpy as np
@@ -552,6 +553,7 @@ class DeviceBuffer:
         p = C.c_void_p()
         _check(lib.ibu_device_alloc(ctx._c, self.nbytes, C.byref(p)))
         self.ptr = p.value
+        ctx._buffers.add(self)   # a context that closes first frees what it still owns (Context.close)
 
     @classmethod
     def wrap(cls, ctx, ptr, nbytes):
@@ -591,6 +593,7 @@ class Context:
         c = C.c_void_p()
         _check(lib.ibu_ctx_create(device, C.byref(c)))
         self._c = c
+        self._buffers = weakref.WeakSet()   # live DeviceBuffers allocated through this context
 
     @property
     def stream(self):
@@ -726,6 +729,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_c", None):
+            for b in list(getattr(self, "_buffers", ())):   # buffers that outlive the context would leak their HBM
+                b.free()
             lib.ibu_ctx_destroy(self._c)
             self._c = None
 

@@ -321,13 +321,16 @@ def test_sort_with_8_byte_aligned_buffers(ctx, oracle, ia):
     assert view.download().tobytes() == oracle.sort_records(recs).tobytes()
 
 
-def test_sort_and_barcode_counts_beyond_2_pow_32_records(ia):
+@pytest.mark.parametrize("n", [4_294_000_000, 4_400_000_000])
+def test_sort_and_barcode_counts_beyond_2_pow_32_records(ia, n):
     """More than 2^32 records on one GPU (4.4e9 x 24 B = 106 GB + as much scratch: the part has 288 GB): the sort's
     tile positions switch to 64 bits, the run tables of the aggregation too.  Size-independent properties: sorted,
-    multiset preserved (count, wrapping sums, XORs), per-barcode counts add up.  """
-    n, bc_len, umi_len = 4_400_000_000, 8, 12
-    assert n > 2**32
+    multiset preserved (count, wrapping sums, XORs), per-barcode counts add up.  
+    And just below 2^32: the largest input of the compact-key passes, whose element positions are 32-bit."""
+    bc_len, umi_len = 8, 12
+    assert abs(n - 2**32) < 2**27
     ctx = ia.Context(0)
+    recs = tmp = None
     try:
         recs, tmp = ctx.alloc(n * 24), ctx.alloc(n * 24)
         ctx.generate(0x1B00007, 0, n, bc_len, umi_len, recs)
@@ -347,4 +350,24 @@ def test_sort_and_barcode_counts_beyond_2_pow_32_records(ia):
         tail = ia.DeviceBuffer.wrap(ctx, recs.ptr + (n - 1) * 24, 24).download(np.uint64)
         assert int(head[0]) == 0 and int(tail[0]) == 4**bc_len - 1
     finally:
+        for b in (recs, tmp):          # before the context goes: a buffer cannot be freed through a closed context
+            if b is not None:
+                b.free()
         ctx.close()
+
+
+def test_context_close_frees_the_buffers_it_still_owns(ia):
+    """A DeviceBuffer that outlives its Context must not keep its HBM: close() frees what is still alive (two 120 GB
+    buffers in a row through two contexts fit only if the first one went)."""
+    big = 120 * 10**9
+    c1 = ia.Context(0)
+    held = c1.alloc(big)
+    c1.close()
+    assert held.ptr == 0
+    c2 = ia.Context(0)
+    try:
+        a, b = c2.alloc(big), c2.alloc(big)
+        a.free()
+        b.free()
+    finally:
+        c2.close()

@@ -60,6 +60,16 @@ pub struct ibu_decode_sink_t {
     /// rows every non-NULL column can hold (ABI revision 3): a longer stream is IBU_ERR_INVALID_ARG, never an overrun
     pub cap_records: usize,
 }
+/// Plan of the compacted keys (the varying bytes of a set of records as 12-byte elements): ibu_key_plan_init.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ibu_key_plan_t {
+    pub csel: [[u32; 3]; 3],
+    pub xsel: [[u32; 2]; 6],
+    pub k: u32,
+    pub index_bytes: u32,
+    pub base: [u64; 3],
+}
 #[repr(C)]
 pub struct ibu_processor_vtable_t {
     pub clone: Option<unsafe extern "C" fn(*mut c_void) -> *mut c_void>,
@@ -178,6 +188,12 @@ extern "C" {
                                    d_pos: *mut u64, stream: *mut c_void) -> i32;
     pub fn ibu_records_first_mismatch(ctx: *mut ibu_ctx_t, d_a: *const c_void, d_b: *const c_void, n: usize, first: *mut u64,
                                       stream: *mut c_void) -> i32;
+    pub fn ibu_records_census(ctx: *mut ibu_ctx_t, d_records: *const c_void, n: usize, out: *mut u64, stream: *mut c_void) -> i32;
+    pub fn ibu_key_plan_init(or_words: *const u64, and_words: *const u64, plan: *mut ibu_key_plan_t) -> i32;
+    pub fn ibu_records_compact(ctx: *mut ibu_ctx_t, plan: *const ibu_key_plan_t, d_records: *const c_void, n: usize,
+                               d_elems: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn ibu_records_expand(ctx: *mut ibu_ctx_t, plan: *const ibu_key_plan_t, d_elems: *const c_void, n: usize,
+                              d_records: *mut c_void, stream: *mut c_void) -> i32;
     pub fn ibu_is_sorted(ctx: *mut ibu_ctx_t, d_records: *const c_void, n: usize, stream: *mut c_void,
                          sorted: *mut i32) -> i32;
     pub fn ibu_load_to_device(ctx: *mut ibu_ctx_t, path: *const c_char, cfg: *const ibu_ring_config_t,

@@ -14,7 +14,7 @@ from collections import namedtuple
 import numpy as np
 
 from . import _lib
-from ._lib import CDecodeSink, CErrorDetail, CHeader, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
+from ._lib import CDecodeSink, CErrorDetail, CKeyPlan, CHeader, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
 
 lib = _lib.load()
 
@@ -539,6 +539,15 @@ def _ring(r):
     return C.byref(CRingConfig(r.get("slots", 0), r.get("slot_records", 0), r.get("feeder_threads", 0), 0))
 
 
+def key_plan(or_words, and_words):
+    """ibu_key_plan_t for records whose OR / AND words are given (Context.census, combined over the shards with | and &).
+    plan.k = number of varying key bytes; compact / expand need plan.k <= 12."""
+    plan = CKeyPlan()
+    _check(lib.ibu_key_plan_init((C.c_uint64 * 3)(*[int(v) & (2**64 - 1) for v in or_words]),
+                                 (C.c_uint64 * 3)(*[int(v) & (2**64 - 1) for v in and_words]), C.byref(plan)))
+    return plan
+
+
 def device_count():
     n = C.c_int32()
     rc = lib.ibu_device_count(C.byref(n))
@@ -682,6 +691,22 @@ class Context:
         """d_pos[j] (u64, device) = first position whose record is >= key j (24-byte records in d_keys); asynchronous."""
         _check(lib.ibu_lower_bound_records(self._c, _dptr(d_sorted_records), n, _dptr(d_keys), k, _dptr(d_pos), stream))
 
+    # compacted keys (the exchange format of the multi-GPU sort)
+    def census(self, d_records, n, stream=None):
+        """{"or": [3], "and": [3], "index_drops": bool, "order_drops": bool} of n device records; synchronises."""
+        out = (C.c_uint64 * 8)()
+        _check(lib.ibu_records_census(self._c, _dptr(d_records), n, out, stream))
+        return {"or": [int(v) for v in out[0:3]], "and": [int(v) for v in out[3:6]], "index_drops": bool(out[6]),
+                "order_drops": bool(out[7])}
+
+    def compact(self, plan, d_records, n, d_elems, stream=None):
+        """n records -> n 12-byte elements (plan: key_plan(); plan.k <= 12); asynchronous."""
+        _check(lib.ibu_records_compact(self._c, C.byref(plan), _dptr(d_records), n, _dptr(d_elems), stream))
+
+    def expand(self, plan, d_elems, n, d_records, stream=None):
+        """n 12-byte elements -> the n records they stand for; asynchronous."""
+        _check(lib.ibu_records_expand(self._c, C.byref(plan), _dptr(d_elems), n, _dptr(d_records), stream))
+
     def first_mismatch(self, d_a, d_b, n, stream=None):
         """Index of the first of n records in which the two device slices differ; n if they are equal
         (`a == b` on record slices: Record derives PartialEq / Eq, record.rs:58)."""
@@ -739,5 +764,5 @@ class Context:
 
 __all__ = ["Header", "Record", "HEADER_SIZE", "MAGIC", "RECORD_SIZE", "VERSION", "IbuError", "load_to_vec",
            "MmapReader", "Reader", "Writer", "ParallelProcessor", "ProcessError", "shard_range", "Context",
-           "DeviceBuffer", "records_array", "REC_DTYPE", "device_count", "PROC_REDUCE", "PROC_DECODE",
+           "DeviceBuffer", "records_array", "key_plan", "REC_DTYPE", "device_count", "PROC_REDUCE", "PROC_DECODE",
            "DEFAULT_BUFFER_SIZE", "BATCH_SIZE"]

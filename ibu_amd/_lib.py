@@ -39,6 +39,10 @@ class CStreamStats(C.Structure):  # ibu_stream_stats_t
                 ("seconds_total", C.c_double), ("seconds_kernel", C.c_double)]
 
 
+class CKeyPlan(C.Structure):  # ibu_key_plan_t
+    _fields_ = [("csel", (u32 * 3) * 3), ("xsel", (u32 * 2) * 6), ("k", u32), ("index_bytes", u32), ("base", u64 * 3)]
+
+
 class CDecodeSink(C.Structure):  # ibu_decode_sink_t
     _fields_ = [("d_bc_ascii", vp), ("d_umi_ascii", vp), ("d_index", vp), ("cap_records", sz)]
 
@@ -139,6 +143,10 @@ SIGNATURES = {
     "ibu_lower_bound_records": (i32, [vp, vp, sz, vp, sz, vp, vp]),
     "ibu_is_sorted": (i32, [vp, vp, sz, vp, P(i32)]),
     "ibu_records_first_mismatch": (i32, [vp, vp, vp, sz, P(u64), vp]),
+    "ibu_records_census": (i32, [vp, vp, sz, P(u64), vp]),
+    "ibu_key_plan_init": (i32, [P(u64), P(u64), P(CKeyPlan)]),
+    "ibu_records_compact": (i32, [vp, P(CKeyPlan), vp, sz, vp, vp]),
+    "ibu_records_expand": (i32, [vp, P(CKeyPlan), vp, sz, vp, vp]),
     "ibu_load_to_device": (i32, [vp, C.c_char_p, P(CRingConfig), P(CHeader), P(vp), sz, P(sz), P(CStreamStats)]),
     "ibu_writer_write_batch_device": (i32, [vp, vp, P(CRingConfig), vp, sz, P(CStreamStats)]),
     "ibu_mmap_process_device": (i32, [vp, vp, P(CRingConfig), i32, sz, sz, vp, P(CStreamStats)]),

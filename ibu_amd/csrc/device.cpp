@@ -4,6 +4,7 @@
 // device; nothing falls back to host arithmetic.  Launch functions are asynchronous, allocate
 // nothing and never synchronise, so callers may capture them into hipGraphs.
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 
 #include "ctx.hpp"
@@ -349,6 +350,57 @@ static int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
     IBU_HIP(hipMalloc(&ctx->d_sort_scratch, need));
     ctx->sort_scratch_bytes = need;
   }
+  return IBU_OK;
+}
+
+// ---- compacted keys: census, plan, records <-> 12-byte elements (the exchange format of the multi-GPU sort) ----------
+static_assert(sizeof(ibu_key_plan_t) == sizeof(ibu::CompactPlan) && offsetof(ibu_key_plan_t, base) == offsetof(ibu::CompactPlan, base) &&
+                  offsetof(ibu_key_plan_t, k) == offsetof(ibu::CompactPlan, k),
+              "ibu_key_plan_t is the kernels' CompactPlan");
+extern "C" int32_t ibu_records_census(ibu_ctx_t* ctx, const void* d_records, size_t n, uint64_t out[8], void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!out) return err_arg("out is NULL");
+  if (n && (!d_records || !aligned8(d_records))) return err_arg("d_records must be non-NULL and 8-byte aligned");
+  rc = ensure_sort_scratch(ctx, 256);
+  if (rc) return rc;
+  hipStream_t st = pick_stream(ctx, stream);
+  uint64_t* d_c = static_cast<uint64_t*>(ctx->d_sort_scratch);
+  IBU_HIP(launch_records_census(ctx->cfg, d_records, n, d_c, st));
+  IBU_HIP(hipMemcpyAsync(out, d_c, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  IBU_HIP(hipStreamSynchronize(st));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_key_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], ibu_key_plan_t* plan) {
+  if (!or_words || !and_words || !plan) return err_arg("NULL argument");
+  compact_plan_init(or_words, and_words, reinterpret_cast<CompactPlan*>(plan));
+  return IBU_OK;
+}
+static int32_t check_plan(const ibu_key_plan_t* plan) {
+  if (!plan) return err_arg("plan is NULL");
+  if (plan->k > 12) return err_arg("more than 12 key bytes vary: these records do not fit 12-byte elements");
+  return IBU_OK;
+}
+extern "C" int32_t ibu_records_compact(ibu_ctx_t* ctx, const ibu_key_plan_t* plan, const void* d_records, size_t n, void* d_elems,
+                                       void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if ((rc = check_plan(plan)) != 0) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || !aligned8(d_records)) return err_arg("d_records must be non-NULL and 8-byte aligned");
+  if (!d_elems || (reinterpret_cast<uintptr_t>(d_elems) & 3u)) return err_arg("d_elems must be non-NULL and 4-byte aligned");
+  IBU_HIP(launch_compact(ctx->cfg, *reinterpret_cast<const CompactPlan*>(plan), d_records, n, d_elems, pick_stream(ctx, stream)));
+  return IBU_OK;
+}
+extern "C" int32_t ibu_records_expand(ibu_ctx_t* ctx, const ibu_key_plan_t* plan, const void* d_elems, size_t n, void* d_records,
+                                      void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if ((rc = check_plan(plan)) != 0) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_records || !aligned8(d_records)) return err_arg("d_records must be non-NULL and 8-byte aligned");
+  if (!d_elems || (reinterpret_cast<uintptr_t>(d_elems) & 3u)) return err_arg("d_elems must be non-NULL and 4-byte aligned");
+  IBU_HIP(launch_expand(ctx->cfg, *reinterpret_cast<const CompactPlan*>(plan), d_elems, n, d_records, pick_stream(ctx, stream)));
   return IBU_OK;
 }
 // BarcodeAnalyzer (parallel.rs:72-98) on sorted device records.

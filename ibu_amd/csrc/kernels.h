@@ -64,6 +64,18 @@ size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
 int sort_num_variants();
 int sort_num_compact_variants();
 hipError_t launch_lower_bound(const void* recs, size_t n, const void* keys, size_t k, uint64_t* pos, hipStream_t st);
+// compacted keys (sort.hip): the varying bytes of a set of records as 12-byte elements.  Layout = ibu_key_plan_t (ibu_hip.h).
+struct CompactPlan {
+  uint32_t csel[3][3];   // compress: element word w = OR over the fields f of perm(f.hi, f.lo, csel[w][f])
+  uint32_t xsel[6][2];   // expand: record dword d (= 2 f + half) = base | perm(e.w1, e.w0, xsel[d][0]) | perm(0, e.w2, xsel[d][1])
+  uint32_t k;            // varying bytes (element bytes k .. 11 are zero); usable while k <= 12
+  uint32_t index_bytes;  // how many of them are index bytes (the least significant element bytes)
+  uint64_t base[3];      // each field with its varying bytes cleared (the AND words)
+};
+void compact_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], CompactPlan* pl);
+hipError_t launch_records_census(const LaunchCfg&, const void* recs, size_t n, uint64_t* d_census /*u64[8]*/, hipStream_t st);
+hipError_t launch_compact(const LaunchCfg&, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st);
+hipError_t launch_expand(const LaunchCfg&, const CompactPlan& pl, const void* elems, size_t n, void* recs, hipStream_t st);
 // per-barcode run-length aggregation of sorted records (sort.hip)
 size_t runs_scratch_bytes(size_t n);
 hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st);

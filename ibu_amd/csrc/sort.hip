@@ -558,13 +558,8 @@ __device__ __forceinline__ u32x3 ld_elem(const Elem* p) {      // 4-byte aligned
 }
 __device__ __forceinline__ void st_elem(Elem* p, u32x3 v) { __builtin_memcpy(p, &v, 12); }
 
-// Byte gathers as v_perm_b32: a selector byte 0..7 picks a byte of the (hi, lo) register pair, 0x0C gives zero.
-struct CompactPlan {
-  u32 csel[3][3];    // compress: element word w = OR over the fields f of perm(f.hi, f.lo, csel[w][f])
-  u32 xsel[6][2];    // expand: record dword d (= 2 f + half) = base | perm(e.w1, e.w0, xsel[d][0]) | perm(0, e.w2, xsel[d][1])
-  u32 k;             // bytes carried (element bytes k .. 11 are zero)
-  u64 base[3];       // each field with its varying bytes cleared (the census' AND words)
-};
+// Byte gathers as v_perm_b32: a selector byte 0..7 picks a byte of the (hi, lo) register pair, 0x0C gives zero (CompactPlan:
+// kernels.h).
 __device__ __forceinline__ u32x3 compress_rec(u64 f0, u64 f1, u64 f2, const CompactPlan& pl) {
   u32 e[3];
 #pragma unroll
@@ -614,8 +609,10 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     const size_t row = (size_t)t * kTileRecs + lane;
     st_elem(out + row, e0);
     st_elem(out + row + kWave, e1);
-    digits[row] = (uint8_t)elem_byte(e0, first_byte);
-    digits[row + kWave] = (uint8_t)elem_byte(e1, first_byte);
+    if (digits) {                                            // uniform (NULL: ibu_records_compact, no pass follows)
+      digits[row] = (uint8_t)elem_byte(e0, first_byte);
+      digits[row + kWave] = (uint8_t)elem_byte(e1, first_byte);
+    }
     if (!more) break;
     t = tn;
     a0 = b0; a1 = b1; a2 = b2;
@@ -627,8 +624,70 @@ extern "C" __global__ void ibu_k_sort_compress_tail(const u64* __restrict__ recs
   if (i >= n) return;
   const u32x3 e = compress_rec(recs[3 * i], recs[3 * i + 1], recs[3 * i + 2], pl);
   st_elem(out + i, e);
-  digits[i] = (uint8_t)elem_byte(e, first_byte);
+  if (digits) digits[i] = (uint8_t)elem_byte(e, first_byte);
 }
+// elements -> records [0, 128 nsub) (recs 16-B aligned): ibu_records_expand (the sort itself expands in its last pass).
+// Two 128-element sub-tiles per iteration (four element loads per lane in flight behind the current ones); lane L owns
+// elements L and L + 64 of a sub-tile.
+static constexpr int kExpandSub = 2;
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_sort_expand(const Elem* __restrict__ in, u32 ntiles /*of 128 * kExpandSub*/, u32 nsub /*128-element sub-tiles in all*/, CompactPlan pl,
+                  uint8_t* __restrict__ recs) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+  uint8_t* tile = lds + wib * kTileBytes;
+  const TileRange tr = tile_range(ntiles, wib);
+  u32 t = tr.t;
+  if (t >= tr.end) return;
+  u32x3 a[2 * kExpandSub];
+  auto issue = [&](u32 tt, u32x3* v) {
+#pragma unroll
+    for (int s = 0; s < kExpandSub; ++s) {
+      u32 sub = tt * kExpandSub + s;
+      sub = sub < nsub ? sub : nsub - 1;                     // the last tile may be half empty: clamped, unconditional
+      v[2 * s] = ld_elem(in + (size_t)sub * kTileRecs + lane);
+      v[2 * s + 1] = ld_elem(in + (size_t)sub * kTileRecs + lane + kWave);
+    }
+  };
+  issue(t, a);
+  for (;;) {
+    const u32 tn = t + tr.stride;
+    const bool more = tn < tr.end;
+    u32x3 b[2 * kExpandSub];
+    issue(more ? tn : t, b);
+#pragma unroll
+    for (int s = 0; s < kExpandSub; ++s) {
+      const u32 sub = t * kExpandSub + s;
+      u64 f[6];
+      expand_elem(a[2 * s], pl, f[0], f[1], f[2]);
+      expand_elem(a[2 * s + 1], pl, f[3], f[4], f[5]);
+      wave_lds_fence();                                      // the previous sub-tile's reads precede these writes
+      u64* r = reinterpret_cast<u64*>(tile + lane * 24);
+      u64* q = reinterpret_cast<u64*>(tile + (lane + kWave) * 24);
+      r[0] = f[0]; r[1] = f[1]; r[2] = f[2];
+      q[0] = f[3]; q[1] = f[4]; q[2] = f[5];
+      wave_lds_fence();
+      if (sub < nsub) {                                      // wave-uniform
+        uint8_t* dst = recs + (size_t)sub * kTileBytes + 16 * lane;
+        st16(dst, *reinterpret_cast<const u32x4*>(tile + 16 * lane));
+        st16(dst + 1024, *reinterpret_cast<const u32x4*>(tile + 1024 + 16 * lane));
+        st16(dst + 2048, *reinterpret_cast<const u32x4*>(tile + 2048 + 16 * lane));
+      }
+    }
+    if (!more) break;
+    t = tn;
+#pragma unroll
+    for (int k = 0; k < 2 * kExpandSub; ++k) a[k] = b[k];
+  }
+}
+extern "C" __global__ void ibu_k_sort_expand_tail(const Elem* __restrict__ in, u64 row0, u64 n, CompactPlan pl, u64* __restrict__ recs) {
+  const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 f0, f1, f2;
+  expand_elem(ld_elem(in + i), pl, f0, f1, f2);
+  recs[3 * i] = f0; recs[3 * i + 1] = f1; recs[3 * i + 2] = f2;
+}
+
 template <int THREADS, int ROUNDS>
 struct CompactShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
@@ -857,6 +916,77 @@ size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) {
   return need;
 }
 
+// The plan of a set of records from its OR / AND words (one rank's census, or the words of all ranks combined): element byte j
+// = the j-th least significant varying byte of the key (index bytes first, barcode bytes last).
+void compact_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], CompactPlan* pl) {
+  for (auto& row : pl->csel) for (uint32_t& v : row) v = 0x0C0C0C0Cu;   // selector 0x0C: a zero byte
+  for (auto& row : pl->xsel) for (uint32_t& v : row) v = 0x0C0C0C0Cu;
+  static const int kFieldLsbFirst[3] = {2, 1, 0};
+  u32 k = 0;
+  pl->index_bytes = 0;
+  for (int fo = 0; fo < 3; ++fo) {
+    const int f = kFieldLsbFirst[fo];
+    const u64 varying = or_words[f] ^ and_words[f];
+    pl->base[f] = and_words[f];
+    for (u32 b = 0; b < 8; ++b)
+      if ((varying >> (8 * b)) & 255u) {
+        if (k < 12) {                                       // element byte k <- byte b of field f, and back
+          uint32_t& cs = pl->csel[k >> 2][f];
+          cs = (cs & ~(255u << (8 * (k & 3)))) | (b << (8 * (k & 3)));
+          uint32_t& xs = pl->xsel[2 * f + (b >> 2)][k < 8 ? 0 : 1];
+          xs = (xs & ~(255u << (8 * (b & 3)))) | ((k < 8 ? k : k - 8) << (8 * (b & 3)));
+        }
+        ++k;
+        pl->base[f] &= ~(255ull << (8 * b));
+      }
+    if (f == 2) pl->index_bytes = k;
+  }
+  pl->k = k;
+}
+hipError_t launch_records_census(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* d_census, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, (u64*)d_census);
+  if (n) launch_census(cfg, recs, n, (u64*)d_census, nullptr, st);
+  return hipGetLastError();
+}
+// records -> 12-byte elements (pl.k <= 12).  16-byte aligned records take the tiled kernel; others one thread per record.
+static void launch_compress(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, u32 first_byte, Elem* out,
+                            uint8_t* digits, hipStream_t st) {
+  const size_t main_rows = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 0 : (n / kTileRecs) * kTileRecs;
+  if (main_rows) {
+    static std::atomic<int> occ;
+    const u32 nt = (u32)(main_rows / kTileRecs);
+    hipLaunchKernelGGL(ibu_k_sort_compress, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress, 0, &occ))),
+                       dim3(kBlock), 0, st, (const uint8_t*)recs, nt, pl, first_byte, out, digits);
+  }
+  if (main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const u64*)recs, (u64)main_rows,
+                       (u64)n, pl, first_byte, out, digits);
+}
+hipError_t launch_compact(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0) return hipSuccess;
+  if (pl.k > 12 || n >= (1ull << 38)) return hipErrorInvalidValue;
+  launch_compress(cfg, pl, recs, n, 0, static_cast<Elem*>(elems), nullptr, st);
+  return hipGetLastError();
+}
+hipError_t launch_expand(const LaunchCfg& cfg, const CompactPlan& pl, const void* elems, size_t n, void* recs, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0) return hipSuccess;
+  if (pl.k > 12 || n >= (1ull << 38)) return hipErrorInvalidValue;
+  const size_t main_rows = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 0 : (n / kTileRecs) * kTileRecs;
+  if (main_rows) {
+    static std::atomic<int> occ;
+    const u32 nsub = (u32)(main_rows / kTileRecs), nt = (nsub + kExpandSub - 1) / kExpandSub;
+    hipLaunchKernelGGL(ibu_k_sort_expand, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_expand, 0, &occ))), dim3(kBlock),
+                       0, st, (const Elem*)elems, nt, nsub, pl, (uint8_t*)recs);
+  }
+  if (main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const Elem*)elems, (u64)main_rows, (u64)n,
+                       pl, (u64*)recs);
+  return hipGetLastError();
+}
+
 // The compact-key path of launch_sort_records (see "COMPACT-KEY passes" above).  first_elem_byte: the first element byte
 // that is sorted (the index bytes below it are carried only).
 static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
@@ -881,17 +1011,7 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     if (e != hipSuccess) return e;
     lds_set[vi].store(true, std::memory_order_relaxed);
   }
-  // compress
-  const size_t main_rows = (n / kTileRecs) * kTileRecs;
-  if (main_rows) {
-    static std::atomic<int> occ;
-    const u32 nt = (u32)(main_rows / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_sort_compress, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress, 0, &occ))),
-                       dim3(kBlock), 0, st, (const uint8_t*)recs, nt, pl, first_elem_byte, src, digits);
-  }
-  if (main_rows < n)
-    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const u64*)recs, (u64)main_rows,
-                       (u64)n, pl, first_elem_byte, src, digits);
+  launch_compress(cfg, pl, recs, n, first_elem_byte, src, digits, st);
   // passes; the last one writes the records themselves
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
@@ -961,28 +1081,9 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   // compact-key path: at most 12 varying bytes (the index bytes are carried even when they are not sorted), n < 2^32,
   // records 16-byte aligned (the tiled compress / expand kernels), tmp at least 4-byte aligned
   if (const CompactVariant* cv = pick_compact(cfg)) {
-    CompactPlan pl{};
-    for (auto& row : pl.csel) for (u32& v : row) v = 0x0C0C0C0Cu;   // selector 0x0C: a zero byte
-    for (auto& row : pl.xsel) for (u32& v : row) v = 0x0C0C0C0Cu;
-    u32 k = 0, first_sorted = 0;
-    for (int fo = 0; fo < 3; ++fo) {
-      const int f = kFieldOrder[fo];
-      const u64 varying = c[f] ^ c[3 + f];
-      pl.base[f] = c[3 + f];
-      for (u32 b = 0; b < 8; ++b)
-        if ((varying >> (8 * b)) & 255u) {
-          if (k < 12) {                                     // element byte k <- byte b of field f, and back
-            u32& cs = pl.csel[k >> 2][f];
-            cs = (cs & ~(255u << (8 * (k & 3)))) | (b << (8 * (k & 3)));
-            u32& xs = pl.xsel[2 * f + (b >> 2)][k < 8 ? 0 : 1];
-            xs = (xs & ~(255u << (8 * (b & 3)))) | ((k < 8 ? k : k - 8) << (8 * (b & 3)));
-          }
-          ++k;
-          pl.base[f] &= ~(255ull << (8 * b));
-        }
-      if (f == 2 && c[6] == 0) first_sorted = k;          // input in index order: the index bytes ride along unsorted
-    }
-    pl.k = k;
+    CompactPlan pl;
+    compact_plan_init(reinterpret_cast<const uint64_t*>(c), reinterpret_cast<const uint64_t*>(c + 3), &pl);
+    const u32 k = pl.k, first_sorted = c[6] == 0 ? pl.index_bytes : 0;   // input in index order: the index bytes ride along unsorted
     const bool ok = npass > 0 && k <= 12 && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
                     (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total;
     if (ok) return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, first_sorted, st);

@@ -66,7 +66,10 @@ def expected_index_sum(n_global):
 #   3. ONE kernel finds the lower bound of every splitter in the sorted shard (ibu_lower_bound_records)
 #   4. send counts -> receive counts with ONE small all_to_all_single of W int64; the only host synchronisation of
 #      the whole sort reads this rank's row and column of the count matrix (all_to_all_single wants Python lists)
-#   5. the records travel in ONE all_to_all_single with uneven splits
+#   5. the records travel in ONE grouped batch of point-to-point messages (_exchange_p2p) — as 12-BYTE ELEMENTS when at most 12 bytes of the
+#      24-byte key vary over ALL ranks (16/12 records with indices below 2^32: 11): every rank's OR / AND words ride the
+#      sample gather, every rank derives the same plan (ibu_key_plan_init), compacts its sorted shard (ibu_records_compact),
+#      ships half the bytes over the per-link-bound xGMI mesh and expands what it received (ibu_records_expand)
 #   6. each rank sorts what it received (W sorted runs) — rank r now holds the r-th key range, globally ordered
 #
 # No pickled objects, no per-record host probes (round 1 did ~(W-1) log2 n `.cpu()` round trips here).  Everything a
@@ -77,6 +80,7 @@ def expected_index_sum(n_global):
 # on CPU under gloo with a numpy stand-in (tests/test_sharding_gloo.py); DeviceSortOps is the product implementation.
 # ---------------------------------------------------------------------------------------------------------------
 _REC = 24
+_ELEM = 12   # a record's varying key bytes (ibu_records_compact)
 
 
 def _rec_key(b):
@@ -92,7 +96,40 @@ class DeviceSortOps:
 
     def _stream(self, like):
         import torch
-        return torch.cuda.current_stream(like.device).cuda_stream
+        h = torch.cuda.current_stream(like.device).cuda_stream
+        # the C ABI reads a NULL stream as "the context's own stream" — a non-blocking stream that torch's (and RCCL's)
+        # work on the legacy default stream is NOT ordered with.  distributed_sort runs inside scope(), which never
+        # leaves the default stream current.
+        assert h != 0, "DeviceSortOps needs a non-default torch stream to be current (use ops.scope(buf))"
+        return h
+
+    def scope(self, like):
+        """Context manager: makes a real (non-default) torch stream current for the duration, ordered behind the caller's
+        current stream on entry and in front of it on exit, so that every kernel of this library, every torch op and
+        every collective of the sort is issued to ONE stream.  (With the legacy default stream current the handle is 0,
+        which the C ABI takes for the context's own stream: kernels and collectives would race.)"""
+        import contextlib
+
+        import torch
+
+        @contextlib.contextmanager
+        def _scope():
+            cur = torch.cuda.current_stream(like.device)
+            if cur.cuda_stream != 0:
+                yield
+                return
+            side = self._side = getattr(self, "_side", None) or torch.cuda.Stream(device=like.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                yield
+            cur.wait_stream(side)
+        return _scope()
+
+    def hand_over(self, t, like):
+        """A tensor produced inside scope() and used by the caller afterwards: tell the caching allocator."""
+        import torch
+        t.record_stream(torch.cuda.current_stream(like.device))
+        return t
 
     def empty(self, nbytes, like):
         import torch
@@ -120,6 +157,28 @@ class DeviceSortOps:
     def fetch(self, buf, i):  # one record as 24 bytes (tools / tests only)
         return bytes(buf[i * _REC:(i + 1) * _REC].cpu().numpy())
 
+    # compacted keys: the exchange format
+    def census_words(self, buf, n):
+        """(OR[3], AND[3]) of this rank's records as Python ints (one small read-back)."""
+        c = self.ctx.census(buf, n, stream=self._stream(buf))
+        return c["or"], c["and"]
+
+    def key_plan(self, or_words, and_words):
+        from . import key_plan
+        return key_plan(or_words, and_words)
+
+    def compact(self, plan, buf, n):
+        elems = self.empty(n * _ELEM, buf)
+        if n:
+            self.ctx.compact(plan, buf, n, elems, stream=self._stream(buf))
+        return elems
+
+    def expand(self, plan, elems, n):
+        out = self.empty(n * _REC, elems)
+        if n:
+            self.ctx.expand(plan, elems, n, out, stream=self._stream(elems))
+        return out
+
 
 def _collective(t, group):
     """The tensor a collective of this process group can take: itself under nccl, a CPU copy under gloo (rehearsal)."""
@@ -127,11 +186,45 @@ def _collective(t, group):
     return t.cpu() if dist.get_backend(group) == "gloo" and t.device.type != "cpu" else t
 
 
-def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None, force=False):
+_P2P_CHUNK = 1 << 28   # bytes per message of the exchange
+
+
+def _exchange_p2p(landed, payload, in_splits, out_splits, rank, world, group, chunk=None):
+    """The bulk exchange of the sort over RCCL: grouped point-to-point messages of at most `chunk` bytes, the rank's own
+    part as a device copy.  Not ONE all_to_all_single, because that call returned wrong bytes for large messages on this
+    stack (ROCm 7.0 RCCL 2.26.6 under torch 2.10: a one-rank self exchange of 1.2e9 bytes or more came back different
+    from its input, 6e8 bytes came back right, on any stream and for any dtype — profiles/README.md, r02_al); xGMI is
+    point-to-point anyway, and a grouped batch keeps all seven links busy at once."""
+    import torch.distributed as dist
+
+    chunk = chunk or _P2P_CHUNK
+    soff, roff = [0], [0]
+    for c in in_splits:
+        soff.append(soff[-1] + c)
+    for c in out_splits:
+        roff.append(roff[-1] + c)
+    if in_splits[rank]:
+        landed[roff[rank]: roff[rank] + out_splits[rank]].copy_(payload[soff[rank]: soff[rank] + in_splits[rank]])
+    p2p = []
+    for j in range(world):
+        if j == rank:
+            continue
+        peer = dist.get_global_rank(group, j) if group is not None else j
+        for o in range(0, in_splits[j], chunk):
+            p2p.append(dist.P2POp(dist.isend, payload[soff[j] + o: soff[j] + min(o + chunk, in_splits[j])], peer, group))
+        for o in range(0, out_splits[j], chunk):
+            p2p.append(dist.P2POp(dist.irecv, landed[roff[j] + o: roff[j] + min(o + chunk, out_splits[j])], peer, group))
+    if p2p:
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
+
+
+def _distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None, force=False, compact=True):
     """Sort the records of all ranks globally.  `buf`: this rank's n records (24 n bytes, uint8 tensor).  Returns
     (out_buf, n_out): rank r holds the r-th contiguous range of the global order; sum of n_out == sum of n.
     `stats` (dict, optional) receives the exchange's byte counts.  `force`: run every collective even in a group of
-    one rank (a one-GPU box rehearsing the RCCL calls of the N > 1 runs)."""
+    one rank (a one-GPU box rehearsing the RCCL calls of the N > 1 runs).  `compact`: ship 12-byte elements instead of
+    24-byte records when the keys of all ranks allow it (False: always records)."""
     import torch
     import torch.distributed as dist
 
@@ -148,15 +241,32 @@ def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None,
     if valid:
         idx = (torch.arange(valid, device=dev, dtype=torch.int64) * n) // valid
         samp[:valid] = ops.rows(buf, n, idx)
-    meta = torch.tensor([valid], dtype=torch.int64, device=dev)
+    use_compact = bool(compact) and hasattr(ops, "census_words")
+    words = [0, 0, 0, -1, -1, -1]                                  # OR / AND identities (as i64)
+    if use_compact:
+        o, a = ops.census_words(buf, n)
+        words = [_to_i64(v) for v in list(o) + list(a)]
+    meta = torch.tensor([valid] + words, dtype=torch.int64, device=dev)
     all_samp = torch.empty((world * s, _REC), dtype=torch.uint8, device=_collective(samp, group).device)
-    all_meta = torch.empty(world, dtype=torch.int64, device=all_samp.device)
+    all_meta = torch.empty(world * 7, dtype=torch.int64, device=all_samp.device)
     dist.all_gather_into_tensor(all_samp, _collective(samp, group), group=group)
     dist.all_gather_into_tensor(all_meta, _collective(meta, group), group=group)
-    all_samp, all_meta = all_samp.to(dev), all_meta.to(dev)
+    all_samp, all_meta = all_samp.to(dev), all_meta.to(dev).view(world, 7)
+    plan = None
+    if use_compact:                                                # every rank combines the same words: the same plan
+        rows = all_meta[:, 1:].tolist()
+        o = [0, 0, 0]
+        a = [_MASK, _MASK, _MASK]
+        for r in rows:
+            for f in range(3):
+                o[f] |= int(r[f]) & _MASK
+                a[f] &= int(r[3 + f]) & _MASK
+        plan = ops.key_plan(o, a)
+        if plan.k > 12:
+            plan = None
     flat = all_samp.reshape(-1).contiguous()
     ops.local_sort(flat, world * s)
-    total_valid = all_meta.sum()                                   # stays on the device
+    total_valid = all_meta[:, 0].sum()                             # stays on the device
     pick = (torch.arange(1, world, device=dev, dtype=torch.int64) * total_valid) // world
     splitters = flat.view(world * s, _REC)[pick]                   # [W-1, 24]; all-ones rows if nobody has a record
     # 3. + 4. bounds and counts
@@ -168,25 +278,42 @@ def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None,
     dist.all_to_all_single(recv_t, _collective(send_t, group), group=group)
     send, recv = [int(v) for v in send_t.tolist()], [int(v) for v in recv_t.tolist()]   # the one host synchronisation
     n_out = sum(recv)
-    out = ops.empty(n_out * _REC, buf)
-    in_splits, out_splits = [c * _REC for c in send], [c * _REC for c in recv]
+    width = _ELEM if plan is not None else _REC                    # bytes per record on the wire
+    payload = ops.compact(plan, buf, n) if plan is not None else buf
+    landed = ops.empty(n_out * width, buf)
+    in_splits, out_splits = [c * width for c in send], [c * width for c in recv]
     # 5. the exchange (timed only when the caller asked for stats: the timing needs two device synchronisations)
     import time
     if stats is not None and dev.type != "cpu":
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     if dist.get_backend(group) == "gloo" and dev.type != "cpu":  # rehearsal transport: stage through the host
-        src, dst = buf[: n * _REC].cpu(), torch.empty(n_out * _REC, dtype=torch.uint8)
+        src, dst = payload[: n * width].cpu(), torch.empty(n_out * width, dtype=torch.uint8)
         dist.all_to_all_single(dst, src, out_splits, in_splits, group=group)
-        out[: n_out * _REC].copy_(dst)
-    else:  # RCCL over xGMI (or gloo on CPU tensors in the logic tests): ordered on the current stream
-        dist.all_to_all_single(out[: n_out * _REC], buf[: n * _REC], out_splits, in_splits, group=group)
+        landed[: n_out * width].copy_(dst)
+    elif dist.get_backend(group) == "gloo":  # CPU tensors in the logic tests
+        dist.all_to_all_single(landed[: n_out * width], payload[: n * width], out_splits, in_splits, group=group)
+    else:  # RCCL over xGMI, ordered on the current stream
+        _exchange_p2p(landed, payload, in_splits, out_splits, rank, world, group)
     if stats is not None:
         if dev.type != "cpu":
             torch.cuda.synchronize(dev)
         stats["exchange_seconds"] = time.perf_counter() - t0
-        stats.update(sent_bytes=(n - send[rank]) * _REC, received_bytes=(n_out - recv[rank]) * _REC, kept_bytes=send[rank] * _REC,
-                     samples_per_rank=s)
+        stats.update(sent_bytes=(n - send[rank]) * width, received_bytes=(n_out - recv[rank]) * width, kept_bytes=send[rank] * width,
+                     samples_per_rank=s, bytes_per_record_on_the_wire=width, varying_key_bytes=(plan.k if plan is not None else None))
+    out = ops.expand(plan, landed, n_out) if plan is not None else landed
     # 6.
     ops.local_sort(out, n_out)
+    return out, n_out
+
+
+def distributed_sort(ops, buf, n, samples_per_rank=None, group=None, stats=None, force=False, compact=True):
+    """Sort the records of all ranks globally (see _distributed_sort).  Device ops run inside ops.scope(): one stream
+    for the library's kernels, torch's ops and the collectives, whatever stream the caller had current."""
+    if not hasattr(ops, "scope"):
+        return _distributed_sort(ops, buf, n, samples_per_rank, group, stats, force, compact)
+    with ops.scope(buf):
+        out, n_out = _distributed_sort(ops, buf, n, samples_per_rank, group, stats, force, compact)
+    if out is not buf:
+        ops.hand_over(out, buf)
     return out, n_out

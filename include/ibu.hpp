@@ -25,6 +25,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <array>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -384,6 +385,11 @@ class Context {
   // index of the first record that differs, n if the slices are equal (Record: PartialEq, record.rs:58)
   size_t first_mismatch(const void* d_a, const void* d_b, size_t n, void* st = nullptr) { uint64_t f = 0; check(ibu_records_first_mismatch(c_, d_a, d_b, n, &f, st)); return (size_t)f; }
   bool is_sorted(const void* d_recs, size_t n, void* st = nullptr) { int32_t s = 0; check(ibu_is_sorted(c_, d_recs, n, st, &s)); return s != 0; }
+  // compacted keys (the exchange format of the multi-GPU sort): OR / AND census, plan, records <-> 12-byte elements
+  std::array<uint64_t, 8> census(const void* d_recs, size_t n, void* st = nullptr) { std::array<uint64_t, 8> c{}; check(ibu_records_census(c_, d_recs, n, c.data(), st)); return c; }
+  static ibu_key_plan_t key_plan(const uint64_t or_words[3], const uint64_t and_words[3]) { ibu_key_plan_t p; check(ibu_key_plan_init(or_words, and_words, &p)); return p; }
+  void compact(const ibu_key_plan_t& plan, const void* d_recs, size_t n, void* d_elems, void* st = nullptr) { check(ibu_records_compact(c_, &plan, d_recs, n, d_elems, st)); }
+  void expand(const ibu_key_plan_t& plan, const void* d_elems, size_t n, void* d_recs, void* st = nullptr) { check(ibu_records_expand(c_, &plan, d_elems, n, d_recs, st)); }
   // BarcodeAnalyzer (parallel.rs:72-98) on sorted device records: (barcode, records, distinct UMIs), ascending barcode
   inline std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> barcode_counts(const void* d_sorted, size_t n);
   // load_to_vec, device form -> (header, device pointer owned by the caller: release with free(), n)

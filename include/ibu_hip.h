@@ -348,6 +348,33 @@ int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t 
  * multi-GPU sample sort (ibu_amd/sharding.py): one launch for all splitters instead of a host binary search. */
 int32_t ibu_lower_bound_records(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, const void* d_keys, size_t k,
                                 uint64_t* d_pos, void* stream);
+/* ---- compacted keys: the bytes of a set of records that VARY, as 12-byte elements --------------------------------------
+ * A record is 24 bytes, but of 16-base barcodes, 12-base UMIs and indices below 2^32 only 4 + 3 + 4 bytes differ between
+ * records.  ibu_sort_records sorts such inputs as 12-byte elements internally; these entry points expose the same
+ * transformation so that the multi-GPU sort (ibu_amd/sharding.py) ships elements instead of records through its one
+ * all-to-all — half the bytes over the point-to-point xGMI links.  There is no reference counterpart (the crate has no sort
+ * and no exchange); the records that come out are the records that went in (record.rs:58-66), byte for byte.
+ *
+ * ibu_records_census: out[0..2] = OR of barcode / umi / index over the n records, out[3..5] = AND (n = 0: 0 and ~0, the
+ *   identities, so words of several shards combine with | and &), out[6] != 0: some index is smaller than its
+ *   predecessor's, out[7] != 0: some record is smaller than its predecessor (not sorted).  Synchronises `stream`.
+ * ibu_key_plan_init: the plan for records whose OR / AND words are given (one shard's, or all shards' combined — every
+ *   rank must use the same plan).  plan->k = number of varying bytes; compact / expand need k <= 12
+ *   (IBU_ERR_INVALID_ARG otherwise).  Element byte j = the j-th least significant varying byte of the key (index bytes
+ *   first, barcode bytes last): elements compared as 96-bit little-endian integers order like the records.
+ * ibu_records_compact: n records -> n elements (12 n bytes at d_elems, 4-byte aligned).  ibu_records_expand: the inverse.
+ *   Asynchronous on `stream`; 16-byte aligned record arrays take the tiled kernels. */
+typedef struct ibu_key_plan {
+  uint32_t csel[3][3]; /* byte-gather selectors, records -> elements (v_perm_b32) */
+  uint32_t xsel[6][2]; /* elements -> records */
+  uint32_t k;          /* varying bytes */
+  uint32_t index_bytes; /* how many of them belong to the index (the least significant element bytes) */
+  uint64_t base[3];    /* the constant bytes of barcode / umi / index */
+} ibu_key_plan_t;
+int32_t ibu_records_census(ibu_ctx_t* ctx, const void* d_records, size_t n, uint64_t out[8], void* stream);
+int32_t ibu_key_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], ibu_key_plan_t* plan);
+int32_t ibu_records_compact(ibu_ctx_t* ctx, const ibu_key_plan_t* plan, const void* d_records, size_t n, void* d_elems, void* stream);
+int32_t ibu_records_expand(ibu_ctx_t* ctx, const ibu_key_plan_t* plan, const void* d_elems, size_t n, void* d_records, void* stream);
 /* `a == b` on two device-resident slices of n records each (Record derives PartialEq / Eq, record.rs:58): *first = the
  * index of the first record that differs, n if none does.  8-byte aligned inputs (16-byte: the fast path).  Synchronises. */
 int32_t ibu_records_first_mismatch(ibu_ctx_t* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first, void* stream);

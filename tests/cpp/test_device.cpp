@@ -94,6 +94,24 @@ TEST(sort_matches_oracle_and_aggregation_follows) {
     for (size_t i = 0; i < k; ++i) CHECK(got[i] == std::make_tuple(b[i], c[i], u[i]));
   }
 }
+TEST(compacted_keys_round_trip) {
+  // census -> plan -> 12-byte elements -> records: the exchange format of the multi-GPU sort (ibu_records_compact / _expand)
+  const size_t n = 100003;
+  auto recs = oracle_records(0x1B00005, 0, n, 16, 12);
+  DeviceBuffer d(ctx(), n * 24), e(ctx(), n * 12), back(ctx(), n * 24);
+  d.upload(recs);
+  auto c = ctx().census(d.ptr(), n);
+  uint64_t o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
+  for (const Record& r : recs) { o[0] |= r.barcode; o[1] |= r.umi; o[2] |= r.index; a[0] &= r.barcode; a[1] &= r.umi; a[2] &= r.index; }
+  for (int f = 0; f < 3; ++f) { CHECK_EQ(c[f], o[f]); CHECK_EQ(c[3 + f], a[f]); }
+  CHECK_EQ(c[6], 0ull);   // the generator's index column increases
+  CHECK(c[7] != 0);       // but the records are not sorted
+  const ibu_key_plan_t plan = device::Context::key_plan(c.data(), c.data() + 3);
+  CHECK_EQ(plan.k, 4u + 3u + 3u);   // 32-bit barcodes, 24-bit UMIs, indices below 2^24
+  ctx().compact(plan, d.ptr(), n, e.ptr());
+  ctx().expand(plan, e.ptr(), n, back.ptr());
+  CHECK_EQ(ctx().first_mismatch(d.ptr(), back.ptr(), n), n);
+}
 TEST(file_streams_to_and_from_the_device) {
   const size_t n = 300001;
   const Header h(16, 12);

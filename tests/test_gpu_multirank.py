@@ -63,13 +63,18 @@ def test_sharded_file_two_ranks(tmp_path, proc, oracle):
         assert out["sums"] == want["sum"] and out["xors"] == want["xor"]
 
 
-def test_distributed_sort_two_ranks():
-    """Sample sort across two ranks (device radix sorts, one all-to-all of the records — staged through the host
-    under gloo here, RCCL in production): every rank sorted, rank ranges ordered, multiset preserved."""
-    out = _torchrun(2, "tools/sharded_sort.py", "--records", "3000001", "--backend", "gloo", "--share-gpu")
+@pytest.mark.parametrize("compact", [True, False])
+def test_distributed_sort_two_ranks(compact):
+    """Sample sort across two ranks (device radix sorts, one all-to-all — staged through the host under gloo here, RCCL in
+    production): every rank sorted, rank ranges ordered, multiset preserved.  16/12 records vary in 10 bytes over both
+    ranks, so the exchange ships 12-byte elements (compact) — half the bytes of the 24-byte records (--no-compact)."""
+    extra = [] if compact else ["--no-compact"]
+    out = _torchrun(2, "tools/sharded_sort.py", "--records", "3000001", "--backend", "gloo", "--share-gpu", *extra)
     assert out["every_rank_sorted"] and out["rank_ranges_ordered"] and out["multiset_preserved"]
     assert out["count"] == 6_000_002 and sum(out["records_per_rank_out"]) == 6_000_002
     assert max(out["records_per_rank_out"]) < 0.6 * 6_000_002  # the splitter balanced the two ranges
+    width = 12 if compact else 24
+    assert out["bytes_per_record_on_the_wire"] == width and (out["varying_key_bytes"] == 10) == compact   # 4 barcode + 3 UMI + 3 index bytes (6e6 records)
     # about half of every shard travels; the transport says what carried it (gloo + host staging here, RCCL in production)
-    assert all(0.3 * 3_000_001 * 24 < b < 0.7 * 3_000_001 * 24 for b in out["exchange_sent_bytes_per_rank"])
+    assert all(0.3 * 3_000_001 * width < b < 0.7 * 3_000_001 * width for b in out["exchange_sent_bytes_per_rank"])
     assert out["backend"] == "gloo" and out["exchange_seconds_max"] > 0

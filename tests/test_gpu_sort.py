@@ -371,3 +371,59 @@ def test_context_close_frees_the_buffers_it_still_owns(ia):
         b.free()
     finally:
         c2.close()
+
+
+# ---- compacted keys: census / plan / records <-> 12-byte elements (the exchange format of the multi-GPU sort) -------
+@pytest.mark.parametrize("n", [0, 1, 2, 127, 128, 129, 255, 256, 257, 5000, 300_007])
+@pytest.mark.parametrize("lens", [(16, 12), (8, 8), (1, 1), (20, 3)])
+@pytest.mark.parametrize("offset", [0, 24])
+def test_compact_and_expand_match_the_numpy_statement(ctx, oracle, ia, n, lens, offset):
+    """ibu_records_census / ibu_key_plan_init / ibu_records_compact / ibu_records_expand against tests/keyplan_np.py;
+    offset 24: the records start at an odd record of a larger buffer (8-byte aligned: one thread per record)."""
+    from tests import keyplan_np as kp
+    recs = _shuffled(oracle, n + 1, *lens)[: n + 1]
+    recs["index"] = np.random.default_rng(n).integers(0, 2**31, n + 1, dtype=np.uint64)
+    d = ctx.upload(recs)
+    part = recs[offset // 24: offset // 24 + n]
+    c = ctx.census(d.ptr + offset, n)
+    assert (c["or"], c["and"]) == kp.census_words(part)
+    if n > 1:
+        assert c["order_drops"] == (oracle.sort_records(part).tobytes() != part.tobytes())
+        assert c["index_drops"] == bool((np.diff(part["index"].astype(np.int64)) < 0).any())
+    plan, want = ia.key_plan(c["or"], c["and"]), kp.Plan(c["or"], c["and"])
+    assert plan.k == want.k and plan.index_bytes == want.index_bytes and [int(b) for b in plan.base] == want.base
+    if n == 0 or plan.k > 12:
+        return
+    e = ctx.alloc(12 * n + 16)
+    ctx.compact(plan, d.ptr + offset, n, e)
+    ctx.synchronize()
+    elems = e.download(count=12 * n).reshape(n, 12)
+    assert elems.tobytes() == kp.compact(want, part).tobytes()
+    # elements compared as 96-bit little-endian integers order like the records
+    as_int = [int.from_bytes(bytes(r), "little") for r in elems[: min(n, 2000)]]
+    keys = [(int(r["barcode"]), int(r["umi"]), int(r["index"])) for r in part[: min(n, 2000)]]
+    assert sorted(range(len(keys)), key=keys.__getitem__) == sorted(range(len(as_int)), key=lambda i: (as_int[i], i)) or len(set(keys)) < len(keys)
+    back = ctx.alloc(24 * n + 48)
+    ctx.expand(plan, e, n, back.ptr + offset)
+    ctx.synchronize()
+    assert ia.DeviceBuffer.wrap(ctx, back.ptr + offset, 24 * n).download().tobytes() == part.tobytes()
+    # elements at a 4-byte boundary (the second element buffer inside tmp starts at 12 n)
+    e4 = ctx.alloc(12 * n + 16)
+    ctx.compact(plan, d.ptr + offset, n, e4.ptr + 4)
+    ctx.expand(plan, e4.ptr + 4, n, back.ptr + offset)
+    ctx.synchronize()
+    assert ia.DeviceBuffer.wrap(ctx, back.ptr + offset, 24 * n).download().tobytes() == part.tobytes()
+
+
+def test_compact_rejects_more_than_12_varying_bytes(ctx, oracle, ia):
+    recs = _shuffled(oracle, 1000, 32, 32)
+    d = ctx.upload(recs)
+    c = ctx.census(d, 1000)
+    plan = ia.key_plan(c["or"], c["and"])
+    assert plan.k > 12
+    e = ctx.alloc(12 * 1000)
+    with pytest.raises(ia.IbuError) as err:
+        ctx.compact(plan, d, 1000, e)
+    assert err.value.kind == "InvalidArg"
+    with pytest.raises(ia.IbuError):
+        ctx.expand(plan, e, 1000, d)

@@ -101,8 +101,32 @@ class _NumpySortOps:
     def fetch(self, buf, i):
         return bytes(buf[i * 24:(i + 1) * 24].numpy())
 
+    # compacted keys (the exchange format): the numpy statement of tests/keyplan_np.py
+    def census_words(self, buf, n):
+        from tests import keyplan_np
+        return keyplan_np.census_words(self._recs(buf, n))
 
-def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir, force=False):
+    def key_plan(self, or_words, and_words):
+        from tests import keyplan_np
+        self.plans = getattr(self, "plans", []) + [keyplan_np.Plan(or_words, and_words)]
+        return self.plans[-1]
+
+    def compact(self, plan, buf, n):
+        import torch
+        from tests import keyplan_np
+        e = keyplan_np.compact(plan, self._recs(buf, n)).reshape(-1)
+        return torch.from_numpy(e.copy()) if n else torch.empty(24, dtype=torch.uint8)
+
+    def expand(self, plan, elems, n):
+        import torch
+        from tests import keyplan_np
+        if n == 0:
+            return torch.empty(24, dtype=torch.uint8)
+        r = keyplan_np.expand(plan, elems[: n * 12].numpy().reshape(n, 12))
+        return torch.from_numpy(np.frombuffer(r.tobytes(), dtype=np.uint8).copy())
+
+
+def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir, force=False, compact=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -119,7 +143,12 @@ def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir, force=Fal
             recs["barcode"] %= 3
             recs["umi"] %= 2
         buf = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).copy()) if counts[rank] else torch.empty(24, dtype=torch.uint8)
-        out, n_out = sharding.distributed_sort(_NumpySortOps(orc), buf, counts[rank], samples_per_rank=16, force=force)
+        stats = {}
+        out, n_out = sharding.distributed_sort(_NumpySortOps(orc), buf, counts[rank], samples_per_rank=16, force=force, stats=stats,
+                                               compact=compact)
+        if rank == 0:
+            with open(os.path.join(out_dir, "wire.txt"), "w") as f:
+                f.write(str(stats["bytes_per_record_on_the_wire"]))
         tot = sharding.global_totals(orc.reduce_records(recs), force=force)
         assert tot["count"] >= counts[rank]
         np.save(os.path.join(out_dir, f"s{rank}.npy"), out[: n_out * 24].numpy())
@@ -129,11 +158,15 @@ def _sort_worker(rank, world, port, counts, seed, lens, skew, out_dir, force=Fal
 
 @pytest.mark.parametrize("counts,lens,skew", [([5000, 7003], (16, 12), False), ([4000, 0, 6001], (16, 12), False),
                                               ([3000, 3000], (4, 4), True), ([1, 2, 3], (32, 32), False), ([0, 0], (16, 12), False)])
-def test_distributed_sort_control_flow(tmp_path, oracle, counts, lens, skew):
+@pytest.mark.parametrize("compact", [True, False])
+def test_distributed_sort_control_flow(tmp_path, oracle, counts, lens, skew, compact):
     import torch.multiprocessing as mp
 
     world, seed = len(counts), 0x1B00006
-    mp.spawn(_sort_worker, args=(world, _free_port(), counts, seed, lens, skew, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_sort_worker, args=(world, _free_port(), counts, seed, lens, skew, str(tmp_path), False, compact), nprocs=world, join=True)
+    # 12-byte elements on the wire whenever the keys of ALL ranks vary in at most 12 bytes ((32,32): 8 + 8 + index bytes > 12)
+    # (no record anywhere: the OR / AND identities make every byte look varying, and there is nothing to ship)
+    assert int(open(tmp_path / "wire.txt").read()) == (12 if compact and lens != (32, 32) and sum(counts) else 24)
     allrecs = oracle.generate(seed, 0, sum(counts), *lens)
     if skew:
         allrecs["barcode"] %= 3
@@ -155,3 +188,45 @@ def test_group_of_one_rank_runs_every_collective_when_forced(tmp_path, oracle):
     mp.spawn(_sort_worker, args=(1, _free_port(), counts, seed, lens, False, str(tmp_path), True), nprocs=1, join=True)
     want = oracle.sort_records(oracle.generate(seed, 0, counts[0], *lens)).tobytes()
     assert np.load(tmp_path / "s0.npy").tobytes() == want
+
+
+# ---- the bulk exchange as grouped point-to-point messages (what the RCCL path uses instead of one all_to_all_single) --
+def _p2p_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from ibu_amd import sharding
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        # rank r sends (r + 1) * 700 * (j + 1) bytes to rank j (0 bytes from rank 1 to rank 2), byte k of that message = (r, j, k)
+        def size(r, j):
+            return 0 if (r, j) == (1, 2) else (r + 1) * 700 * (j + 1)
+
+        def msg(r, j):
+            k = np.arange(size(r, j))
+            return ((k * 7 + r * 31 + j * 101) % 251).astype(np.uint8)
+
+        in_splits = [size(rank, j) for j in range(world)]
+        out_splits = [size(j, rank) for j in range(world)]
+        payload = torch.from_numpy(np.concatenate([msg(rank, j) for j in range(world)]))
+        landed = torch.zeros(sum(out_splits), dtype=torch.uint8)
+        sharding._exchange_p2p(landed, payload, in_splits, out_splits, rank, world, None, chunk=1000)   # several chunks per pair
+        want = np.concatenate([msg(j, rank) for j in range(world)])
+        assert landed.numpy().tobytes() == want.tobytes()
+        ref = torch.zeros_like(landed)
+        dist.all_to_all_single(ref, payload, out_splits, in_splits)
+        assert torch.equal(ref, landed)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("1")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_as_point_to_point_chunks_equals_all_to_all(tmp_path):
+    import torch.multiprocessing as mp
+
+    world = 3
+    mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="one rank, but every collective runs (RCCL rehearsal on a one-GPU box)")
     ap.add_argument("--lens", default="16,12")
+    ap.add_argument("--no-compact", action="store_true", help="ship 24-byte records even when 12-byte elements would do")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -56,7 +57,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     stats = {}
-    out, n_out = sharding.distributed_sort(sharding.DeviceSortOps(ctx), buf, n, stats=stats, force=a.force_dist)
+    out, n_out = sharding.distributed_sort(sharding.DeviceSortOps(ctx), buf, n, stats=stats, force=a.force_dist, compact=not a.no_compact)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -76,6 +77,7 @@ def main():
         print(json.dumps({"ranks": world, "records_per_rank_in": n, "records_per_rank_out": [e[1] for e in edges],
                           "seconds": round(dt, 4), "M_records_per_s": round(n * world / dt / 1e6, 1),
                           "backend": a.backend, "transport": ("RCCL" if a.backend == "nccl" else "gloo, staged through the host (rehearsal)"),
+                          "bytes_per_record_on_the_wire": stats.get("bytes_per_record_on_the_wire"), "varying_key_bytes": stats.get("varying_key_bytes"),
                           "exchange_sent_bytes_per_rank": [e[3] for e in edges], "exchange_seconds_max": round(max(e[4] for e in edges), 4),
                           "exchange_GBps_per_rank": round(max(e[3] for e in edges) / max(max(e[4] for e in edges), 1e-9) / 1e9, 2),
                           "every_rank_sorted": all(e[0] for e in edges), "rank_ranges_ordered": ordered,

@@ -46,6 +46,7 @@ def parse():
                         "weak: --records per GPU")
     p.add_argument("--no-wide-leg", action="store_true", help="skip the (32,32) leg (configs[2]) on one GPU")
     p.add_argument("--wide-records", type=float, default=0, help="records of the (32,32) leg (0 = same as --records)")
+    p.add_argument("--no-sort-leg", action="store_true", help="skip the sort + per-barcode aggregation leg on one GPU")
     p.add_argument("--bc-len", type=int, default=16)
     p.add_argument("--umi-len", type=int, default=12)
     p.add_argument("--seed", type=lambda s: int(s, 0), default=0x1B00003)
@@ -219,6 +220,64 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
                 encode_ms_by_set_of_output=per_array["back"], kept_probe_ms_decode_encode=[round(v, 3) for v in final],
                 first_placement_decode_frac=round(bytes_per_launch / (probes[0][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
     return leg, info
+
+
+def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3):
+    """Device sort by (barcode, umi, index) (record.rs:58 ordering, header.rs:111-113 sorted flag) of the headline's
+    synthetic records, in read order (index increasing: the index passes are skipped) and with the index column replaced
+    by random 30-bit values, then the per-barcode aggregation (parallel.rs:72-98) of the sorted records.  Checked, not
+    trusted: sorted, and count / wrapping sums / XORs unchanged."""
+    import statistics
+    import ctypes as C
+
+    from ibu_amd import _check, _dptr, lib
+
+    d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)
+    cols = [ctx.alloc(8 * n) for _ in range(4)]
+    out = {"workload": f"{n:.3g} records bc_len={bc_len} umi_len={umi_len}: ibu_sort_records on resident records, median of {rounds}"}
+    try:
+        for name in ("read_order", "random_index"):
+            ts = []
+            for _ in range(rounds + 1):
+                ctx.generate(seed, 0, n, bc_len, umi_len, d)
+                if name == "random_index":     # another stream's 15-base barcode column as the index column
+                    ctx.deserialize(d, n, cols[0], cols[1], cols[2])
+                    ctx.generate(seed + 1, 0, n, 15, 1, t)
+                    ctx.deserialize(t, n, cols[3], cols[2], cols[2])
+                    ctx.serialize(cols[0], cols[1], cols[3], n, d)
+                before = ctx.reduce(d, n)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                ctx.sort_records(d, t, n)
+                ctx.synchronize()
+                ts.append(time.perf_counter() - t0)
+            sec = statistics.median(ts[1:])
+            ok = bool(ctx.is_sorted(d, n)) and ctx.reduce(d, n) == before
+            out[name] = {"seconds": sec, "records_per_s": n / sec, "sorted_and_multiset_preserved": ok}
+            if not ok:
+                raise SystemExit("device sort: result not sorted or records changed")
+        # aggregation of the sorted records: size query (count pass + scan), then the whole call into device arrays
+        nb, npairs = C.c_size_t(), C.c_size_t()
+        _check(lib.ibu_barcode_counts(ctx._c, _dptr(d), n, None, None, None, 0, C.byref(nb), C.byref(npairs), None))
+        u = max(nb.value, 1)
+        outs = [ctx.alloc(8 * u) for _ in range(3)]
+        ts = []
+        for _ in range(rounds + 1):
+            t0 = time.perf_counter()
+            _check(lib.ibu_barcode_counts(ctx._c, _dptr(d), n, _dptr(outs[0]), _dptr(outs[1]), _dptr(outs[2]), u, C.byref(nb),
+                                          C.byref(npairs), None))
+            ctx.synchronize()
+            ts.append(time.perf_counter() - t0)
+        import numpy as np
+        counts_sum = int(outs[1].download(np.uint64)[: nb.value].sum()) if nb.value <= 1 << 27 else None
+        out["barcode_counts"] = {"seconds": statistics.median(ts[1:]), "distinct_barcodes": nb.value, "barcode_umi_pairs": npairs.value,
+                                 "counts_add_up": (counts_sum == n) if counts_sum is not None else None}
+        for b in outs:
+            b.free()
+    finally:
+        for b in [d, t] + cols:
+            b.free()
+    return out
 
 
 class Leg:
@@ -428,6 +487,17 @@ def main():
         }
         wl.free()
 
+    sort_leg = None
+    if world == 1 and not args.no_sort_leg:
+        # SURVEY 8f-2 / 8f-3 on the same box: device sort by (barcode, umi, index) of the headline's records and the per-barcode
+        # aggregation of the result — outside the headline's timed region, never part of `value`
+        leg.free()
+        torch.cuda.empty_cache()
+        try:
+            sort_leg = sort_and_aggregate(ctx, n, bc_len, umi_len, args.seed)
+        except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
+            sort_leg = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         bpr = 24 + bc_len + umi_len + 8
         # rank 0's own launch: its records x algorithmic bytes / its measured decode time
@@ -476,6 +546,8 @@ def main():
         }
         if wide:
             out["config2_32_32"] = wide
+        if sort_leg:
+            out["sort_leg"] = sort_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -218,7 +218,10 @@ ibu_k_sort_scan_rows(u32* __restrict__ table, u32 nchunks, u32* __restrict__ row
 // a dedicated scan workgroup handing prefixes out, and three tiles per CU did not change that.  Precomputed positions
 // cost 2.2 B/record/pass of extra traffic and no waiting at all.
 // =====================================================================================================
-static constexpr int kTilesPerBlock = 1024;                   // tiles per scan block
+#ifndef IBU_TILES_PER_BLOCK
+#define IBU_TILES_PER_BLOCK 256   // 1024: the position walk of a block (ibu_k_sort_tilepos) took 0.30 ms per pass at 1e9 records; 256: 3 ms less per sort
+#endif
+static constexpr int kTilesPerBlock = IBU_TILES_PER_BLOCK;                   // tiles per scan block
 
 // ---- tile counts from the records (first pass): chunk-field trick of ibu_k_reduce, no LDS staging ------------------
 // One workgroup per tile.  The wave stride (3072 B = 384 u64) is a multiple of 3, so the u64 in slot (k, h) of a lane's
@@ -1001,15 +1004,14 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
   Elem* src = static_cast<Elem*>(tmp);
   Elem* dst = reinterpret_cast<Elem*>(static_cast<uint8_t*>(tmp) + 12 * n);
 
-  const int vi = (int)(&cv - kCompact);
-  static std::atomic<bool> lds_set[kNumCompact];
+  // every call, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive
+  // several GPUs through several contexts (a few microseconds against a sort of milliseconds)
   hipError_t e;
-  if (cv.lds > 48 * 1024 && !lds_set[vi].load(std::memory_order_relaxed)) {
+  if (cv.lds > 48 * 1024) {
     e = hipFuncSetAttribute(cv.scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(cv.scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
-    lds_set[vi].store(true, std::memory_order_relaxed);
   }
   launch_compress(cfg, pl, recs, n, first_elem_byte, src, digits, st);
   // passes; the last one writes the records themselves
@@ -1089,13 +1091,10 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     if (ok) return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, first_sorted, st);
   }
 
-  static std::atomic<bool> lds_set[kNumSweep][2];
-  const int vi = (int)(&sv - kSweep);
   const void* scatter = L.idx64 ? sv.scatter64 : sv.scatter32;
-  if (sv.lds > 48 * 1024 && !lds_set[vi][L.idx64].load(std::memory_order_relaxed)) {
+  if (sv.lds > 48 * 1024) {   // per call: the attribute is per device (see launch_compact_passes)
     e = hipFuncSetAttribute(scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv.lds);
     if (e != hipSuccess) return e;
-    lds_set[vi][L.idx64].store(true, std::memory_order_relaxed);
   }
 
   u64* src = static_cast<u64*>(recs);

@@ -201,6 +201,9 @@ extern "C" {
                               n: *mut usize, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_writer_write_batch_device(w: *mut ibu_writer_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
                                          d_records: *const c_void, n: usize, stats: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_writer_write_batch_device_on(w: *mut ibu_writer_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
+                                            d_records: *const c_void, n: usize, producer_stream: *mut c_void,
+                                            stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_mmap_process_device(m: *const ibu_mmap_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
                                    proc_: i32, shard: usize, n_shards: usize, sink: *mut c_void,
                                    stats: *mut ibu_stream_stats_t) -> i32;

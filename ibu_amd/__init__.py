@@ -216,10 +216,11 @@ class Writer:
         for r in records:
             self.write_record(r)
 
-    def write_batch_device(self, ctx, d_records, n, ring=None):
-        """Device-resident AoS records -> pinned ring -> this writer (write_batch rules)."""
+    def write_batch_device(self, ctx, d_records, n, ring=None, stream=None):
+        """Device-resident AoS records -> pinned ring -> this writer (write_batch rules).  `stream`: the stream the
+        records were produced on (None: the context's own)."""
         st = CStreamStats()
-        _check(lib.ibu_writer_write_batch_device(self._w, ctx._c, _ring(ring), _dptr(d_records), n, C.byref(st)))
+        _check(lib.ibu_writer_write_batch_device_on(self._w, ctx._c, _ring(ring), _dptr(d_records), n, stream, C.byref(st)))
         return st
 
     def write_ascii_batch(self, ctx, bc_ascii, umi_ascii, bc_len, umi_len, index=None, first_index=0, ring=None):

@@ -265,6 +265,11 @@ extern "C" int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ib
 // ------------------------------------------------------------------------------------------
 extern "C" int32_t ibu_writer_write_batch_device(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                                  const void* d_records, size_t n, ibu_stream_stats_t* stats) {
+  return ibu_writer_write_batch_device_on(w, ctx, cfg, d_records, n, nullptr, stats);
+}
+extern "C" int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
+                                                    const void* d_records, size_t n, void* producer_stream,
+                                                    ibu_stream_stats_t* stats) {
   if (!w || !ctx || (!d_records && n)) return err_arg("NULL argument");
   IBU_HIP(hipSetDevice(ctx->device));
   const double t0 = now_s();
@@ -275,8 +280,8 @@ extern "C" int32_t ibu_writer_write_batch_device(ibu_writer_t* w, ibu_ctx_t* ctx
   const size_t slot_records = r.slot_bytes / IBU_RECORD_SIZE;
   const size_t nchunks = (n + slot_records - 1) / slot_records;
   const uint8_t* src = static_cast<const uint8_t*>(d_records);
-  // the caller's producer kernels ran on ctx->stream: order the copy stream behind them
-  IBU_HIP(hipEventRecord(r.consumed[0], ctx->stream));
+  // the records were produced on `producer_stream` (NULL: the context's own stream): order the copy stream behind it
+  IBU_HIP(hipEventRecord(r.consumed[0], pick_stream(ctx, producer_stream)));
   IBU_HIP(hipStreamWaitEvent(ctx->copy_stream, r.consumed[0], 0));
   auto issue = [&](size_t c) -> int32_t {
     const uint32_t s = (uint32_t)(c % r.slots);

@@ -174,7 +174,9 @@ class Writer {
     return v;
   }
   // device-resident AoS records -> pinned ring -> this writer, same buffered/direct rule (writer.rs:321-351)
-  inline StreamStats write_batch_device(device::Context& ctx, const void* d_records, size_t n, const RingConfig* ring = nullptr);
+  // producer_stream: the stream the records were produced on (nullptr: the context's own)
+  inline StreamStats write_batch_device(device::Context& ctx, const void* d_records, size_t n, const RingConfig* ring = nullptr,
+                                        void* producer_stream = nullptr);
   // n rows of host ASCII (+ optional index column; nullptr -> first_index + i) -> GPU 2-bit encode -> this writer
   // (README.md:38-47's encode-then-write loop as one batch call).  Throws InvalidBase{first_bad, n_bad}.
   inline StreamStats write_ascii_batch(device::Context& ctx, const uint8_t* bc_ascii, const uint8_t* umi_ascii, const uint64_t* index,
@@ -439,9 +441,9 @@ inline std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> Context::barcode_co
 }
 }  // namespace device
 
-inline StreamStats Writer::write_batch_device(device::Context& ctx, const void* d_records, size_t n, const RingConfig* ring) {
+inline StreamStats Writer::write_batch_device(device::Context& ctx, const void* d_records, size_t n, const RingConfig* ring, void* producer_stream) {
   StreamStats st{};
-  check(ibu_writer_write_batch_device(w_, ctx.raw(), ring, d_records, n, &st));
+  check(ibu_writer_write_batch_device_on(w_, ctx.raw(), ring, d_records, n, producer_stream, &st));
   return st;
 }
 inline StreamStats Writer::write_ascii_batch(device::Context& ctx, const uint8_t* bc_ascii, const uint8_t* umi_ascii, const uint64_t* index,

@@ -410,11 +410,16 @@ int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_conf
 
 /* Device analogue of Writer::write_batch (writer.rs:315-351): n device-resident AoS records
  * are copied back through the ring and appended to the writer (same buffered/direct rules).
- * Stream ordering: the copies are ordered behind ibu_ctx_stream(ctx) ONLY.  Records produced by a kernel entry point
- * that was given another stream must be complete (hipStreamSynchronize / an event the context stream waits on) before
- * this call.  Likewise ibu_codec_status reads ONE status word per context: encodes issued on several streams share it. */
+ * Stream ordering: the copies are ordered behind ibu_ctx_stream(ctx).  Records produced by a kernel entry point that was
+ * given another stream: use ibu_writer_write_batch_device_on below (or complete them first).  ibu_codec_status reads ONE
+ * status word per context: encodes issued on several streams share it. */
 int32_t ibu_writer_write_batch_device(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                       const void* d_records, size_t n, ibu_stream_stats_t* stats);
+/* The same, with the stream the records were produced on (a kernel entry point that was given `stream`, e.g. a sort on the
+ * caller's stream): the copies wait for the work queued on `producer_stream` so far; NULL = ibu_ctx_stream(ctx), i.e. the
+ * call above. */
+int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
+                                         const void* d_records, size_t n, void* producer_stream, ibu_stream_stats_t* stats);
 
 /* Device processors for process_parallel. */
 enum {

@@ -103,6 +103,35 @@ def test_write_batch_device_file_equals_oracle_file(ia, ctx, oracle, tmp_path, n
     assert p.read_bytes() == q.read_bytes()
 
 
+def test_write_batch_device_on_a_producer_stream(ia, ctx, oracle, tmp_path):
+    """ibu_writer_write_batch_device_on: the records are produced on the CALLER's stream (here: generated and sorted on a
+    second stream, 30e6 records so that the sort is still running when the writer is called) and the copies wait for it —
+    the file holds the sorted records, not what the buffer held before."""
+    n, bc_len, umi_len = 30_000_000, 16, 12
+    other = ia.Context(0)                                 # its stream serves as "the caller's stream": not this context's
+    s = other.stream
+    d, t = ctx.alloc(n * 24), ctx.alloc(n * 24)
+    ctx.generate(SEED, 0, n, bc_len, umi_len, d)          # on the context's stream ...
+    ctx.synchronize()
+    want = ctx.reduce(d, n)
+    h = ia.Header(bc_len, umi_len)
+    h.set_sorted()
+    p = tmp_path / "sorted.ibu"
+    w = ia.Writer.from_path(p, h)
+    ctx.sort_records(d, t, n, stream=s)                   # ... sorted on the caller's
+    w.write_batch_device(ctx, d, n, stream=s)
+    w.finish()
+    w.close()
+    other.close()
+    hdr, recs = ia.load_to_vec(p)
+    assert hdr.sorted() and len(recs) == n
+    keys = np.stack([recs["barcode"], recs["umi"], recs["index"]], axis=1)
+    a, b = keys[:-1], keys[1:]
+    lt = (a[:, 0] < b[:, 0]) | ((a[:, 0] == b[:, 0]) & ((a[:, 1] < b[:, 1]) | ((a[:, 1] == b[:, 1]) & (a[:, 2] <= b[:, 2]))))
+    assert bool(lt.all())
+    assert oracle.reduce_records(recs) == want
+
+
 def test_write_batch_device_mixes_with_host_writes(ia, ctx, oracle):
     """Buffered rule of writer.rs:321-351 holds when device batches interleave with write_record."""
     n = 1000

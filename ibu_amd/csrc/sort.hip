@@ -952,19 +952,25 @@ hipError_t launch_records_census(const LaunchCfg& cfg, const void* recs, size_t 
   if (n) launch_census(cfg, recs, n, (u64*)d_census, nullptr, st);
   return hipGetLastError();
 }
-// records -> 12-byte elements (pl.k <= 12).  16-byte aligned records take the tiled kernel; others one thread per record.
+// records -> 12-byte elements (pl.k <= 12).  Records that start at an odd record of a larger array (8- but not 16-byte
+// aligned) are PEELED like everywhere else (kcommon.hpp): one record through the per-record kernel brings the rest to a
+// 16-byte boundary for the tiled kernel (the elements need no more than their 4-byte alignment).
 static void launch_compress(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, u32 first_byte, Elem* out,
                             uint8_t* digits, hipStream_t st) {
-  const size_t main_rows = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 0 : (n / kTileRecs) * kTileRecs;
+  const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? (n ? 1 : 0) : 0;
+  const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
+  if (head)
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(1), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)head, pl, first_byte, out, digits);
   if (main_rows) {
     static std::atomic<int> occ;
     const u32 nt = (u32)(main_rows / kTileRecs);
     hipLaunchKernelGGL(ibu_k_sort_compress, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress, 0, &occ))),
-                       dim3(kBlock), 0, st, (const uint8_t*)recs, nt, pl, first_byte, out, digits);
+                       dim3(kBlock), 0, st, static_cast<const uint8_t*>(recs) + 24 * head, nt, pl, first_byte, out + head,
+                       digits ? digits + head : digits);
   }
-  if (main_rows < n)
-    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const u64*)recs, (u64)main_rows,
-                       (u64)n, pl, first_byte, out, digits);
+  if (head + main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const u64*)recs,
+                       (u64)(head + main_rows), (u64)n, pl, first_byte, out, digits);
 }
 hipError_t launch_compact(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st) {
   (void)hipGetLastError();
@@ -977,16 +983,19 @@ hipError_t launch_expand(const LaunchCfg& cfg, const CompactPlan& pl, const void
   (void)hipGetLastError();
   if (n == 0) return hipSuccess;
   if (pl.k > 12 || n >= (1ull << 38)) return hipErrorInvalidValue;
-  const size_t main_rows = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 0 : (n / kTileRecs) * kTileRecs;
+  const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 1 : 0;   // peeled: see launch_compress
+  const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
+  if (head)
+    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(1), dim3(256), 0, st, (const Elem*)elems, (u64)0, (u64)head, pl, (u64*)recs);
   if (main_rows) {
     static std::atomic<int> occ;
     const u32 nsub = (u32)(main_rows / kTileRecs), nt = (nsub + kExpandSub - 1) / kExpandSub;
     hipLaunchKernelGGL(ibu_k_sort_expand, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_expand, 0, &occ))), dim3(kBlock),
-                       0, st, (const Elem*)elems, nt, nsub, pl, (uint8_t*)recs);
+                       0, st, static_cast<const Elem*>(elems) + head, nt, nsub, pl, static_cast<uint8_t*>(recs) + 24 * head);
   }
-  if (main_rows < n)
-    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(tail_grid(n - main_rows)), dim3(256), 0, st, (const Elem*)elems, (u64)main_rows, (u64)n,
-                       pl, (u64*)recs);
+  if (head + main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const Elem*)elems,
+                       (u64)(head + main_rows), (u64)n, pl, (u64*)recs);
   return hipGetLastError();
 }
 

@@ -363,7 +363,7 @@ int32_t ibu_lower_bound_records(ibu_ctx_t* ctx, const void* d_sorted_records, si
  *   (IBU_ERR_INVALID_ARG otherwise).  Element byte j = the j-th least significant varying byte of the key (index bytes
  *   first, barcode bytes last): elements compared as 96-bit little-endian integers order like the records.
  * ibu_records_compact: n records -> n elements (12 n bytes at d_elems, 4-byte aligned).  ibu_records_expand: the inverse.
- *   Asynchronous on `stream`; 16-byte aligned record arrays take the tiled kernels. */
+ *   Asynchronous on `stream`; record arrays that are 8- but not 16-byte aligned (a shard at an odd record) peel one record. */
 typedef struct ibu_key_plan {
   uint32_t csel[3][3]; /* byte-gather selectors, records -> elements (v_perm_b32) */
   uint32_t xsel[6][2]; /* elements -> records */

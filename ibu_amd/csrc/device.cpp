@@ -106,6 +106,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->cfg.sort_variant = (int)value;
     return IBU_OK;
   }
+  if (strcmp(key, "sort_guess") == 0) {
+    if (value < 0 || value > (1ll << 31)) return err_arg("sort_guess out of range");
+    ctx->cfg.sort_guess = (int)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "sort_compact") == 0) {
     if (value < 0 || value > sort_num_compact_variants()) return err_arg("sort_compact out of range");
     ctx->cfg.sort_compact = (int)value;

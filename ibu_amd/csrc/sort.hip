@@ -11,6 +11,7 @@
 // varying digit one pass of count / scan / scatter, where only the FIRST count reads the records: later passes count from a
 // 1-byte-per-record digit side stream the previous scatter left behind (details above the pass kernels).
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "kcommon.hpp"
 #include "kernels.h"
@@ -585,15 +586,22 @@ __device__ __forceinline__ u32 elem_byte(u32x3 e, u32 byte) {   // byte: uniform
 }
 // records [0, 128 ntiles) -> elements + first digit; tiled like the census (recs 16-B aligned).  Lane L owns records L and
 // L + 64 of the tile: stride-24 ds_read_b64 is conflict-free and each of its two element stores is 768 contiguous bytes.
-extern "C" __global__ void __launch_bounds__(kBlock, 8)
+// CENSUS: the exact census (OR / AND words, order flags: CensusAcc) of the same records is accumulated on the way — the
+// speculative path of the sort, whose plan comes from a SAMPLE and is checked against this census afterwards.
+template <bool CENSUS>
+__global__ void __launch_bounds__(kBlock, 8)
 ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, Elem* __restrict__ out,
-                    uint8_t* __restrict__ digits) {
+                    uint8_t* __restrict__ digits, u64* __restrict__ census) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kTileBytes;
   const TileRange tr = tile_range(ntiles, wib);             // which tiles this wave sweeps (kcommon.hpp)
   u32 t = tr.t;
-  if (t >= tr.end) return;
+  CensusAcc acc;
+  if (t >= tr.end) {
+    if constexpr (CENSUS) acc.flush(census, nullptr);        // identities: every wave takes part in the shuffles
+    return;
+  }
   const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
   u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
   for (;;) {
@@ -601,6 +609,11 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     const bool more = tn < tr.end;                           // wave-uniform; the prefetch is unconditional (kcommon.hpp)
     src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
     const u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
+    u64 pv[3] = {0, 0, 0};                                   // the record in front of the tile (lane 0 only)
+    if (CENSUS && lane == 0 && t > 0) {
+      const u64* g = reinterpret_cast<const u64*>(recs + (size_t)t * kTileBytes) - 3;
+      pv[0] = g[0]; pv[1] = g[1]; pv[2] = g[2];
+    }
     wave_lds_fence();
     *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
     *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
@@ -608,6 +621,13 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     wave_lds_fence();
     const u64* r = reinterpret_cast<const u64*>(tile + lane * 24);
     const u64* q = reinterpret_cast<const u64*>(tile + (lane + kWave) * 24);
+    if constexpr (CENSUS) {
+      acc.rec(r[0], r[1], r[2]);
+      acc.rec(q[0], q[1], q[2]);
+      if (lane > 0) { pv[0] = r[-3]; pv[1] = r[-2]; pv[2] = r[-1]; }
+      if (lane > 0 || t > 0) acc.pair(pv[0], pv[1], pv[2], r[0], r[1], r[2]);
+      acc.pair(q[-3], q[-2], q[-1], q[0], q[1], q[2]);
+    }
     const u32x3 e0 = compress_rec(r[0], r[1], r[2], pl), e1 = compress_rec(q[0], q[1], q[2], pl);
     const size_t row = (size_t)t * kTileRecs + lane;
     st_elem(out + row, e0);
@@ -620,6 +640,12 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     t = tn;
     a0 = b0; a1 = b1; a2 = b2;
   }
+  if constexpr (CENSUS) acc.flush(census, nullptr);
+}
+// the digit stream of a pass from the elements themselves (the speculative path guessed another first pass)
+extern "C" __global__ void ibu_k_sort_digits(const Elem* __restrict__ in, u64 n, u32 byte, uint8_t* __restrict__ digits) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) digits[i] = (uint8_t)elem_byte(ld_elem(in + i), byte);
 }
 extern "C" __global__ void ibu_k_sort_compress_tail(const u64* __restrict__ recs, u64 row0, u64 n, CompactPlan pl, u32 first_byte,
                                                     Elem* __restrict__ out, uint8_t* __restrict__ digits) {
@@ -956,21 +982,29 @@ hipError_t launch_records_census(const LaunchCfg& cfg, const void* recs, size_t 
 // aligned) are PEELED like everywhere else (kcommon.hpp): one record through the per-record kernel brings the rest to a
 // 16-byte boundary for the tiled kernel (the elements need no more than their 4-byte alignment).
 static void launch_compress(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, u32 first_byte, Elem* out,
-                            uint8_t* digits, hipStream_t st) {
+                            uint8_t* digits, hipStream_t st, u64* census = nullptr) {   // census: 16-byte aligned records only
   const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? (n ? 1 : 0) : 0;
   const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
   if (head)
     hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(1), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)head, pl, first_byte, out, digits);
   if (main_rows) {
-    static std::atomic<int> occ;
+    static std::atomic<int> occ[2];
     const u32 nt = (u32)(main_rows / kTileRecs);
-    hipLaunchKernelGGL(ibu_k_sort_compress, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress, 0, &occ))),
-                       dim3(kBlock), 0, st, static_cast<const uint8_t*>(recs) + 24 * head, nt, pl, first_byte, out + head,
-                       digits ? digits + head : digits);
+    const uint8_t* base = static_cast<const uint8_t*>(recs) + 24 * head;
+    if (census)
+      hipLaunchKernelGGL(ibu_k_sort_compress<true>, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<true>, 0, &occ[1]))),
+                         dim3(kBlock), 0, st, base, nt, pl, first_byte, out + head, digits ? digits + head : digits, census);
+    else
+      hipLaunchKernelGGL(ibu_k_sort_compress<false>, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<false>, 0, &occ[0]))),
+                         dim3(kBlock), 0, st, base, nt, pl, first_byte, out + head, digits ? digits + head : digits, (u64*)nullptr);
   }
-  if (head + main_rows < n)
+  if (head + main_rows < n) {
     hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const u64*)recs,
                        (u64)(head + main_rows), (u64)n, pl, first_byte, out, digits);
+    if (census)   // the rest rows of the census (each row also against its predecessor)
+      hipLaunchKernelGGL(ibu_k_sort_census_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const u64*)recs,
+                         (u64)(head + main_rows), (u64)n, census, (u32*)nullptr);
+  }
 }
 hipError_t launch_compact(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st) {
   (void)hipGetLastError();
@@ -1001,8 +1035,11 @@ hipError_t launch_expand(const LaunchCfg& cfg, const CompactPlan& pl, const void
 
 // The compact-key path of launch_sort_records (see "COMPACT-KEY passes" above).  first_elem_byte: the first element byte
 // that is sorted (the index bytes below it are carried only).
+// passes[0 .. npass): the element bytes to sort by, ascending.  compressed: the elements (and the digit stream of
+// `digits_byte`) are already in place — the speculative path ran the compress pass itself.
 static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
-                                        const CompactPlan& pl, u32 first_elem_byte, hipStream_t st) {
+                                        const CompactPlan& pl, const u32* passes, u32 npass, hipStream_t st, bool compressed = false,
+                                        u32 digits_byte = 0) {
   const SortLayout L = sort_layout(n, cv.tile);
   u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
   u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
@@ -1022,19 +1059,22 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     e = hipFuncSetAttribute(cv.scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
   }
-  launch_compress(cfg, pl, recs, n, first_elem_byte, src, digits, st);
+  if (!compressed) launch_compress(cfg, pl, recs, n, passes[0], src, digits, st);
+  else if (digits_byte != passes[0])
+    hipLaunchKernelGGL(ibu_k_sort_digits, dim3((u32)cfg.cus * 8), dim3(256), 0, st, (const Elem*)src, (u64)n, passes[0], digits);
   // passes; the last one writes the records themselves
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
-  for (u32 b = first_elem_byte; b < pl.k; ++b) {
+  for (u32 pi = 0; pi < npass; ++pi) {
+    const u32 b = passes[pi];
     hipLaunchKernelGGL(cv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n,
                        L.ntiles, counts);
     hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
     hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
     hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
                        (const u64*)blockoff, (const u64*)binbase, pos);
-    const bool last = b + 1 == pl.k;
-    u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? b : b + 1;
+    const bool last = pi + 1 == npass;
+    u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? b : passes[pi + 1];
     const Elem* src_arg = src;
     void* dst_arg = last ? recs : static_cast<void*>(dst);
     const u32* pos_arg = pos;
@@ -1047,6 +1087,11 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
   return hipGetLastError();
 }
 
+// IBU_TRACE_SORT=1: one line per sort on stderr saying which path it took (tests assert on it; never set in production)
+static bool trace_sort() {
+  static const bool on = [] { const char* v = getenv("IBU_TRACE_SORT"); return v && *v && *v != '0'; }();
+  return on;
+}
 // Not purely asynchronous: the census result comes back to the host (one 64-byte read) to pick the passes; everything
 // after that is queued on `st`.
 hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size_t n, void* scratch,
@@ -1066,14 +1111,56 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   void* pos = sc + L.pos;
   uint8_t* digits = sc + L.digits;
 
-  hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
-  launch_census(cfg, recs, n, census, nullptr, st);
+  // Compact-key path (see "COMPACT-KEY passes"): n < 2^32, records 16-byte aligned (the tiled compress kernel), tmp at least
+  // 4-byte aligned.  Whether at most 12 key bytes vary is the census' to say.
+  const CompactVariant* cv = pick_compact(cfg);
+  const bool compact_ok = cv && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
+                          (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total;
+  hipError_t e;
+  // SPECULATION (large inputs): the census and the compress pass both read all the records.  A census of three SAMPLE
+  // ranges (first / middle / last 32 Ki records: tens of microseconds) guesses which bytes vary; the compress pass runs on
+  // that guess at once and accumulates the EXACT census on the way; afterwards the guess only has to COVER the truth (every
+  // byte that really varies is in the elements: bytes it carried needlessly are constant digits, their passes are skipped).
+  // A guess that missed a byte costs the compress pass it wasted, and the sort goes on from the exact census as before.
+  bool speculated = false;
+  CompactPlan gpl;
+  u64 g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gmask[3] = {0, 0, 0};
+  u32 gfirst = 0;
+  static constexpr size_t kSample = 32768;
+  // cfg.sort_guess: 0 = never, 1 = inputs of 2^23 records and more, k > 1 = inputs of k records and more (a test knob)
+  const size_t guess_min = cfg.sort_guess == 1 ? (size_t)1 << 23 : ((size_t)cfg.sort_guess > 4 * kSample ? (size_t)cfg.sort_guess : 4 * kSample);
+  if (compact_ok && cfg.sort_guess && n >= guess_min) {
+    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
+    const size_t starts[3] = {0, (n / 2) & ~(size_t)1, (n - kSample) & ~(size_t)1};   // even rows: 16-byte aligned
+    for (size_t s0 : starts) launch_census(cfg, static_cast<const u64*>(recs) + 3 * s0, kSample, census, nullptr, st);
+    e = hipMemcpyAsync(g, census, sizeof g, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    compact_plan_init(reinterpret_cast<const uint64_t*>(g), reinterpret_cast<const uint64_t*>(g + 3), &gpl);
+    if (gpl.k >= 1 && gpl.k <= 12) {
+      for (int f = 0; f < 3; ++f)
+        for (u32 b = 0; b < 8; ++b)
+          if (((g[f] ^ g[3 + f]) >> (8 * b)) & 255u) gmask[f] |= 255ull << (8 * b);
+      gfirst = (g[6] == 0 && gpl.index_bytes < gpl.k) ? gpl.index_bytes : 0;   // the sample's guess of the first sorted byte
+      hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
+      launch_compress(cfg, gpl, recs, n, gfirst, static_cast<Elem*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
+      speculated = true;
+    }
+  }
+  if (!speculated) {
+    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
+    launch_census(cfg, recs, n, census, nullptr, st);
+  }
   u64 c[8];
-  hipError_t e = hipMemcpyAsync(c, census, sizeof c, hipMemcpyDeviceToHost, st);
+  e = hipMemcpyAsync(c, census, sizeof c, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
-  if (c[7] == 0) return hipSuccess;  // no record is smaller than its predecessor: already sorted
+  if (c[7] == 0) {                   // no record is smaller than its predecessor: already sorted
+    if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu already sorted%s\n", n, speculated ? " (a speculative compress pass was spent)" : "");
+    return hipSuccess;
+  }
 
   // which digits vary.  The sort is stable and the index is the LEAST significant field: if the input already runs in
   // non-decreasing index order (the usual case: records are written in read order), ties on (barcode, umi) keep that
@@ -1088,17 +1175,43 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     for (u32 b = 0; b < 8; ++b)
       if ((varying >> (8 * b)) & 255u) passes[npass++] = {(u32)f, 8 * b};   // constant digits: the pass would be the identity
   }
-
-  // compact-key path: at most 12 varying bytes (the index bytes are carried even when they are not sorted), n < 2^32,
-  // records 16-byte aligned (the tiled compress / expand kernels), tmp at least 4-byte aligned
-  if (const CompactVariant* cv = pick_compact(cfg)) {
+  if (compact_ok && npass > 0) {
+    u32 ebytes[12], ne = 0;
+    if (speculated) {
+      bool covered = true;
+      for (int f = 0; f < 3; ++f)
+        if ((c[f] ^ c[3 + f]) & ~gmask[f]) covered = false;
+      if (covered) {                                        // the elements in tmp hold every byte that varies
+        CompactPlan pl = gpl;
+        u32 j = 0;
+        for (int fo = 0; fo < 3; ++fo) {
+          const int f = kFieldOrder[fo];
+          pl.base[f] = c[3 + f] & ~gmask[f];
+          for (u32 b = 0; b < 8; ++b)
+            if ((gmask[f] >> (8 * b)) & 255u) {             // element byte j = byte b of field f
+              const bool varies = ((c[f] ^ c[3 + f]) >> (8 * b)) & 255u, sorted_on = !(f == 2 && c[6] == 0);
+              if (varies && sorted_on) ebytes[ne++] = j;
+              ++j;
+            }
+        }
+        if (ne) {
+          if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact-speculated passes=%u first_digit_guess=%s\n", n, ne, gfirst == ebytes[0] ? "hit" : "miss");
+          return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst);
+        }
+      }
+      if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu guess did not cover the varying bytes\n", n);
+    }
     CompactPlan pl;
     compact_plan_init(reinterpret_cast<const uint64_t*>(c), reinterpret_cast<const uint64_t*>(c + 3), &pl);
-    const u32 k = pl.k, first_sorted = c[6] == 0 ? pl.index_bytes : 0;   // input in index order: the index bytes ride along unsorted
-    const bool ok = npass > 0 && k <= 12 && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
-                    (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total;
-    if (ok) return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, first_sorted, st);
+    if (pl.k <= 12) {
+      for (u32 j = c[6] == 0 ? pl.index_bytes : 0; j < pl.k; ++j) ebytes[ne++] = j;   // input in index order: the index bytes ride along unsorted
+      if (ne) {
+        if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact passes=%u\n", n, ne);
+        return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st);
+      }
+    }
   }
+  if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=24-byte passes=%d\n", n, npass);
 
   const void* scatter = L.idx64 ? sv.scatter64 : sv.scatter32;
   if (sv.lds > 48 * 1024) {   // per call: the attribute is per device (see launch_compact_passes)

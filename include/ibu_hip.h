@@ -240,6 +240,10 @@ int32_t ibu_device_count(int32_t* n);
  *                           with indices below 2^32: 11) the passes move 12-byte elements instead of records.  0 = never
  *                           (24-byte passes only), 1 = default tile shape, 2..8 = A/B tile shapes (sort.hip, kCompact).
  *                           Same result either way, byte for byte.
+ *   "sort_guess"     0 | 1 | k  large compact-key sorts read the records once instead of twice: a census of three sample ranges
+ *                           guesses the varying bytes, the compress pass runs on the guess and takes the exact census on the
+ *                           way; a guess that missed a byte is detected and the sort continues from the exact census.
+ *                           0 = never, 1 = inputs of 2^23 records and more (default), k = of k records and more.
  *   "base_order"     0 | 1  bit order of the 2-bit codec for every pack / unpack / decode / encode issued through
  *                           this context (device kernels and the stream entry points alike):
  *                             0 = IBU_BASE_ORDER_LSB_FIRST (default): base i at bits [2i, 2i+1], "ACGT" -> 0b11100100

@@ -12,6 +12,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    os.environ.setdefault("IBU_TRACE_SORT", "1")   # the library says on stderr which path a sort took (test_gpu_sort.py asserts on it)
     # built artefacts are not in git: a fresh checkout builds them once (hipcc cross-compiles without a GPU)
     import subprocess
     if not os.path.exists(os.path.join(ROOT, "ibu_amd", "libibu_hip.so")):

@@ -83,6 +83,65 @@ def test_sort_compact_tile_shapes(ia, oracle, compact):
         c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx_guess(ia):
+    """A context whose sorts speculate from 131 072 records on (the default starts at 2^23): compress on a sampled guess
+    of the varying bytes, exact census in the same pass."""
+    c = ia.Context(0)
+    c.set_option("sort_guess", 131_072)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003])
+@pytest.mark.parametrize("case", ["random_index", "index_order", "guess_misses_a_barcode_byte", "guess_misses_an_index_byte",
+                                  "index_order_broken_outside_the_samples", "already_sorted", "one_umi_byte_constant_in_the_samples"])
+def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, case, capfd):
+    """The speculative path: the samples are the first, the middle and the last 32 768 records.  Whatever the samples
+    suggest, the result is the oracle's — a guess that does not cover the truth is detected by the exact census."""
+    recs = _shuffled(oracle, n, 16, 12)
+    rng = np.random.default_rng(n)
+    quarter = n // 4 + 7                                   # a row no sample range contains
+    assert 32_768 < quarter < n // 2 - 1 or n < 140_000
+    if n < 140_000:
+        quarter = 32_768 + (n // 2 - 32_768) // 2          # between the first and the middle sample
+    if case == "random_index":
+        recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
+    elif case == "index_order":
+        recs["index"] = np.arange(n, dtype=np.uint64)
+    elif case == "guess_misses_a_barcode_byte":
+        recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
+        recs["barcode"][quarter] |= np.uint64(1) << np.uint64(61)       # byte 7 of the barcode varies in ONE record
+    elif case == "guess_misses_an_index_byte":
+        recs["index"] = rng.integers(0, 2**16, n, dtype=np.uint64)
+        recs["index"][quarter] = 2**40 + 5
+    elif case == "index_order_broken_outside_the_samples":
+        recs["index"] = np.arange(n, dtype=np.uint64)
+        recs["barcode"] %= 50                                  # ties, so that the index order decides
+        recs["umi"] %= 3
+        recs["index"][quarter], recs["index"][quarter + 1] = recs["index"][quarter + 1], recs["index"][quarter]
+        recs["barcode"][quarter + 1], recs["umi"][quarter + 1] = recs["barcode"][quarter], recs["umi"][quarter]
+    elif case == "already_sorted":
+        recs = oracle.sort_records(recs)
+    elif case == "one_umi_byte_constant_in_the_samples":
+        recs["index"] = np.arange(n, dtype=np.uint64)
+        recs["umi"] &= np.uint64(0xFFFF)
+        recs["umi"][quarter] |= np.uint64(0x7F0000)
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    assert _sort_on_device(ctx_guess, recs)[0] == want
+    trace = capfd.readouterr().err                         # IBU_TRACE_SORT=1 (conftest): which path the library took
+    expect = {"random_index": "path=compact-speculated passes=11 first_digit_guess=hit",
+              "index_order": "path=compact-speculated passes=7 first_digit_guess=hit",
+              "guess_misses_a_barcode_byte": "guess did not cover",
+              "guess_misses_an_index_byte": "guess did not cover",
+              "index_order_broken_outside_the_samples": "first_digit_guess=miss",
+              "already_sorted": "already sorted (a speculative compress pass was spent)",
+              "one_umi_byte_constant_in_the_samples": "guess did not cover"}[case]
+    assert expect in trace, trace
+    assert _sort_on_device(ctx24, recs)[0] == want
+
+
 @pytest.mark.parametrize("n", [2, 129, 5000, 300_007])
 @pytest.mark.parametrize("nbytes", [1, 5, 11, 12, 13, 24])
 def test_sort_with_scattered_varying_bytes(ctx, oracle, ia, n, nbytes):

@@ -64,7 +64,7 @@ pub struct ibu_decode_sink_t {
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct ibu_key_plan_t {
-    pub csel: [[u32; 3]; 3],
+    pub csel: [[u32; 3]; 4],
     pub xsel: [[u32; 2]; 6],
     pub k: u32,
     pub index_bytes: u32,

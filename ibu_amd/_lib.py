@@ -40,7 +40,7 @@ class CStreamStats(C.Structure):  # ibu_stream_stats_t
 
 
 class CKeyPlan(C.Structure):  # ibu_key_plan_t
-    _fields_ = [("csel", (u32 * 3) * 3), ("xsel", (u32 * 2) * 6), ("k", u32), ("index_bytes", u32), ("base", u64 * 3)]
+    _fields_ = [("csel", (u32 * 3) * 4), ("xsel", (u32 * 2) * 6), ("k", u32), ("index_bytes", u32), ("base", u64 * 3)]
 
 
 class CDecodeSink(C.Structure):  # ibu_decode_sink_t

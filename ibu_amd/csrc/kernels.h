@@ -67,9 +67,9 @@ int sort_num_compact_variants();
 hipError_t launch_lower_bound(const void* recs, size_t n, const void* keys, size_t k, uint64_t* pos, hipStream_t st);
 // compacted keys (sort.hip): the varying bytes of a set of records as 12-byte elements.  Layout = ibu_key_plan_t (ibu_hip.h).
 struct CompactPlan {
-  uint32_t csel[3][3];   // compress: element word w = OR over the fields f of perm(f.hi, f.lo, csel[w][f])
-  uint32_t xsel[6][2];   // expand: record dword d (= 2 f + half) = base | perm(e.w1, e.w0, xsel[d][0]) | perm(0, e.w2, xsel[d][1])
-  uint32_t k;            // varying bytes (element bytes k .. 11 are zero); usable while k <= 12
+  uint32_t csel[4][3];   // compress: element word w = OR over the fields f of perm(f.hi, f.lo, csel[w][f])
+  uint32_t xsel[6][2];   // expand: record dword d (= 2 f + half) = base | perm(e.w1, e.w0, xsel[d][0]) | perm(e.w3 or 0, e.w2, xsel[d][1])
+  uint32_t k;            // varying bytes (the element bytes above them are zero): 12-byte elements while k <= 12, 16-byte ones (inside the sort) while k <= 16
   uint32_t index_bytes;  // how many of them are index bytes (the least significant element bytes)
   uint64_t base[3];      // each field with its varying bytes cleared (the AND words)
 };

@@ -553,44 +553,65 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
 // lane that loads whole elements needs no LDS staging in front of the ranking.  The result is the same permutation as the
 // 24-byte passes give (stable LSD over the same digits; constant bytes never decide a comparison).
 // =====================================================================================================
+// Elements of W 32-bit words: W = 3 (12 bytes: at most 12 varying key bytes) or W = 4 (16 bytes: 13 .. 16).  ElemT<W>: in
+// memory (4-byte aligned); EV<W>: in registers.
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
-struct __attribute__((packed, aligned(4))) Elem { u32 w[3]; };
-static_assert(sizeof(Elem) == 12, "12-byte elements");
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
-__device__ __forceinline__ u32x3 ld_elem(const Elem* p) {      // 4-byte aligned: one global_load_dwordx3, read once (nt)
-  return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(p));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+template <int W> struct __attribute__((packed, aligned(4))) ElemT { u32 w[W]; };
+typedef ElemT<3> Elem;                                        // the 12-byte element of the C ABI (ibu_records_compact)
+static_assert(sizeof(ElemT<3>) == 12 && sizeof(ElemT<4>) == 16, "element sizes");
+template <int W> struct EV { u32 w[W]; };
+template <int W>
+__device__ __forceinline__ EV<W> ld_elem(const ElemT<W>* p) {  // 4-byte aligned: ONE global_load_dwordx3 / x4, read once (nt)
+  EV<W> v;
+  if constexpr (W == 3) {
+    const u32x3 t = __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(p));
+    v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z;
+  } else {
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(p));
+    v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+  }
+  return v;
 }
-__device__ __forceinline__ void st_elem(Elem* p, u32x3 v) { __builtin_memcpy(p, &v, 12); }
+template <int W>
+__device__ __forceinline__ void st_elem(ElemT<W>* p, EV<W> v) { __builtin_memcpy(p, &v, 4 * W); }
 
 // Byte gathers as v_perm_b32: a selector byte 0..7 picks a byte of the (hi, lo) register pair, 0x0C gives zero (CompactPlan:
 // kernels.h).
-__device__ __forceinline__ u32x3 compress_rec(u64 f0, u64 f1, u64 f2, const CompactPlan& pl) {
-  u32 e[3];
+template <int W>
+__device__ __forceinline__ EV<W> compress_rec(u64 f0, u64 f1, u64 f2, const CompactPlan& pl) {
+  EV<W> e;
 #pragma unroll
-  for (int w = 0; w < 3; ++w)
-    e[w] = __builtin_amdgcn_perm((u32)(f0 >> 32), (u32)f0, pl.csel[w][0]) | __builtin_amdgcn_perm((u32)(f1 >> 32), (u32)f1, pl.csel[w][1]) |
-           __builtin_amdgcn_perm((u32)(f2 >> 32), (u32)f2, pl.csel[w][2]);
-  return u32x3{e[0], e[1], e[2]};
+  for (int w = 0; w < W; ++w)
+    e.w[w] = __builtin_amdgcn_perm((u32)(f0 >> 32), (u32)f0, pl.csel[w][0]) | __builtin_amdgcn_perm((u32)(f1 >> 32), (u32)f1, pl.csel[w][1]) |
+             __builtin_amdgcn_perm((u32)(f2 >> 32), (u32)f2, pl.csel[w][2]);
+  return e;
 }
-__device__ __forceinline__ void expand_elem(u32x3 v, const CompactPlan& pl, u64& f0, u64& f1, u64& f2) {
-  u32 d[6];
+template <int W>
+__device__ __forceinline__ void expand_elem(EV<W> v, const CompactPlan& pl, u64& f0, u64& f1, u64& f2) {
+  u32 d[6], w3 = 0;
+  if constexpr (W == 4) w3 = v.w[3];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) d[k] = __builtin_amdgcn_perm(v.y, v.x, pl.xsel[k][0]) | __builtin_amdgcn_perm(0u, v.z, pl.xsel[k][1]);
+  for (int k = 0; k < 6; ++k) d[k] = __builtin_amdgcn_perm(v.w[1], v.w[0], pl.xsel[k][0]) | __builtin_amdgcn_perm(w3, v.w[2], pl.xsel[k][1]);
   f0 = pl.base[0] | ((u64)d[1] << 32) | d[0];
   f1 = pl.base[1] | ((u64)d[3] << 32) | d[2];
   f2 = pl.base[2] | ((u64)d[5] << 32) | d[4];
 }
-__device__ __forceinline__ u32 elem_byte(u32x3 e, u32 byte) {   // byte: uniform
+template <int W>
+__device__ __forceinline__ u32 elem_byte(EV<W> e, u32 byte) {  // byte: uniform
   const u32 w = byte >> 2;
-  return ((w == 0 ? e.x : w == 1 ? e.y : e.z) >> (8 * (byte & 3))) & 255u;
+  u32 x = w == 0 ? e.w[0] : w == 1 ? e.w[1] : e.w[2];
+  if constexpr (W == 4) x = w == 3 ? e.w[3] : x;
+  return (x >> (8 * (byte & 3))) & 255u;
 }
 // records [0, 128 ntiles) -> elements + first digit; tiled like the census (recs 16-B aligned).  Lane L owns records L and
 // L + 64 of the tile: stride-24 ds_read_b64 is conflict-free and each of its two element stores is 768 contiguous bytes.
 // CENSUS: the exact census (OR / AND words, order flags: CensusAcc) of the same records is accumulated on the way — the
 // speculative path of the sort, whose plan comes from a SAMPLE and is checked against this census afterwards.
-template <bool CENSUS>
+template <bool CENSUS, int W>
 __global__ void __launch_bounds__(kBlock, 8)
-ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, Elem* __restrict__ out,
+ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, ElemT<W>* __restrict__ out,
                     uint8_t* __restrict__ digits, u64* __restrict__ census) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -628,13 +649,13 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
       if (lane > 0 || t > 0) acc.pair(pv[0], pv[1], pv[2], r[0], r[1], r[2]);
       acc.pair(q[-3], q[-2], q[-1], q[0], q[1], q[2]);
     }
-    const u32x3 e0 = compress_rec(r[0], r[1], r[2], pl), e1 = compress_rec(q[0], q[1], q[2], pl);
+    const EV<W> e0 = compress_rec<W>(r[0], r[1], r[2], pl), e1 = compress_rec<W>(q[0], q[1], q[2], pl);
     const size_t row = (size_t)t * kTileRecs + lane;
-    st_elem(out + row, e0);
-    st_elem(out + row + kWave, e1);
+    st_elem<W>(out + row, e0);
+    st_elem<W>(out + row + kWave, e1);
     if (digits) {                                            // uniform (NULL: ibu_records_compact, no pass follows)
-      digits[row] = (uint8_t)elem_byte(e0, first_byte);
-      digits[row + kWave] = (uint8_t)elem_byte(e1, first_byte);
+      digits[row] = (uint8_t)elem_byte<W>(e0, first_byte);
+      digits[row + kWave] = (uint8_t)elem_byte<W>(e1, first_byte);
     }
     if (!more) break;
     t = tn;
@@ -643,24 +664,27 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
   if constexpr (CENSUS) acc.flush(census, nullptr);
 }
 // the digit stream of a pass from the elements themselves (the speculative path guessed another first pass)
-extern "C" __global__ void ibu_k_sort_digits(const Elem* __restrict__ in, u64 n, u32 byte, uint8_t* __restrict__ digits) {
+template <int W>
+__global__ void ibu_k_sort_digits(const ElemT<W>* __restrict__ in, u64 n, u32 byte, uint8_t* __restrict__ digits) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) digits[i] = (uint8_t)elem_byte(ld_elem(in + i), byte);
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) digits[i] = (uint8_t)elem_byte<W>(ld_elem<W>(in + i), byte);
 }
-extern "C" __global__ void ibu_k_sort_compress_tail(const u64* __restrict__ recs, u64 row0, u64 n, CompactPlan pl, u32 first_byte,
-                                                    Elem* __restrict__ out, uint8_t* __restrict__ digits) {
+template <int W>
+__global__ void ibu_k_sort_compress_tail(const u64* __restrict__ recs, u64 row0, u64 n, CompactPlan pl, u32 first_byte,
+                                         ElemT<W>* __restrict__ out, uint8_t* __restrict__ digits) {
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u32x3 e = compress_rec(recs[3 * i], recs[3 * i + 1], recs[3 * i + 2], pl);
-  st_elem(out + i, e);
-  if (digits) digits[i] = (uint8_t)elem_byte(e, first_byte);
+  const EV<W> e = compress_rec<W>(recs[3 * i], recs[3 * i + 1], recs[3 * i + 2], pl);
+  st_elem<W>(out + i, e);
+  if (digits) digits[i] = (uint8_t)elem_byte<W>(e, first_byte);
 }
 // elements -> records [0, 128 nsub) (recs 16-B aligned): ibu_records_expand (the sort itself expands in its last pass).
 // Two 128-element sub-tiles per iteration (four element loads per lane in flight behind the current ones); lane L owns
 // elements L and L + 64 of a sub-tile.
 static constexpr int kExpandSub = 2;
-extern "C" __global__ void __launch_bounds__(kBlock, 8)
-ibu_k_sort_expand(const Elem* __restrict__ in, u32 ntiles /*of 128 * kExpandSub*/, u32 nsub /*128-element sub-tiles in all*/, CompactPlan pl,
+template <int W>
+__global__ void __launch_bounds__(kBlock, 8)
+ibu_k_sort_expand(const ElemT<W>* __restrict__ in, u32 ntiles /*of 128 * kExpandSub*/, u32 nsub /*128-element sub-tiles in all*/, CompactPlan pl,
                   uint8_t* __restrict__ recs) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
@@ -668,28 +692,28 @@ ibu_k_sort_expand(const Elem* __restrict__ in, u32 ntiles /*of 128 * kExpandSub*
   const TileRange tr = tile_range(ntiles, wib);
   u32 t = tr.t;
   if (t >= tr.end) return;
-  u32x3 a[2 * kExpandSub];
-  auto issue = [&](u32 tt, u32x3* v) {
+  EV<W> a[2 * kExpandSub];
+  auto issue = [&](u32 tt, EV<W>* v) {
 #pragma unroll
     for (int s = 0; s < kExpandSub; ++s) {
       u32 sub = tt * kExpandSub + s;
       sub = sub < nsub ? sub : nsub - 1;                     // the last tile may be half empty: clamped, unconditional
-      v[2 * s] = ld_elem(in + (size_t)sub * kTileRecs + lane);
-      v[2 * s + 1] = ld_elem(in + (size_t)sub * kTileRecs + lane + kWave);
+      v[2 * s] = ld_elem<W>(in + (size_t)sub * kTileRecs + lane);
+      v[2 * s + 1] = ld_elem<W>(in + (size_t)sub * kTileRecs + lane + kWave);
     }
   };
   issue(t, a);
   for (;;) {
     const u32 tn = t + tr.stride;
     const bool more = tn < tr.end;
-    u32x3 b[2 * kExpandSub];
+    EV<W> b[2 * kExpandSub];
     issue(more ? tn : t, b);
 #pragma unroll
     for (int s = 0; s < kExpandSub; ++s) {
       const u32 sub = t * kExpandSub + s;
       u64 f[6];
-      expand_elem(a[2 * s], pl, f[0], f[1], f[2]);
-      expand_elem(a[2 * s + 1], pl, f[3], f[4], f[5]);
+      expand_elem<W>(a[2 * s], pl, f[0], f[1], f[2]);
+      expand_elem<W>(a[2 * s + 1], pl, f[3], f[4], f[5]);
       wave_lds_fence();                                      // the previous sub-tile's reads precede these writes
       u64* r = reinterpret_cast<u64*>(tile + lane * 24);
       u64* q = reinterpret_cast<u64*>(tile + (lane + kWave) * 24);
@@ -709,32 +733,33 @@ ibu_k_sort_expand(const Elem* __restrict__ in, u32 ntiles /*of 128 * kExpandSub*
     for (int k = 0; k < 2 * kExpandSub; ++k) a[k] = b[k];
   }
 }
-extern "C" __global__ void ibu_k_sort_expand_tail(const Elem* __restrict__ in, u64 row0, u64 n, CompactPlan pl, u64* __restrict__ recs) {
+template <int W>
+__global__ void ibu_k_sort_expand_tail(const ElemT<W>* __restrict__ in, u64 row0, u64 n, CompactPlan pl, u64* __restrict__ recs) {
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 f0, f1, f2;
-  expand_elem(ld_elem(in + i), pl, f0, f1, f2);
+  expand_elem<W>(ld_elem<W>(in + i), pl, f0, f1, f2);
   recs[3 * i] = f0; recs[3 * i + 1] = f1; recs[3 * i + 2] = f2;
 }
 
-template <int THREADS, int ROUNDS>
+template <int THREADS, int ROUNDS, int W>
 struct CompactShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
-  // LDS: stage 12 T | gdelta 256 x u32 | whist NW x 256 x u32 | misc 16 x u32 | sbin T bytes
-  static constexpr size_t lds = 12 * (size_t)T + 4 * kBins + 4 * (size_t)NW * kBins + 64 + (size_t)T;
+  // LDS: stage 4 W T | gdelta 256 x u32 | whist NW x 256 x u32 | misc 16 x u32 | sbin T bytes
+  static constexpr size_t lds = 4 * (size_t)W * T + 4 * kBins + 4 * (size_t)NW * kBins + 64 + (size_t)T;
 };
 // One pass over element byte `byte`; nbyte: the next pass's byte (the digit side stream it leaves behind).
 // LAST: the last pass — every element leaves as the 24-byte record it stands for, straight into the caller's array
 // (`dst` = the records, `pl` = the expansion; no side stream): the expand kernel and one element round trip are saved.
-template <int THREADS, int ROUNDS, bool LAST>
+template <int THREADS, int ROUNDS, bool LAST, int W>
 __global__ void __launch_bounds__(THREADS)
-ibu_k_sort_scatter12(const Elem* __restrict__ src, void* __restrict__ dst_v, u32 n, u32 byte, u32 nbyte, const u32* __restrict__ pos,
-                     uint8_t* __restrict__ digits, CompactPlan pl) {
-  typedef CompactShape<THREADS, ROUNDS> S;
+ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, u32 n, u32 byte, u32 nbyte, const u32* __restrict__ pos,
+                         uint8_t* __restrict__ digits, CompactPlan pl) {
+  typedef CompactShape<THREADS, ROUNDS, W> S;
   constexpr int T = S::T, NW = S::NW, PER_WAVE = S::PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u32* stage = reinterpret_cast<u32*>(smem);                 // the tile in digit order
-  u32* gdelta = stage + 3 * T;                               // global element index of slot p of bin d = gdelta[d] + p
+  u32* gdelta = stage + W * T;                               // global element index of slot p of bin d = gdelta[d] + p
   u32* whist = gdelta + kBins;
   u32* misc = whist + NW * kBins;
   uint8_t* sbin = reinterpret_cast<uint8_t*>(misc + 16);
@@ -752,11 +777,11 @@ ibu_k_sort_scatter12(const Elem* __restrict__ src, void* __restrict__ dst_v, u32
   const u32 mypos = tid < (u32)kBins ? pos[(size_t)tile * kBins + tid] : 0;
 
   // 1. every lane loads its elements (unconditional, clamped) and the per-wave counters are cleared
-  u32x3 v[ROUNDS];
+  EV<W> v[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const u32 slot = wib * PER_WAVE + r * kWave + lane;
-    v[r] = ld_elem(src + tbase + (slot < cnt ? slot : cnt - 1));
+    v[r] = ld_elem<W>(src + tbase + (slot < cnt ? slot : cnt - 1));
   }
 #pragma unroll
   for (int k = 0; k < kBins / kWave; ++k) whist[wib * kBins + lane + kWave * k] = 0;
@@ -768,7 +793,7 @@ ibu_k_sort_scatter12(const Elem* __restrict__ src, void* __restrict__ dst_v, u32
   for (int r = 0; r < ROUNDS; ++r) {
     const u32 slot = wib * PER_WAVE + r * kWave + lane;
     const bool valid = slot < cnt;
-    const u32 d = elem_byte(v[r], byte);
+    const u32 d = elem_byte<W>(v[r], byte);
     u64 m = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -810,7 +835,8 @@ ibu_k_sort_scatter12(const Elem* __restrict__ src, void* __restrict__ dst_v, u32
     const u32 slot = wib * PER_WAVE + r * kWave + lane;
     if (slot < cnt) {
       const u32 p = whist[wib * kBins + dig[r]] + rk[r];
-      stage[3 * p] = v[r].x; stage[3 * p + 1] = v[r].y; stage[3 * p + 2] = v[r].z;
+#pragma unroll
+      for (int w = 0; w < W; ++w) stage[W * p + w] = v[r].w[w];
       sbin[p] = (uint8_t)dig[r];
     }
   }
@@ -823,15 +849,17 @@ ibu_k_sort_scatter12(const Elem* __restrict__ src, void* __restrict__ dst_v, u32
     const u32 p = tid + THREADS * r;
     if (p < cnt) {
       const u32 g = gdelta[sbin[p]] + p;
-      const u32x3 e{stage[3 * p], stage[3 * p + 1], stage[3 * p + 2]};
+      EV<W> e;
+#pragma unroll
+      for (int w = 0; w < W; ++w) e.w[w] = stage[W * p + w];
       if constexpr (LAST) {
         u64 f0, f1, f2;
-        expand_elem(e, pl, f0, f1, f2);
+        expand_elem<W>(e, pl, f0, f1, f2);
         u64* o = static_cast<u64*>(dst_v) + 3 * (size_t)g;
         o[0] = f0; o[1] = f1; o[2] = f2;
       } else {
-        st_elem(static_cast<Elem*>(dst_v) + g, e);
-        digits[g] = (uint8_t)elem_byte(e, nbyte);
+        st_elem<W>(static_cast<ElemT<W>*>(dst_v) + g, e);
+        if (nbyte < 4 * W) digits[g] = (uint8_t)elem_byte<W>(e, nbyte);   // uniform; >= 4 W: no pass follows on elements
       }
     }
   }
@@ -914,23 +942,25 @@ struct CompactVariant {
   const void* scatter_last;
   void (*counts_bytes)(const uint8_t*, u64, u32, uint16_t*);
 };
-template <int TH, int R>
+template <int TH, int R, int W>
 static CompactVariant compact_variant() {
-  typedef CompactShape<TH, R> S;
-  return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter12<TH, R, false>),
-          reinterpret_cast<const void*>(ibu_k_sort_scatter12<TH, R, true>), ibu_k_sort_tilecounts_bytes<S::T>};
+  typedef CompactShape<TH, R, W> S;
+  return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, false, W>),
+          reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, true, W>), ibu_k_sort_tilecounts_bytes<S::T>};
 }
-static const CompactVariant kCompact[] = {
-    compact_variant<256, 20>(),   // 1 (default): 5120-element tiles (60 KiB), 4 waves, two workgroups per CU (1e9 records: 73.7 ms)
-    compact_variant<256, 16>(),   // 2: 4096-element tiles (75.2 ms)
-    compact_variant<256, 8>(),    // 3: 2048-element tiles (94 ms: runs of 8 elements = 96 bytes)
-    compact_variant<512, 8>(),    // 4: 4096-element tiles, 8 waves (79-83 ms)
-    compact_variant<512, 16>(),   // 5: 8192-element tiles, 8 waves, one workgroup per CU (99 ms)
-    compact_variant<1024, 8>(),   // 6: 8192-element tiles, 16 waves (97 ms)
-    compact_variant<1024, 4>(),   // 7: 4096-element tiles, 16 waves (79-83 ms)
-    compact_variant<256, 12>(),   // 8: 3072-element tiles, three workgroups per CU (86 ms)
+static const CompactVariant kCompact[] = {   // 12-byte elements
+    compact_variant<256, 20, 3>(),   // 1 (default): 5120-element tiles (60 KiB), 4 waves, two workgroups per CU (1e9 records: 73.7 ms)
+    compact_variant<256, 16, 3>(),   // 2: 4096-element tiles (75.2 ms)
+    compact_variant<256, 8, 3>(),    // 3: 2048-element tiles (94 ms: runs of 8 elements = 96 bytes)
+    compact_variant<512, 8, 3>(),    // 4: 4096-element tiles, 8 waves (79-83 ms)
+    compact_variant<512, 16, 3>(),   // 5: 8192-element tiles, 8 waves, one workgroup per CU (99 ms)
+    compact_variant<1024, 8, 3>(),   // 6: 8192-element tiles, 16 waves (97 ms)
+    compact_variant<1024, 4, 3>(),   // 7: 4096-element tiles, 16 waves (79-83 ms)
+    compact_variant<256, 12, 3>(),   // 8: 3072-element tiles, three workgroups per CU (86 ms)
 };
 static constexpr int kNumCompact = sizeof(kCompact) / sizeof(kCompact[0]);
+// 16-byte elements (13 .. 16 varying bytes): 4096-element tiles = 64 KiB of elements, two workgroups per CU
+static const CompactVariant kCompact16 = compact_variant<256, 16, 4>();
 int sort_num_compact_variants() { return kNumCompact; }
 static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
   return cfg.sort_compact >= 1 && cfg.sort_compact <= kNumCompact ? &kCompact[cfg.sort_compact - 1] : nullptr;
@@ -939,14 +969,17 @@ static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
 size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) {
   size_t need = sort_layout(n, pick_variant(cfg).tile).total;
   if (const CompactVariant* cv = pick_compact(cfg)) {
-    const size_t c = sort_layout(n, cv->tile).total;
-    if (c > need) need = c;
+    for (const CompactVariant* v : {cv, &kCompact16}) {
+      const size_t c = sort_layout(n, v->tile).total;
+      if (c > need) need = c;
+    }
   }
   return need;
 }
 
 // The plan of a set of records from its OR / AND words (one rank's census, or the words of all ranks combined): element byte j
-// = the j-th least significant varying byte of the key (index bytes first, barcode bytes last).
+// = the j-th least significant varying byte of the key (index bytes first, barcode bytes last).  Selectors are filled for the
+// first 16 varying bytes: k <= 12 fits 12-byte elements, k <= 16 the sort's 16-byte elements.
 void compact_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], CompactPlan* pl) {
   for (auto& row : pl->csel) for (uint32_t& v : row) v = 0x0C0C0C0Cu;   // selector 0x0C: a zero byte
   for (auto& row : pl->xsel) for (uint32_t& v : row) v = 0x0C0C0C0Cu;
@@ -959,11 +992,11 @@ void compact_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], 
     pl->base[f] = and_words[f];
     for (u32 b = 0; b < 8; ++b)
       if ((varying >> (8 * b)) & 255u) {
-        if (k < 12) {                                       // element byte k <- byte b of field f, and back
+        if (k < 16) {                                       // element byte k <- byte b of field f, and back
           uint32_t& cs = pl->csel[k >> 2][f];
           cs = (cs & ~(255u << (8 * (k & 3)))) | (b << (8 * (k & 3)));
-          uint32_t& xs = pl->xsel[2 * f + (b >> 2)][k < 8 ? 0 : 1];
-          xs = (xs & ~(255u << (8 * (b & 3)))) | ((k < 8 ? k : k - 8) << (8 * (b & 3)));
+          uint32_t& xs = pl->xsel[2 * f + (b >> 2)][k < 8 ? 0 : 1];   // element words (w1, w0) / (w3, w2)
+          xs = (xs & ~(255u << (8 * (b & 3)))) | ((k & 7u) << (8 * (b & 3)));
         }
         ++k;
         pl->base[f] &= ~(255ull << (8 * b));
@@ -978,65 +1011,74 @@ hipError_t launch_records_census(const LaunchCfg& cfg, const void* recs, size_t 
   if (n) launch_census(cfg, recs, n, (u64*)d_census, nullptr, st);
   return hipGetLastError();
 }
-// records -> 12-byte elements (pl.k <= 12).  Records that start at an odd record of a larger array (8- but not 16-byte
+// records -> elements of W words (pl.k <= 4 W).  Records that start at an odd record of a larger array (8- but not 16-byte
 // aligned) are PEELED like everywhere else (kcommon.hpp): one record through the per-record kernel brings the rest to a
 // 16-byte boundary for the tiled kernel (the elements need no more than their 4-byte alignment).
-static void launch_compress(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, u32 first_byte, Elem* out,
+template <int W>
+static void launch_compress(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, u32 first_byte, ElemT<W>* out,
                             uint8_t* digits, hipStream_t st, u64* census = nullptr) {   // census: 16-byte aligned records only
   const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? (n ? 1 : 0) : 0;
   const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
   if (head)
-    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(1), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)head, pl, first_byte, out, digits);
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail<W>, dim3(1), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)head, pl, first_byte, out, digits);
   if (main_rows) {
     static std::atomic<int> occ[2];
     const u32 nt = (u32)(main_rows / kTileRecs);
     const uint8_t* base = static_cast<const uint8_t*>(recs) + 24 * head;
     if (census)
-      hipLaunchKernelGGL(ibu_k_sort_compress<true>, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<true>, 0, &occ[1]))),
+      hipLaunchKernelGGL((ibu_k_sort_compress<true, W>), dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<true, W>, 0, &occ[1]))),
                          dim3(kBlock), 0, st, base, nt, pl, first_byte, out + head, digits ? digits + head : digits, census);
     else
-      hipLaunchKernelGGL(ibu_k_sort_compress<false>, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<false>, 0, &occ[0]))),
+      hipLaunchKernelGGL((ibu_k_sort_compress<false, W>), dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<false, W>, 0, &occ[0]))),
                          dim3(kBlock), 0, st, base, nt, pl, first_byte, out + head, digits ? digits + head : digits, (u64*)nullptr);
   }
   if (head + main_rows < n) {
-    hipLaunchKernelGGL(ibu_k_sort_compress_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const u64*)recs,
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail<W>, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const u64*)recs,
                        (u64)(head + main_rows), (u64)n, pl, first_byte, out, digits);
     if (census)   // the rest rows of the census (each row also against its predecessor)
       hipLaunchKernelGGL(ibu_k_sort_census_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const u64*)recs,
                          (u64)(head + main_rows), (u64)n, census, (u32*)nullptr);
   }
 }
+template <int W>
+static void launch_expand_w(const LaunchCfg& cfg, const CompactPlan& pl, const ElemT<W>* elems, size_t n, void* recs, hipStream_t st) {
+  const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 1 : 0;   // peeled: see launch_compress
+  const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
+  if (head)
+    hipLaunchKernelGGL(ibu_k_sort_expand_tail<W>, dim3(1), dim3(256), 0, st, elems, (u64)0, (u64)head, pl, (u64*)recs);
+  if (main_rows) {
+    static std::atomic<int> occ;
+    const u32 nsub = (u32)(main_rows / kTileRecs), nt = (nsub + kExpandSub - 1) / kExpandSub;
+    hipLaunchKernelGGL(ibu_k_sort_expand<W>, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_expand<W>, 0, &occ))), dim3(kBlock),
+                       0, st, elems + head, nt, nsub, pl, static_cast<uint8_t*>(recs) + 24 * head);
+  }
+  if (head + main_rows < n)
+    hipLaunchKernelGGL(ibu_k_sort_expand_tail<W>, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, elems, (u64)(head + main_rows),
+                       (u64)n, pl, (u64*)recs);
+}
 hipError_t launch_compact(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st) {
   (void)hipGetLastError();
   if (n == 0) return hipSuccess;
   if (pl.k > 12 || n >= (1ull << 38)) return hipErrorInvalidValue;
-  launch_compress(cfg, pl, recs, n, 0, static_cast<Elem*>(elems), nullptr, st);
+  launch_compress<3>(cfg, pl, recs, n, 0, static_cast<Elem*>(elems), nullptr, st);
   return hipGetLastError();
 }
 hipError_t launch_expand(const LaunchCfg& cfg, const CompactPlan& pl, const void* elems, size_t n, void* recs, hipStream_t st) {
   (void)hipGetLastError();
   if (n == 0) return hipSuccess;
   if (pl.k > 12 || n >= (1ull << 38)) return hipErrorInvalidValue;
-  const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? 1 : 0;   // peeled: see launch_compress
-  const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
-  if (head)
-    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(1), dim3(256), 0, st, (const Elem*)elems, (u64)0, (u64)head, pl, (u64*)recs);
-  if (main_rows) {
-    static std::atomic<int> occ;
-    const u32 nsub = (u32)(main_rows / kTileRecs), nt = (nsub + kExpandSub - 1) / kExpandSub;
-    hipLaunchKernelGGL(ibu_k_sort_expand, dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_expand, 0, &occ))), dim3(kBlock),
-                       0, st, static_cast<const Elem*>(elems) + head, nt, nsub, pl, static_cast<uint8_t*>(recs) + 24 * head);
-  }
-  if (head + main_rows < n)
-    hipLaunchKernelGGL(ibu_k_sort_expand_tail, dim3(tail_grid(n - head - main_rows)), dim3(256), 0, st, (const Elem*)elems,
-                       (u64)(head + main_rows), (u64)n, pl, (u64*)recs);
+  launch_expand_w<3>(cfg, pl, static_cast<const Elem*>(elems), n, recs, st);
   return hipGetLastError();
 }
 
-// The compact-key path of launch_sort_records (see "COMPACT-KEY passes" above).  first_elem_byte: the first element byte
-// that is sorted (the index bytes below it are carried only).
+// The compact-key path of launch_sort_records (see "COMPACT-KEY passes" above), W words per element.
 // passes[0 .. npass): the element bytes to sort by, ascending.  compressed: the elements (and the digit stream of
 // `digits_byte`) are already in place — the speculative path ran the compress pass itself.
+// W = 3: both element buffers live in tmp (12 n bytes each) and the last pass always writes the records.
+// W = 4: 16 n + 16 n bytes do not fit in tmp, so the second buffer is the head of the RECORD ARRAY (its contents are dead once
+//        the elements exist).  The last pass can write records into that array only while reading from tmp, i.e. when the
+//        pass count is odd; with an even count it stays an element pass (recs -> tmp) and an expand pass (tmp -> recs) follows.
+template <int W>
 static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
                                         const CompactPlan& pl, const u32* passes, u32 npass, hipStream_t st, bool compressed = false,
                                         u32 digits_byte = 0) {
@@ -1047,8 +1089,9 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
   uint16_t* counts = reinterpret_cast<uint16_t*>(sc + L.counts);
   u32* pos = reinterpret_cast<u32*>(sc + L.pos);
   uint8_t* digits = sc + L.digits;
-  Elem* src = static_cast<Elem*>(tmp);
-  Elem* dst = reinterpret_cast<Elem*>(static_cast<uint8_t*>(tmp) + 12 * n);
+  ElemT<W>* src = static_cast<ElemT<W>*>(tmp);
+  ElemT<W>* dst = W == 3 ? reinterpret_cast<ElemT<W>*>(static_cast<uint8_t*>(tmp) + 12 * n) : static_cast<ElemT<W>*>(recs);
+  const bool fuse_last = W == 3 || (npass & 1u);
 
   // every call, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive
   // several GPUs through several contexts (a few microseconds against a sort of milliseconds)
@@ -1059,9 +1102,9 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     e = hipFuncSetAttribute(cv.scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
   }
-  if (!compressed) launch_compress(cfg, pl, recs, n, passes[0], src, digits, st);
+  if (!compressed) launch_compress<W>(cfg, pl, recs, n, passes[0], src, digits, st);
   else if (digits_byte != passes[0])
-    hipLaunchKernelGGL(ibu_k_sort_digits, dim3((u32)cfg.cus * 8), dim3(256), 0, st, (const Elem*)src, (u64)n, passes[0], digits);
+    hipLaunchKernelGGL(ibu_k_sort_digits<W>, dim3((u32)cfg.cus * 8), dim3(256), 0, st, (const ElemT<W>*)src, (u64)n, passes[0], digits);
   // passes; the last one writes the records themselves
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
@@ -1073,17 +1116,18 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
     hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
                        (const u64*)blockoff, (const u64*)binbase, pos);
-    const bool last = pi + 1 == npass;
-    u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? b : passes[pi + 1];
-    const Elem* src_arg = src;
-    void* dst_arg = last ? recs : static_cast<void*>(dst);
+    const bool last = pi + 1 == npass, to_records = last && fuse_last;
+    u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? 4u * W : passes[pi + 1];   // 4 W: no digit stream behind the last pass
+    const ElemT<W>* src_arg = src;
+    void* dst_arg = to_records ? recs : static_cast<void*>(dst);
     const u32* pos_arg = pos;
     CompactPlan pl_arg = pl;
     void* args[] = {&src_arg, &dst_arg, &n_arg, &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
-    e = hipLaunchKernel(last ? cv.scatter_last : cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
+    e = hipLaunchKernel(to_records ? cv.scatter_last : cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
     if (e != hipSuccess) return e;
-    Elem* t = src; src = dst; dst = t;
+    ElemT<W>* t = src; src = dst; dst = t;
   }
+  if (!fuse_last) launch_expand_w<W>(cfg, pl, src, n, recs, st);   // W = 4, even pass count: the elements ended in tmp
   return hipGetLastError();
 }
 
@@ -1115,7 +1159,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   // 4-byte aligned.  Whether at most 12 key bytes vary is the census' to say.
   const CompactVariant* cv = pick_compact(cfg);
   const bool compact_ok = cv && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
-                          (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total;
+                          (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total &&
+                          scratch_bytes >= sort_layout(n, kCompact16.tile).total;
   hipError_t e;
   // SPECULATION (large inputs): the census and the compress pass both read all the records.  A census of three SAMPLE
   // ranges (first / middle / last 32 Ki records: tens of microseconds) guesses which bytes vary; the compress pass runs on
@@ -1138,13 +1183,14 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return e;
     compact_plan_init(reinterpret_cast<const uint64_t*>(g), reinterpret_cast<const uint64_t*>(g + 3), &gpl);
-    if (gpl.k >= 1 && gpl.k <= 12) {
+    if (gpl.k >= 1 && gpl.k <= 16) {                        // 12-byte elements, or 16-byte ones for 13 .. 16 varying bytes
       for (int f = 0; f < 3; ++f)
         for (u32 b = 0; b < 8; ++b)
           if (((g[f] ^ g[3 + f]) >> (8 * b)) & 255u) gmask[f] |= 255ull << (8 * b);
       gfirst = (g[6] == 0 && gpl.index_bytes < gpl.k) ? gpl.index_bytes : 0;   // the sample's guess of the first sorted byte
       hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
-      launch_compress(cfg, gpl, recs, n, gfirst, static_cast<Elem*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
+      if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
+      else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, kCompact16.tile).digits, st, census);
       speculated = true;
     }
   }
@@ -1176,7 +1222,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       if ((varying >> (8 * b)) & 255u) passes[npass++] = {(u32)f, 8 * b};   // constant digits: the pass would be the identity
   }
   if (compact_ok && npass > 0) {
-    u32 ebytes[12], ne = 0;
+    u32 ebytes[16], ne = 0;
     if (speculated) {
       bool covered = true;
       for (int f = 0; f < 3; ++f)
@@ -1195,19 +1241,23 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
             }
         }
         if (ne) {
-          if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact-speculated passes=%u first_digit_guess=%s\n", n, ne, gfirst == ebytes[0] ? "hit" : "miss");
-          return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst);
+          if (trace_sort())
+            fprintf(stderr, "ibu sort: n=%zu path=compact-speculated element_bytes=%d passes=%u first_digit_guess=%s\n", n, pl.k <= 12 ? 12 : 16, ne,
+                    gfirst == ebytes[0] ? "hit" : "miss");
+          return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst)
+                            : launch_compact_passes<4>(cfg, kCompact16, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst);
         }
       }
       if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu guess did not cover the varying bytes\n", n);
     }
     CompactPlan pl;
     compact_plan_init(reinterpret_cast<const uint64_t*>(c), reinterpret_cast<const uint64_t*>(c + 3), &pl);
-    if (pl.k <= 12) {
+    if (pl.k <= 16) {
       for (u32 j = c[6] == 0 ? pl.index_bytes : 0; j < pl.k; ++j) ebytes[ne++] = j;   // input in index order: the index bytes ride along unsorted
       if (ne) {
-        if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact passes=%u\n", n, ne);
-        return launch_compact_passes(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st);
+        if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact element_bytes=%d passes=%u\n", n, pl.k <= 12 ? 12 : 16, ne);
+        return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st)
+                          : launch_compact_passes<4>(cfg, kCompact16, recs, tmp, n, sc, pl, ebytes, ne, st);
       }
     }
   }

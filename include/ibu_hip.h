@@ -237,7 +237,8 @@ int32_t ibu_device_count(int32_t* n);
  *   "sort_variant"   0..7   tile shape / write-out mode of the radix passes (0 = default; the rest are A/B builds of the
  *                           same algorithm kept for measurement: ibu_amd/csrc/sort.hip, kSweep)
  *   "sort_compact"   0..8   compact-key passes of the sort: when at most 12 bytes of the 24-byte key vary (16/12 records
- *                           with indices below 2^32: 11) the passes move 12-byte elements instead of records.  0 = never
+ *                           with indices below 2^32: 11) the passes move 12-byte elements instead of records, when 13 .. 16
+ *                           vary, 16-byte elements.  0 = never
  *                           (24-byte passes only), 1 = default tile shape, 2..8 = A/B tile shapes (sort.hip, kCompact).
  *                           Same result either way, byte for byte.
  *   "sort_guess"     0 | 1 | k  large compact-key sorts read the records once instead of twice: a census of three sample ranges
@@ -331,8 +332,9 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
  * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch.  The context
  * additionally keeps (and grows on demand) about 1.75 B per record of its own scratch.  Any n the
  * device can hold (n < 2^40); synchronises `stream` once (a 64-byte census read-back picks the passes).
- * Stable LSD radix sort over the key bytes that vary; when at most 12 of them do (and n < 2^32, d_records 16-byte
- * aligned) the passes run on 12-byte compacted keys held in d_tmp (option "sort_compact"). */
+ * Stable LSD radix sort over the key bytes that vary; when at most 16 of them do (and n < 2^32, d_records 16-byte
+ * aligned) the passes run on 12- or 16-byte compacted keys held in d_tmp (and, for 16-byte keys, in the head of
+ * d_records) (option "sort_compact"). */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
 /* Per-barcode aggregation of SORTED device records: the device form of the reference's BarcodeAnalyzer
  * processor (src/parallel.rs:72-98 — HashMap<barcode, count> merged in on_batch_complete).  Writes, in
@@ -369,7 +371,7 @@ int32_t ibu_lower_bound_records(ibu_ctx_t* ctx, const void* d_sorted_records, si
  * ibu_records_compact: n records -> n elements (12 n bytes at d_elems, 4-byte aligned).  ibu_records_expand: the inverse.
  *   Asynchronous on `stream`; record arrays that are 8- but not 16-byte aligned (a shard at an odd record) peel one record. */
 typedef struct ibu_key_plan {
-  uint32_t csel[3][3]; /* byte-gather selectors, records -> elements (v_perm_b32) */
+  uint32_t csel[4][3]; /* byte-gather selectors, records -> elements (v_perm_b32); row 3: the sort's 16-byte elements */
   uint32_t xsel[6][2]; /* elements -> records */
   uint32_t k;          /* varying bytes */
   uint32_t index_bytes; /* how many of them belong to the index (the least significant element bytes) */

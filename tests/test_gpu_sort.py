@@ -94,24 +94,26 @@ def ctx_guess(ia):
 
 
 @pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003])
-@pytest.mark.parametrize("case", ["random_index", "index_order", "guess_misses_a_barcode_byte", "guess_misses_an_index_byte",
+@pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 10-11 varying bytes: 12-byte elements; 14-15: 16-byte elements
+@pytest.mark.parametrize("case", ["random_index", "index_order", "guess_misses_a_umi_byte", "guess_misses_an_index_byte",
                                   "index_order_broken_outside_the_samples", "already_sorted", "one_umi_byte_constant_in_the_samples"])
-def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, case, capfd):
+def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd):
     """The speculative path: the samples are the first, the middle and the last 32 768 records.  Whatever the samples
     suggest, the result is the oracle's — a guess that does not cover the truth is detected by the exact census."""
-    recs = _shuffled(oracle, n, 16, 12)
+    from tests import keyplan_np as kp
+    recs = _shuffled(oracle, n, *lens)
     rng = np.random.default_rng(n)
     quarter = n // 4 + 7                                   # a row no sample range contains
-    assert 32_768 < quarter < n // 2 - 1 or n < 140_000
     if n < 140_000:
         quarter = 32_768 + (n // 2 - 32_768) // 2          # between the first and the middle sample
+    assert 32_768 <= quarter < n // 2 - 1
     if case == "random_index":
         recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
     elif case == "index_order":
         recs["index"] = np.arange(n, dtype=np.uint64)
-    elif case == "guess_misses_a_barcode_byte":
+    elif case == "guess_misses_a_umi_byte":
         recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
-        recs["barcode"][quarter] |= np.uint64(1) << np.uint64(61)       # byte 7 of the barcode varies in ONE record
+        recs["umi"][quarter] |= np.uint64(1) << np.uint64(44)           # byte 5 of the UMI varies in ONE record
     elif case == "guess_misses_an_index_byte":
         recs["index"] = rng.integers(0, 2**16, n, dtype=np.uint64)
         recs["index"][quarter] = 2**40 + 5
@@ -131,22 +133,27 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, case, capfd):
     capfd.readouterr()
     assert _sort_on_device(ctx_guess, recs)[0] == want
     trace = capfd.readouterr().err                         # IBU_TRACE_SORT=1 (conftest): which path the library took
-    expect = {"random_index": "path=compact-speculated passes=11 first_digit_guess=hit",
-              "index_order": "path=compact-speculated passes=7 first_digit_guess=hit",
-              "guess_misses_a_barcode_byte": "guess did not cover",
+    k = kp.Plan(*kp.census_words(recs)).k                  # varying key bytes of the whole input
+    width = 12 if k <= 12 else 16
+    expect = {"random_index": f"path=compact-speculated element_bytes={width} passes={k} first_digit_guess=hit",
+              "index_order": f"path=compact-speculated element_bytes={width}",
+              "guess_misses_a_umi_byte": "guess did not cover",
               "guess_misses_an_index_byte": "guess did not cover",
               "index_order_broken_outside_the_samples": "first_digit_guess=miss",
               "already_sorted": "already sorted (a speculative compress pass was spent)",
               "one_umi_byte_constant_in_the_samples": "guess did not cover"}[case]
     assert expect in trace, trace
+    if "did not cover" in expect:                          # ... and the sort went on from the exact census
+        assert (f"path=compact element_bytes={12 if k <= 12 else 16}" if k <= 16 else "path=24-byte") in trace, trace
     assert _sort_on_device(ctx24, recs)[0] == want
 
 
 @pytest.mark.parametrize("n", [2, 129, 5000, 300_007])
-@pytest.mark.parametrize("nbytes", [1, 5, 11, 12, 13, 24])
+@pytest.mark.parametrize("nbytes", [1, 5, 11, 12, 13, 14, 16, 17, 24])
 def test_sort_with_scattered_varying_bytes(ctx, oracle, ia, n, nbytes):
     """The compact-key path gathers whichever bytes vary — not only the low bytes of each field — and carries the constant
-    ones through the census' AND words; 12 varying bytes still fit an element, 13 take the 24-byte passes."""
+    ones through the census' AND words; 12 varying bytes still fit a 12-byte element, 13 .. 16 a 16-byte one (whose second
+    buffer is the record array itself: odd and even pass counts end differently), 17 take the 24-byte passes."""
     rng = np.random.default_rng(nbytes * 1000 + n)
     which = np.sort(rng.permutation(24)[:nbytes])          # byte positions of the record that vary
     raw = np.tile(rng.integers(0, 256, 24, dtype=np.uint8), (n, 1))   # every other byte: the same value in all records

@@ -367,7 +367,7 @@ extern "C" int32_t ibu_records_census(ibu_ctx_t* ctx, const void* d_records, siz
   if (rc) return rc;
   if (!out) return err_arg("out is NULL");
   if (n && (!d_records || !aligned8(d_records))) return err_arg("d_records must be non-NULL and 8-byte aligned");
-  rc = ensure_sort_scratch(ctx, 256);
+  rc = ensure_sort_scratch(ctx, 4096);   // the census slots (sort.hip: kCensusBytes)
   if (rc) return rc;
   hipStream_t st = pick_stream(ctx, stream);
   uint64_t* d_c = static_cast<uint64_t*>(ctx->d_sort_scratch);

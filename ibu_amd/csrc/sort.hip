@@ -41,6 +41,8 @@ __device__ __forceinline__ bool rec_less(u64 b, u64 u, u64 x, u64 pb, u64 pu, u6
 // records in its LDS slice with three coalesced dwordx4 loads, lane L then owns records 2L and 2L+1 and reads record
 // 2L-1 from the slice as well (lane 0: one 24-byte global load of the record before the tile).
 // =====================================================================================================
+static constexpr int kCensusSlots = 64;                       // power of two
+static constexpr size_t kCensusBytes = (size_t)kCensusSlots * 8 * sizeof(u64);   // 4 KiB at the head of the sort scratch
 struct CensusAcc {
   u64 o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
   bool index_drops = false, order_drops = false;
@@ -49,11 +51,15 @@ struct CensusAcc {
     if (x < px) index_drops = true;                       // input not in index order: the index passes are needed
     if (rec_less(b, u, x, pb, pu, px)) order_drops = true;  // not already sorted
   }
-  // c == nullptr: only the order flag is wanted (ibu_is_sorted); flag32 != nullptr receives it
+  // c == nullptr: only the order flag is wanted (ibu_is_sorted); flag32 != nullptr receives it.
+  // c: kCensusSlots x 8 words; a workgroup adds into slot blockIdx % kCensusSlots and ibu_k_sort_census_fold folds the slots
+  // into slot 0 afterwards.  (With ONE slot the ~43 000 same-address atomics of a resident grid's waves took 0.5 ms — more
+  // than the census of a million records itself.)
   __device__ __forceinline__ void flush(u64* c, u32* flag32) {
     const u32 lane = threadIdx.x & (kWave - 1);
     if (flag32 && __ballot(order_drops) && lane == 0) atomicOr(flag32, 1u);
     if (!c) return;
+    c += 8 * (blockIdx.x & (kCensusSlots - 1));
     if (__ballot(index_drops) && lane == 0) atomicOr(&c[6], 1ull);
     if (__ballot(order_drops) && lane == 0) atomicOr(&c[7], 1ull);
 #pragma unroll
@@ -66,10 +72,26 @@ struct CensusAcc {
   }
 };
 
-extern "C" __global__ void ibu_k_sort_census_init(u64* c) {
-  if (threadIdx.x < 3) c[threadIdx.x] = 0;
-  else if (threadIdx.x < 6) c[threadIdx.x] = ~0ull;
-  else if (threadIdx.x < 8) c[threadIdx.x] = 0;  // [6]: some index smaller than its predecessor's; [7]: some record smaller
+extern "C" __global__ void ibu_k_sort_census_init(u64* c) {   // one block of kCensusSlots * 8 threads
+  const u32 w = threadIdx.x & 7u;
+  c[threadIdx.x] = (w >= 3 && w < 6) ? ~0ull : 0;            // [0..2] OR, [3..5] AND, [6]: some index smaller than its predecessor's; [7]: some record smaller
+}
+// slots -> slot 0 (one wave: lane = slot)
+extern "C" __global__ void ibu_k_sort_census_fold(u64* c) {
+  const u32 lane = threadIdx.x;
+  u64 v[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) v[w] = c[8 * lane + w];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const u64 o = shfl_xor64(v[w], m);
+      v[w] = (w >= 3 && w < 6) ? (v[w] & o) : (v[w] | o);
+    }
+  if (lane == 0)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) c[w] = v[w];
 }
 // recs0: row 0 of the caller's array (8-B aligned); the tiles start at row `row0` (16-B aligned there).
 extern "C" __global__ void __launch_bounds__(kBlock, 8)
@@ -867,7 +889,7 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
 
 // =====================================================================================================
 // Host side.  Scratch layout (bytes), all offsets 256-byte aligned:
-//   census u64[8] | binbase u64[256] | blocksum u32[nblocks][256] | blockoff u64[nblocks][256] | counts u16[ntiles][256]
+//   census u64[64][8] | binbase u64[256] | blocksum u32[nblocks][256] | blockoff u64[nblocks][256] | counts u16[ntiles][256]
 //   | pos IDX[ntiles][256] | digits u8[ntiles * T]
 struct SortLayout {
   size_t binbase, blocksum, blockoff, counts, pos, digits, total;
@@ -881,7 +903,7 @@ static SortLayout sort_layout(size_t n, int tile) {
   L.nblocks = (u32)((nt + kTilesPerBlock - 1) / kTilesPerBlock);
   L.idx64 = n >= (1ull << 32);
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  size_t o = 256;
+  size_t o = kCensusBytes;                                   // the census slots sit in front
   L.binbase = o; o = up(o + 8 * kBins);
   L.blocksum = o; o = up(o + 4 * (size_t)L.nblocks * kBins);
   L.blockoff = o; o = up(o + 8 * (size_t)L.nblocks * kBins);
@@ -1007,8 +1029,9 @@ void compact_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], 
 }
 hipError_t launch_records_census(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* d_census, hipStream_t st) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, (u64*)d_census);
+  hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, (u64*)d_census);
   if (n) launch_census(cfg, recs, n, (u64*)d_census, nullptr, st);
+  hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, (u64*)d_census);
   return hipGetLastError();
 }
 // records -> elements of W words (pl.k <= 4 W).  Records that start at an odd record of a larger array (8- but not 16-byte
@@ -1175,9 +1198,10 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   // cfg.sort_guess: 0 = never, 1 = inputs of 2^23 records and more, k > 1 = inputs of k records and more (a test knob)
   const size_t guess_min = cfg.sort_guess == 1 ? (size_t)1 << 23 : ((size_t)cfg.sort_guess > 4 * kSample ? (size_t)cfg.sort_guess : 4 * kSample);
   if (compact_ok && cfg.sort_guess && n >= guess_min) {
-    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
+    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
     const size_t starts[3] = {0, (n / 2) & ~(size_t)1, (n - kSample) & ~(size_t)1};   // even rows: 16-byte aligned
     for (size_t s0 : starts) launch_census(cfg, static_cast<const u64*>(recs) + 3 * s0, kSample, census, nullptr, st);
+    hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, census);
     e = hipMemcpyAsync(g, census, sizeof g, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(st);
@@ -1188,16 +1212,17 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         for (u32 b = 0; b < 8; ++b)
           if (((g[f] ^ g[3 + f]) >> (8 * b)) & 255u) gmask[f] |= 255ull << (8 * b);
       gfirst = (g[6] == 0 && gpl.index_bytes < gpl.k) ? gpl.index_bytes : 0;   // the sample's guess of the first sorted byte
-      hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
+      hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
       if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
       else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, kCompact16.tile).digits, st, census);
       speculated = true;
     }
   }
   if (!speculated) {
-    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(64), 0, st, census);
+    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
     launch_census(cfg, recs, n, census, nullptr, st);
   }
+  hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, census);
   u64 c[8];
   e = hipMemcpyAsync(c, census, sizeof c, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;

@@ -61,10 +61,10 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 2 * sizeof(uint64_t));
-  if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_acc), 8 * sizeof(uint64_t));
+  if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_acc), kReduceAccBytes);
   if (rc == hipSuccess) rc = hipMalloc(reinterpret_cast<void**>(&ctx->d_flag), 16);
   if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 16 * sizeof(uint64_t), hipHostMallocDefault);
-  if (rc == hipSuccess) rc = hipMemsetAsync(ctx->d_acc, 0, 8 * sizeof(uint64_t), ctx->stream);
+  if (rc == hipSuccess) rc = hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream);
   if (rc == hipSuccess) rc = launch_fill2(ctx->d_status, ~0ull, 0, ctx->stream);
   if (rc == hipSuccess) rc = hipStreamSynchronize(ctx->stream);
   if (rc != hipSuccess) {
@@ -253,7 +253,7 @@ extern "C" int32_t ibu_codec_status(ibu_ctx_t* ctx, void* stream, uint64_t* firs
 extern "C" int32_t ibu_reduce_reset(ibu_ctx_t* ctx, void* stream) {
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;
-  IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, 8 * sizeof(uint64_t), pick_stream(ctx, stream)));
+  IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, pick_stream(ctx, stream)));
   return IBU_OK;
 }
 extern "C" int32_t ibu_reduce(ibu_ctx_t* ctx, const void* d_records, size_t n, void* stream) {
@@ -269,6 +269,7 @@ extern "C" int32_t ibu_reduce_fetch(ibu_ctx_t* ctx, void* stream, ibu_reduce_res
   if (rc) return rc;
   if (!out) return err_arg("out is NULL");
   hipStream_t st = pick_stream(ctx, stream);
+  IBU_HIP(launch_reduce_fold(ctx->d_acc, st));
   IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_acc, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   IBU_HIP(hipStreamSynchronize(st));
   out->count = ctx->h_pinned[0];

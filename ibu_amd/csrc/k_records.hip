@@ -162,12 +162,15 @@ ibu_k_reduce(const uint8_t* __restrict__ recs, u32 ntiles, u64 n_total, u64* __r
 #pragma unroll
     for (int g = 0; g < 3; ++g) { part[wib][g] = S[g]; part[wib][3 + g] = X[g]; }
   __syncthreads();
+  // acc: kReduceSlots x 8 words; a workgroup adds into slot blockIdx % kReduceSlots, ibu_k_reduce_fold folds them at fetch
+  // time (one slot: ~1800 same-address atomics per word at the end of a resident grid, ~0.1 ms — most of a small batch)
+  u64* slot = acc + 8 * (blockIdx.x & (kReduceSlots - 1));
   if (threadIdx.x < 6) {
     u64 v = part[0][threadIdx.x];
     for (int w = 1; w < kWavesPerBlock; ++w)
       v = threadIdx.x < 3 ? v + part[w][threadIdx.x] : v ^ part[w][threadIdx.x];
-    if (threadIdx.x < 3) { if (v) atomicAdd(&acc[1 + threadIdx.x], v); }
-    else                 { if (v) atomicXor(&acc[1 + threadIdx.x], v); }
+    if (threadIdx.x < 3) { if (v) atomicAdd(&slot[1 + threadIdx.x], v); }
+    else                 { if (v) atomicXor(&slot[1 + threadIdx.x], v); }
   }
   if (blockIdx.x == 0 && threadIdx.x == 6) atomicAdd(&acc[0], n_total);
 }
@@ -304,12 +307,35 @@ extern "C" __global__ void ibu_k_reduce_tail(const u64* __restrict__ recs, u64 r
   for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
     for (int g = 0; g < 3; ++g) { S[g] += shfl_xor_u64(S[g], m); X[g] ^= shfl_xor_u64(X[g], m); }
-  if ((threadIdx.x & (kWave - 1)) == 0)
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    u64* slot = acc + 8 * (blockIdx.x & (kReduceSlots - 1));
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-      if (S[g]) atomicAdd(&acc[1 + g], S[g]);
-      if (X[g]) atomicXor(&acc[4 + g], X[g]);
+      if (S[g]) atomicAdd(&slot[1 + g], S[g]);
+      if (X[g]) atomicXor(&slot[4 + g], X[g]);
     }
+  }
+}
+// slots -> slot 0, the other slots cleared (so that further ibu_reduce calls keep accumulating): one wave, lane = slot
+extern "C" __global__ void ibu_k_reduce_fold(u64* acc) {
+  const u32 lane = threadIdx.x;
+  u64 v[7];
+#pragma unroll
+  for (int w = 0; w < 7; ++w) v[w] = acc[8 * lane + w];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int w = 0; w < 7; ++w) {
+      const u64 o = shfl_xor_u64(v[w], m);
+      v[w] = w < 4 ? v[w] + o : v[w] ^ o;
+    }
+#pragma unroll
+  for (int w = 0; w < 7; ++w) acc[8 * lane + w] = lane == 0 ? v[w] : 0;
+}
+hipError_t launch_reduce_fold(uint64_t* acc, hipStream_t st) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ibu_k_reduce_fold, dim3(1), dim3(kReduceSlots), 0, st, (u64*)acc);
+  return hipGetLastError();
 }
 extern "C" __global__ void ibu_k_fill_u64(u64* p, u64 v0, u64 v1) { p[0] = v0; p[1] = v1; }
 

@@ -50,7 +50,10 @@ hipError_t launch_unpack(const LaunchCfg&, const uint64_t* codes, size_t n, uint
                          hipStream_t st);
 hipError_t launch_pack(const LaunchCfg&, const uint8_t* in, size_t n, uint32_t len, uint64_t* codes,
                        uint64_t* status, hipStream_t st);
+static constexpr int kReduceSlots = 64;   // acc: kReduceSlots x 8 u64 (slot 0 after launch_reduce_fold: count, 3 sums, 3 XORs)
+static constexpr size_t kReduceAccBytes = (size_t)kReduceSlots * 8 * sizeof(uint64_t);
 hipError_t launch_reduce(const LaunchCfg&, const void* recs, size_t n, uint64_t* acc, hipStream_t st);
+hipError_t launch_reduce_fold(uint64_t* acc, hipStream_t st);
 hipError_t launch_generate(const LaunchCfg&, uint64_t seed, uint64_t first, size_t n, uint32_t bc_len,
                            uint32_t umi_len, void* recs, hipStream_t st);
 hipError_t launch_copy(const LaunchCfg&, const void* src, void* dst, size_t bytes, hipStream_t st);

@@ -335,7 +335,7 @@ extern "C" int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
   KernelClock kc;
   rc = kc.init(r.slots);
   if (rc) return rc;
-  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, 8 * sizeof(uint64_t), ctx->stream));
+  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream));
   const size_t slot_records = r.slot_bytes / IBU_RECORD_SIZE;
   const uint8_t* base = static_cast<const uint8_t*>(ibu_mmap_base(m)) + IBU_HEADER_SIZE;
   size_t k = 0;
@@ -382,7 +382,7 @@ extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, c
   KernelClock kc;
   rc = kc.init(r.slots);
   if (rc) return rc;
-  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, 8 * sizeof(uint64_t), ctx->stream));
+  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream));
   const size_t slot_records = r.slot_bytes / IBU_RECORD_SIZE;
   size_t total = 0, k = 0;
   bool eof = false;

@@ -486,6 +486,25 @@ pub mod device {
             check(unsafe { ffi::ibu_records_first_mismatch(self.raw, a.ptr, b.ptr, n, &mut f, std::ptr::null_mut()) })?;
             Ok(f as usize)
         }
+        /// OR / AND census of n device records: `[or; 3], [and; 3], index_drops, order_drops` (ibu_records_census).
+        pub fn census(&self, recs: &DeviceBuf, n: usize) -> Result<[u64; 8]> {
+            let mut c = [0u64; 8];
+            check(unsafe { ffi::ibu_records_census(self.raw, recs.ptr, n, c.as_mut_ptr(), std::ptr::null_mut()) })?;
+            Ok(c)
+        }
+        /// Plan of the compacted keys for records with these OR / AND words (ibu_key_plan_init); `plan.k` = varying bytes.
+        pub fn key_plan(or_words: &[u64; 3], and_words: &[u64; 3]) -> Result<ffi::ibu_key_plan_t> {
+            let mut p = std::mem::MaybeUninit::<ffi::ibu_key_plan_t>::uninit();
+            check(unsafe { ffi::ibu_key_plan_init(or_words.as_ptr(), and_words.as_ptr(), p.as_mut_ptr()) })?;
+            Ok(unsafe { p.assume_init() })
+        }
+        /// n records -> n 12-byte elements (plan.k <= 12) and back: the exchange format of the multi-GPU sort.
+        pub fn compact(&self, plan: &ffi::ibu_key_plan_t, recs: &DeviceBuf, n: usize, elems: &DeviceBuf) -> Result<()> {
+            check(unsafe { ffi::ibu_records_compact(self.raw, plan, recs.ptr, n, elems.ptr, std::ptr::null_mut()) })
+        }
+        pub fn expand(&self, plan: &ffi::ibu_key_plan_t, elems: &DeviceBuf, n: usize, recs: &DeviceBuf) -> Result<()> {
+            check(unsafe { ffi::ibu_records_expand(self.raw, plan, elems.ptr, n, recs.ptr, std::ptr::null_mut()) })
+        }
         pub fn is_sorted(&self, recs: &DeviceBuf, n: usize) -> Result<bool> {
             let mut s = 0i32;
             check(unsafe { ffi::ibu_is_sorted(self.raw, recs.ptr, n, std::ptr::null_mut(), &mut s) })?;

@@ -983,8 +983,17 @@ static const CompactVariant kCompact[] = {   // 12-byte elements
     compact_variant<256, 12, 3>(),   // 8: 3072-element tiles, three workgroups per CU (86 ms)
 };
 static constexpr int kNumCompact = sizeof(kCompact) / sizeof(kCompact[0]);
-// 16-byte elements (13 .. 16 varying bytes): 4096-element tiles = 64 KiB of elements, two workgroups per CU
-static const CompactVariant kCompact16 = compact_variant<256, 16, 4>();
+// 16-byte elements (13 .. 16 varying bytes); shape = kCompact16[sort_compact - 1] where there is one, the first otherwise
+static const CompactVariant kCompact16s[] = {
+    compact_variant<256, 16, 4>(),   // 4096-element tiles = 64 KiB of elements, two workgroups per CU
+    compact_variant<256, 12, 4>(),   // 3072-element tiles
+    compact_variant<512, 8, 4>(),    // 4096-element tiles, 8 waves
+    compact_variant<256, 8, 4>(),    // 2048-element tiles, four workgroups per CU
+};
+static constexpr int kNumCompact16 = sizeof(kCompact16s) / sizeof(kCompact16s[0]);
+static const CompactVariant& pick_compact16(const LaunchCfg& cfg) {
+  return kCompact16s[cfg.sort_compact >= 1 && cfg.sort_compact <= kNumCompact16 ? cfg.sort_compact - 1 : 0];
+}
 int sort_num_compact_variants() { return kNumCompact; }
 static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
   return cfg.sort_compact >= 1 && cfg.sort_compact <= kNumCompact ? &kCompact[cfg.sort_compact - 1] : nullptr;
@@ -993,7 +1002,7 @@ static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
 size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) {
   size_t need = sort_layout(n, pick_variant(cfg).tile).total;
   if (const CompactVariant* cv = pick_compact(cfg)) {
-    for (const CompactVariant* v : {cv, &kCompact16}) {
+    for (const CompactVariant* v : {cv, &kCompact16s[0], &kCompact16s[1], &kCompact16s[2], &kCompact16s[3]}) {
       const size_t c = sort_layout(n, v->tile).total;
       if (c > need) need = c;
     }
@@ -1185,7 +1194,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   const CompactVariant* cv = pick_compact(cfg);
   const bool compact_ok = cv && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
                           (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total &&
-                          scratch_bytes >= sort_layout(n, kCompact16.tile).total;
+                          scratch_bytes >= sort_layout(n, pick_compact16(cfg).tile).total;
   hipError_t e;
   // SPECULATION (large inputs): the census and the compress pass both read all the records.  A census of three SAMPLE
   // ranges (first / middle / last 32 Ki records: tens of microseconds) guesses which bytes vary; the compress pass runs on
@@ -1216,7 +1225,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       gfirst = (g[6] == 0 && gpl.index_bytes < gpl.k) ? gpl.index_bytes : 0;   // the sample's guess of the first sorted byte
       hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
       if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
-      else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, kCompact16.tile).digits, st, census);
+      else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, pick_compact16(cfg).tile).digits, st, census);
       speculated = true;
     }
   }
@@ -1272,7 +1281,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
             fprintf(stderr, "ibu sort: n=%zu path=compact-speculated element_bytes=%d passes=%u first_digit_guess=%s\n", n, pl.k <= 12 ? 12 : 16, ne,
                     gfirst == ebytes[0] ? "hit" : "miss");
           return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst)
-                            : launch_compact_passes<4>(cfg, kCompact16, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst);
+                            : launch_compact_passes<4>(cfg, pick_compact16(cfg), recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst);
         }
       }
       if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu guess did not cover the varying bytes\n", n);
@@ -1284,7 +1293,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       if (ne) {
         if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact element_bytes=%d passes=%u\n", n, pl.k <= 12 ? 12 : 16, ne);
         return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st)
-                          : launch_compact_passes<4>(cfg, kCompact16, recs, tmp, n, sc, pl, ebytes, ne, st);
+                          : launch_compact_passes<4>(cfg, pick_compact16(cfg), recs, tmp, n, sc, pl, ebytes, ne, st);
       }
     }
   }

@@ -77,6 +77,8 @@ def test_sort_compact_tile_shapes(ia, oracle, compact):
             recs = _shuffled(oracle, n, 16, 12)
             recs["index"] = np.random.default_rng(n).integers(0, 2**30, n, dtype=np.uint64)
             assert _sort_on_device(c, recs)[0] == oracle.sort_records(recs).tobytes(), (compact, n)
+        wide = _shuffled(oracle, 70_001, 32, 12)           # 8 + 3 + 3 varying bytes: the 16-byte element shapes (1 .. 4)
+        assert _sort_on_device(c, wide)[0] == oracle.sort_records(wide).tobytes(), compact
         with pytest.raises(ia.IbuError):
             c.set_option("sort_compact", 99)
     finally:

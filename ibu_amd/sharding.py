@@ -1,6 +1,7 @@
 """Multi-GPU sharding of a record stream: one process per GPU, contiguous record ranges, no
 data-path collective for the codec / reduce path; the distributed SORT at the bottom of this module is the one
-operation with a real exchange step (one all-to-all of the records over RCCL / xGMI).
+operation with a real exchange step (one bulk exchange of the records — as 12-byte compacted keys where the keys allow — over
+RCCL / xGMI).
 
 The partition is the reference's static split (src/io/mmap.rs:297-307: `per = len / n`, the
 remainder goes to the LAST shard), applied to ranks instead of OS threads.  Outputs concatenate in
@@ -57,7 +58,7 @@ def expected_index_sum(n_global):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Distributed sort by (barcode, umi, index) across ranks: sample sort.  The ONE place on this path with a real
-# exchange step, so the one place RCCL moves bulk data: an all-to-all of the records over xGMI (every GPU ships
+# exchange step, so the one place RCCL moves bulk data: an all-to-all exchange of the records over xGMI (every GPU ships
 # about (W-1)/W of its shard; point-to-point links, so all 7 are busy at once).
 #
 #   1. every rank sorts its shard locally (ibu_sort_records, on torch's current stream)

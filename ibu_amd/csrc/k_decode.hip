@@ -67,8 +67,17 @@ __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs<dec_nt<
 // (len % 4 != 0) and generic kernels would spill there, so they get 168 (3 waves/SIMD).  72 VGPRs
 // (7 waves/SIMD) measured as fast as 64 (8) for the streaming kernels (profiles/r01_b sweep).
 // (NT = 2 holds twice the tile registers: 5 waves/SIMD.)
+// (Round 3: the code objects' metadata showed five instantiations with scratch under those budgets — (12,12), (12,32), (32,12)
+// at NT = 2, whose length-12 gathers hold more addresses than the dword reads of 16 / 32, and (10,10) both orders;
+// tools/kernel_resources.py, now a CPU test.  They get one wave per SIMD less.)
 template <int BC, int UM, bool MSB>
-__global__ void __launch_bounds__(kBlock, (dword_len(BC) && dword_len(UM)) ? (dec_nt<BC, UM>() > 1 ? 5 : 7) - (MSB ? 1 : 0) : 3)
+constexpr int dec_waves() {
+  if (!(dword_len(BC) && dword_len(UM))) return (BC == 10 && UM == 10) ? 2 : 3;
+  if (dec_nt<BC, UM>() > 1) return (BC == 12 || UM == 12) ? 4 : (MSB ? 4 : 5);
+  return MSB ? 6 : 7;
+}
+template <int BC, int UM, bool MSB>
+__global__ void __launch_bounds__(kBlock, (dec_waves<BC, UM, MSB>()))
 ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
              uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
   constexpr int kDecBytes = kTileBytes * dec_nt<BC, UM>();

@@ -43,10 +43,15 @@ __device__ __forceinline__ bool rec_less(u64 b, u64 u, u64 x, u64 pb, u64 pu, u6
 // =====================================================================================================
 static constexpr int kCensusSlots = 64;                       // power of two
 static constexpr size_t kCensusBytes = (size_t)kCensusSlots * 8 * sizeof(u64);   // 4 KiB at the head of the sort scratch
+// Register diet (round 3): the accumulator keeps ONE word per field, d |= x ^ ref, where `ref` is a wave-uniform record that
+// is itself part of the launch's rows (the first one: scalar loads, SGPRs).  OR = ref | d and AND = ref & ~d hold exactly for
+// any set of rows that contains ref, and the per-wave words (ref | d_w, ref & ~d_w) merge to exactly that under the atomics
+// below — so three u64 per lane do the work of six.  (With six, ibu_k_sort_compress<true, W> spilled 36 / 72 bytes per lane
+// under its 64-VGPR budget and wrote 20.3 B/record instead of 13: profiles/r02_ar_pmc_WRITE_SIZE_sort_1e9.csv.)
 struct CensusAcc {
-  u64 o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
+  u64 d[3] = {0, 0, 0};
   bool index_drops = false, order_drops = false;
-  __device__ __forceinline__ void rec(u64 b, u64 u, u64 x) { o[0] |= b; o[1] |= u; o[2] |= x; a[0] &= b; a[1] &= u; a[2] &= x; }
+  __device__ __forceinline__ void rec(u64 b, u64 u, u64 x, const u64 (&ref)[3]) { d[0] |= b ^ ref[0]; d[1] |= u ^ ref[1]; d[2] |= x ^ ref[2]; }
   __device__ __forceinline__ void pair(u64 pb, u64 pu, u64 px, u64 b, u64 u, u64 x) {
     if (x < px) index_drops = true;                       // input not in index order: the index passes are needed
     if (rec_less(b, u, x, pb, pu, px)) order_drops = true;  // not already sorted
@@ -55,22 +60,23 @@ struct CensusAcc {
   // c: kCensusSlots x 8 words; a workgroup adds into slot blockIdx % kCensusSlots and ibu_k_sort_census_fold folds the slots
   // into slot 0 afterwards.  (With ONE slot the ~43 000 same-address atomics of a resident grid's waves took 0.5 ms — more
   // than the census of a million records itself.)
-  __device__ __forceinline__ void flush(u64* c, u32* flag32) {
+  // any_rows: wave-uniform, false for a wave that saw no row (its ref is not part of anything: it must add nothing).
+  __device__ __forceinline__ void flush(u64* c, u32* flag32, const u64 (&ref)[3], bool any_rows) {
     const u32 lane = threadIdx.x & (kWave - 1);
     // (the flag only ever goes 0 -> 1: a wave that already sees it set has nothing to add — on unsorted input that spares
     // thousands of same-address atomics, ~80 us of a resident grid's tail)
     if (flag32 && __ballot(order_drops) && lane == 0 && *reinterpret_cast<volatile u32*>(flag32) == 0) atomicOr(flag32, 1u);
-    if (!c) return;
+    if (!c || !any_rows) return;
     c += 8 * (blockIdx.x & (kCensusSlots - 1));
     if (__ballot(index_drops) && lane == 0) atomicOr(&c[6], 1ull);
     if (__ballot(order_drops) && lane == 0) atomicOr(&c[7], 1ull);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-      for (int f = 0; f < 3; ++f) { o[f] |= shfl_xor64(o[f], m); a[f] &= shfl_xor64(a[f], m); }
+      for (int f = 0; f < 3; ++f) d[f] |= shfl_xor64(d[f], m);
     if (lane == 0)
 #pragma unroll
-      for (int f = 0; f < 3; ++f) { atomicOr(&c[f], o[f]); atomicAnd(&c[3 + f], a[f]); }
+      for (int f = 0; f < 3; ++f) { atomicOr(&c[f], ref[f] | d[f]); atomicAnd(&c[3 + f], ref[f] & ~d[f]); }
   }
 };
 
@@ -104,8 +110,11 @@ ibu_k_sort_census(const u64* __restrict__ recs0, u64 row0, u32 ntiles, u64* __re
   uint8_t* tile = lds + wib * kTileBytes;
   const u32 nwaves = gridDim.x * kWavesPerBlock;
   const uint8_t* base = reinterpret_cast<const uint8_t*>(recs0 + 3 * row0);
+  const u64* rp = recs0 + 3 * row0;                         // ntiles >= 1: the first tiled row is a row of this launch
+  const u64 ref[3] = {rp[0], rp[1], rp[2]};                 // uniform address: scalar loads
   CensusAcc acc;
   u32 t = logical_block() * kWavesPerBlock + wib;
+  const bool any_rows = t < ntiles;
   if (t < ntiles) {
     const uint8_t* src = base + (size_t)t * kTileBytes + 16 * lane;
     u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
@@ -127,8 +136,8 @@ ibu_k_sort_census(const u64* __restrict__ recs0, u64 row0, u32 ntiles, u64* __re
       const u64* r = reinterpret_cast<const u64*>(tile + (2 * lane) * 24);  // records 2L, 2L+1 (and 2L-1 just below)
       if (lane > 0) { p[0] = r[-3]; p[1] = r[-2]; p[2] = r[-1]; }
       const u64 x0 = r[0], x1 = r[1], x2 = r[2], y0 = r[3], y1 = r[4], y2 = r[5];
-      acc.rec(x0, x1, x2);
-      acc.rec(y0, y1, y2);
+      acc.rec(x0, x1, x2, ref);
+      acc.rec(y0, y1, y2, ref);
       if (has_prev) acc.pair(p[0], p[1], p[2], x0, x1, x2);
       acc.pair(x0, x1, x2, y0, y1, y2);
       if (!more) break;
@@ -136,19 +145,23 @@ ibu_k_sort_census(const u64* __restrict__ recs0, u64 row0, u32 ntiles, u64* __re
       a0 = b0; a1 = b1; a2 = b2;
     }
   }
-  acc.flush(c, flag32);
+  acc.flush(c, flag32, ref, any_rows);
 }
 // rows [row0, n), one thread per row (the n % 128 rest, a peeled first row); compares with row - 1 as well
 extern "C" __global__ void ibu_k_sort_census_tail(const u64* __restrict__ recs, u64 row0, u64 n, u64* __restrict__ c,
                                                   u32* __restrict__ flag32) {
   CensusAcc acc;
   const u64 i = row0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 w0 = row0 + ((u64)blockIdx.x * blockDim.x + (threadIdx.x & ~(u32)(kWave - 1)));   // the wave's first row
+  const bool any_rows = w0 < n;                              // wave-uniform
+  const u64* rp = recs + 3 * (any_rows ? w0 : row0);
+  const u64 ref[3] = {rp[0], rp[1], rp[2]};
   if (i < n) {
     const u64 b = recs[3 * i], u = recs[3 * i + 1], x = recs[3 * i + 2];
-    acc.rec(b, u, x);
+    acc.rec(b, u, x, ref);
     if (i > 0) acc.pair(recs[3 * i - 3], recs[3 * i - 2], recs[3 * i - 1], b, u, x);
   }
-  acc.flush(c, flag32);
+  acc.flush(c, flag32, ref, any_rows);
 }
 static void launch_census(const LaunchCfg& cfg, const void* recs, size_t n, u64* census, u32* flag32, hipStream_t st) {
   const Span sp[1] = {{recs, 24}};
@@ -634,7 +647,7 @@ __device__ __forceinline__ u32 elem_byte(EV<W> e, u32 byte) {  // byte: uniform
 // CENSUS: the exact census (OR / AND words, order flags: CensusAcc) of the same records is accumulated on the way — the
 // speculative path of the sort, whose plan comes from a SAMPLE and is checked against this census afterwards.
 template <bool CENSUS, int W>
-__global__ void __launch_bounds__(kBlock, 8)
+__global__ void __launch_bounds__(kBlock, CENSUS ? (W == 4 ? 6 : 7) : 8)   // the launcher keeps at most 7 workgroups per CU resident (LaunchCfg); 16-byte elements with the census need 80 VGPRs
 ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, ElemT<W>* __restrict__ out,
                     uint8_t* __restrict__ digits, u64* __restrict__ census) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
@@ -642,11 +655,10 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
   uint8_t* tile = lds + wib * kTileBytes;
   const TileRange tr = tile_range(ntiles, wib);             // which tiles this wave sweeps (kcommon.hpp)
   u32 t = tr.t;
+  if (t >= tr.end) return;                                   // wave-uniform: a wave without tiles adds nothing to the census
   CensusAcc acc;
-  if (t >= tr.end) {
-    if constexpr (CENSUS) acc.flush(census, nullptr);        // identities: every wave takes part in the shuffles
-    return;
-  }
+  const u64* rp = reinterpret_cast<const u64*>(recs);        // row 0 of this launch: the census' reference record (CensusAcc)
+  const u64 ref[3] = {CENSUS ? rp[0] : 0, CENSUS ? rp[1] : 0, CENSUS ? rp[2] : 0};
   const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
   u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
   for (;;) {
@@ -667,8 +679,8 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     const u64* r = reinterpret_cast<const u64*>(tile + lane * 24);
     const u64* q = reinterpret_cast<const u64*>(tile + (lane + kWave) * 24);
     if constexpr (CENSUS) {
-      acc.rec(r[0], r[1], r[2]);
-      acc.rec(q[0], q[1], q[2]);
+      acc.rec(r[0], r[1], r[2], ref);
+      acc.rec(q[0], q[1], q[2], ref);
       if (lane > 0) { pv[0] = r[-3]; pv[1] = r[-2]; pv[2] = r[-1]; }
       if (lane > 0 || t > 0) acc.pair(pv[0], pv[1], pv[2], r[0], r[1], r[2]);
       acc.pair(q[-3], q[-2], q[-1], q[0], q[1], q[2]);
@@ -685,7 +697,7 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
     t = tn;
     a0 = b0; a1 = b1; a2 = b2;
   }
-  if constexpr (CENSUS) acc.flush(census, nullptr);
+  if constexpr (CENSUS) acc.flush(census, nullptr, ref, true);
 }
 // the digit stream of a pass from the elements themselves (the speculative path guessed another first pass)
 template <int W>

@@ -45,6 +45,23 @@ def test_library_carries_gfx950_code_object():
     assert "gfx950" in out and "ibu_k_decode" in out and "ibu_k_encode" in out
 
 
+def test_no_product_kernel_uses_scratch():
+    """Every gfx950 kernel in the library must fit its register budget: `.private_segment_fixed_size` of the code
+    objects' metadata (tools/kernel_resources.py, needs no GPU) is 0 for all of them.  A spilling streaming kernel
+    writes and re-reads its spills through HBM: round 2's compress-with-census spilled 36 bytes per lane and wrote
+    20.3 B/record instead of 13 without any test noticing."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from ibu_amd import _lib
+    ks = kernel_resources.all_kernels(_lib.SO_PATH)
+    assert len(ks) > 200 and any("ibu_k_sort_compress<true, 3>" in k for k in ks), sorted(ks)[:5]
+    spilling = {k: v["private_segment_fixed_size"] for k, v in ks.items() if v.get("private_segment_fixed_size", 0)}
+    assert not spilling, spilling
+    dynamic = [k for k, v in ks.items() if v.get("uses_dynamic_stack", 0)]
+    assert not dynamic, dynamic
+
+
 def test_header_compiles_as_c_and_cxx(tmp_path):
     c = tmp_path / "t.c"
     c.write_text('#include "ibu_hip.h"\n_Static_assert(sizeof(ibu_header_t)==32 && sizeof(ibu_record_t)==24, "pod");\n'

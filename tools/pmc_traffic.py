@@ -21,17 +21,29 @@ import sys
 from collections import defaultdict
 
 
-def per_kernel(pmc_dir, counter):
-    """kernel name -> mean counter value per dispatch (main kernels only: tails are negligible)."""
-    files = glob.glob(os.path.join(pmc_dir, counter, "**", "*counter_collection.csv"), recursive=True)
+def per_kernel(pmc_dir, counter, info=None):
+    """kernel name -> mean counter value per dispatch (main kernels only: tails are negligible).
+
+    rocprofv3 writes one counter_collection.csv per PROCESS it saw (the python launcher, helper processes): every file
+    is read and merged, never just the first of the glob (round 2 read files[0], which for the sort passes was another
+    process's file, and the "sort" section came out empty).  info (optional dict) receives, per kernel, the register /
+    scratch figures the profiler records with every dispatch."""
+    files = sorted(glob.glob(os.path.join(pmc_dir, counter, "**", "*counter_collection.csv"), recursive=True))
     if not files:
         raise SystemExit(f"no counter_collection.csv under {pmc_dir}/{counter}")
     acc = defaultdict(list)
-    with open(files[0]) as f:
-        for row in csv.DictReader(f):
-            if row.get("Counter_Name") != counter:
-                continue
-            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    for path in files:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+                if info is not None:
+                    info[row["Kernel_Name"]] = {"Scratch_Size": int(row.get("Scratch_Size") or 0), "VGPR_Count": int(row.get("VGPR_Count") or 0),
+                                                "SGPR_Count": int(row.get("SGPR_Count") or 0), "LDS_Block_Size": int(row.get("LDS_Block_Size") or 0),
+                                                "dispatches": len(acc[row["Kernel_Name"]])}
+    if not acc:
+        raise SystemExit(f"no {counter} rows in {files}")
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -62,10 +74,13 @@ def main():
                     "hbm_bytes_per_record": round(rd + wr, 3), "algorithmic_bytes_per_record": alg[k]}
     sort_dir = pmc_dir.rstrip("/") + "_sort"
     if os.path.isdir(sort_dir):  # every ibu_k_sort_* kernel: mean bytes per record per launch (FETCH doubled as above)
-        sf, sw = per_kernel(sort_dir, "FETCH_SIZE"), per_kernel(sort_dir, "WRITE_SIZE")
-        out["sort"] = {name.split("(")[0].replace("void ", ""): {
-            "read_bytes_per_record": round(2 * f_kib * 1024 / n, 3), "write_bytes_per_record": round(sw.get(name, 0.0) * 1024 / n, 3)}
+        info = {}
+        sf, sw = per_kernel(sort_dir, "FETCH_SIZE", info), per_kernel(sort_dir, "WRITE_SIZE", info)
+        out["sort"] = {name.split("(")[0].replace("void ", ""): dict(
+            read_bytes_per_record=round(2 * f_kib * 1024 / n, 3), write_bytes_per_record=round(sw.get(name, 0.0) * 1024 / n, 3), **info.get(name, {}))
             for name, f_kib in sorted(sf.items()) if "ibu_k_sort" in name or "ibu_k_copy" in name}
+        if not out["sort"]:
+            raise SystemExit(f"no ibu_k_sort_* kernel in the counter files under {sort_dir}")
     print(json.dumps(out, indent=1))
 
 

@@ -7,12 +7,14 @@
 #      tools/kbench.py and tools/sortbench.py -> pmc CSVs + pmc_traffic.json (round-tagged)
 # Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 N=${2:-1e9}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "[profile_round] $(date +%T) $*"; }
+# rocprofv3 writes one file per process it saw: the one to keep is the LARGEST (the python process that ran the kernels)
+largest() { find "$1" -name "$2" -printf '%s %p\n' | sort -rn | head -1 | cut -d' ' -f2-; }
 
 step "bench (unprofiled)"
 python3 bench.py > "$OUT/${TAG}_bench_1e9.json" 2> "$OUT/bench.err" || exit 1
@@ -21,7 +23,7 @@ step "bench under rocprofv3 --kernel-trace --stats"
 # (--placement-tries 1: the probes of placement probing would be averaged into the per-kernel statistics)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline --placement-tries 1 \
   > "$OUT/${TAG}_bench_1e9_under_rocprof.json" 2> "$OUT/prof_bench.err" || exit 1
-cp "$(find "$OUT/prof_bench" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
+cp "$(largest "$OUT/prof_bench" '*kernel_stats.csv')" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
 
 step "sortbench (unprofiled)"
 python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg > "$OUT/${TAG}_sortbench_random_index.jsonl" 2> "$OUT/sort.err" || exit 1
@@ -30,17 +32,17 @@ python3 tools/sortbench.py --records "$N" --rounds 3 --skip-agg > "$OUT/${TAG}_s
 step "sortbench under rocprofv3 --kernel-trace --stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sort" -- python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg \
   > "$OUT/${TAG}_sortbench_under_rocprof.jsonl" 2> "$OUT/prof_sort.err" || exit 1
-cp "$(find "$OUT/prof_sort" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_sort_1e9_kernel_stats.csv"
+cp "$(largest "$OUT/prof_sort" '*kernel_stats.csv')" "$OUT/${TAG}_sort_1e9_kernel_stats.csv"
 
 for C in FETCH_SIZE WRITE_SIZE; do
   step "pmc $C over kbench"
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc/$C" -- python3 tools/kbench.py --records "$N" --rounds 2 \
     > "$OUT/pmc_kbench_$C.log" 2>&1 || exit 1
-  cp "$(find "$OUT/pmc/$C" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_${C}_kbench_1e9.csv"
+  cp "$(largest "$OUT/pmc/$C" '*counter_collection.csv')" "$OUT/${TAG}_pmc_${C}_kbench_1e9.csv"
   step "pmc $C over sortbench"
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_sort/$C" -- python3 tools/sortbench.py --records "$N" --rounds 1 --random-index --skip-agg \
     > "$OUT/pmc_sort_$C.log" 2>&1 || exit 1
-  cp "$(find "$OUT/pmc_sort/$C" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_${C}_sort_1e9.csv"
+  cp "$(largest "$OUT/pmc_sort/$C" '*counter_collection.csv')" "$OUT/${TAG}_pmc_${C}_sort_1e9.csv"
 done
 python3 tools/pmc_traffic.py "$OUT/pmc" "$N" 16,12 "$TAG" > "$OUT/pmc_traffic.json" || exit 1
 rm -rf "$OUT/prof_bench" "$OUT/prof_sort"   # the raw traces are large; the summaries above are what is kept

@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace ibu {
 
@@ -403,12 +405,20 @@ static inline int peel_rows(const Span* s, int k) {
   return -1;
 }
 // Split n rows into head (tail kernel) + main (tiled kernel, `tile` rows per tile) + rest (tail kernel).
+// IBU_TRACE_ROWS=1 (tests only, read per call): one stderr line per split saying how many rows took which kernel, so that a
+// test can assert that an odd-record shard still runs tiled WITHOUT timing anything (a wall-clock ratio in the
+// correctness suite is a flake on a pool whose placements differ by 20 %).
 struct RowSplit { size_t head, main; };
 static inline RowSplit split_rows(const Span* s, int k, size_t n, size_t tile) {
   const int h = peel_rows(s, k);
-  if (h < 0) return {n, 0};
-  const size_t head = (size_t)h < n ? (size_t)h : n;
-  return {head, ((n - head) / tile) * tile};
+  RowSplit rs{n, 0};
+  if (h >= 0) {
+    rs.head = (size_t)h < n ? (size_t)h : n;
+    rs.main = ((n - rs.head) / tile) * tile;
+  }
+  if (const char* v = getenv("IBU_TRACE_ROWS"))
+    if (*v && *v != '0') fprintf(stderr, "ibu rows: n=%zu head=%zu tiled=%zu rest=%zu tile=%zu\n", n, rs.head, rs.main, n - rs.head - rs.main, tile);
+  return rs;
 }
 template <class T> static inline T* adv(T* p, size_t bytes) {
   return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes) : p;

@@ -1230,7 +1230,9 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return e;
     compact_plan_init(reinterpret_cast<const uint64_t*>(g), reinterpret_cast<const uint64_t*>(g + 3), &gpl);
-    if (gpl.k >= 1 && gpl.k <= 16) {                        // 12-byte elements, or 16-byte ones for 13 .. 16 varying bytes
+    // g[7] == 0: no sample row is smaller than its predecessor — the input may well be sorted already, and then the
+    // read-only census below (24 B/record) answers that; a speculative compress pass (37 B/record) would be spent first.
+    if (g[7] != 0 && gpl.k >= 1 && gpl.k <= 16) {           // 12-byte elements, or 16-byte ones for 13 .. 16 varying bytes
       for (int f = 0; f < 3; ++f)
         for (u32 b = 0; b < 8; ++b)
           if (((g[f] ^ g[3 + f]) >> (8 * b)) & 255u) gmask[f] |= 255ull << (8 * b);
@@ -1239,6 +1241,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
       else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, pick_compact16(cfg).tile).digits, st, census);
       speculated = true;
+    } else if (g[7] == 0 && trace_sort()) {
+      fprintf(stderr, "ibu sort: n=%zu samples in order: read-only census first\n", n);
     }
   }
   if (!speculated) {
@@ -1252,7 +1256,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
   if (c[7] == 0) {                   // no record is smaller than its predecessor: already sorted
-    if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu already sorted%s\n", n, speculated ? " (a speculative compress pass was spent)" : "");
+    if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu already sorted%s\n", n, speculated ? " (a speculative compress pass was spent)" : "");   // spent only when the samples saw a drop and the whole did not: impossible, the samples are rows of the whole
     return hipSuccess;
   }
 

@@ -98,7 +98,8 @@ def ctx_guess(ia):
 @pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003])
 @pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 10-11 varying bytes: 12-byte elements; 14-15: 16-byte elements
 @pytest.mark.parametrize("case", ["random_index", "index_order", "guess_misses_a_umi_byte", "guess_misses_an_index_byte",
-                                  "index_order_broken_outside_the_samples", "already_sorted", "one_umi_byte_constant_in_the_samples"])
+                                  "index_order_broken_outside_the_samples", "already_sorted", "one_umi_byte_constant_in_the_samples",
+                                  "sorted_in_the_samples_only"])
 def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd):
     """The speculative path: the samples are the first, the middle and the last 32 768 records.  Whatever the samples
     suggest, the result is the oracle's — a guess that does not cover the truth is detected by the exact census."""
@@ -127,6 +128,10 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
         recs["barcode"][quarter + 1], recs["umi"][quarter + 1] = recs["barcode"][quarter], recs["umi"][quarter]
     elif case == "already_sorted":
         recs = oracle.sort_records(recs)
+    elif case == "sorted_in_the_samples_only":                 # one swap where no sample looks: the census finds it, no speculation
+        recs = oracle.sort_records(recs)
+        recs[[quarter, quarter + 1]] = recs[[quarter + 1, quarter]]
+        assert recs[quarter].tobytes() != recs[quarter + 1].tobytes()
     elif case == "one_umi_byte_constant_in_the_samples":
         recs["index"] = np.arange(n, dtype=np.uint64)
         recs["umi"] &= np.uint64(0xFFFF)
@@ -142,9 +147,14 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
               "guess_misses_a_umi_byte": "guess did not cover",
               "guess_misses_an_index_byte": "guess did not cover",
               "index_order_broken_outside_the_samples": "first_digit_guess=miss",
-              "already_sorted": "already sorted (a speculative compress pass was spent)",
+              "already_sorted": "samples in order: read-only census first",   # round 3: sorted input costs ONE read-only pass again
+              "sorted_in_the_samples_only": "samples in order: read-only census first",
               "one_umi_byte_constant_in_the_samples": "guess did not cover"}[case]
     assert expect in trace, trace
+    if case == "already_sorted":
+        assert "already sorted" in trace and "speculative compress pass was spent" not in trace and "path=" not in trace, trace
+    if case == "sorted_in_the_samples_only":
+        assert f"path=compact element_bytes={width}" in trace and "speculated" not in trace, trace
     if "did not cover" in expect:                          # ... and the sort went on from the exact census
         assert (f"path=compact element_bytes={12 if k <= 12 else 16}" if k <= 16 else "path=24-byte") in trace, trace
     assert _sort_on_device(ctx24, recs)[0] == want

@@ -101,6 +101,33 @@ __device__ __forceinline__ TileRange tile_range(u32 ntiles, u32 wib) {
   return {logical_block() * (u32)kWavesPerBlock + wib, gridDim.x * (u32)kWavesPerBlock, ntiles};
 }
 
+// The sweep of a wave over its tiles with the next tile's loads always in flight: two register sets take turns (phase A
+// works on `a` while `b` loads, phase B the reverse), so a set is never COPIED — `a = b` at the end of an iteration makes
+// the compiler wait for b's loads right there (v_mov needs the data) and the prefetch is drained once per tile (seen in
+// the ISA of round 2's census / compress / expand loops: s_waitcnt vmcnt(..) in front of the copies).
+// load(regs, tile): issue the tile's loads, unconditionally (the last iteration re-loads its own tile).  body(regs, tile).
+template <class Regs, class Load, class Body>
+__device__ __forceinline__ void sweep_tiles(const TileRange tr, Load load, Body body) {
+  u32 t = tr.t;
+  if (t >= tr.end) return;                         // wave-uniform
+  Regs a, b;
+  load(a, t);
+  for (;;) {
+    u32 tn = t + tr.stride;
+    bool more = tn < tr.end;                       // wave-uniform
+    load(b, more ? tn : t);
+    body(a, t);
+    if (!more) break;
+    t = tn;
+    tn = t + tr.stride;
+    more = tn < tr.end;
+    load(a, more ? tn : t);
+    body(b, t);
+    if (!more) break;
+    t = tn;
+  }
+}
+
 #ifndef IBU_NT_LOAD
 #define IBU_NT_LOAD 1
 #endif

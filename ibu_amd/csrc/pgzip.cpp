@@ -1219,7 +1219,11 @@ int ParallelGunzip::next_batch(std::vector<Span>& out, bool* eof) {
       if (t) out.push_back(Span{c.o8.at0(), t});
       left -= t;
     }
-    P.flip ^= 1;                                       // the next batch decodes into the other set of buffers
+    // The next batch decodes into the other set of buffers — but only when THIS one handed pieces out: the set the caller
+    // may still be reading (the batch before, `pieces stay valid until the call after the next one`: pgzip.hpp) is the other
+    // one, and an iteration that delivered nothing (4 MiB of empty members, empty stored / sync-flush blocks) must come back
+    // to the set it has just used, not decode over the caller's.
+    if (!out.empty()) P.flip ^= 1;
     P.cur = std::move(lastc.inf);
     P.cur.segs.clear();
     const size_t shift = P.cur.bp >> 3;

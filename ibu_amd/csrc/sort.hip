@@ -102,50 +102,53 @@ extern "C" __global__ void ibu_k_sort_census_fold(u64* c) {
     for (int w = 0; w < 8; ++w) c[w] = v[w];
 }
 // recs0: row 0 of the caller's array (8-B aligned); the tiles start at row `row0` (16-B aligned there).
+// The record IN FRONT of a tile (the partner of the tile's first record in the order checks) travels with the tile: its 24
+// bytes are the tail of the 32 bytes in front of the tile, which every lane loads as one more dwordx4 of the prefetch (two
+// distinct chunks, one cache line) and lanes 0 / 1 stage right in front of the tile in LDS — so record 2L-1 is `r[-3 .. -1]`
+// for lane 0 too.  (Round 2 had lane 0 fetch it with a separate 24-byte global load INSIDE the iteration that used it: the
+// wait for that load was a vmcnt(0), which also waited for the next tile's prefetch — every iteration paid a full memory
+// latency; ibu_k_sort_compress<true> likewise: 8.5 ms against 6.7 without the census.)
+static constexpr int kPrevBytes = 32;                         // staged in front of each wave's tile
+static constexpr int kSliceBytes = kTileBytes + kPrevBytes;
+__device__ __forceinline__ const uint8_t* prev_chunk(const uint8_t* tile_src, bool has_prev, u32 lane) {
+  return (has_prev ? tile_src - kPrevBytes : tile_src) + 16 * (lane & 1u);   // no record in front: any valid bytes (ignored)
+}
+struct CensusRegs { u32x4 v[4]; };                            // a tile (three dwordx4 per lane) + the 32 bytes in front of it
 extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_sort_census(const u64* __restrict__ recs0, u64 row0, u32 ntiles, u64* __restrict__ c, u32* __restrict__ flag32) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kSliceBytes];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kTileBytes;
-  const u32 nwaves = gridDim.x * kWavesPerBlock;
+  uint8_t* tile = lds + wib * kSliceBytes + kPrevBytes;
   const uint8_t* base = reinterpret_cast<const uint8_t*>(recs0 + 3 * row0);
   const u64* rp = recs0 + 3 * row0;                         // ntiles >= 1: the first tiled row is a row of this launch
   const u64 ref[3] = {rp[0], rp[1], rp[2]};                 // uniform address: scalar loads
   CensusAcc acc;
-  u32 t = logical_block() * kWavesPerBlock + wib;
-  const bool any_rows = t < ntiles;
-  if (t < ntiles) {
-    const uint8_t* src = base + (size_t)t * kTileBytes + 16 * lane;
-    u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
-    for (;;) {
-      const u32 tn = t + nwaves;
-      const bool more = tn < ntiles;               // wave-uniform; the prefetch is unconditional (kcommon.hpp)
-      src = base + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
-      const u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
-      // the record before this lane's pair: lane 0 fetches the one before the tile (if any) from global memory
-      const u64 grow = row0 + (u64)t * kTileRecs;  // global row of the tile's first record
-      u64 p[3] = {0, 0, 0};
-      const bool has_prev = lane > 0 || grow > 0;
-      if (lane == 0 && grow > 0) { const u64* q = recs0 + 3 * (grow - 1); p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; }
-      wave_lds_fence();
-      *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
-      *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
-      *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
-      wave_lds_fence();
-      const u64* r = reinterpret_cast<const u64*>(tile + (2 * lane) * 24);  // records 2L, 2L+1 (and 2L-1 just below)
-      if (lane > 0) { p[0] = r[-3]; p[1] = r[-2]; p[2] = r[-1]; }
-      const u64 x0 = r[0], x1 = r[1], x2 = r[2], y0 = r[3], y1 = r[4], y2 = r[5];
-      acc.rec(x0, x1, x2, ref);
-      acc.rec(y0, y1, y2, ref);
-      if (has_prev) acc.pair(p[0], p[1], p[2], x0, x1, x2);
-      acc.pair(x0, x1, x2, y0, y1, y2);
-      if (!more) break;
-      t = tn;
-      a0 = b0; a1 = b1; a2 = b2;
-    }
-  }
-  acc.flush(c, flag32, ref, any_rows);
+  const TileRange tr = {logical_block() * (u32)kWavesPerBlock + wib, gridDim.x * (u32)kWavesPerBlock, ntiles};
+  sweep_tiles<CensusRegs>(
+      tr,
+      [&](CensusRegs& g, u32 t) {
+        const uint8_t* src = base + (size_t)t * kTileBytes;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g.v[k] = ld16(src + 1024 * k + 16 * lane);
+        g.v[3] = ld16(prev_chunk(src, row0 + (u64)t * kTileRecs > 0, lane));
+      },
+      [&](const CensusRegs& g, u32 t) {
+        const bool has_prev = lane > 0 || row0 + (u64)t * kTileRecs > 0;   // global row of the tile's first record > 0
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = g.v[k];
+        if (lane < 2) *reinterpret_cast<u32x4*>(tile - kPrevBytes + 16 * lane) = g.v[3];
+        wave_lds_fence();
+        const u64* r = reinterpret_cast<const u64*>(tile + (2 * lane) * 24);  // records 2L, 2L+1 (and 2L-1 just below)
+        const u64 p0 = r[-3], p1 = r[-2], p2 = r[-1];
+        const u64 x0 = r[0], x1 = r[1], x2 = r[2], y0 = r[3], y1 = r[4], y2 = r[5];
+        acc.rec(x0, x1, x2, ref);
+        acc.rec(y0, y1, y2, ref);
+        if (has_prev) acc.pair(p0, p1, p2, x0, x1, x2);
+        acc.pair(x0, x1, x2, y0, y1, y2);
+      });
+  acc.flush(c, flag32, ref, tr.t < tr.end);
 }
 // rows [row0, n), one thread per row (the n % 128 rest, a peeled first row); compares with row - 1 as well
 extern "C" __global__ void ibu_k_sort_census_tail(const u64* __restrict__ recs, u64 row0, u64 n, u64* __restrict__ c,
@@ -647,56 +650,51 @@ __device__ __forceinline__ u32 elem_byte(EV<W> e, u32 byte) {  // byte: uniform
 // CENSUS: the exact census (OR / AND words, order flags: CensusAcc) of the same records is accumulated on the way — the
 // speculative path of the sort, whose plan comes from a SAMPLE and is checked against this census afterwards.
 template <bool CENSUS, int W>
-__global__ void __launch_bounds__(kBlock, CENSUS ? (W == 4 ? 6 : 7) : 8)   // the launcher keeps at most 7 workgroups per CU resident (LaunchCfg); 16-byte elements with the census need 80 VGPRs
+__global__ void __launch_bounds__(kBlock, CENSUS ? (W == 4 ? 5 : 7) : 8)   // the launcher keeps at most 7 workgroups per CU resident (LaunchCfg); 16-byte elements with the census need 84 VGPRs
 ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, ElemT<W>* __restrict__ out,
                     uint8_t* __restrict__ digits, u64* __restrict__ census) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  constexpr int kSlice = CENSUS ? kSliceBytes : kTileBytes;  // with the census: the record in front of the tile is staged too (ibu_k_sort_census)
+  constexpr int kLead = CENSUS ? kPrevBytes : 0;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kSlice];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kTileBytes;
+  uint8_t* tile = lds + wib * kSlice + kLead;
   const TileRange tr = tile_range(ntiles, wib);             // which tiles this wave sweeps (kcommon.hpp)
-  u32 t = tr.t;
-  if (t >= tr.end) return;                                   // wave-uniform: a wave without tiles adds nothing to the census
+  if (tr.t >= tr.end) return;                                // wave-uniform: a wave without tiles adds nothing to the census
   CensusAcc acc;
   const u64* rp = reinterpret_cast<const u64*>(recs);        // row 0 of this launch: the census' reference record (CensusAcc)
   const u64 ref[3] = {CENSUS ? rp[0] : 0, CENSUS ? rp[1] : 0, CENSUS ? rp[2] : 0};
-  const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
-  u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
-  for (;;) {
-    const u32 tn = t + tr.stride;
-    const bool more = tn < tr.end;                           // wave-uniform; the prefetch is unconditional (kcommon.hpp)
-    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
-    const u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
-    u64 pv[3] = {0, 0, 0};                                   // the record in front of the tile (lane 0 only)
-    if (CENSUS && lane == 0 && t > 0) {
-      const u64* g = reinterpret_cast<const u64*>(recs + (size_t)t * kTileBytes) - 3;
-      pv[0] = g[0]; pv[1] = g[1]; pv[2] = g[2];
-    }
-    wave_lds_fence();
-    *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
-    *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
-    *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
-    wave_lds_fence();
-    const u64* r = reinterpret_cast<const u64*>(tile + lane * 24);
-    const u64* q = reinterpret_cast<const u64*>(tile + (lane + kWave) * 24);
-    if constexpr (CENSUS) {
-      acc.rec(r[0], r[1], r[2], ref);
-      acc.rec(q[0], q[1], q[2], ref);
-      if (lane > 0) { pv[0] = r[-3]; pv[1] = r[-2]; pv[2] = r[-1]; }
-      if (lane > 0 || t > 0) acc.pair(pv[0], pv[1], pv[2], r[0], r[1], r[2]);
-      acc.pair(q[-3], q[-2], q[-1], q[0], q[1], q[2]);
-    }
-    const EV<W> e0 = compress_rec<W>(r[0], r[1], r[2], pl), e1 = compress_rec<W>(q[0], q[1], q[2], pl);
-    const size_t row = (size_t)t * kTileRecs + lane;
-    st_elem<W>(out + row, e0);
-    st_elem<W>(out + row + kWave, e1);
-    if (digits) {                                            // uniform (NULL: ibu_records_compact, no pass follows)
-      digits[row] = (uint8_t)elem_byte<W>(e0, first_byte);
-      digits[row + kWave] = (uint8_t)elem_byte<W>(e1, first_byte);
-    }
-    if (!more) break;
-    t = tn;
-    a0 = b0; a1 = b1; a2 = b2;
-  }
+  struct Regs { u32x4 v[CENSUS ? 4 : 3]; };
+  sweep_tiles<Regs>(
+      tr,
+      [&](Regs& g, u32 t) {
+        const uint8_t* src = recs + (size_t)t * kTileBytes;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g.v[k] = ld16(src + 1024 * k + 16 * lane);
+        if constexpr (CENSUS) g.v[3] = ld16(prev_chunk(src, t > 0, lane));
+      },
+      [&](const Regs& g, u32 t) {
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = g.v[k];
+        if constexpr (CENSUS) { if (lane < 2) *reinterpret_cast<u32x4*>(tile - kPrevBytes + 16 * lane) = g.v[3]; }
+        wave_lds_fence();
+        const u64* r = reinterpret_cast<const u64*>(tile + lane * 24);
+        const u64* q = reinterpret_cast<const u64*>(tile + (lane + kWave) * 24);
+        if constexpr (CENSUS) {
+          acc.rec(r[0], r[1], r[2], ref);
+          acc.rec(q[0], q[1], q[2], ref);
+          if (lane > 0 || t > 0) acc.pair(r[-3], r[-2], r[-1], r[0], r[1], r[2]);   // lane 0: the record in front of the tile
+          acc.pair(q[-3], q[-2], q[-1], q[0], q[1], q[2]);
+        }
+        const EV<W> e0 = compress_rec<W>(r[0], r[1], r[2], pl), e1 = compress_rec<W>(q[0], q[1], q[2], pl);
+        const size_t row = (size_t)t * kTileRecs + lane;
+        st_elem<W>(out + row, e0);
+        st_elem<W>(out + row + kWave, e1);
+        if (digits) {                                        // uniform (NULL: ibu_records_compact, no pass follows)
+          digits[row] = (uint8_t)elem_byte<W>(e0, first_byte);
+          digits[row + kWave] = (uint8_t)elem_byte<W>(e1, first_byte);
+        }
+      });
   if constexpr (CENSUS) acc.flush(census, nullptr, ref, true);
 }
 // the digit stream of a pass from the elements themselves (the speculative path guessed another first pass)
@@ -778,6 +776,9 @@ __global__ void ibu_k_sort_expand_tail(const ElemT<W>* __restrict__ in, u64 row0
   recs[3 * i] = f0; recs[3 * i + 1] = f1; recs[3 * i + 2] = f2;
 }
 
+#ifndef IBU_LAST_MODE
+#define IBU_LAST_MODE 1   // write-out of the last compact pass: 0 = one lane per record (3 x 8-byte stores), 1 = one lane per half record (dwordx3)
+#endif
 template <int THREADS, int ROUNDS, int W>
 struct CompactShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
@@ -880,6 +881,36 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
 
   // 5. write out: lane = element, consecutive lanes write the consecutive elements of a run (dwordx3 each; plain stores:
   //    the L2 merges the pieces of a run that neighbouring tiles write); 6. the next pass's digit at the new position
+  if constexpr (LAST && IBU_LAST_MODE == 1) {
+    // The last pass writes 24-byte records.  One lane per HALF record (12 bytes = dwords [3j, 3j+3) of the record, j = lane
+    // parity): consecutive lanes write consecutive 12-byte pieces, so a wave's store instruction covers 768 contiguous
+    // bytes of a run — the store shape of the element passes, which run at the box's copy rate.  (One lane per record
+    // = three 8-byte stores at a 24-byte stride: every instruction touches twelve 128-byte lines for a third of their
+    // bytes, three times; measured 8.4-9.0 ms per 1e9 records against 4.8 ms for an element pass of 2/3 the bytes.)
+    const u32 j = tid & 1u;
+    u32 hsel[3][2], hbase[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      hsel[k][0] = j ? pl.xsel[3 + k][0] : pl.xsel[k][0];
+      hsel[k][1] = j ? pl.xsel[3 + k][1] : pl.xsel[k][1];
+      const u64 bf = j ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
+      hbase[k] = ((3 * (j ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * ROUNDS; ++r) {
+      const u32 p = (tid + THREADS * r) >> 1;               // element slot; lanes 2q, 2q+1 share it
+      if (p < cnt) {
+        const u32 g = gdelta[sbin[p]] + p;
+        u32 e[4] = {stage[W * p], stage[W * p + 1], stage[W * p + 2], 0};
+        if constexpr (W == 4) e[3] = stage[W * p + 3];
+        u32x3 o;
+        o.x = hbase[0] | __builtin_amdgcn_perm(e[1], e[0], hsel[0][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[0][1]);
+        o.y = hbase[1] | __builtin_amdgcn_perm(e[1], e[0], hsel[1][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[1][1]);
+        o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
+        *reinterpret_cast<u32x3_a4*>(static_cast<uint8_t*>(dst_v) + 24 * (size_t)g + 12 * j) = o;
+      }
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const u32 p = tid + THREADS * r;
@@ -898,6 +929,7 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
         if (nbyte < 4 * W) digits[g] = (uint8_t)elem_byte<W>(e, nbyte);   // uniform; >= 4 W: no pass follows on elements
       }
     }
+  }
   }
 }
 

@@ -407,13 +407,13 @@ TEST(compressed_inputs_decode_to_the_plain_records) {  // reader.rs:345-352
   if (!dir) return;  // only run with the fixture directory
   auto want = load_to_vec(std::string(dir) + "/plain.ibu").second;
   size_t seen = 0;
-  for (const char* name : {"plain.ibu", "a.gz", "multi.gz", "a.bgz", "a.bz2", "a.xz", "a.zst"}) {
+  for (const char* name : {"plain.ibu", "a.gz", "multi.gz", "holes.gz", "a.bgz", "a.bz2", "a.xz", "a.zst"}) {
     Reader r = Reader::from_path(std::string(dir) + "/" + name);
     CHECK(r.header() == Header(16, 12));
     CHECK(r.collect() == want);
     ++seen;
   }
-  CHECK_EQ(seen, 7u);
+  CHECK_EQ(seen, 8u);
   CHECK_THROWS(Niffler, Reader::from_path(std::string(dir) + "/cut.bgz").collect(), {});
 }
 

@@ -39,6 +39,10 @@ def _compressed_fixture(d, oracle):
     raw = (d / "plain.ibu").read_bytes()
     (d / "a.gz").write_bytes(gzip.compress(raw, 1))
     (d / "multi.gz").write_bytes(gzip.compress(raw[:100_003], 1) + gzip.compress(raw[100_003:], 1))
+    # payloads separated by more than (inflate threads x chunk) bytes of EMPTY members: batches that deliver nothing must not
+    # recycle the chunk buffers the caller is still reading (pgzip.cpp next_batch) — ASan / TSan see it if they do
+    hole = gzip.compress(b"", 6) * 2500
+    (d / "holes.gz").write_bytes(gzip.compress(raw[:300_011], 1) + hole + gzip.compress(raw[300_011:700_001], 6) + hole + gzip.compress(raw[700_001:], 9) + hole)
     (d / "a.bgz").write_bytes(bgzf_compress(raw))
     (d / "cut.bgz").write_bytes(bgzf_compress(raw)[:200_000])
     (d / "a.bz2").write_bytes(bz2.compress(raw, 1))

@@ -264,3 +264,29 @@ def test_gzip_through_a_pipe(tmp_path):
     assert out.returncode == 0, out.stderr.decode()[-500:]
     k, digest = out.stdout.decode().split()
     assert int(k) == len(P["records"]) // 24 and digest == hashlib.md5(P["records"]).hexdigest()
+
+
+def test_batches_that_deliver_nothing_do_not_reuse_the_callers_buffers(tmp_path, monkeypatch):
+    """ADVICE r02 (pgzip.cpp next_batch): a batch whose accepted chunks produce no output — here more than threads x chunk
+    bytes of EMPTY gzip members between two payloads — used to flip the chunk-buffer set anyway, so the following batch
+    decoded into the set whose pieces the caller was still reading (`valid until the call after the next one`).  The
+    bytes must be the sequential decoder's, for every placement of the empty stretch; the ASan / TSan builds of
+    tests/test_cpp.py (IBU_RUN_ASAN=1) run the same input and see the overwrite itself."""
+    P = payloads()
+    a, b, c = P["records"][:24 * 20_000], P["text"][:24 * 9_000], P["records"][24 * 20_000:24 * 50_000]
+    empty = _zc(b"", 6)
+    assert len(empty) == 20
+    hole = empty * 2500                                       # 50 000 bytes: three whole batches of 4 x 4096 with no output
+    sync = zlib.compressobj(6, zlib.DEFLATED, 31)
+    flushes = sync.compress(b"") + b"".join(sync.flush(zlib.Z_SYNC_FLUSH) for _ in range(4000)) + sync.flush()   # empty stored blocks only
+    raw = _header() + a + b + c
+    blob = _zc(_header() + a, 1) + hole + _zc(b, 6) + flushes + hole + _zc(c, 9) + hole
+    assert zlib.decompressobj(31).decompress(blob[:len(_zc(_header() + a, 1))]) == _header() + a
+    p = tmp_path / "holes.ibu.gz"
+    p.write_bytes(blob)
+    monkeypatch.setenv("IBU_NO_PARALLEL_GZIP", "1")
+    want = _read_all(p)
+    assert want == raw[32:]
+    for threads, chunk in ((4, 4096), (2, 4096), (8, 8192)):
+        _knobs(monkeypatch, threads, chunk)
+        assert _read_all(p) == want, (threads, chunk)

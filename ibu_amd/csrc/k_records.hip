@@ -10,94 +10,86 @@ namespace ibu {
 // =============================================================================================
 // K1  deserialise AoS -> three u64 columns          K1' serialise columns -> AoS
 // =============================================================================================
-__device__ __forceinline__ void deserialize_tile(uint8_t* tile, u32x4 a0, u32x4 a1, u32x4 a2, u32 t, u64* bc,
-                                                 u64* umi, u64* idx, u32 lane) {
-  wave_lds_fence();
-  *reinterpret_cast<u32x4*>(tile + 16 * lane) = a0;
-  *reinterpret_cast<u32x4*>(tile + 1024 + 16 * lane) = a1;
-  *reinterpret_cast<u32x4*>(tile + 2048 + 16 * lane) = a2;
-  wave_lds_fence();
-  const u64* r0 = reinterpret_cast<const u64*>(tile + (2 * lane) * 24);
-  const u64* r1 = reinterpret_cast<const u64*>(tile + (2 * lane + 1) * 24);
-  u64* cols[3] = {bc, umi, idx};
-#pragma unroll
-  for (int f = 0; f < 3; ++f) {
-    u64 x = r0[f], y = r1[f];
-    u32x4 o; o.x = (u32)x; o.y = (u32)(x >> 32); o.z = (u32)y; o.w = (u32)(y >> 32);
-    st16(reinterpret_cast<uint8_t*>(cols[f]) + (size_t)t * 1024 + 16 * lane, o);
-  }
-}
+// NT tiles of 128 records per wave iteration (kRecNT).  Decode's recipe (NT = 2: twice the bytes in flight per wave) was tried
+// here in round 3 and bought nothing — one process, same buffers, 1e9 records (profiles/r03_c_kbench_rec_nt.jsonl):
+// deserialize 7.69 ms (NT 1) / 7.74 (NT 2), serialize 7.74 / 7.83, i.e. 6.2 TB/s = 0.775-0.78 of peak either way, above the
+// plain copy kernel on the same box (5.8 TB/s); both kernels' store rounds are full with one tile already.  NT stays 1.
+#ifndef IBU_REC_NT
+#define IBU_REC_NT 1
+#endif
+static constexpr int kRecNT = IBU_REC_NT;
+static constexpr int kRecTileRecs = kTileRecs * kRecNT, kRecTileBytes = kTileBytes * kRecNT;
+struct RecRegs { u32x4 v[3 * kRecNT]; };
 
-extern "C" __global__ void __launch_bounds__(kBlock, 8)
+extern "C" __global__ void __launch_bounds__(kBlock, kRecNT > 1 ? 5 : 8)
 ibu_k_deserialize(const uint8_t* __restrict__ recs, u32 ntiles, u64* __restrict__ bc,
                   u64* __restrict__ umi, u64* __restrict__ idx) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kRecTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kTileBytes;
-  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
-  const u32 nwaves = tr.stride;
-  u32 t = tr.t;
-  ntiles = tr.end;
-  if (t >= ntiles) return;
-  const uint8_t* src = recs + (size_t)t * kTileBytes + 16 * lane;
-  u32x4 a0 = ld16(src), a1 = ld16(src + 1024), a2 = ld16(src + 2048);
-  for (;;) {                                   // two phases, register sets swap roles: see decode
-    u32 tn = t + nwaves;
-    bool more = tn < ntiles;
-    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
-    u32x4 b0 = ld16(src), b1 = ld16(src + 1024), b2 = ld16(src + 2048);
-    deserialize_tile(tile, a0, a1, a2, t, bc, umi, idx, lane);
-    if (!more) break;
-    t = tn;
-    tn = t + nwaves;
-    more = tn < ntiles;
-    src = recs + (size_t)(more ? tn : t) * kTileBytes + 16 * lane;
-    a0 = ld16(src); a1 = ld16(src + 1024); a2 = ld16(src + 2048);
-    deserialize_tile(tile, b0, b1, b2, t, bc, umi, idx, lane);
-    if (!more) break;
-    t = tn;
-  }
+  uint8_t* tile = lds + wib * kRecTileBytes;
+  u64* const cols[3] = {bc, umi, idx};
+  sweep_tiles<RecRegs>(                            // two register sets take turns (kcommon.hpp)
+      tile_range(ntiles, wib),
+      [&](RecRegs& g, u32 t) {
+        const uint8_t* src = recs + (size_t)t * kRecTileBytes + 16 * lane;
+#pragma unroll
+        for (int k = 0; k < 3 * kRecNT; ++k) g.v[k] = ld16(src + 1024 * k);
+      },
+      [&](const RecRegs& g, u32 t) {
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 3 * kRecNT; ++k) *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = g.v[k];
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < kRecNT; ++j) {         // chunk c of a column = records 2c, 2c+1
+          const u32 c = lane + 64 * j;
+          const u64* r0 = reinterpret_cast<const u64*>(tile + (2 * c) * 24);
+          const u64* r1 = r0 + 3;
+#pragma unroll
+          for (int f = 0; f < 3; ++f) {
+            const u64 x = r0[f], y = r1[f];
+            u32x4 o; o.x = (u32)x; o.y = (u32)(x >> 32); o.z = (u32)y; o.w = (u32)(y >> 32);
+            st16(reinterpret_cast<uint8_t*>(cols[f]) + (size_t)t * (1024 * kRecNT) + 16 * c, o);
+          }
+        }
+      });
 }
 
-extern "C" __global__ void __launch_bounds__(kBlock, 8)
+extern "C" __global__ void __launch_bounds__(kBlock, kRecNT > 1 ? 5 : 8)
 ibu_k_serialize(const u64* __restrict__ bc, const u64* __restrict__ umi, const u64* __restrict__ idx,
                 u32 ntiles, uint8_t* __restrict__ recs) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kRecTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kTileBytes;
-  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
-  const u32 nwaves = tr.stride;
-  u32 t = tr.t;
-  ntiles = tr.end;
-  if (t >= ntiles) return;
-  size_t off = (size_t)t * 1024 + 16 * lane;   // records 2*lane, 2*lane+1 of each column
-  u32x4 c0 = ld16(reinterpret_cast<const uint8_t*>(bc) + off);
-  u32x4 c1 = ld16(reinterpret_cast<const uint8_t*>(umi) + off);
-  u32x4 c2 = ld16(reinterpret_cast<const uint8_t*>(idx) + off);
-  for (;;) {
-    wave_lds_fence();
-    u32x4* r = reinterpret_cast<u32x4*>(tile + lane * 48);  // two adjacent records = 48 B
-    u32x4 w0, w1, w2;
-    w0.x = c0.x; w0.y = c0.y; w0.z = c1.x; w0.w = c1.y;     // bc[2l]   umi[2l]
-    w1.x = c2.x; w1.y = c2.y; w1.z = c0.z; w1.w = c0.w;     // idx[2l]  bc[2l+1]
-    w2.x = c1.z; w2.y = c1.w; w2.z = c2.z; w2.w = c2.w;     // umi[2l+1] idx[2l+1]
-    r[0] = w0; r[1] = w1; r[2] = w2;
-    const u32 tn = t + nwaves;
-    const bool more = tn < ntiles;
-    off = (size_t)(more ? tn : t) * 1024 + 16 * lane;       // unconditional: see decode
-    c0 = ld16(reinterpret_cast<const uint8_t*>(bc) + off);
-    c1 = ld16(reinterpret_cast<const uint8_t*>(umi) + off);
-    c2 = ld16(reinterpret_cast<const uint8_t*>(idx) + off);
-    wave_lds_fence();
-    uint8_t* dst = recs + (size_t)t * kTileBytes + 16 * lane;
-    st16(dst, *reinterpret_cast<const u32x4*>(tile + 16 * lane));
-    st16(dst + 1024, *reinterpret_cast<const u32x4*>(tile + 1024 + 16 * lane));
-    st16(dst + 2048, *reinterpret_cast<const u32x4*>(tile + 2048 + 16 * lane));
-    if (!more) break;
-    t = tn;
-  }
+  uint8_t* tile = lds + wib * kRecTileBytes;
+  const uint8_t* const cols[3] = {reinterpret_cast<const uint8_t*>(bc), reinterpret_cast<const uint8_t*>(umi),
+                                  reinterpret_cast<const uint8_t*>(idx)};
+  sweep_tiles<RecRegs>(
+      tile_range(ntiles, wib),
+      [&](RecRegs& g, u32 t) {                     // v[3 j + f]: records 2c, 2c+1 of column f, c = lane + 64 j
+#pragma unroll
+        for (int j = 0; j < kRecNT; ++j)
+#pragma unroll
+          for (int f = 0; f < 3; ++f) g.v[3 * j + f] = ld16(cols[f] + (size_t)t * (1024 * kRecNT) + 16 * (lane + 64 * j));
+      },
+      [&](const RecRegs& g, u32 t) {
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < kRecNT; ++j) {
+          const u32x4 c0 = g.v[3 * j], c1 = g.v[3 * j + 1], c2 = g.v[3 * j + 2];
+          u32x4* r = reinterpret_cast<u32x4*>(tile + (lane + 64 * j) * 48);  // two adjacent records = 48 B
+          u32x4 w0, w1, w2;
+          w0.x = c0.x; w0.y = c0.y; w0.z = c1.x; w0.w = c1.y;     // bc[2c]   umi[2c]
+          w1.x = c2.x; w1.y = c2.y; w1.z = c0.z; w1.w = c0.w;     // idx[2c]  bc[2c+1]
+          w2.x = c1.z; w2.y = c1.w; w2.z = c2.z; w2.w = c2.w;     // umi[2c+1] idx[2c+1]
+          r[0] = w0; r[1] = w1; r[2] = w2;
+        }
+        wave_lds_fence();
+        uint8_t* dst = recs + (size_t)t * kRecTileBytes + 16 * lane;
+#pragma unroll
+        for (int k = 0; k < 3 * kRecNT; ++k) st16(dst + 1024 * k, *reinterpret_cast<const u32x4*>(tile + 1024 * k + 16 * lane));
+      });
 }
 
 
@@ -347,12 +339,12 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, 8}, {umi, 8}, {idx, 8}};
-  const RowSplit rs = split_rows(sp, 4, n, kTileRecs);   // peel rows until every array is 16-B aligned
+  const RowSplit rs = split_rows(sp, 4, n, kRecTileRecs);   // peel rows until every array is 16-B aligned
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_deserialize_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)rs.head,
                        (u64*)bc, (u64*)umi, (u64*)idx);
   if (rs.main) {
-    u32 ntiles = (u32)(rs.main / kTileRecs);
+    u32 ntiles = (u32)(rs.main / kRecTileRecs);
     static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_deserialize,
                        dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_deserialize, 0, &occ))), dim3(kBlock), 0, st,
@@ -370,12 +362,12 @@ hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, 8}, {umi, 8}, {idx, 8}};
-  const RowSplit rs = split_rows(sp, 4, n, kTileRecs);
+  const RowSplit rs = split_rows(sp, 4, n, kRecTileRecs);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_serialize_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)bc, (const u64*)umi,
                        (const u64*)idx, (u64)0, (u64)rs.head, (u64*)recs);
   if (rs.main) {
-    u32 ntiles = (u32)(rs.main / kTileRecs);
+    u32 ntiles = (u32)(rs.main / kRecTileRecs);
     static std::atomic<int> occ;
     hipLaunchKernelGGL(ibu_k_serialize, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_serialize, 0, &occ))),
                        dim3(kBlock), 0, st, adv((const u64*)bc, 8 * rs.head), adv((const u64*)umi, 8 * rs.head),

@@ -54,10 +54,12 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--placement-tries", type=int, default=0,
-                   help="allocate the resident arrays this many times (all sets held at once, memory permitting), probe each "
-                        "with one decode+encode, keep the fastest arrays and free the others BEFORE the timed region; every "
-                        "probe is printed.  0 (default) = as many as fit, at most 12: 3 for 1e9 records on one GPU, 12 for the "
-                        "shards of an 8-GPU run.  1 = take the first allocation (round-1 behaviour).  See place_leg()")
+                   help="candidates per resident array for the library's placement probing (ibu_device_alloc_probed: all "
+                        "candidates of an array held at once, a write and a read streamed over each, the fastest kept, the "
+                        "others freed) BEFORE the timed region; every probe is printed.  0 (default) = as many as fit, at most "
+                        "16: 3-5 for the arrays of 1e9 records on one GPU, 16 for the shards of an 8-GPU run.  1 = plain "
+                        "ibu_device_alloc (what a caller that does not probe gets; also measured and reported in every run "
+                        "as value_first_placement).  See place_leg()")
     # rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never used by the driver):
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: collectives on CPU tensors")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")
@@ -152,73 +154,38 @@ def traffic_from_profile(bc_len, umi_len, n):
 
 
 def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
-    """Placement probing.  On this part the rate of a read+write streaming kernel depends on WHERE the driver put the
-    arrays' physical pages: the same kernel on the same GPU runs 9.4 ... 11.3 ms from one allocation to the next
-    (profiles/README.md: pool survey, r02_placement_pmc, r02_ag — physical regions in buddy-block runs, L2 tag-pipeline
-    stalls, not translation), and an allocation keeps its speed for as long as it lives.  A job that keeps its shard
-    resident can therefore choose: allocate the set a few times (holding the earlier sets, so that the allocator has to
-    hand out other pages), time the kernels on them, keep the fastest ARRAYS, free the rest.  All of it happens before the
-    timed region, costs well under a second once, and every probe is reported in the line (`placement`), the first one
-    being what a job that does not probe would have got."""
+    """Placement probing — since round 3 a LIBRARY call, not bench-side logic.  On this part the rate of a read+write
+    streaming kernel depends on WHERE the driver put the arrays' physical pages: the same kernel on the same GPU runs
+    9.4 ... 11.3 ms from one allocation to the next (profiles/README.md: pool survey, r02_placement_pmc, r02_ag — physical
+    regions in buddy-block runs, L2 tag-pipeline stalls, not translation), and an allocation keeps its speed for as long
+    as it lives.  A job that keeps its shard resident can therefore choose, and any caller of the C ABI can do so with
+    `ibu_device_alloc_probed(ctx, bytes, tries, &ptr, &report)`: up to `tries` candidates of ONE array held at once, a write
+    and a read streamed over each, the fastest kept, the rest freed.
+
+    What this function does around it: (1) a first set of arrays from plain `ibu_device_alloc` is timed with one
+    decode + encode — what a caller that does not probe gets, reported as `first_placement_*` and at top level as
+    `value_first_placement`; (2) unless --placement-tries 1, that set is freed and every array is allocated again through
+    the probing call.  All of it happens before the timed region; every candidate's time is in the line (`placement`)."""
     free_b, _ = torch.cuda.mem_get_info(dev)
-    # 0 = auto.  Small shards get more tries: at the shard size of an 8-GPU run the rate is two-valued and only about one
-    # set in four to twelve draws the fast value (profiles/experiments/r02_ag_pl_125e6.json), and the job's time is the
-    # slowest rank's.
-    tries = max(1, min(tries or 16, int(free_b * 0.94 / max(sharers, 1) // max(set_bytes, 1))))   # sharers: ranks on this GPU (rehearsals)
-    legs, probes = [], []
-    for _ in range(tries):
-        try:
-            leg = make()
-        except RuntimeError:           # out of memory on a later set (fragmentation, another process on the card):
-            if not legs:               # the sets that exist are the candidates
-                raise
-            torch.cuda.empty_cache()
-            break
-        legs.append(leg)
-        probes.append(leg.probe() if tries > 1 else None)
-    tries = len(legs)
-    if tries > 1 and probes[0] is None:
-        probes[0] = legs[0].probe()
-    info = {"tries": tries, "kept": 0, "probe_ms_decode_encode": [[round(v, 3) for v in p] for p in probes] if tries > 1 else None}
+    first = make(1)
+    first_probe = first.probe()
+    bytes_per_launch = first.n * (24 + first.bc_len + first.umi_len + 8)
+    info = {"tries": 1, "first_placement_probe_ms_decode_encode": [round(v, 3) for v in first_probe],
+            "first_placement_decode_frac": round(bytes_per_launch / (first_probe[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "first_placement_records_per_s": first.n / ((first_probe[0] + first_probe[1]) * 1e-3)}
+    # 0 = auto: as many candidates as fit beside the arrays already chosen, at most 16.  The largest array (24 B/record)
+    # sets the bound: the other arrays of the set stay allocated while it is probed.
+    biggest = max(24 * first.n, 1)
+    fit = int((free_b * 0.94 / max(sharers, 1) - set_bytes) // biggest) + 1
+    tries = max(1, min(tries or 16, fit, 16))
     if tries == 1:
-        return legs[0], info
-    # The arrays of the sets hold the same data and can be mixed freely, and a kernel's time follows mostly the arrays it
-    # WRITES — one slow array spoils its set.  So the choice is made per array, one coordinate at a time, starting from the
-    # best whole set: each of the three decode outputs (decode timed with that one array taken from every set in turn),
-    # then the records decode reads, then the array encode writes.  5 T launches of ~10 ms, once; all of them in the line.
-    T = tries
-    names = ("recs", "bc", "umi", "idx", "back")
-    base = min(range(T), key=lambda t: probes[t][0] + probes[t][1])
-    cur = {k: base for k in names}
-    leg = legs[base]
-
-    def arrays(c):
-        return {k: getattr(legs[c[k]], k) for k in names}
-
-    per_array = {}
-    for name in ("bc", "umi", "idx", "recs"):
-        ms = [leg.probe_decode_arrays(arrays({**cur, name: t})) for t in range(T)]
-        cur[name] = min(range(T), key=ms.__getitem__)
-        per_array[name] = [round(v, 3) for v in ms]
-    ms = [leg.probe_encode_arrays(arrays({**cur, "back": t})) for t in range(T)]
-    cur["back"] = min(range(T), key=ms.__getitem__)
-    per_array["back"] = [round(v, 3) for v in ms]
-    final = (leg.probe_decode_arrays(arrays(cur)), leg.probe_encode_arrays(arrays(cur)))
-    if final[0] + final[1] > probes[base][0] + probes[base][1]:      # the coordinates did not add up: the best whole set it is
-        cur = {k: base for k in names}
-        final = probes[base]
-    keep = arrays(cur)
-    for other in legs:                                   # drop every array, then hand the chosen ones to the kept leg
-        other.recs = other.bc = other.umi = other.idx = other.back = None
-    for k in names:
-        setattr(leg, k, keep[k])
-    keep = legs = None
-    torch.cuda.empty_cache()
-    bytes_per_launch = leg.n * (24 + leg.bc_len + leg.umi_len + 8)
-    info.update(kept={"records": cur["recs"], "bc": cur["bc"], "umi": cur["umi"], "idx": cur["idx"], "output": cur["back"]}, best_whole_set=base,
-                decode_ms_by_set_of_one_array={"bc": per_array["bc"], "umi": per_array["umi"], "idx": per_array["idx"], "records": per_array["recs"]},
-                encode_ms_by_set_of_output=per_array["back"], kept_probe_ms_decode_encode=[round(v, 3) for v in final],
-                first_placement_decode_frac=round(bytes_per_launch / (probes[0][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+        return first, info
+    first.free()
+    first = None
+    leg = make(tries)
+    probe = leg.probe()
+    info.update(tries=tries, library_call="ibu_device_alloc_probed(ctx, bytes, tries, &ptr, &report) per array",
+                per_array=leg.reports, kept_probe_ms_decode_encode=[round(v, 3) for v in probe])
     return leg, info
 
 
@@ -268,10 +235,17 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3):
                                           C.byref(npairs), None))
             ctx.synchronize()
             ts.append(time.perf_counter() - t0)
-        import numpy as np
-        counts_sum = int(outs[1].download(np.uint64)[: nb.value].sum()) if nb.value <= 1 << 27 else None
+        # the check runs on the device at every size (round 2 summed the column on the host and skipped it above 2^27
+        # barcodes, i.e. at the driver's size): (barcode, count, unique) rows are serialised into the free scratch array and
+        # reduced with K4 — sum of the counts column == n, sum of the distinct-UMI column == the pair count, and
+        # barcodes <= pairs <= n
+        ctx.serialize(outs[0], outs[1], outs[2], nb.value, t)
+        agg = ctx.reduce(t, nb.value)
+        adds_up = (agg["count"] == nb.value and agg["sum"][1] == n and agg["sum"][2] == npairs.value and nb.value <= npairs.value <= n)
         out["barcode_counts"] = {"seconds": statistics.median(ts[1:]), "distinct_barcodes": nb.value, "barcode_umi_pairs": npairs.value,
-                                 "counts_add_up": (counts_sum == n) if counts_sum is not None else None}
+                                 "counts_add_up": bool(adds_up), "checked": "device-side K4 reduce of the (barcode, count, unique) columns"}
+        if not adds_up:
+            raise SystemExit("ibu_barcode_counts: the counts column does not add up to the record count")
         for b in outs:
             b.free()
     finally:
@@ -284,14 +258,21 @@ class Leg:
     """One resident workload: this rank's shard [first, first + n) of the synthetic stream, its output columns and the
     re-encoded records.  step() = K2 decode followed by K3 encode."""
 
-    def __init__(self, ctx, torch, dev, st, seed, first, n, bc_len, umi_len):
-        self.ctx, self.torch, self.st, self.n, self.bc_len, self.umi_len = ctx, torch, st, n, bc_len, umi_len
+    def __init__(self, ctx, torch, dev, st, seed, first, n, bc_len, umi_len, tries=1):
+        self.ctx, self.torch, self.dev, self.st, self.n, self.bc_len, self.umi_len = ctx, torch, dev, st, n, bc_len, umi_len
+        self.reports = {}
 
-        def buf(nbytes):
-            return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        def buf(name, nbytes):   # the library's allocator: plain, or with placement probing (ibu_device_alloc_probed)
+            nbytes = max(nbytes, 16)
+            if tries <= 1:
+                return ctx.alloc(nbytes)
+            b, rep = ctx.alloc_probed(nbytes, tries)
+            self.reports[name] = rep
+            return b
 
-        self.recs, self.back = buf(n * 24), buf(n * 24)
-        self.bc, self.umi, self.idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
+        # largest arrays first: they are probed while the least memory is taken
+        self.recs, self.back = buf("records", n * 24), buf("output", n * 24)
+        self.bc, self.umi, self.idx = buf("bc", n * bc_len), buf("umi", n * umi_len), buf("idx", n * 8)
         ctx.generate(seed, first, n, bc_len, umi_len, self.recs, stream=st)
         torch.cuda.synchronize()
 
@@ -355,7 +336,7 @@ class Leg:
     def copy_ceiling(self):
         """This box's own copy ceiling (plain dwordx4 copy kernel, recs -> the barcode column), outside the timed region:
         the second denominator SURVEY 8d asks for next to the 8 TB/s spec peak; boxes of this pool differ by ~20 %."""
-        torch, nbytes = self.torch, min(self.bc.numel(), self.recs.numel())
+        torch, nbytes = self.torch, min(self.bc.nbytes, self.recs.nbytes)
         ms = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -381,13 +362,19 @@ class Leg:
             first_diff = self.ctx.first_mismatch(self.recs, self.back, n, stream=self.st)
             chunk = 1 << 30
             nb = n * 24
-            same = all(bool(torch.equal(self.recs[o:min(o + chunk, nb)], self.back[o:min(o + chunk, nb)])) for o in range(0, nb, chunk))
+            ta, tb = torch.as_tensor(self.recs, device=self.dev), torch.as_tensor(self.back, device=self.dev)   # __cuda_array_interface__ views
+            assert ta.data_ptr() == self.recs.ptr and ta.numel() >= nb and ta.dtype == torch.uint8
+            same = all(bool(torch.equal(ta[o:min(o + chunk, nb)], tb[o:min(o + chunk, nb)])) for o in range(0, nb, chunk))
+            del ta, tb
             ok = same and first_diff == n and red == red_back and red["count"] == n
             if not ok:
                 raise SystemExit("round trip encode(decode(x)) != x")
         return red, ok
 
     def free(self):
+        for b in (self.recs, self.back, self.bc, self.umi, self.idx):
+            if b is not None:
+                b.free()
         self.recs = self.back = self.bc = self.umi = self.idx = None
         self.torch.cuda.empty_cache()
 
@@ -437,7 +424,7 @@ def main():
         if use_dist:
             dist.barrier()
 
-    leg, placement = place_leg(lambda: Leg(ctx, torch, dev, st, args.seed, first, n, bc_len, umi_len), args.placement_tries,
+    leg, placement = place_leg(lambda tries: Leg(ctx, torch, dev, st, args.seed, first, n, bc_len, umi_len, tries), args.placement_tries,
                                n * (48 + bc_len + umi_len + 8), torch, dev, sharers=world if args.share_gpu else 1)
     elapsed, dec_ms, enc_ms = leg.timed(args.steps, args.warmup, barrier)
     per_rank = [[float(n), dec_ms, enc_ms, elapsed]]
@@ -470,7 +457,7 @@ def main():
         # BASELINE configs[2]: maximum width, encode+decode on one GPU — a short leg outside the headline's timed region
         leg.free()
         nw = int(args.wide_records) or n
-        wl, w_placement = place_leg(lambda: Leg(ctx, torch, dev, st, 0x1B00002, 0, nw, 32, 32), min(args.placement_tries or 2, 2),
+        wl, w_placement = place_leg(lambda tries: Leg(ctx, torch, dev, st, 0x1B00002, 0, nw, 32, 32, tries), min(args.placement_tries or 2, 2),
                                     nw * (48 + 72), torch, dev)
         w_steps = max(1, min(args.steps, 5))
         w_el, w_dec, w_enc = wl.timed(w_steps, 1, barrier)
@@ -509,6 +496,10 @@ def main():
         out = {
             "metric": "records/s, fused 2-bit decode+encode of 24-byte IBU records (HBM-resident)",
             "value": n_global * args.steps / elapsed,
+            # what a caller that takes plain allocations gets (one decode + one encode on the first set of arrays, this rank, before
+            # any probing: placement.first_placement_*), scaled to the job like `value`; `value` itself is measured on arrays from
+            # ibu_device_alloc_probed unless --placement-tries 1.  Compare THIS number with round 1 / BENCH_r01.
+            "value_first_placement": placement["first_placement_records_per_s"] * (n_global / max(n, 1)),
             "unit": "records/s",
             "n_gpus": world,
             "steps": args.steps,

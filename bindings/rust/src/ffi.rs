@@ -53,6 +53,14 @@ pub struct ibu_stream_stats_t {
     pub seconds_kernel: f64,
 }
 #[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct ibu_alloc_probe_t {
+    pub tries: u32,
+    pub chosen: u32,
+    pub ms: [f32; 16],
+}
+
+#[repr(C)]
 pub struct ibu_decode_sink_t {
     pub d_bc_ascii: *mut u8,
     pub d_umi_ascii: *mut u8,
@@ -157,6 +165,8 @@ extern "C" {
                                         h_bc_ascii: *const u8, h_umi_ascii: *const u8, h_index: *const u64, first_index: u64,
                                         n: usize, bc_len: u32, umi_len: u32, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_device_alloc(ctx: *mut ibu_ctx_t, bytes: usize, d_ptr: *mut *mut c_void) -> i32;
+    pub fn ibu_device_alloc_probed(ctx: *mut ibu_ctx_t, bytes: usize, tries: u32, d_ptr: *mut *mut c_void,
+                                   report: *mut ibu_alloc_probe_t) -> i32;
     pub fn ibu_device_free(ctx: *mut ibu_ctx_t, d_ptr: *mut c_void) -> i32;
     pub fn ibu_memcpy_h2d(ctx: *mut ibu_ctx_t, d_dst: *mut c_void, h_src: *const c_void, bytes: usize,
                           stream: *mut c_void) -> i32;
@@ -207,6 +217,12 @@ extern "C" {
     pub fn ibu_mmap_process_device(m: *const ibu_mmap_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
                                    proc_: i32, shard: usize, n_shards: usize, sink: *mut c_void,
                                    stats: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_mmap_process_devices(m: *const ibu_mmap_t, devices: *const i32, n_devices: usize, cfg: *const ibu_ring_config_t,
+                                    proc_: i32, sinks: *mut c_void, total: *mut ibu_reduce_result_t,
+                                    stats: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_mmap_process_contexts(m: *const ibu_mmap_t, ctxs: *const *mut ibu_ctx_t, n_ctxs: usize,
+                                     cfg: *const ibu_ring_config_t, proc_: i32, sinks: *mut c_void,
+                                     total: *mut ibu_reduce_result_t, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_reader_process_device(r: *mut ibu_reader_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
                                      proc_: i32, sink: *mut c_void, stats: *mut ibu_stream_stats_t) -> i32;
 }

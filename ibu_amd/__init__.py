@@ -14,7 +14,7 @@ from collections import namedtuple
 import numpy as np
 
 from . import _lib
-from ._lib import CDecodeSink, CErrorDetail, CKeyPlan, CHeader, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
+from ._lib import CAllocProbe, CDecodeSink, CErrorDetail, CKeyPlan, CHeader, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
 
 lib = _lib.load()
 
@@ -496,6 +496,34 @@ class MmapReader:
             lambda c, rg, s, st: lib.ibu_mmap_process_device(self._m, c, rg, proc, shard, n_shards, s, st),
             proc, sink, ring, (h.bc_len, h.umi_len))
 
+    def process_devices(self, devices=(), proc=PROC_REDUCE, sinks=None, ring=None, contexts=None):
+        """process_parallel(processor, n) with a GPU per worker, in ONE call (mmap.rs:286-332; ibu_mmap_process_devices):
+        worker i = one host thread + one context on devices[i], shard i of the static split, first error in worker order
+        wins.  devices = () means every visible device.  contexts: a list of Contexts to reuse instead of device ordinals
+        (ibu_mmap_process_contexts).  PROC_REDUCE -> (total, [partial per device], [stats]); PROC_DECODE: `sinks` = one
+        (d_bc, d_umi, d_index, cap_records) per device, each on its device -> (count, None, [stats])."""
+        n = len(contexts) if contexts is not None else (len(devices) or device_count())
+        stats = (CStreamStats * max(n, 1))()
+        total = CReduceResult()
+        if proc == PROC_REDUCE:
+            parts = (CReduceResult * max(n, 1))()
+            sink_p = C.cast(parts, C.c_void_p)
+        else:
+            if sinks is None or len(sinks) != n:
+                raise ValueError("PROC_DECODE needs one sink per device")
+            arr = (CDecodeSink * n)(*[CDecodeSink(_dptr(a), _dptr(b), _dptr(c), int(cap)) for a, b, c, cap in sinks])
+            sink_p = C.cast(arr, C.c_void_p)
+        if contexts is not None:
+            cs = (C.c_void_p * n)(*[c._c for c in contexts])
+            _check(lib.ibu_mmap_process_contexts(self._m, cs, n, _ring(ring), proc, sink_p, C.byref(total), stats))
+        else:
+            devs = (C.c_int32 * len(devices))(*devices) if len(devices) else None
+            _check(lib.ibu_mmap_process_devices(self._m, devs, len(devices), _ring(ring), proc, sink_p, C.byref(total), stats))
+        as_dict = lambda r: {"count": r.count, "sum": list(r.sum), "xor": list(r.xor_)}
+        if proc == PROC_REDUCE:
+            return as_dict(total), [as_dict(parts[i]) for i in range(n)], list(stats)[:n]
+        return total.count, None, list(stats)[:n]
+
     def decode_to_host(self, ctx, shard=0, n_shards=1, ring=None, want=("bc", "umi", "index")):
         """One shard -> (barcode ASCII [n, bc_len], UMI ASCII [n, umi_len], index [n]) as numpy arrays in host
         memory, unpacked on the GPU.  Columns not in `want` come back as None."""
@@ -572,6 +600,12 @@ class DeviceBuffer:
         b.ctx, b.ptr, b.nbytes, b.owned = ctx, int(ptr), int(nbytes), False
         return b
 
+    @property
+    def __cuda_array_interface__(self):
+        """Flat uint8 view for consumers of the CUDA array interface (torch.as_tensor(buf, device=...) on ROCm too):
+        bench.py uses it to compare buffers with torch as a checker that is not this library."""
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
     def upload(self, host):
         a = np.ascontiguousarray(host)
         assert a.nbytes <= self.nbytes
@@ -617,6 +651,16 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def alloc_probed(self, nbytes, tries):
+        """ibu_device_alloc_probed: up to `tries` candidate allocations (all held at once), the one a write + read streams
+        over fastest is kept, the others freed.  -> (DeviceBuffer, {"tries", "chosen", "ms": [...]})."""
+        p, rep = C.c_void_p(), CAllocProbe()
+        _check(lib.ibu_device_alloc_probed(self._c, int(nbytes), int(tries), C.byref(p), C.byref(rep)))
+        b = DeviceBuffer.wrap(self, p.value, nbytes)
+        b.owned = True
+        self._buffers.add(b)
+        return b, {"tries": rep.tries, "chosen": rep.chosen, "ms": [round(float(rep.ms[k]), 4) for k in range(rep.tries)]}
 
     def upload(self, host):
         a = np.ascontiguousarray(host)

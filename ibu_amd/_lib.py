@@ -43,6 +43,10 @@ class CKeyPlan(C.Structure):  # ibu_key_plan_t
     _fields_ = [("csel", (u32 * 3) * 4), ("xsel", (u32 * 2) * 6), ("k", u32), ("index_bytes", u32), ("base", u64 * 3)]
 
 
+class CAllocProbe(C.Structure):  # ibu_alloc_probe_t
+    _fields_ = [("tries", u32), ("chosen", u32), ("ms", C.c_float * 16)]
+
+
 class CDecodeSink(C.Structure):  # ibu_decode_sink_t
     _fields_ = [("d_bc_ascii", vp), ("d_umi_ascii", vp), ("d_index", vp), ("cap_records", sz)]
 
@@ -125,6 +129,7 @@ SIGNATURES = {
     "ibu_writer_write_ascii_batch": (i32, [vp, vp, vp, vp, vp, vp, u64, sz, u32, u32, vp]),
     "ibu_barcode_counts": (i32, [vp, vp, sz, vp, vp, vp, sz, P(sz), P(sz), vp]),
     "ibu_device_alloc": (i32, [vp, sz, P(vp)]),
+    "ibu_device_alloc_probed": (i32, [vp, sz, u32, P(vp), P(CAllocProbe)]),
     "ibu_device_free": (i32, [vp, vp]),
     "ibu_memcpy_h2d": (i32, [vp, vp, vp, sz, vp]),
     "ibu_memcpy_d2h": (i32, [vp, vp, vp, sz, vp]),
@@ -151,6 +156,8 @@ SIGNATURES = {
     "ibu_writer_write_batch_device": (i32, [vp, vp, P(CRingConfig), vp, sz, P(CStreamStats)]),
     "ibu_writer_write_batch_device_on": (i32, [vp, vp, P(CRingConfig), vp, sz, vp, P(CStreamStats)]),
     "ibu_mmap_process_device": (i32, [vp, vp, P(CRingConfig), i32, sz, sz, vp, P(CStreamStats)]),
+    "ibu_mmap_process_devices": (i32, [vp, P(i32), sz, P(CRingConfig), i32, vp, P(CReduceResult), P(CStreamStats)]),
+    "ibu_mmap_process_contexts": (i32, [vp, P(vp), sz, P(CRingConfig), i32, vp, P(CReduceResult), P(CStreamStats)]),
     "ibu_reader_process_device": (i32, [vp, vp, P(CRingConfig), i32, vp, P(CStreamStats)]),
 }
 

@@ -138,6 +138,70 @@ extern "C" int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr) 
   IBU_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
   return IBU_OK;
 }
+// Placement probing behind the ABI (round 3; bench.py did this in Python in round 2).  On this part the rate of a streaming
+// kernel depends on WHERE the driver put an array's physical pages (the same kernel runs 9.4 ... 11.3 ms from one allocation to
+// the next; the rate belongs to the physical region and an allocation keeps it for as long as it lives: profiles/README.md
+// r02_ag).  A caller that keeps an array resident can therefore choose: allocate `tries` candidates — all held at once, so that
+// the allocator has to hand out different pages —, stream a write and a read over each (the write-only generator kernel and the
+// read-only reduce kernel over the whole range, timed with events on the context's stream, second run of two), keep the
+// fastest, free the rest.  Allocation stops quietly at the first candidate that does not fit.  The contents are unspecified.
+extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, void** d_ptr, ibu_alloc_probe_t* report) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!d_ptr) return err_arg("d_ptr is NULL");
+  if (report) memset(report, 0, sizeof *report);
+  if (tries < 1) tries = 1;
+  if (tries > IBU_ALLOC_PROBE_MAX) tries = IBU_ALLOC_PROBE_MAX;
+  const size_t nrec = bytes / IBU_RECORD_SIZE;
+  if (nrec < 4096) tries = 1;                   // nothing to measure on a few kilobytes
+  void* cand[IBU_ALLOC_PROBE_MAX] = {nullptr};
+  float ms[IBU_ALLOC_PROBE_MAX] = {0};
+  uint32_t got = 0;
+  for (; got < tries; ++got) {
+    hipError_t e = hipMalloc(&cand[got], bytes ? bytes : 16);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      cand[got] = nullptr;
+      if (got == 0) return hip_fail(e, "hipMalloc");
+      break;                                    // the candidates that exist are the field
+    }
+  }
+  uint32_t best = 0;
+  if (got > 1) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream);
+    for (uint32_t k = 0; k < got && e == hipSuccess; ++k)
+      for (int run = 0; run < 2 && e == hipSuccess; ++run) {   // the first run touches the pages' translations
+        e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess) e = launch_generate(ctx->cfg, 0x1B0, 0, nrec, 32, 32, cand[k], ctx->stream);
+        if (e == hipSuccess) e = launch_reduce(ctx->cfg, cand[k], nrec, ctx->d_acc, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[k], e0, e1);
+      }
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream);   // the accumulator is the caller's again
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) {
+      for (uint32_t k = 0; k < got; ++k) (void)hipFree(cand[k]);
+      return hip_fail(e, "ibu_device_alloc_probed");
+    }
+    for (uint32_t k = 1; k < got; ++k)
+      if (ms[k] < ms[best]) best = k;
+    for (uint32_t k = 0; k < got; ++k)
+      if (k != best) (void)hipFree(cand[k]);
+  }
+  *d_ptr = cand[best];
+  if (report) {
+    report->tries = got;
+    report->chosen = best;
+    for (uint32_t k = 0; k < got; ++k) report->ms[k] = ms[k];
+  }
+  return IBU_OK;
+}
 extern "C" int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr) {
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;

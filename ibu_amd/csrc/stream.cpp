@@ -363,6 +363,100 @@ extern "C" int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
 }
 
 // ------------------------------------------------------------------------------------------
+// MmapReader::process_parallel across DEVICES in one call (mmap.rs:286-332 with a GPU per worker)
+// ------------------------------------------------------------------------------------------
+// The reference's loop: n workers, worker i owns shard i of the static split (mmap.rs:297-307), workers are joined in spawn
+// order and the first Err in that order is the call's result (quirk Q12).  Here a worker is one host thread driving one
+// context (= one device): ibu_mmap_process_device(m, ctx_i, cfg, proc, i, n, sink_i).  No data-path collective exists: the
+// only cross-device value is the reduce processor's {count, 3 wrapping sums, 3 XORs}, seven words per device, added on the
+// host by the calling thread once the workers are joined (latency-bound, the xGMI links play no part).
+// A worker's error detail lives in ITS thread's slot; the winner's is copied into the caller's.
+namespace {
+int32_t process_contexts(const ibu_mmap_t* m, ibu_ctx_t* const* ctxs, size_t n, const ibu_ring_config_t* cfg, int32_t proc,
+                         void* sinks, ibu_reduce_result_t* total, ibu_stream_stats_t* stats) {
+  if (proc != IBU_PROC_REDUCE && proc != IBU_PROC_DECODE) return err_arg("unknown device processor");
+  if (proc == IBU_PROC_DECODE && !sinks) return err_arg("IBU_PROC_DECODE needs one ibu_decode_sink_t per device");
+  std::vector<int32_t> rc;
+  std::vector<ibu_error_detail_t> detail;
+  std::vector<ibu_reduce_result_t> part;
+  try {
+    rc.assign(n, IBU_OK);
+    detail.resize(n);
+    part.resize(n);
+  } catch (...) {
+    return caught_io("ibu_mmap_process_devices");
+  }
+  for (auto& r : part) memset(&r, 0, sizeof r);
+  run_pieces((unsigned)n, [&](unsigned i) {     // never throws; a thread that cannot start runs on the caller (common.hpp)
+    void* sink = proc == IBU_PROC_REDUCE ? static_cast<void*>(&part[i]) : static_cast<void*>(static_cast<ibu_decode_sink_t*>(sinks) + i);
+    rc[i] = ibu_mmap_process_device(m, ctxs[i], cfg, proc, i, n, sink, stats ? stats + i : nullptr);
+    if (rc[i] != IBU_OK) detail[i] = tls_error();
+  });
+  for (size_t i = 0; i < n; ++i)
+    if (rc[i] != IBU_OK) {                      // first error in worker order (mmap.rs:326-328)
+      tls_error() = detail[i];
+      return rc[i];
+    }
+  ibu_reduce_result_t t;
+  memset(&t, 0, sizeof t);
+  if (proc == IBU_PROC_REDUCE) {
+    for (size_t i = 0; i < n; ++i) {
+      t.count += part[i].count;
+      for (int f = 0; f < 3; ++f) { t.sum[f] += part[i].sum[f]; t.xor_[f] ^= part[i].xor_[f]; }   // wrapping (mod 2^64), as the device adds
+    }
+    if (sinks) memcpy(sinks, part.data(), n * sizeof(ibu_reduce_result_t));
+  } else {
+    t.count = ibu_mmap_len(m);                  // every shard decoded: the whole map
+  }
+  if (total) *total = t;
+  return IBU_OK;
+}
+}  // namespace
+
+extern "C" int32_t ibu_mmap_process_contexts(const ibu_mmap_t* m, ibu_ctx_t* const* ctxs, size_t n_ctxs, const ibu_ring_config_t* cfg,
+                                             int32_t proc, void* sinks, ibu_reduce_result_t* total, ibu_stream_stats_t* stats) {
+  if (!m || !ctxs || n_ctxs == 0) return err_arg("NULL argument or no context");
+  if (n_ctxs > 1024) return err_arg("more than 1024 contexts");
+  for (size_t i = 0; i < n_ctxs; ++i) {
+    if (!ctxs[i]) return err_arg("a context is NULL");
+    for (size_t j = 0; j < i; ++j)
+      if (ctxs[j] == ctxs[i]) return err_arg("the same context twice (a context serves one host thread; create two on one device instead)");
+  }
+  return process_contexts(m, ctxs, n_ctxs, cfg, proc, sinks, total, stats);
+}
+
+extern "C" int32_t ibu_mmap_process_devices(const ibu_mmap_t* m, const int32_t* devices, size_t n_devices, const ibu_ring_config_t* cfg,
+                                            int32_t proc, void* sinks, ibu_reduce_result_t* total, ibu_stream_stats_t* stats) {
+  if (!m) return err_arg("NULL argument");
+  std::vector<int32_t> all;
+  std::vector<ibu_ctx_t*> ctxs;
+  try {
+    if (n_devices == 0) {                       // "0 = all of them", as num_threads == 0 means all cores (mmap.rs:292-296)
+      int32_t c = 0;
+      int32_t rc = ibu_device_count(&c);
+      if (rc) return rc;
+      if (c <= 0) return set_error(IBU_ERR_NO_DEVICE, 0, 0, 0, "no HIP device visible");
+      for (int32_t d = 0; d < c; ++d) all.push_back(d);
+      devices = all.data();
+      n_devices = all.size();
+    } else if (!devices) {
+      return err_arg("devices is NULL");
+    }
+    if (n_devices > 1024) return err_arg("more than 1024 devices");
+    ctxs.assign(n_devices, nullptr);
+  } catch (...) {
+    return caught_io("ibu_mmap_process_devices");
+  }
+  int32_t rc = IBU_OK;
+  for (size_t i = 0; i < n_devices && rc == IBU_OK; ++i) rc = ibu_ctx_create(devices[i], &ctxs[i]);   // in order: the first bad ordinal is the error
+  if (rc == IBU_OK) rc = process_contexts(m, ctxs.data(), n_devices, cfg, proc, sinks, total, stats);
+  const ibu_error_detail_t keep = tls_error();
+  for (ibu_ctx_t* c : ctxs) ibu_ctx_destroy(c);
+  if (rc != IBU_OK) tls_error() = keep;
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
 // streaming Reader (plain / gzip), device form
 // ------------------------------------------------------------------------------------------
 extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,

@@ -18,6 +18,7 @@
 //                                          MmapReader::process_device_*, Reader::process_device_*
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <istream>
@@ -130,6 +131,8 @@ class Context;
 using StreamStats = ibu_stream_stats_t;
 using RingConfig = ibu_ring_config_t;
 using ReduceResult = ibu_reduce_result_t;
+using DecodeSink = ibu_decode_sink_t;   // {d_bc_ascii, d_umi_ascii, d_index, cap_records}: device columns and the rows they hold
+using AllocProbe = ibu_alloc_probe_t;
 
 // ---- io/writer.rs ----------------------------------------------------------------------------------------------
 class Writer {
@@ -241,8 +244,10 @@ class Reader {
   iterator end() { return iterator{this, std::nullopt}; }
   // device: stream the rest of this reader (plain or gzip) through the pinned ring
   inline std::pair<ReduceResult, StreamStats> process_device_reduce(device::Context& ctx, const RingConfig* ring = nullptr);
-  // cap_records: rows the columns hold; a longer stream throws IbuError (InvalidArg) instead of writing past them
-  inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records, const RingConfig* ring = nullptr);
+  // sink.cap_records: rows the columns hold; a longer stream throws IbuError (InvalidArg) instead of writing past them.
+  // (The sink is ONE argument on purpose: revision 3 had squeezed `size_t cap_records` in front of other defaulted size_t
+  // parameters, and a revision-2 positional call still compiled with shifted meanings.  Old calls no longer compile.)
+  inline StreamStats process_device_decode(device::Context& ctx, const DecodeSink& sink, const RingConfig* ring = nullptr);
   ibu_reader_t* raw() const { return r_; }
 
  private:
@@ -329,8 +334,14 @@ class MmapReader {
   // device: ONE shard of the same static split per GPU / rank
   inline std::pair<ReduceResult, StreamStats> process_device_reduce(device::Context& ctx, size_t shard = 0, size_t n_shards = 1,
                                                                      const RingConfig* ring = nullptr) const;
-  inline StreamStats process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records,
-                                           size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
+  inline StreamStats process_device_decode(device::Context& ctx, const DecodeSink& sink, size_t shard = 0, size_t n_shards = 1,
+                                           const RingConfig* ring = nullptr) const;
+  // process_parallel(processor, n) with a GPU per worker, ONE call (mmap.rs:286-332): worker i = a host thread + a context on
+  // devices[i], shard i of the static split; an empty list = every visible device (num_threads == 0 = every core).  The
+  // reduce form returns the total (wrapping sums, XORs) and the per-device partials; the decode form fills sinks[i] on devices[i].
+  inline std::pair<ReduceResult, std::vector<ReduceResult>> process_devices_reduce(const std::vector<int32_t>& devices = {},
+                                                                                   const RingConfig* ring = nullptr) const;
+  inline void process_devices_decode(const std::vector<int32_t>& devices, std::vector<DecodeSink>& sinks, const RingConfig* ring = nullptr) const;
   // one shard -> ASCII barcodes / UMIs + index column in HOST memory, unpacked on the GPU
   struct Decoded { std::vector<uint8_t> bc, umi; std::vector<uint64_t> index; StreamStats stats; };
   inline Decoded decode_to_host(device::Context& ctx, size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
@@ -401,6 +412,10 @@ class Context {
     return {h, p, n};
   }
   void* alloc(size_t bytes) { void* p = nullptr; check(ibu_device_alloc(c_, bytes, &p)); return p; }
+  // for arrays that stay resident: up to `tries` candidates, the one that streams fastest is kept (ibu_device_alloc_probed)
+  void* alloc_probed(size_t bytes, uint32_t tries, AllocProbe* report = nullptr) {
+    void* p = nullptr; check(ibu_device_alloc_probed(c_, bytes, tries, &p, report)); return p;
+  }
   void free(void* p) { check(ibu_device_free(c_, p)); }
   void upload(void* d_dst, const void* h_src, size_t bytes) { check(ibu_memcpy_h2d(c_, d_dst, h_src, bytes, nullptr)); synchronize(); }
   void download(void* h_dst, const void* d_src, size_t bytes) { check(ibu_memcpy_d2h(c_, h_dst, d_src, bytes, nullptr)); synchronize(); }
@@ -467,8 +482,8 @@ inline std::pair<ReduceResult, StreamStats> Reader::process_device_reduce(device
   check(ibu_reader_process_device(r_, ctx.raw(), ring, IBU_PROC_REDUCE, &r, &st));
   return {r, st};
 }
-inline StreamStats Reader::process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records, const RingConfig* ring) {
-  ibu_decode_sink_t sink{d_bc, d_umi, d_idx, cap_records}; StreamStats st{};
+inline StreamStats Reader::process_device_decode(device::Context& ctx, const DecodeSink& sink_in, const RingConfig* ring) {
+  ibu_decode_sink_t sink = sink_in; StreamStats st{};
   check(ibu_reader_process_device(r_, ctx.raw(), ring, IBU_PROC_DECODE, &sink, &st));
   return st;
 }
@@ -478,11 +493,30 @@ inline std::pair<ReduceResult, StreamStats> MmapReader::process_device_reduce(de
   check(ibu_mmap_process_device(m_, ctx.raw(), ring, IBU_PROC_REDUCE, shard, n_shards, &r, &st));
   return {r, st};
 }
-inline StreamStats MmapReader::process_device_decode(device::Context& ctx, uint8_t* d_bc, uint8_t* d_umi, uint64_t* d_idx, size_t cap_records, size_t shard,
-                                                     size_t n_shards, const RingConfig* ring) const {
-  ibu_decode_sink_t sink{d_bc, d_umi, d_idx, cap_records}; StreamStats st{};
+inline StreamStats MmapReader::process_device_decode(device::Context& ctx, const DecodeSink& sink_in, size_t shard, size_t n_shards,
+                                                     const RingConfig* ring) const {
+  ibu_decode_sink_t sink = sink_in; StreamStats st{};
   check(ibu_mmap_process_device(m_, ctx.raw(), ring, IBU_PROC_DECODE, shard, n_shards, &sink, &st));
   return st;
+}
+inline std::pair<ReduceResult, std::vector<ReduceResult>> MmapReader::process_devices_reduce(const std::vector<int32_t>& devices,
+                                                                                             const RingConfig* ring) const {
+  size_t n = devices.size();
+  if (n == 0) n = (size_t)device::device_count();
+  ReduceResult total{};
+  std::vector<ReduceResult> parts(n ? n : 1);
+  check(ibu_mmap_process_devices(m_, devices.empty() ? nullptr : devices.data(), devices.size(), ring, IBU_PROC_REDUCE, parts.data(), &total, nullptr));
+  parts.resize(n);
+  return {total, parts};
+}
+inline void MmapReader::process_devices_decode(const std::vector<int32_t>& devices, std::vector<DecodeSink>& sinks, const RingConfig* ring) const {
+  if (devices.empty() || sinks.size() != devices.size()) {
+    ibu_error_detail_t d{};
+    d.code = IBU_ERR_INVALID_ARG;
+    snprintf(d.message, sizeof d.message, "Invalid argument: one DecodeSink per listed device");
+    throw IbuError(IBU_ERR_INVALID_ARG, d);
+  }
+  check(ibu_mmap_process_devices(m_, devices.data(), devices.size(), ring, IBU_PROC_DECODE, sinks.data(), nullptr, nullptr));
 }
 
 }  // namespace ibu

@@ -261,6 +261,22 @@ int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value);
 /* Device memory helpers for callers without their own allocator (tests in C, Rust shim). */
 int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr);
 int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr);
+/* ibu_device_alloc with PLACEMENT PROBING, for arrays that stay resident (no reference counterpart: the crate holds its records in
+ * a Vec, reader.rs:528; this is the device-side "where does the Vec live" decision).  On MI355X the rate of a streaming kernel
+ * depends on which physical pages the driver handed out — the same kernel on the same GPU runs 9.4 ... 11.3 ms from one
+ * allocation to the next, and an allocation keeps its rate for as long as it lives.  Allocates up to `tries` candidates of
+ * `bytes` bytes (all held at once, so that they are different pages; stops quietly at the first that does not fit), streams
+ * one write and one read over each, keeps the fastest in *d_ptr and frees the others.  tries <= 1, or fewer than 4096
+ * records' worth of bytes: a plain allocation.  `report` (nullable) says what was measured; candidate 0 is what
+ * ibu_device_alloc would have returned.  Contents unspecified.  Uses the context's stream and reduce accumulator
+ * (which it leaves reset), synchronises; release with ibu_device_free. */
+#define IBU_ALLOC_PROBE_MAX 16
+typedef struct ibu_alloc_probe {
+  uint32_t tries;                  /* candidates that were allocated and timed (<= the request) */
+  uint32_t chosen;                 /* the one kept */
+  float ms[IBU_ALLOC_PROBE_MAX];   /* write + read time of each candidate over its whole range (0 when nothing was timed) */
+} ibu_alloc_probe_t;
+int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, void** d_ptr, ibu_alloc_probe_t* report);
 int32_t ibu_memcpy_h2d(ibu_ctx_t* ctx, void* d_dst, const void* h_src, size_t bytes, void* stream);
 int32_t ibu_memcpy_d2h(ibu_ctx_t* ctx, void* h_dst, const void* d_src, size_t bytes, void* stream);
 
@@ -449,6 +465,23 @@ typedef struct ibu_decode_sink {
 int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                 int32_t proc, size_t shard, size_t n_shards, void* sink,
                                 ibu_stream_stats_t* stats);
+
+/* MmapReader::process_parallel(processor, n) (mmap.rs:286-332) with a GPU per worker, in ONE call: worker i = one host thread
+ * + one context on devices[i], shard i of the static split (ibu_shard_range(len, n_devices, i): per = len / n, remainder to
+ * the last), workers joined in spawn order, the first error in that order is the call's (quirk Q12; the other workers still
+ * run to completion, as the reference's detached threads do).  n_devices == 0: every visible device, as num_threads == 0
+ * means every core (mmap.rs:292-296); an ordinal may appear more than once (two workers sharing a GPU).
+ *   proc == IBU_PROC_REDUCE: `sinks` = NULL or ibu_reduce_result_t[n_devices] (the per-device partials); *total (nullable) =
+ *     their sum — count and the three sums wrapping mod 2^64, the three XORs — added on the host: seven words per device,
+ *     no collective (the path shards with no exchange step).
+ *   proc == IBU_PROC_DECODE: `sinks` = ibu_decode_sink_t[n_devices]; sink i's columns live on devices[i] and hold shard i's
+ *     rows (row r of the shard at column + r * len); total->count = records decoded.
+ * `stats`: NULL or ibu_stream_stats_t[n_devices].  The context form takes contexts the caller keeps (their rings, streams and
+ * scratch are reused from call to call); the device form creates and destroys one context per entry. */
+int32_t ibu_mmap_process_devices(const ibu_mmap_t* m, const int32_t* devices, size_t n_devices, const ibu_ring_config_t* cfg,
+                                 int32_t proc, void* sinks, ibu_reduce_result_t* total, ibu_stream_stats_t* stats);
+int32_t ibu_mmap_process_contexts(const ibu_mmap_t* m, ibu_ctx_t* const* ctxs, size_t n_ctxs, const ibu_ring_config_t* cfg,
+                                  int32_t proc, void* sinks, ibu_reduce_result_t* total, ibu_stream_stats_t* stats);
 
 /* Streaming Reader (plain or gzip; reader.rs:345-352 path) -> device processor: host inflate
  * thread -> pinned ring -> H2D || kernel.  Consumes the reader to EOF. */

@@ -147,9 +147,22 @@ TEST(file_streams_to_and_from_the_device) {
     count += r.count; sum2 += r.sum[2];
   }
   CHECK_EQ(count, want.count); CHECK_EQ(sum2, want.sum[2]);
+  {  // the same three workers in ONE call (process_parallel with a GPU per worker; the box has one GPU, so it is listed thrice)
+    auto [total, parts] = m.process_devices_reduce({0, 0, 0}, &ring);
+    CHECK_EQ(total.count, want.count);
+    for (int f = 0; f < 3; ++f) { CHECK_EQ(total.sum[f], want.sum[f]); CHECK_EQ(total.xor_[f], want.xor_[f]); }
+    CHECK_EQ(parts.size(), (size_t)3);
+    for (size_t s = 0; s < 3; ++s) { auto range = shard_range(n, 3, s); CHECK_EQ(parts[s].count, (uint64_t)(range.second - range.first)); }
+    auto [all, per_device] = m.process_devices_reduce();   // every visible device
+    CHECK_EQ(all.count, want.count); CHECK_EQ(per_device.size(), (size_t)device::device_count());
+    AllocProbe rep{};
+    void* p = ctx().alloc_probed(24 * n, 3, &rep);          // resident arrays may choose their placement
+    CHECK_EQ(rep.tries, 3u); CHECK(rep.chosen < 3u);
+    ctx().free(p);
+  }
   DeviceBuffer bc(ctx(), n * 16), umi(ctx(), n * 12), idx(ctx(), n * 8);
   Reader r = Reader::from_path(path);
-  r.process_device_decode(ctx(), bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), n, &ring);
+  r.process_device_decode(ctx(), DecodeSink{bc.as<uint8_t>(), umi.as<uint8_t>(), idx.as<uint64_t>(), n}, &ring);
   std::vector<uint8_t> wbc(n * 16), wumi(n * 12);
   std::vector<uint64_t> widx(n);
   orc_decode_records(reinterpret_cast<const orc_record*>(recs.data()), n, 16, 12, wbc.data(), wumi.data(), widx.data());

@@ -85,6 +85,20 @@ def test_device_entry_points_fail_loudly_without_gpu():
     with pytest.raises(ibu_amd.IbuError) as ei:
         ibu_amd.Context(0)
     assert ei.value.kind == "NoDevice"
+    # the one-call multi-device form too: no device list -> "all devices" -> none visible -> NoDevice, never a host loop
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "x.ibu")
+        w = ibu_amd.Writer.from_path(path, ibu_amd.Header(16, 12))
+        w.write_batch(ibu_amd.records_array([(1, 2, 3), (4, 5, 6)]))
+        w.finish()
+        w.close()
+        m = ibu_amd.MmapReader.new(path)
+        for devices in ((), (0,), (0, 0)):
+            with pytest.raises(ibu_amd.IbuError) as ei:
+                m.process_devices(devices, ibu_amd.PROC_REDUCE)
+            assert ei.value.kind == "NoDevice", devices
+        m.close()
 
 
 def test_product_never_touches_the_oracle():

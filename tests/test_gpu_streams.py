@@ -390,3 +390,112 @@ def test_decode_sink_too_small_is_an_error_not_an_overrun(ia, ctx, oracle, tmp_p
     with pytest.raises(TypeError):
         m.process_device(ctx, ia.PROC_DECODE, sink=(d_bc.ptr, d_umi.ptr, d_idx.ptr), ring=SMALL_RING)  # raw pointers need a capacity
     m.close()
+
+
+# ---- process_parallel with a GPU per worker, one call (ibu_mmap_process_devices / _contexts; mmap.rs:286-332) ---------------
+@pytest.mark.parametrize("n", [0, 1, 3, 10_000, 1_000_003])
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0, 0, 0)])
+def test_process_devices_reduce_equals_the_oracles_process_parallel(ia, oracle, tmp_path, n, devices):
+    """One call drives one host thread + context per listed device over the reference's static split; the per-device
+    partials are the oracle's per-shard sums and their host-side total is what the reference's process_parallel (the
+    oracle's restatement, same number of workers) reports.  N DISTINCT devices is unmeasured here: the test box has one
+    GPU, so the list repeats ordinal 0 (legal, and the same code path: a thread and a context per entry)."""
+    p = tmp_path / "m.ibu"
+    recs = _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    total, parts, stats = m.process_devices(devices, ia.PROC_REDUCE, ring=SMALL_RING)
+    want = oracle.Mmap(str(p)).process_parallel(len(devices), cores=64)
+    assert total == {"count": want.count, "sum": list(want.sum), "xor": list(want.xor_)} == oracle.reduce_records(recs)
+    for i in range(len(devices)):
+        a, b = oracle.shard_range(n, len(devices), i)
+        assert parts[i] == oracle.reduce_records(recs[a:b]) and stats[i].records == b - a
+    # ... and equals the single-device call
+    c = ia.Context(0)
+    one, _ = m.process_device(c, ia.PROC_REDUCE, ring=SMALL_RING)
+    assert one == total
+    # the context form reuses caller-owned contexts (twice: the rings survive)
+    cs = [ia.Context(0) for _ in devices]
+    for _ in range(2):
+        t2, p2, _ = m.process_devices(proc=ia.PROC_REDUCE, ring=SMALL_RING, contexts=cs)
+        assert t2 == total and p2 == parts
+    with pytest.raises(ia.IbuError) as e:
+        m.process_devices(proc=ia.PROC_REDUCE, contexts=[cs[0], cs[0]])
+    assert e.value.kind == "InvalidArg"
+    for x in cs + [c]:
+        x.close()
+    m.close()
+
+
+def test_process_devices_all_visible_devices(ia, oracle, tmp_path):
+    """devices = () -> every visible device, as num_threads == 0 means every core (mmap.rs:292-296)."""
+    n = 70_001
+    p = tmp_path / "all.ibu"
+    recs = _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    total, parts, _ = m.process_devices((), ia.PROC_REDUCE)
+    assert len(parts) == ia.device_count() >= 1 and total == oracle.reduce_records(recs)
+    m.close()
+
+
+@pytest.mark.parametrize("lens", [(16, 12), (15, 11)])
+def test_process_devices_decode_concatenates_in_shard_order(ia, ctx, oracle, tmp_path, lens):
+    bc_len, umi_len = lens
+    n, devices = 200_003, (0, 0, 0)
+    p = tmp_path / "d.ibu"
+    recs = _write_file(oracle, p, n, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len)
+    m = ia.MmapReader.new(p)
+    sinks = []
+    for s in range(len(devices)):
+        a, b = ia.shard_range(n, len(devices), s)
+        sinks.append((ctx.alloc((b - a) * bc_len), ctx.alloc((b - a) * umi_len), ctx.alloc((b - a) * 8), b - a))
+    count, _, stats = m.process_devices(devices, ia.PROC_DECODE, sinks=sinks, ring=SMALL_RING)
+    assert count == n and sum(s.records for s in stats) == n
+    assert b"".join(s[0].download().tobytes() for s in sinks) == bc.tobytes()
+    assert b"".join(s[1].download().tobytes() for s in sinks) == umi.tobytes()
+    assert b"".join(s[2].download().tobytes() for s in sinks) == idx.tobytes()
+    m.close()
+
+
+def test_process_devices_first_error_in_worker_order_wins(ia, ctx, oracle, tmp_path):
+    """mmap.rs:326-328 (Q12): handles are joined in spawn order and the first Err is the call's.  Worker 1 and worker 2
+    both fail (sinks too small); the error reported is worker 1's, with ITS detail — not worker 2's, whichever finished
+    first.  A bad device ordinal fails before any worker starts."""
+    n = 90_000
+    p = tmp_path / "e.ibu"
+    _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    k = n // 3
+    big = lambda: (ctx.alloc(k * 16), ctx.alloc(k * 12), ctx.alloc(k * 8), k)
+    sinks = [big(), big()[:3] + (k - 7,), big()[:3] + (k - 9,)]
+    with pytest.raises(ia.IbuError) as e:
+        m.process_devices((0, 0, 0), ia.PROC_DECODE, sinks=sinks, ring=SMALL_RING)
+    assert e.value.kind == "InvalidArg" and (e.value.a, e.value.b) == (k, k - 7)
+    with pytest.raises(ia.IbuError) as e:
+        m.process_devices((0, 99), ia.PROC_REDUCE)
+    assert e.value.kind == "NoDevice"
+    with pytest.raises(ValueError):
+        m.process_devices((0, 0), ia.PROC_DECODE, sinks=sinks[:1])
+    m.close()
+
+
+def test_alloc_probed_keeps_one_usable_candidate(ia, ctx, oracle):
+    """ibu_device_alloc_probed: `tries` candidates are timed (write + read over the whole range), one is kept, the rest
+    freed; what comes back is ordinary device memory.  No rate is asserted (that is bench.py's to report)."""
+    n = 2_000_003
+    free0 = None
+    buf, rep = ctx.alloc_probed(24 * n, 4)
+    assert rep["tries"] == 4 and 0 <= rep["chosen"] < 4 and len(rep["ms"]) == 4 and all(v > 0 for v in rep["ms"])
+    assert rep["ms"][rep["chosen"]] == min(rep["ms"])
+    ctx.generate(SEED, 0, n, 16, 12, buf)
+    want = oracle.generate(SEED, 0, n, 16, 12)
+    assert buf.download().tobytes() == want.tobytes()
+    assert ctx.reduce(buf, n) == oracle.reduce_records(want)       # the probe left the context's accumulator reset
+    buf.free()
+    small, rep = ctx.alloc_probed(1000, 8)                          # too small to measure: a plain allocation
+    assert rep["tries"] == 1 and rep["chosen"] == 0
+    small.free()
+    one, rep = ctx.alloc_probed(24 * n, 1)
+    assert rep["tries"] == 1
+    one.free()
+    del free0

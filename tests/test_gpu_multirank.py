@@ -37,8 +37,10 @@ def test_bench_two_ranks_on_one_gpu_strong():
     assert out["config"]["records_per_rank"] == [50_000_000, 50_000_001]  # remainder to the last shard (mmap.rs:297-307)
     assert out["kernel_ms_ranks"]["decode"]["min"] <= out["kernel_ms_ranks"]["decode"]["max"]
     assert out["allreduce_ms"] > 0 and "config2_32_32" not in out
-    assert out["placement"]["tries"] >= 4 and len(out["placement"]["probe_ms_decode_encode"]) == out["placement"]["tries"]  # small shards: auto tries
-    assert set(out["placement"]["kept"]) == {"records", "bc", "umi", "idx", "output"}
+    # small shards: auto tries; the probing is the library's (ibu_device_alloc_probed per array), every candidate's time in the line
+    assert out["placement"]["tries"] >= 4 and set(out["placement"]["per_array"]) == {"records", "bc", "umi", "idx", "output"}
+    assert all(r["tries"] >= 2 and len(r["ms"]) == r["tries"] and 0 <= r["chosen"] < r["tries"] for r in out["placement"]["per_array"].values())
+    assert out["value_first_placement"] > 0 and out["placement"]["first_placement_decode_frac"] > 0
     assert abs(out["value"] - 100_000_001 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
 

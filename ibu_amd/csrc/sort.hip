@@ -934,11 +934,138 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
 }
 
 // =====================================================================================================
+// PREFIX + FINISH (round 3): wide keys.  LSD over all varying bytes costs a pass per byte — 24 passes of ~50 B/record for
+// full-range (32,32) records.  But once the records are sorted by their most significant P varying bytes (P LSD passes,
+// least significant of the P first), everything that is left to decide lies INSIDE runs of equal prefix ("segments"),
+// and for P = ceil(log256(n / 64)) a segment of well-spread keys holds a few dozen records.  ibu_k_sort_finish completes the
+// sort in ONE more pass: a workgroup takes the segments that START in its tile of T records (from the first segment head
+// in the tile to the first head at or behind the tile's end — up to M records of look-ahead), stages them in LDS, ranks
+// every record inside its segment by counting the records of the segment that order before it under the full 24-byte key
+// (quadratic in the segment length, which is why segments longer than M are refused), permutes in LDS and writes the
+// chunk out as consecutive 8-byte words.  3 passes + 1 instead of 24 at 1e9 records.
+//   Keys that are NOT well spread (a few heavy prefixes) make long segments: the kernel then raises the overflow flag and the
+// host falls back to the full LSD passes (the prefix-sorted records are a permutation of the input; records with equal
+// keys are equal byte for byte, so nothing is lost but the time of the P passes).
+// =====================================================================================================
+static constexpr int kFinishT = 2048, kFinishM = 512;        // 60 KiB of records + 12 KiB of tables: two workgroups per CU
+template <int T, int M>
+struct FinishShape {
+  static constexpr int L = T + M;                             // records staged per workgroup (+ 1 in front)
+  // LDS: stage 24 (L + 1) | head u8 [L + 1] (padded) | segstart u16 [L] | seglen u16 [L] | misc 16 x u32
+  static constexpr size_t lds = 24 * (size_t)(L + 1) + ((L + 1 + 15) & ~15) + 2 * (size_t)L + 2 * (size_t)L + 64;
+};
+template <int T, int M>
+__global__ void __launch_bounds__(kSortThreads)
+ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64 pm0, u64 pm1, u64 pm2, u32* __restrict__ overflow) {
+  typedef FinishShape<T, M> S;
+  constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  u64* stage = reinterpret_cast<u64*>(smem) + 3;             // record i of the window at stage[3 i]; record -1 = the one in front
+  uint8_t* head = reinterpret_cast<uint8_t*>(stage + 3 * L);  // head[i]: record i starts a segment
+  uint16_t* segstart = reinterpret_cast<uint16_t*>(head + ((L + 1 + 15) & ~15));
+  uint16_t* seglen = segstart + L;
+  u32* misc = reinterpret_cast<u32*>(seglen + L);             // [0] first head in the tile, [1] first head at / behind T, [2] too long
+  const u32 tid = threadIdx.x;
+  const u64 base = (u64)blockIdx.x * T;
+  if (base >= n) return;
+  const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;   // records of the window that exist
+  // 1. stage the window (and the record in front of it) — consecutive lanes, consecutive 8-byte words
+  const u64* g = src + 3 * base;
+  if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+    const u32x4* g4 = reinterpret_cast<const u32x4*>(g);
+    u32x4* s4 = reinterpret_cast<u32x4*>(stage);              // stage is 8 (mod 16)-aligned: write as two halves
+    const u32 nch = (3 * len) >> 1;
+    for (u32 c = tid; c < nch; c += kSortThreads) {
+      const u32x4 v = ld16(g4 + c);
+      stage[2 * c] = ((u64)v.y << 32) | v.x;
+      stage[2 * c + 1] = ((u64)v.w << 32) | v.z;
+    }
+    if (tid == 0 && ((3 * len) & 1u)) stage[3 * len - 1] = g[3 * len - 1];
+    (void)s4;
+  } else {
+    for (u32 w = tid; w < 3 * len; w += kSortThreads) stage[w] = g[w];
+  }
+  if (tid < 3) stage[(int)tid - 3] = base > 0 ? g[(int)tid - 3] : 0;
+  if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
+  __syncthreads();
+  // 2. segment heads: the prefix differs from the predecessor's (row 0 of the array is a head)
+  for (u32 i = tid; i < len; i += kSortThreads) {
+    const u64* r = stage + 3 * i;
+    const bool h = (base + i == 0) || (((r[0] ^ r[-3]) & pm0) | ((r[1] ^ r[-2]) & pm1) | ((r[2] ^ r[-1]) & pm2)) != 0;
+    head[i] = h;
+    if (h) atomicMin(&misc[i < (u32)T ? 0 : 1], i);
+  }
+  __syncthreads();
+  const u32 begin = misc[0];
+  u32 end = misc[1];
+  if (end == 0xFFFFFFFFu && base + len == n) end = len;       // the array ends inside the window: that is the last segment's end
+  if (begin == 0xFFFFFFFFu) {                                 // no segment starts in this tile: the tile is the inside of one that is
+    if (tid == 0 && len > (u32)M) *overflow = 1u;             // longer than a tile — its owner overflows as well; say so here too
+    return;
+  }
+  if (end == 0xFFFFFFFFu) {                                   // the last segment of the tile runs past the look-ahead
+    if (tid == 0) *overflow = 1u;
+    return;
+  }
+  // 3. every head walks its segment: segstart for the members, seglen at the head
+  for (u32 i = begin + tid; i < end; i += kSortThreads)
+    if (head[i]) {
+      u32 j = i + 1;
+      while (j < end && !head[j]) ++j;
+      if (j - i > (u32)M) misc[2] = 1u;
+      else {
+        for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
+        seglen[i] = (uint16_t)(j - i);
+      }
+    }
+  __syncthreads();
+  if (misc[2]) {                                              // a segment longer than M: ranking by counting would be quadratic in it
+    if (tid == 0) *overflow = 1u;
+    return;
+  }
+  // 4. rank inside the segment under the full key (ties: window order — equal keys are equal records)
+  u64 k0[PER], k1[PER], k2[PER];
+  u32 target[PER];
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const u32 i = begin + tid + kSortThreads * r;
+    target[r] = 0xFFFFFFFFu;
+    if (i < end) {
+      const u64* me = stage + 3 * i;
+      k0[r] = me[0]; k1[r] = me[1]; k2[r] = me[2];
+      const u32 s0 = segstart[i], s1 = s0 + seglen[s0];
+      u32 cnt = 0;
+      for (u32 j = s0; j < s1; ++j) {
+        const u64* o = stage + 3 * j;
+        const u64 b = o[0], u = o[1], x = o[2];
+        const bool less = rec_less(b, u, x, k0[r], k1[r], k2[r]);
+        const bool same = b == k0[r] && u == k1[r] && x == k2[r];
+        cnt += (less || (same && j < i)) ? 1u : 0u;
+      }
+      target[r] = s0 + cnt;
+    }
+  }
+  __syncthreads();                                            // every record is in registers: permute in place
+#pragma unroll
+  for (int r = 0; r < PER; ++r)
+    if (target[r] != 0xFFFFFFFFu) {
+      u64* o = stage + 3 * target[r];
+      o[0] = k0[r]; o[1] = k1[r]; o[2] = k2[r];
+    }
+  __syncthreads();
+  // 5. the chunk [begin, end) leaves as consecutive 8-byte words
+  u64* out = dst + 3 * (base + begin);
+  const u64* in = stage + 3 * begin;
+  for (u32 w = tid; w < 3 * (end - begin); w += kSortThreads) out[w] = in[w];
+}
+
+// =====================================================================================================
 // Host side.  Scratch layout (bytes), all offsets 256-byte aligned:
 //   census u64[64][8] | binbase u64[256] | blocksum u32[nblocks][256] | blockoff u64[nblocks][256] | counts u16[ntiles][256]
 //   | pos IDX[ntiles][256] | digits u8[ntiles * T]
+static constexpr size_t kMiscBytes = 256;                     // behind the census slots: [0] the finishing kernel's overflow flag (u32)
 struct SortLayout {
-  size_t binbase, blocksum, blockoff, counts, pos, digits, total;
+  size_t misc, binbase, blocksum, blockoff, counts, pos, digits, total;
   u32 ntiles, nblocks;
   bool idx64;
 };
@@ -950,6 +1077,7 @@ static SortLayout sort_layout(size_t n, int tile) {
   L.idx64 = n >= (1ull << 32);
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o = kCensusBytes;                                   // the census slots sit in front
+  L.misc = o; o = up(o + kMiscBytes);
   L.binbase = o; o = up(o + 8 * kBins);
   L.blocksum = o; o = up(o + 4 * (size_t)L.nblocks * kBins);
   L.blockoff = o; o = up(o + 8 * (size_t)L.nblocks * kBins);
@@ -1345,61 +1473,99 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       }
     }
   }
-  if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=24-byte passes=%d\n", n, npass);
-
   const void* scatter = L.idx64 ? sv.scatter64 : sv.scatter32;
   if (sv.lds > 48 * 1024) {   // per call: the attribute is per device (see launch_compact_passes)
     e = hipFuncSetAttribute(scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv.lds);
     if (e != hipSuccess) return e;
   }
 
-  u64* src = static_cast<u64*>(recs);
-  u64* dst = static_cast<u64*>(tmp);
-  // An odd number of passes would leave the result in `tmp` (a 48 B/record copy back).  The first pass's counting kernel
-  // reads every record anyway: with an odd count it also writes them to `tmp` (24 B/record) and the passes run
-  // tmp -> recs -> tmp ... -> recs.
-  const bool stage = (npass & 1) && npass > 0;
   const u32 nfull = (u32)(n / sv.tile);          // tiles with all T records
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
-  for (int p = 0; p < npass; ++p) {
-    // counts of every tile: from the records for the first pass, from the digit side stream afterwards
-    if (p == 0) {
-      const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (stage ? reinterpret_cast<uintptr_t>(dst) : 0)) & 15u) == 0;
-      const u32 fast = aligned ? nfull : 0;
-      if (fast)
-        hipLaunchKernelGGL(sv.counts_recs, dim3(fast < cap ? fast : cap), dim3(kSortThreads), 0, st, (const uint8_t*)src, fast,
-                           passes[p].field, passes[p].shift, counts, stage ? reinterpret_cast<uint8_t*>(dst) : (uint8_t*)nullptr);
-      if (fast < L.ntiles)
-        hipLaunchKernelGGL(sv.counts_tail, dim3(L.ntiles - fast), dim3(kSortThreads), 0, st, (const u64*)src, (u64)n, fast,
-                           passes[p].field, passes[p].shift, counts, stage ? dst : (u64*)nullptr);
-      if (stage) { u64* t = src; src = dst; dst = t; }   // the records now sit in tmp: scatter tmp -> recs
-    } else {
-      hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits,
-                         (u64)n, L.ntiles, counts);
+  // LSD passes over ps[0 .. np) (least significant first), ping-pong between recs and tmp.  want_in_tmp: where the result is
+  // wanted.  The first pass's counting kernel reads every record anyway: when the parity of np would leave the result in
+  // the other array, it also copies the records across (24 B/record) and the passes start from there.
+  auto lsd = [&](const Pass* ps, int np, bool want_in_tmp) -> hipError_t {
+    u64* src = static_cast<u64*>(recs);
+    u64* dst = static_cast<u64*>(tmp);
+    const bool stage = ((np & 1) != 0) != want_in_tmp;
+    for (int p = 0; p < np; ++p) {
+      // counts of every tile: from the records for the first pass, from the digit side stream afterwards
+      if (p == 0) {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (stage ? reinterpret_cast<uintptr_t>(dst) : 0)) & 15u) == 0;
+        const u32 fast = aligned ? nfull : 0;
+        if (fast)
+          hipLaunchKernelGGL(sv.counts_recs, dim3(fast < cap ? fast : cap), dim3(kSortThreads), 0, st, (const uint8_t*)src, fast,
+                             ps[p].field, ps[p].shift, counts, stage ? reinterpret_cast<uint8_t*>(dst) : (uint8_t*)nullptr);
+        if (fast < L.ntiles)
+          hipLaunchKernelGGL(sv.counts_tail, dim3(L.ntiles - fast), dim3(kSortThreads), 0, st, (const u64*)src, (u64)n, fast,
+                             ps[p].field, ps[p].shift, counts, stage ? dst : (u64*)nullptr);
+        if (stage) { u64* t = src; src = dst; dst = t; }   // the records now sit in the other array
+      } else {
+        hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits,
+                           (u64)n, L.ntiles, counts);
+      }
+      hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
+      hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
+      if (L.idx64)
+        hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+                           (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
+      else
+        hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+                           (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
+      const bool last = p + 1 == np;
+      const u32 nf = last ? 3u : ps[p + 1].field, ns = last ? 0u : ps[p + 1].shift;
+      u64 n_arg = n;
+      u32 f_arg = ps[p].field, s_arg = ps[p].shift, nf_arg = nf, ns_arg = ns;
+      const u64* src_arg = src;
+      void* args[] = {&src_arg, &dst, &n_arg, &f_arg, &s_arg, &nf_arg, &ns_arg, &pos, &digits};
+      hipError_t le = hipLaunchKernel(scatter, dim3((L.ntiles + 7u) & ~7u), dim3(sv.threads), args, sv.lds, st);   // multiple of 8: XCD-aware tile order
+      if (le != hipSuccess) return le;
+      u64* t = src; src = dst; dst = t;
     }
-    hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
-    hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
-    if (L.idx64)
-      hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
-                         (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
-    else
-      hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
-                         (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
-    const bool last = p + 1 == npass;
-    const u32 nf = last ? 3u : passes[p + 1].field, ns = last ? 0u : passes[p + 1].shift;
-    u64 n_arg = n;
-    u32 f_arg = passes[p].field, s_arg = passes[p].shift, nf_arg = nf, ns_arg = ns;
-    const u64* src_arg = src;
-    void* args[] = {&src_arg, &dst, &n_arg, &f_arg, &s_arg, &nf_arg, &ns_arg, &pos, &digits};
-    e = hipLaunchKernel(scatter, dim3((L.ntiles + 7u) & ~7u), dim3(sv.threads), args, sv.lds, st);   // multiple of 8: XCD-aware tile order
-    if (e != hipSuccess) return e;
-    u64* t = src; src = dst; dst = t;
+    return hipGetLastError();
+  };
+
+  // PREFIX + FINISH (see ibu_k_sort_finish): P = the fewest prefix bytes that leave about 64 records per segment of well-spread
+  // keys; worth it when at least three passes are saved.  cfg.sort_hybrid: 0 = never, 1 = auto, 2 = whenever a pass is saved
+  // (tests).  The result of the P passes is wanted in tmp: the finishing kernel writes the records back into `recs`.
+  {
+    int P = 1;
+    for (u64 segs = 256; n / segs > 64 && P < 8; segs <<= 8) ++P;
+    const int margin = cfg.sort_hybrid == 2 ? 1 : 3;
+    if (cfg.sort_hybrid && npass >= P + margin && n < (1ull << 40)) {
+      u32* d_overflow = reinterpret_cast<u32*>(sc + L.misc);
+      e = hipMemsetAsync(d_overflow, 0, 4, st);
+      if (e != hipSuccess) return e;
+      const Pass* ps = passes + (npass - P);     // the P most significant varying bytes
+      u64 pm[3] = {0, 0, 0};
+      for (int p = 0; p < P; ++p) pm[ps[p].field] |= 255ull << ps[p].shift;
+      e = lsd(ps, P, true);
+      if (e != hipSuccess) return e;
+      typedef FinishShape<kFinishT, kFinishM> FS;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_sort_finish<kFinishT, kFinishM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS::lds);
+      if (e != hipSuccess) return e;
+      const u64 nblk = (n + kFinishT - 1) / kFinishT;
+      hipLaunchKernelGGL((ibu_k_sort_finish<kFinishT, kFinishM>), dim3((u32)nblk), dim3(kSortThreads), FS::lds, st, (const u64*)tmp,
+                         static_cast<u64*>(recs), (u64)n, pm[0], pm[1], pm[2], d_overflow);
+      u32 overflow = 0;
+      e = hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess) return e;
+      e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return e;
+      if (!overflow) {
+        if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=prefix+finish prefix_passes=%d of %d varying bytes\n", n, P, npass);
+        return hipSuccess;
+      }
+      // segments too long for the finishing kernel (heavy prefixes): the prefix-sorted records in tmp are a permutation of the
+      // input — copy them back and run every pass
+      if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu prefix+finish overflowed (long runs of equal prefix): all %d passes\n", n, npass);
+      e = launch_copy(cfg, tmp, recs, n * 24, st);
+      if (e != hipSuccess) return e;
+    }
   }
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (src != static_cast<u64*>(recs)) return launch_copy(cfg, src, recs, n * 24, st);  // odd number of passes
-  return hipSuccess;
+  if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=24-byte passes=%d\n", n, npass);
+  return lsd(passes, npass, false);
 }
 
 // =====================================================================================================

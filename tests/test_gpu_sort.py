@@ -45,26 +45,118 @@ def _shuffled(oracle, n, bc_len, umi_len, seed=SEED):
 
 @pytest.fixture(scope="module")
 def ctx24(ia):
-    """A context that never takes the compact-key path (sort_compact = 0): the 24-byte passes stay covered."""
+    """A context that never takes the compact-key path (sort_compact = 0) nor the prefix + finish path (sort_hybrid = 0): the
+    plain 24-byte LSD passes stay covered."""
     c = ia.Context(0)
     c.set_option("sort_compact", 0)
+    c.set_option("sort_hybrid", 0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_pf(ia):
+    """24-byte records, prefix + finish whenever it saves a pass (sort_hybrid = 2): LSD over the top P varying bytes, then
+    ibu_k_sort_finish completes every run of equal prefix in LDS — or overflows on long runs and falls back to all passes."""
+    c = ia.Context(0)
+    c.set_option("sort_compact", 0)
+    c.set_option("sort_hybrid", 2)
     yield c
     c.close()
 
 
 @pytest.mark.parametrize("n", SIZES)
-def test_sort_random_16_12(ctx, ctx24, oracle, n):
+def test_sort_random_16_12(ctx, ctx24, ctx_pf, oracle, n):
     recs = _shuffled(oracle, n, 16, 12)
     want = oracle.sort_records(recs).tobytes()
     got, d = _sort_on_device(ctx, recs)          # 11 varying bytes: 12-byte elements (compact-key passes)
     assert got == want
     assert ctx.is_sorted(d, n)
     assert _sort_on_device(ctx24, recs)[0] == want
+    assert _sort_on_device(ctx_pf, recs)[0] == want
     idx_order = recs.copy()
     idx_order["index"] = np.arange(n, dtype=np.uint64)   # input in index order: the index bytes ride along unsorted
     want = oracle.sort_records(idx_order).tobytes()
     assert _sort_on_device(ctx, idx_order)[0] == want
     assert _sort_on_device(ctx24, idx_order)[0] == want
+    assert _sort_on_device(ctx_pf, idx_order)[0] == want
+
+
+def _full_range(n, seed):
+    """(32,32) records with every one of the 24 bytes varying: BASELINE configs[2]'s widths with full-range values."""
+    import ibu_amd as ia
+    rng = np.random.default_rng(seed)
+    recs = np.empty(n, dtype=ia.REC_DTYPE)
+    for f in ("barcode", "umi", "index"):
+        recs[f] = rng.integers(0, 2**64, n, dtype=np.uint64)
+    return recs
+
+
+@pytest.mark.parametrize("n", [300, 2047, 2048, 2049, 2560, 2561, 4096, 70_001, 1_000_003, 3_000_001])
+def test_wide_keys_take_prefix_and_finish(ctx, ctx24, oracle, n, capfd):
+    """More than 16 varying key bytes (full-range (32,32) records: 24): instead of one LSD pass per byte, P passes over the
+    most significant varying bytes and one finishing pass (ibu_k_sort_finish).  Same bytes as the oracle's qsort and as
+    the plain passes; the trace says which path ran."""
+    recs = _full_range(n, n)
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    got, d = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == want and ctx.is_sorted(d, n)
+    P = 1 if n <= 16_384 else 2 if n <= 4_194_304 else 3
+    assert f"path=prefix+finish prefix_passes={P} of 24 varying bytes" in trace, trace
+    assert _sort_on_device(ctx24, recs)[0] == want
+
+
+def test_wide_keys_prefix_and_finish_segment_edges(ctx_pf, oracle, ia, capfd):
+    """Runs of equal prefix (segments) of every awkward shape: exactly the 512 records the finishing kernel accepts,
+    one more (overflow -> all passes), runs crossing the 2048-record tile boundary, a run reaching the end of the array,
+    exact duplicates inside a run, the array ending inside the look-ahead window."""
+    rng = np.random.default_rng(99)
+
+    def build(run_lengths, dup=False):
+        recs = _full_range(sum(run_lengths), 7)
+        pos = 0
+        for k, m in enumerate(run_lengths):
+            recs["barcode"][pos:pos + m] = (np.uint64(k) << np.uint64(56)) | (recs["barcode"][pos:pos + m] & np.uint64((1 << 48) - 1))   # top byte = run id, second byte 0: one prefix per run
+            pos += m
+        if dup:
+            recs[1::2] = recs[0:len(recs[1::2]) * 2:2]                # every record twice, in place: equal neighbours inside runs
+        rng.shuffle(recs)
+        return recs
+
+    for lengths, overflow in (([512] * 5, False), ([513] + [100] * 20, True), ([300, 400, 500, 512, 336, 10, 2000 - 10][:6] + [7] * 30, False),
+                              ([200] * 25 + [90], False), ([512, 512, 512, 512, 1], False), ([100] * 9 + [2000], True)):
+        for dup in (False, True):
+            recs = build(lengths, dup)
+            capfd.readouterr()
+            got, _ = _sort_on_device(ctx_pf, recs)
+            trace = capfd.readouterr().err
+            assert got == oracle.sort_records(recs).tobytes(), (lengths, dup)
+            assert ("overflowed" in trace) == overflow and (("path=prefix+finish" in trace) != overflow), (lengths, trace)
+
+
+def test_wide_keys_heavy_prefixes_fall_back_to_all_passes(ctx, oracle, capfd):
+    """Keys that are not well spread — here two values of the most significant varying bytes — make runs far longer than the
+    finishing kernel accepts: it raises its overflow flag and the sort runs every pass on the prefix-sorted records."""
+    n = 300_007
+    recs = _full_range(n, 3)
+    recs["barcode"] = (recs["barcode"] & np.uint64((1 << 40) - 1)) | (np.uint64(0xABCDEF) << np.uint64(40)) * (recs["index"] & np.uint64(1))
+    capfd.readouterr()
+    got, d = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == oracle.sort_records(recs).tobytes()
+    assert "prefix+finish overflowed" in trace and "path=24-byte" in trace, trace
+
+
+def test_wide_keys_of_a_shard_at_an_odd_record(ctx, oracle):
+    n = 200_001
+    recs = _full_range(n, 11)
+    d, t = ctx.alloc((n + 1) * 24), ctx.alloc((n + 1) * 24)
+    ctx.copy(d.ptr + 24, ctx.upload(recs), n * 24)
+    ctx.sort_records(d.ptr + 24, t.ptr + 24, n)
+    ctx.synchronize()
+    assert d.download(count=n * 24, offset=24).tobytes() == oracle.sort_records(recs).tobytes()
 
 
 @pytest.mark.parametrize("compact", [2, 3, 4, 5, 6, 7, 8])

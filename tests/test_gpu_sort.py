@@ -103,30 +103,35 @@ def test_wide_keys_take_prefix_and_finish(ctx, ctx24, oracle, n, capfd):
     got, d = _sort_on_device(ctx, recs)
     trace = capfd.readouterr().err
     assert got == want and ctx.is_sorted(d, n)
-    P = 1 if n <= 16_384 else 2 if n <= 4_194_304 else 3
+    P = 1 if n < 9 * 256 else 2 if n < 9 * 65_536 else 3   # the fewest prefix bytes that leave at most 8 records per segment
     assert f"path=prefix+finish prefix_passes={P} of 24 varying bytes" in trace, trace
     assert _sort_on_device(ctx24, recs)[0] == want
 
 
 def test_wide_keys_prefix_and_finish_segment_edges(ctx_pf, oracle, ia, capfd):
     """Runs of equal prefix (segments) of every awkward shape: exactly the 512 records the finishing kernel accepts,
-    one more (overflow -> all passes), runs crossing the 2048-record tile boundary, a run reaching the end of the array,
-    exact duplicates inside a run, the array ending inside the look-ahead window."""
+    one more (overflow -> all passes), runs crossing the 2048-record tile boundaries, a run reaching the end of the array,
+    exact duplicates inside a run, the array ending inside the look-ahead window — with one prefix byte (fewer than 2304
+    records) and with two."""
     rng = np.random.default_rng(99)
 
     def build(run_lengths, dup=False):
         recs = _full_range(sum(run_lengths), 7)
         pos = 0
-        for k, m in enumerate(run_lengths):
-            recs["barcode"][pos:pos + m] = (np.uint64(k) << np.uint64(56)) | (recs["barcode"][pos:pos + m] & np.uint64((1 << 48) - 1))   # top byte = run id, second byte 0: one prefix per run
+        for k, m in enumerate(run_lengths):                 # the two top bytes of the barcode = the run's id (k, k): one prefix per run
+            recs["barcode"][pos:pos + m] = (np.uint64(k * 257) << np.uint64(48)) | (recs["barcode"][pos:pos + m] & np.uint64((1 << 48) - 1))
             pos += m
         if dup:
             recs[1::2] = recs[0:len(recs[1::2]) * 2:2]                # every record twice, in place: equal neighbours inside runs
         rng.shuffle(recs)
         return recs
 
-    for lengths, overflow in (([512] * 5, False), ([513] + [100] * 20, True), ([300, 400, 500, 512, 336, 10, 2000 - 10][:6] + [7] * 30, False),
-                              ([200] * 25 + [90], False), ([512, 512, 512, 512, 1], False), ([100] * 9 + [2000], True)):
+    cases = [([512] * 4, False), ([513] + [100] * 17, True), ([300, 400, 500, 512, 336, 10] + [7] * 30, False),   # one prefix byte
+             ([200] * 11 + [90], False), ([512, 512, 512, 512, 1], False), ([100] * 3 + [2000], True),
+             ([512] * 20 + [3] * 230, False), ([40] * 120 + [513] + [40] * 100, True), ([2, 510, 512, 1, 1023 - 512, 512] * 9, False),   # two
+             ([1] * 150 + [254] * 100, False), ([100] * 200 + [4096], True)]
+    for lengths, overflow in cases:
+        assert len(lengths) <= 255 + 1 and (sum(lengths) < 2304 or 2304 <= sum(lengths) < 9 * 65_536)
         for dup in (False, True):
             recs = build(lengths, dup)
             capfd.readouterr()
@@ -134,6 +139,7 @@ def test_wide_keys_prefix_and_finish_segment_edges(ctx_pf, oracle, ia, capfd):
             trace = capfd.readouterr().err
             assert got == oracle.sort_records(recs).tobytes(), (lengths, dup)
             assert ("overflowed" in trace) == overflow and (("path=prefix+finish" in trace) != overflow), (lengths, trace)
+            assert f"prefix_passes={1 if len(recs) < 2304 else 2} " in trace or overflow, trace
 
 
 def test_wide_keys_heavy_prefixes_fall_back_to_all_passes(ctx, oracle, capfd):

@@ -374,6 +374,22 @@ impl MmapReader {
         })?;
         Ok(out)
     }
+    /// `process_parallel(processor, n)` with a GPU per worker, in ONE call (src/io/mmap.rs:286-332): worker i is a host
+    /// thread + a context on `devices[i]` taking shard i of the static split; an empty list means every visible device
+    /// (as `num_threads == 0` means every core).  Returns the total (count, wrapping sums, XORs) and the per-device
+    /// partials; the first error in worker order is the call's error (quirk Q12).
+    pub fn process_devices(&self, devices: &[i32]) -> Result<(ffi::ibu_reduce_result_t, Vec<ffi::ibu_reduce_result_t>)> {
+        let n = if devices.is_empty() { device::device_count()? as usize } else { devices.len() };
+        let mut total = ffi::ibu_reduce_result_t::default();
+        let mut parts = vec![ffi::ibu_reduce_result_t::default(); n.max(1)];
+        check(unsafe {
+            ffi::ibu_mmap_process_devices(self.raw, if devices.is_empty() { std::ptr::null() } else { devices.as_ptr() },
+                                          devices.len(), std::ptr::null(), 1, parts.as_mut_ptr() as *mut c_void,
+                                          &mut total, std::ptr::null_mut())
+        })?;
+        parts.truncate(n);
+        Ok((total, parts))
+    }
 }
 impl Drop for MmapReader {
     fn drop(&mut self) {
@@ -429,6 +445,12 @@ impl ParallelReader for MmapReader {
 // ---- device side ------------------------------------------------------------------------------------------
 pub mod device {
     use super::*;
+    /// Visible HIP devices (`ibu_device_count`).
+    pub fn device_count() -> Result<i32> {
+        let mut n = 0i32;
+        check(unsafe { ffi::ibu_device_count(&mut n) })?;
+        Ok(n)
+    }
     pub struct Context {
         pub(crate) raw: *mut ffi::ibu_ctx_t,
     }
@@ -448,6 +470,14 @@ pub mod device {
             let mut p = std::ptr::null_mut();
             check(unsafe { ffi::ibu_device_alloc(self.raw, bytes, &mut p) })?;
             Ok(DeviceBuf { ptr: p, bytes, ctx: self, _p: PhantomData })
+        }
+        /// For arrays that stay resident: up to `tries` candidate allocations, the one a write + read streams over
+        /// fastest is kept (placement probing, `ibu_device_alloc_probed`).
+        pub fn alloc_probed(&self, bytes: usize, tries: u32) -> Result<(DeviceBuf<'_>, ffi::ibu_alloc_probe_t)> {
+            let mut p = std::ptr::null_mut();
+            let mut rep = ffi::ibu_alloc_probe_t::default();
+            check(unsafe { ffi::ibu_device_alloc_probed(self.raw, bytes, tries, &mut p, &mut rep) })?;
+            Ok((DeviceBuf { ptr: p, bytes, ctx: self, _p: PhantomData }, rep))
         }
         /// K2: AoS records -> barcode ASCII, UMI ASCII, index column (async on the context stream).
         pub fn decode_ascii(&self, recs: &DeviceBuf, n: usize, h: &Header, bc: &DeviceBuf, umi: &DeviceBuf, idx: &DeviceBuf) -> Result<()> {

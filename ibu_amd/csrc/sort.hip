@@ -1070,6 +1070,191 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
   for (u32 w = tid; w < 3 * (end - begin); w += kSortThreads) out[w] = in[w];
 }
 
+// ---- the same on compact elements (W words): P element passes, then this kernel ranks inside the runs of equal prefix, and
+// every element leaves as the 24-byte record it stands for (the chunk is contiguous in the output: one lane per half record,
+// dwordx3, fully coalesced).  Elements compare as W-word little-endian integers, which is the record order (COMPACT-KEY
+// passes); index bytes that the passes do not sort on (input in index order) take part in the comparison here — the same
+// result, because the passes are stable and the input's index order is the element order on those bytes.
+template <int W, int T, int M>
+struct FinishElemShape {
+  static constexpr int L = T + M;
+  static constexpr size_t lds = 4 * (size_t)W * (L + 1) + ((L + 1 + 15) & ~15) + 2 * (size_t)L + 2 * (size_t)L + 64;
+};
+template <int W>
+__device__ __forceinline__ u32 elem_before(const u32* a, const u32* b, u32 tie) {   // a orders before b (W-word integers; tie: what equal elements answer)
+  u32 r = tie;
+#pragma unroll
+  for (int w = 0; w < W; ++w) r = (u32)(a[w] < b[w]) | ((u32)(a[w] == b[w]) & r);   // from the least significant word up
+  return r;
+}
+template <int W, int T, int M>
+__global__ void __launch_bounds__(kSortThreads)
+ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, u32 n, EV<W> pm, CompactPlan pl, u32* __restrict__ overflow) {
+  typedef FinishElemShape<W, T, M> S;
+  constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  u32* stage = reinterpret_cast<u32*>(smem) + W;             // element i of the window at stage[W i]; element -1 = the one in front
+  uint8_t* head = reinterpret_cast<uint8_t*>(stage + W * L);
+  uint16_t* segstart = reinterpret_cast<uint16_t*>(head + ((L + 1 + 15) & ~15));
+  uint16_t* seglen = segstart + L;
+  u32* misc = reinterpret_cast<u32*>(seglen + L);
+  const u32 tid = threadIdx.x;
+  const u64 base64 = (u64)blockIdx.x * T;
+  if (base64 >= n) return;
+  const u32 base = (u32)base64;
+  const u32 len = n - base < (u32)L ? n - base : (u32)L;
+  // 1. stage the window: one element per lane and step (dwordx3 / dwordx4, consecutive lanes on consecutive elements)
+  for (u32 i = tid; i < len; i += kSortThreads) {
+    const EV<W> v = ld_elem<W>(src + base + i);
+#pragma unroll
+    for (int w = 0; w < W; ++w) stage[W * i + w] = v.w[w];
+  }
+  if (tid == 0) {
+    EV<W> v;
+#pragma unroll
+    for (int w = 0; w < W; ++w) v.w[w] = 0;
+    if (base > 0) v = ld_elem<W>(src + base - 1);
+#pragma unroll
+    for (int w = 0; w < W; ++w) stage[w - W] = v.w[w];
+  }
+  if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
+  __syncthreads();
+  // 2. heads
+  for (u32 i = tid; i < len; i += kSortThreads) {
+    u32 diff = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) diff |= (stage[W * i + w] ^ stage[W * i + w - W]) & pm.w[w];
+    const bool h = (base + i == 0) || diff != 0;
+    head[i] = h;
+    if (h) atomicMin(&misc[i < (u32)T ? 0 : 1], i);
+  }
+  __syncthreads();
+  const u32 begin = misc[0];
+  u32 end = misc[1];
+  if (end == 0xFFFFFFFFu && base + len == n) end = len;
+  if (begin == 0xFFFFFFFFu) {
+    if (tid == 0 && len > (u32)M) *overflow = 1u;
+    return;
+  }
+  if (end == 0xFFFFFFFFu) {
+    if (tid == 0) *overflow = 1u;
+    return;
+  }
+  // 3. segments
+  for (u32 i = begin + tid; i < end; i += kSortThreads)
+    if (head[i]) {
+      u32 j = i + 1;
+      while (j < end && !head[j]) ++j;
+      if (j - i > (u32)M) misc[2] = 1u;
+      else {
+        for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
+        seglen[i] = (uint16_t)(j - i);
+      }
+    }
+  __syncthreads();
+  if (misc[2]) {
+    if (tid == 0) *overflow = 1u;
+    return;
+  }
+  // 4. rank inside the segment (a segment of one record — the usual case — costs nothing)
+  u32 me[PER][W];
+  u32 target[PER];
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const u32 i = begin + tid + kSortThreads * r;
+    target[r] = 0xFFFFFFFFu;
+    if (i < end) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) me[r][w] = stage[W * i + w];
+      const u32 s0 = segstart[i], m = seglen[s0];
+      u32 cnt = 0;
+      if (m > 1)
+        for (u32 j = s0; j < s0 + m; j += 2) {
+          const u32 j1 = j + 1 < s0 + m ? j + 1 : j;           // clamped: in the window, not counted
+          u32 a[W], b[W];
+#pragma unroll
+          for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
+          cnt += elem_before<W>(a, me[r], (u32)(j < i));
+          cnt += elem_before<W>(b, me[r], (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
+        }
+      target[r] = s0 + cnt;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PER; ++r)
+    if (target[r] != 0xFFFFFFFFu) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) stage[W * target[r] + w] = me[r][w];
+    }
+  __syncthreads();
+  // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out)
+  const u32 j = tid & 1u;
+  u32 hsel[3][2], hbase[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    hsel[k][0] = j ? pl.xsel[3 + k][0] : pl.xsel[k][0];
+    hsel[k][1] = j ? pl.xsel[3 + k][1] : pl.xsel[k][1];
+    const u64 bf = j ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
+    hbase[k] = ((3 * (j ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
+  }
+  uint8_t* out = static_cast<uint8_t*>(dst_v) + 24 * (size_t)base;
+  for (u32 h = 2 * begin + tid; h < 2 * end; h += kSortThreads) {   // kSortThreads is even: a lane keeps its half
+    const u32 p = h >> 1;
+    u32 e[4] = {stage[W * p], stage[W * p + 1], stage[W * p + 2], 0};
+    if constexpr (W == 4) e[3] = stage[W * p + 3];
+    u32x3 o;
+    o.x = hbase[0] | __builtin_amdgcn_perm(e[1], e[0], hsel[0][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[0][1]);
+    o.y = hbase[1] | __builtin_amdgcn_perm(e[1], e[0], hsel[1][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[1][1]);
+    o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
+    *reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * j) = o;
+  }
+}
+
+// How long are the runs of equal prefix going to be?  Estimated BEFORE the path is chosen, from the sample ranges the
+// speculative census reads anyway: every sample record is compressed on the fly, and for each candidate prefix length
+// P = 1 .. kMaxPrefix its top P element bytes are inserted into an exact (64-bit hashed, open addressing) table; the
+// number of PAIRS of sample records with equal prefix comes out per P.  With m sample records out of n, a record shares
+// its prefix with about 1 + (n / m) * 2 pairs / m records of the whole input — for well-spread keys that is 1 + n / 256^P,
+// for keys with few distinct prefixes (barcodes from a whitelist) it is large, and the sort then takes a longer prefix
+// or the plain passes.  (The samples are contiguous ranges: grouped input over-estimates, which errs on the safe side;
+// an under-estimate is caught by the finishing kernel's overflow flag.)
+static constexpr int kMaxPrefix = 8;
+static constexpr u32 kPairSlotsMax = 1u << 18;                // per P: 98 304 sample records -> load factor 0.375
+template <int W>
+__global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 s0, u64 s1, u64 s2, u32 per_range, CompactPlan pl, u32 k,
+                                        u32 kPairSlots /*power of two*/, u64* __restrict__ keys /*[kMaxPrefix][slots]*/, u32* __restrict__ cnts,
+                                        u64* __restrict__ pairs) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * per_range) return;
+  const u32 rg = t / per_range;
+  const u64 row = (rg == 0 ? s0 : rg == 1 ? s1 : s2) + (t - rg * per_range);
+  const EV<W> e = compress_rec<W>(recs[3 * row], recs[3 * row + 1], recs[3 * row + 2], pl);
+  for (u32 P = 1; P <= (u32)kMaxPrefix && P <= k; ++P) {
+    u64 h = 0x9E3779B97F4A7C15ull * P;                        // hash of element bytes [k - P, k)
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int lo = (int)(k - P) - 4 * w;                    // first prefix byte inside word w (may be <= 0: whole word, >= 4: none)
+      const u32 mask = lo >= 4 ? 0u : lo <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * lo));
+      h = (h ^ (u64)(e.w[w] & mask)) * 0xBF58476D1CE4E5B9ull;
+      h ^= h >> 29;
+    }
+    h = (h ^ (h >> 32)) * 0x94D049BB133111EBull;
+    h ^= h >> 31;
+    if (h == 0) h = 1;
+    u64* kt = keys + (size_t)(P - 1) * kPairSlots;
+    u32* ct = cnts + (size_t)(P - 1) * kPairSlots;
+    for (u32 slot = (u32)h & (kPairSlots - 1), probes = 0; probes < kPairSlots; slot = (slot + 1) & (kPairSlots - 1), ++probes) {
+      const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&kt[slot]), 0ull, (unsigned long long)h);
+      if (old == 0 || old == h) {
+        const u32 before = atomicAdd(&ct[slot], 1u);          // records with this prefix seen so far: that many new pairs
+        if (before) atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[P - 1]), (unsigned long long)before);
+        break;
+      }
+    }
+  }
+}
+
 // =====================================================================================================
 // Host side.  Scratch layout (bytes), all offsets 256-byte aligned:
 //   census u64[64][8] | binbase u64[256] | blocksum u32[nblocks][256] | blockoff u64[nblocks][256] | counts u16[ntiles][256]
@@ -1295,10 +1480,15 @@ hipError_t launch_expand(const LaunchCfg& cfg, const CompactPlan& pl, const void
 // W = 4: 16 n + 16 n bytes do not fit in tmp, so the second buffer is the head of the RECORD ARRAY (its contents are dead once
 //        the elements exist).  The last pass can write records into that array only while reading from tmp, i.e. when the
 //        pass count is odd; with an even count it stays an element pass (recs -> tmp) and an expand pass (tmp -> recs) follows.
+// finish_prefix = P > 0: PREFIX + FINISH on elements — only the top P of `passes` run (as element passes), then
+// ibu_k_sort_finish_elems completes the runs of equal prefix and writes the records; if it overflows (long runs), all passes run
+// after all, starting from the prefix-sorted elements wherever they ended (elems_at).  W = 4 needs an even P (the elements must
+// end in tmp: the records are written over the other buffer).
+static bool trace_sort();
 template <int W>
 static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
                                         const CompactPlan& pl, const u32* passes, u32 npass, hipStream_t st, bool compressed = false,
-                                        u32 digits_byte = 0) {
+                                        u32 digits_byte = 0, u32 finish_prefix = 0, ElemT<W>* elems_at = nullptr) {
   const SortLayout L = sort_layout(n, cv.tile);
   u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
   u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
@@ -1306,8 +1496,9 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
   uint16_t* counts = reinterpret_cast<uint16_t*>(sc + L.counts);
   u32* pos = reinterpret_cast<u32*>(sc + L.pos);
   uint8_t* digits = sc + L.digits;
-  ElemT<W>* src = static_cast<ElemT<W>*>(tmp);
-  ElemT<W>* dst = W == 3 ? reinterpret_cast<ElemT<W>*>(static_cast<uint8_t*>(tmp) + 12 * n) : static_cast<ElemT<W>*>(recs);
+  ElemT<W>* const half2 = W == 3 ? reinterpret_cast<ElemT<W>*>(static_cast<uint8_t*>(tmp) + 12 * n) : static_cast<ElemT<W>*>(recs);
+  ElemT<W>* src = elems_at ? elems_at : static_cast<ElemT<W>*>(tmp);
+  ElemT<W>* dst = src == half2 ? static_cast<ElemT<W>*>(tmp) : half2;
   const bool fuse_last = W == 3 || (npass & 1u);
 
   // every call, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive
@@ -1319,13 +1510,14 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     e = hipFuncSetAttribute(cv.scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
   }
-  if (!compressed) launch_compress<W>(cfg, pl, recs, n, passes[0], src, digits, st);
-  else if (digits_byte != passes[0])
-    hipLaunchKernelGGL(ibu_k_sort_digits<W>, dim3((u32)cfg.cus * 8), dim3(256), 0, st, (const ElemT<W>*)src, (u64)n, passes[0], digits);
-  // passes; the last one writes the records themselves
+  const u32 first_pass = finish_prefix ? npass - finish_prefix : 0;
+  if (!compressed) launch_compress<W>(cfg, pl, recs, n, passes[first_pass], src, digits, st);
+  else if (digits_byte != passes[first_pass])
+    hipLaunchKernelGGL(ibu_k_sort_digits<W>, dim3((u32)cfg.cus * 8), dim3(256), 0, st, (const ElemT<W>*)src, (u64)n, passes[first_pass], digits);
+  // passes; the last one writes the records themselves (with a finishing pass behind them, none of them does)
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   const u32 cap = (u32)cfg.cus * 8;
-  for (u32 pi = 0; pi < npass; ++pi) {
+  for (u32 pi = first_pass; pi < npass; ++pi) {
     const u32 b = passes[pi];
     hipLaunchKernelGGL(cv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n,
                        L.ntiles, counts);
@@ -1333,7 +1525,7 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
     hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
                        (const u64*)blockoff, (const u64*)binbase, pos);
-    const bool last = pi + 1 == npass, to_records = last && fuse_last;
+    const bool last = pi + 1 == npass, to_records = last && fuse_last && !finish_prefix;
     u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? 4u * W : passes[pi + 1];   // 4 W: no digit stream behind the last pass
     const ElemT<W>* src_arg = src;
     void* dst_arg = to_records ? recs : static_cast<void*>(dst);
@@ -1343,6 +1535,28 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     e = hipLaunchKernel(to_records ? cv.scatter_last : cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
     if (e != hipSuccess) return e;
     ElemT<W>* t = src; src = dst; dst = t;
+  }
+  if (finish_prefix) {
+    constexpr int FT = W == 3 ? 4096 : 3072, FM = 512;       // 77 / 75 KiB of LDS: two workgroups per CU
+    typedef FinishElemShape<W, FT, FM> FS;
+    u32* d_overflow = reinterpret_cast<u32*>(sc + L.misc);
+    e = hipMemsetAsync(d_overflow, 0, 4, st);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_sort_finish_elems<W, FT, FM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS::lds);
+    if (e != hipSuccess) return e;
+    EV<W> pm;                                                 // the prefix bytes as word masks
+    for (int w = 0; w < W; ++w) pm.w[w] = 0;
+    for (u32 pi = first_pass; pi < npass; ++pi) pm.w[passes[pi] >> 2] |= 255u << (8 * (passes[pi] & 3));
+    hipLaunchKernelGGL((ibu_k_sort_finish_elems<W, FT, FM>), dim3((u32)((n + FT - 1) / FT)), dim3(kSortThreads), FS::lds, st, (const ElemT<W>*)src, recs,
+                       (u32)n, pm, pl, d_overflow);
+    u32 overflow = 0;
+    e = hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    if (!overflow) return hipGetLastError();
+    if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu prefix+finish overflowed (long runs of equal prefix): all %u passes\n", n, npass);
+    return launch_compact_passes<W>(cfg, cv, recs, tmp, n, sc, pl, passes, npass, st, true, 0xFFFFFFFFu, 0, src);   // elements: a permutation of the input's
   }
   if (!fuse_last) launch_expand_w<W>(cfg, pl, src, n, recs, st);   // W = 4, even pass count: the elements ended in tmp
   return hipGetLastError();
@@ -1387,7 +1601,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   bool speculated = false;
   CompactPlan gpl;
   u64 g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gmask[3] = {0, 0, 0};
-  u32 gfirst = 0;
+  u32 gfirst = 0, hybP = 0;
+  double hyb_seg = 0;
   static constexpr size_t kSample = 32768;
   // cfg.sort_guess: 0 = never, 1 = inputs of 2^23 records and more, k > 1 = inputs of k records and more (a test knob)
   const size_t guess_min = cfg.sort_guess == 1 ? (size_t)1 << 23 : ((size_t)cfg.sort_guess > 4 * kSample ? (size_t)cfg.sort_guess : 4 * kSample);
@@ -1408,6 +1623,44 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         for (u32 b = 0; b < 8; ++b)
           if (((g[f] ^ g[3 + f]) >> (8 * b)) & 255u) gmask[f] |= 255ull << (8 * b);
       gfirst = (g[6] == 0 && gpl.index_bytes < gpl.k) ? gpl.index_bytes : 0;   // the sample's guess of the first sorted byte
+      // PREFIX + FINISH on the elements?  Only if the runs of equal prefix are going to be short: the pair count of the sample
+      // says (ibu_k_sort_sample_pairs; the tables live in tmp, which nothing uses yet).
+      if (cfg.sort_hybrid) {
+        const u32 sorted_guess = gpl.k - gfirst;             // passes the plain path would run
+        u32 slots = kPairSlotsMax;
+        while (slots > 1024 && (size_t)slots * 12 * kMaxPrefix + 64 > n * 24) slots >>= 1;
+        const u32 per_range = (u32)(kSample < slots / 8 ? kSample : slots / 8);   // load factor <= 3/8
+        const size_t m = 3 * (size_t)per_range;
+        uint8_t* tb = static_cast<uint8_t*>(tmp);
+        u64* d_pairs = reinterpret_cast<u64*>(tb);
+        u64* d_keys = reinterpret_cast<u64*>(tb + 64);
+        u32* d_cnts = reinterpret_cast<u32*>(tb + 64 + (size_t)slots * 8 * kMaxPrefix);
+        if ((reinterpret_cast<uintptr_t>(tmp) & 7u) == 0 && (size_t)slots * 12 * kMaxPrefix + 64 <= n * 24) {
+          e = hipMemsetAsync(tb, 0, 64 + (size_t)slots * 12 * kMaxPrefix, st);
+          if (e != hipSuccess) return e;
+          const u64* r64 = static_cast<const u64*>(recs);
+          if (gpl.k <= 12)
+            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, (u64)starts[0], (u64)starts[1], (u64)starts[2],
+                               per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
+          else
+            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, (u64)starts[0], (u64)starts[1], (u64)starts[2],
+                               per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
+          u64 pairs[kMaxPrefix];
+          e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
+          if (e != hipSuccess) return e;
+          e = hipStreamSynchronize(st);
+          if (e != hipSuccess) return e;
+          // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
+          for (u32 P = 1; P <= (u32)kMaxPrefix && P <= gpl.k; ++P) {
+            const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[P - 1] / (double)m);
+            if (seg <= 8.0) { hybP = P; hyb_seg = seg; break; }
+          }
+          if (hybP && gpl.k > 12 && (hybP & 1u)) ++hybP;       // 16-byte elements must end in tmp: an even number of passes
+          const u32 margin = cfg.sort_hybrid == 2 ? 1u : 2u;
+          if (hybP && (hybP + margin > sorted_guess || hybP > gpl.k - gfirst)) hybP = 0;   // not worth it / would reach into unsorted index bytes
+          if (hybP) gfirst = gpl.k - hybP;                   // the digit stream the compress pass leaves: the first prefix pass's
+        }
+      }
       hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
       if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
       else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, pick_compact16(cfg).tile).digits, st, census);
@@ -1462,6 +1715,14 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
               if (varies && sorted_on) ebytes[ne++] = j;
               ++j;
             }
+        }
+        // prefix + finish: the prefix the estimate was made for must be the top hybP SORTED bytes of the elements
+        if (ne && hybP && hybP < ne && ebytes[ne - hybP] == pl.k - hybP) {
+          if (trace_sort())
+            fprintf(stderr, "ibu sort: n=%zu path=compact-prefix+finish element_bytes=%d prefix_passes=%u of %u estimated_run=%.2f\n", n,
+                    pl.k <= 12 ? 12 : 16, hybP, ne, hyb_seg);
+          return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst, hybP)
+                            : launch_compact_passes<4>(cfg, pick_compact16(cfg), recs, tmp, n, sc, pl, ebytes, ne, st, true, gfirst, hybP);
         }
         if (ne) {
           if (trace_sort())

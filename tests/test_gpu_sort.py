@@ -189,6 +189,18 @@ def ctx_guess(ia):
     of the varying bytes, exact census in the same pass."""
     c = ia.Context(0)
     c.set_option("sort_guess", 131_072)
+    c.set_option("sort_hybrid", 0)                     # the plain element passes behind the guess (prefix + finish: ctx_guess_pf)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_guess_pf(ia):
+    """Speculation from 131 072 records on AND prefix + finish on the elements (the default for large inputs): a pair count
+    over the sample ranges estimates how long the runs of equal prefix will be; short runs -> P element passes over the
+    top P bytes + ibu_k_sort_finish_elems, long runs -> the plain passes."""
+    c = ia.Context(0)
+    c.set_option("sort_guess", 131_072)
     yield c
     c.close()
 
@@ -256,6 +268,53 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
     if "did not cover" in expect:                          # ... and the sort went on from the exact census
         assert (f"path=compact element_bytes={12 if k <= 12 else 16}" if k <= 16 else "path=24-byte") in trace, trace
     assert _sort_on_device(ctx24, recs)[0] == want
+
+
+@pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003, 5_000_001])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 12-byte and 16-byte elements
+@pytest.mark.parametrize("case", ["random_index", "index_order", "whitelist_barcodes", "heavy_run_outside_the_samples", "duplicates",
+                                  "guess_misses_a_umi_byte"])
+def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens, case, capfd):
+    """The compact-key sort of large inputs: well-spread keys (short estimated runs) take P prefix passes + the finishing
+    kernel; keys with few distinct prefixes (barcodes from a whitelist) take a longer prefix or the plain passes; a heavy run
+    the samples did not see overflows the finishing kernel, and all passes run.  Always the oracle's bytes."""
+    recs = _shuffled(oracle, n, *lens)
+    rng = np.random.default_rng(n + len(case))
+    recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
+    quarter = n // 4 + 7
+    if n < 140_000:
+        quarter = 32_768 + (n // 2 - 32_768) // 2
+    if case == "index_order":
+        recs["index"] = np.arange(n, dtype=np.uint64)
+    elif case == "whitelist_barcodes":                         # ~n / 500 distinct barcodes: runs of ~500 under a barcode-only prefix
+        wl = np.unique(recs["barcode"][: max(n // 500, 2)])
+        recs["barcode"] = wl[rng.integers(0, len(wl), n)]
+    elif case == "heavy_run_outside_the_samples":              # 3000 records with one (barcode, umi) where no sample looks
+        span = min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000)
+        span = max(span, 600)
+        recs["barcode"][quarter:quarter + span] = recs["barcode"][quarter]
+        recs["umi"][quarter:quarter + span] = recs["umi"][quarter]
+    elif case == "duplicates":
+        recs[1::2] = recs[0:len(recs[1::2]) * 2:2]
+        rng.shuffle(recs)
+    elif case == "guess_misses_a_umi_byte":
+        recs["umi"][quarter] |= np.uint64(1) << np.uint64(44)
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    got, d = _sort_on_device(ctx_guess_pf, recs)
+    trace = capfd.readouterr().err
+    assert got == want and ctx_guess_pf.is_sorted(d, n)
+    if case in ("random_index", "index_order", "duplicates"):
+        assert "path=compact-prefix+finish" in trace and "overflowed" not in trace, trace
+    elif case == "heavy_run_outside_the_samples":
+        assert "path=compact-prefix+finish" in trace and "overflowed" in trace, trace
+    elif case == "guess_misses_a_umi_byte":
+        assert "guess did not cover" in trace and "prefix+finish" not in trace, trace
+    elif case == "whitelist_barcodes":                         # never a 4-byte (barcode-only) prefix: longer, or the plain passes
+        assert "overflowed" not in trace, trace
+        if "path=compact-prefix+finish" in trace:
+            p = int(trace.split("prefix_passes=")[1].split()[0])
+            assert p > (4 if lens[0] == 16 else 8), trace
 
 
 @pytest.mark.parametrize("n", [2, 129, 5000, 300_007])

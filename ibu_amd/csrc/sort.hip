@@ -947,7 +947,15 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
 // host falls back to the full LSD passes (the prefix-sorted records are a permutation of the input; records with equal
 // keys are equal byte for byte, so nothing is lost but the time of the P passes).
 // =====================================================================================================
-static constexpr int kFinishT = 2048, kFinishM = 512;        // 60 KiB of records + 12 KiB of tables: two workgroups per CU
+#ifndef IBU_FINISH24_T
+#define IBU_FINISH24_T 1024
+#endif
+#ifndef IBU_FINISH24_M
+#define IBU_FINISH24_M 256
+#endif
+// 1024-record tiles + 256 of look-ahead: 37 KiB of LDS, four workgroups per CU.  1e9 full-range (32,32) records (profiles r03_o):
+// (2048, 512) 17.2 ms, (1024, 512) 15.7, (1536, 256) 12.8, (1024, 256) 12.4.
+static constexpr int kFinishT = IBU_FINISH24_T, kFinishM = IBU_FINISH24_M;
 template <int T, int M>
 struct FinishShape {
   static constexpr int L = T + M;                             // records staged per workgroup (+ 1 in front)
@@ -973,15 +981,23 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
   const u64* g = src + 3 * base;
   if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
     const u32x4* g4 = reinterpret_cast<const u32x4*>(g);
-    u32x4* s4 = reinterpret_cast<u32x4*>(stage);              // stage is 8 (mod 16)-aligned: write as two halves
-    const u32 nch = (3 * len) >> 1;
-    for (u32 c = tid; c < nch; c += kSortThreads) {
-      const u32x4 v = ld16(g4 + c);
-      stage[2 * c] = ((u64)v.y << 32) | v.x;
-      stage[2 * c + 1] = ((u64)v.w << 32) | v.z;
+    const u32 nch = (3 * len) >> 1;                           // 16-byte chunks of the window (stage itself is 8 (mod 16)-aligned: two halves)
+    constexpr int CH = (3 * L / 2 + kSortThreads - 1) / kSortThreads;
+    u32x4 v[CH];                                              // every load of a thread issued before its first LDS write (see the element kernel)
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      const u32 c = tid + kSortThreads * r;
+      v[r] = ld16(g4 + (c < nch ? c : (nch ? nch - 1 : 0)));
+    }
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      const u32 c = tid + kSortThreads * r;
+      if (c < nch) {
+        stage[2 * c] = ((u64)v[r].y << 32) | v[r].x;
+        stage[2 * c + 1] = ((u64)v[r].w << 32) | v[r].z;
+      }
     }
     if (tid == 0 && ((3 * len) & 1u)) stage[3 * len - 1] = g[3 * len - 1];
-    (void)s4;
   } else {
     for (u32 w = tid; w < 3 * len; w += kSortThreads) stage[w] = g[w];
   }
@@ -1098,116 +1114,159 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   uint16_t* segstart = reinterpret_cast<uint16_t*>(head + ((L + 1 + 15) & ~15));
   uint16_t* seglen = segstart + L;
   u32* misc = reinterpret_cast<u32*>(seglen + L);
-  const u32 tid = threadIdx.x;
-  const u64 base64 = (u64)blockIdx.x * T;
-  if (base64 >= n) return;
-  const u32 base = (u32)base64;
-  const u32 len = n - base < (u32)L ? n - base : (u32)L;
-  // 1. stage the window: one element per lane and step (dwordx3 / dwordx4, consecutive lanes on consecutive elements)
-  for (u32 i = tid; i < len; i += kSortThreads) {
-    const EV<W> v = ld_elem<W>(src + base + i);
-#pragma unroll
-    for (int w = 0; w < W; ++w) stage[W * i + w] = v.w[w];
-  }
-  if (tid == 0) {
-    EV<W> v;
-#pragma unroll
-    for (int w = 0; w < W; ++w) v.w[w] = 0;
-    if (base > 0) v = ld_elem<W>(src + base - 1);
-#pragma unroll
-    for (int w = 0; w < W; ++w) stage[w - W] = v.w[w];
-  }
-  if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
-  __syncthreads();
-  // 2. heads
-  for (u32 i = tid; i < len; i += kSortThreads) {
-    u32 diff = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) diff |= (stage[W * i + w] ^ stage[W * i + w - W]) & pm.w[w];
-    const bool h = (base + i == 0) || diff != 0;
-    head[i] = h;
-    if (h) atomicMin(&misc[i < (u32)T ? 0 : 1], i);
-  }
-  __syncthreads();
-  const u32 begin = misc[0];
-  u32 end = misc[1];
-  if (end == 0xFFFFFFFFu && base + len == n) end = len;
-  if (begin == 0xFFFFFFFFu) {
-    if (tid == 0 && len > (u32)M) *overflow = 1u;
-    return;
-  }
-  if (end == 0xFFFFFFFFu) {
-    if (tid == 0) *overflow = 1u;
-    return;
-  }
-  // 3. segments
-  for (u32 i = begin + tid; i < end; i += kSortThreads)
-    if (head[i]) {
-      u32 j = i + 1;
-      while (j < end && !head[j]) ++j;
-      if (j - i > (u32)M) misc[2] = 1u;
-      else {
-        for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
-        seglen[i] = (uint16_t)(j - i);
-      }
-    }
-  __syncthreads();
-  if (misc[2]) {
-    if (tid == 0) *overflow = 1u;
-    return;
-  }
-  // 4. rank inside the segment (a segment of one record — the usual case — costs nothing)
-  u32 me[PER][W];
-  u32 target[PER];
-#pragma unroll
-  for (int r = 0; r < PER; ++r) {
-    const u32 i = begin + tid + kSortThreads * r;
-    target[r] = 0xFFFFFFFFu;
-    if (i < end) {
-#pragma unroll
-      for (int w = 0; w < W; ++w) me[r][w] = stage[W * i + w];
-      const u32 s0 = segstart[i], m = seglen[s0];
-      u32 cnt = 0;
-      if (m > 1)
-        for (u32 j = s0; j < s0 + m; j += 2) {
-          const u32 j1 = j + 1 < s0 + m ? j + 1 : j;           // clamped: in the window, not counted
-          u32 a[W], b[W];
-#pragma unroll
-          for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
-          cnt += elem_before<W>(a, me[r], (u32)(j < i));
-          cnt += elem_before<W>(b, me[r], (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
-        }
-      target[r] = s0 + cnt;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < PER; ++r)
-    if (target[r] != 0xFFFFFFFFu) {
-#pragma unroll
-      for (int w = 0; w < W; ++w) stage[W * target[r] + w] = me[r][w];
-    }
-  __syncthreads();
-  // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out)
-  const u32 j = tid & 1u;
+  const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
+  const u32 ntiles = (u32)(((u64)n + T - 1) / T);
+  u32 tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  // the half record this lane writes in step 5 (lane parity; kSortThreads is even)
+  const u32 hj = tid & 1u;
   u32 hsel[3][2], hbase[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    hsel[k][0] = j ? pl.xsel[3 + k][0] : pl.xsel[k][0];
-    hsel[k][1] = j ? pl.xsel[3 + k][1] : pl.xsel[k][1];
-    const u64 bf = j ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
-    hbase[k] = ((3 * (j ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
+    hsel[k][0] = hj ? pl.xsel[3 + k][0] : pl.xsel[k][0];
+    hsel[k][1] = hj ? pl.xsel[3 + k][1] : pl.xsel[k][1];
+    const u64 bf = hj ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
+    hbase[k] = ((3 * (hj ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
   }
-  uint8_t* out = static_cast<uint8_t*>(dst_v) + 24 * (size_t)base;
-  for (u32 h = 2 * begin + tid; h < 2 * end; h += kSortThreads) {   // kSortThreads is even: a lane keeps its half
-    const u32 p = h >> 1;
-    u32 e[4] = {stage[W * p], stage[W * p + 1], stage[W * p + 2], 0};
-    if constexpr (W == 4) e[3] = stage[W * p + 3];
-    u32x3 o;
-    o.x = hbase[0] | __builtin_amdgcn_perm(e[1], e[0], hsel[0][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[0][1]);
-    o.y = hbase[1] | __builtin_amdgcn_perm(e[1], e[0], hsel[1][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[1][1]);
-    o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
-    *reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * j) = o;
+  // A window's loads: one element per lane and step (dwordx3 / dwordx4, consecutive lanes on consecutive elements), ALL issued
+  // before anything waits for them (unconditional, clamped) — and the NEXT tile's window is loaded while this one is worked on
+  // (persistent grid, two register sets).  As a load-then-store loop in a one-tile workgroup the kernel paid 18 memory
+  // latencies per tile: 18.8 ms per 1e9 records; loads issued together 14.5 ms; prefetched as here: see profiles/README.md.
+  auto load = [&](u32 t, EV<W>* v, EV<W>& front) {
+    const u32 base = t * (u32)T;
+    const u32 len = n - base < (u32)L ? n - base : (u32)L;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const u32 i = tid + kSortThreads * r;
+      v[r] = ld_elem<W>(src + base + (i < len ? i : len - 1));
+    }
+    front = ld_elem<W>(src + (base > 0 ? base - 1 : 0));      // every lane the same element (one line); used by thread 0
+  };
+  auto work = [&](u32 t, const EV<W>* v, const EV<W>& front) {
+    const u32 base = t * (u32)T;
+    const u32 len = n - base < (u32)L ? n - base : (u32)L;
+    // 1. stage
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const u32 i = tid + kSortThreads * r;
+      if (i < len) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) stage[W * i + w] = v[r].w[w];
+      }
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) stage[w - W] = base > 0 ? front.w[w] : 0u;
+    }
+    if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    // 2. heads (with short runs nearly every element is one: the first head of a wave's 64 goes to the LDS word, not 64 atomics)
+    for (u32 i0 = tid - lane; i0 < len; i0 += kSortThreads) {
+      const u32 i = i0 + lane;
+      bool h = false;
+      if (i < len) {
+        u32 diff = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) diff |= (stage[W * i + w] ^ stage[W * i + w - W]) & pm.w[w];
+        h = (base + i == 0) || diff != 0;
+        head[i] = h;
+      }
+      const u64 lo = __ballot(h && i < (u32)T), hi = __ballot(h && i >= (u32)T);
+      if (lane == 0) {
+        if (lo) atomicMin(&misc[0], i0 + (u32)__builtin_ctzll(lo));
+        if (hi) atomicMin(&misc[1], i0 + (u32)__builtin_ctzll(hi));
+      }
+    }
+    __syncthreads();
+    const u32 begin = misc[0];
+    u32 end = misc[1];
+    if (end == 0xFFFFFFFFu && base + len == n) end = len;     // the array ends inside the window
+    if (begin == 0xFFFFFFFFu) {                               // the tile is the inside of a run longer than a tile
+      if (tid == 0 && len > (u32)M) *overflow = 1u;
+      return;
+    }
+    if (end == 0xFFFFFFFFu) {                                 // the tile's last run goes past the look-ahead
+      if (tid == 0) *overflow = 1u;
+      return;
+    }
+    // 3. segments
+    for (u32 i = begin + tid; i < end; i += kSortThreads)
+      if (head[i]) {
+        u32 j = i + 1;
+        while (j < end && !head[j]) ++j;
+        if (j - i > (u32)M) misc[2] = 1u;
+        else {
+          for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
+          seglen[i] = (uint16_t)(j - i);
+        }
+      }
+    __syncthreads();
+    if (misc[2]) {
+      if (tid == 0) *overflow = 1u;
+      return;
+    }
+    // 4. rank inside the segment (a segment of one record — the usual case — costs nothing)
+    u32 me[PER][W];
+    u32 target[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const u32 i = begin + tid + kSortThreads * r;
+      target[r] = 0xFFFFFFFFu;
+      if (i < end) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) me[r][w] = stage[W * i + w];
+        const u32 s0 = segstart[i], m = seglen[s0];
+        u32 cnt = 0;
+        if (m > 1)
+          for (u32 j = s0; j < s0 + m; j += 2) {
+            const u32 j1 = j + 1 < s0 + m ? j + 1 : j;         // clamped: in the window, not counted
+            u32 a[W], b[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
+            cnt += elem_before<W>(a, me[r], (u32)(j < i));
+            cnt += elem_before<W>(b, me[r], (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
+          }
+        target[r] = s0 + cnt;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+      if (target[r] != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) stage[W * target[r] + w] = me[r][w];
+      }
+    __syncthreads();
+    // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out)
+    uint8_t* out = static_cast<uint8_t*>(dst_v) + 24 * (size_t)base;
+    for (u32 h = 2 * begin + tid; h < 2 * end; h += kSortThreads) {   // kSortThreads is even: a lane keeps its half
+      const u32 p = h >> 1;
+      u32 e[4] = {stage[W * p], stage[W * p + 1], stage[W * p + 2], 0};
+      if constexpr (W == 4) e[3] = stage[W * p + 3];
+      u32x3 o;
+      o.x = hbase[0] | __builtin_amdgcn_perm(e[1], e[0], hsel[0][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[0][1]);
+      o.y = hbase[1] | __builtin_amdgcn_perm(e[1], e[0], hsel[1][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[1][1]);
+      o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
+      *reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * hj) = o;
+    }
+  };
+  EV<W> va[PER], vb[PER], fa, fb;
+  load(tile, va, fa);
+  for (;;) {                                                  // two register sets take turns (kcommon.hpp, sweep_tiles)
+    u32 next = tile + gridDim.x;
+    bool more = next < ntiles;
+    load(more ? next : tile, vb, fb);
+    work(tile, va, fa);
+    if (!more) break;
+    tile = next;
+    __syncthreads();                                          // step 5's LDS reads precede the next tile's stage writes
+    next = tile + gridDim.x;
+    more = next < ntiles;
+    load(more ? next : tile, va, fa);
+    work(tile, vb, fb);
+    if (!more) break;
+    tile = next;
+    __syncthreads();
   }
 }
 
@@ -1537,7 +1596,16 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     ElemT<W>* t = src; src = dst; dst = t;
   }
   if (finish_prefix) {
-    constexpr int FT = W == 3 ? 4096 : 3072, FM = 512;       // 77 / 75 KiB of LDS: two workgroups per CU
+#ifndef IBU_FINISH_T
+#define IBU_FINISH_T 2048
+#endif
+#ifndef IBU_FINISH_M
+#define IBU_FINISH_M 256
+#endif
+    // 2048-element tiles + 256 of look-ahead: 39 / 48 KiB of LDS and 128 / 161 VGPRs -> four / three workgroups per CU.  Measured
+    // at 1e9 records 16/12 (profiles r03_m, r03_n): (4096, 512) 12.2 ms, (3072, 256) 12.1, (2048, 512) 9.4, (2048, 256) 7.8-8.0,
+    // (2048, 128) 8.0, (1536, 256) 8.0, (1024, 256) 8.6, (1024, 128) 8.4.
+    constexpr int FT = IBU_FINISH_T, FM = IBU_FINISH_M;
     typedef FinishElemShape<W, FT, FM> FS;
     u32* d_overflow = reinterpret_cast<u32*>(sc + L.misc);
     e = hipMemsetAsync(d_overflow, 0, 4, st);
@@ -1547,7 +1615,14 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     EV<W> pm;                                                 // the prefix bytes as word masks
     for (int w = 0; w < W; ++w) pm.w[w] = 0;
     for (u32 pi = first_pass; pi < npass; ++pi) pm.w[passes[pi] >> 2] |= 255u << (8 * (passes[pi] & 3));
-    hipLaunchKernelGGL((ibu_k_sort_finish_elems<W, FT, FM>), dim3((u32)((n + FT - 1) / FT)), dim3(kSortThreads), FS::lds, st, (const ElemT<W>*)src, recs,
+    static std::atomic<int> focc;
+    int fper = focc.load(std::memory_order_relaxed);
+    if (fper <= 0) {                                          // persistent grid, exactly resident (LDS and registers decide)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fper, ibu_k_sort_finish_elems<W, FT, FM>, kSortThreads, FS::lds) != hipSuccess || fper <= 0) fper = 1;
+      focc.store(fper, std::memory_order_relaxed);
+    }
+    const u32 ftiles = (u32)((n + FT - 1) / FT), fgrid = (u32)fper * (u32)cfg.cus;
+    hipLaunchKernelGGL((ibu_k_sort_finish_elems<W, FT, FM>), dim3(ftiles < fgrid ? ftiles : fgrid), dim3(kSortThreads), FS::lds, st, (const ElemT<W>*)src, recs,
                        (u32)n, pm, pl, d_overflow);
     u32 overflow = 0;
     e = hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st);
@@ -1656,7 +1731,9 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
             if (seg <= 8.0) { hybP = P; hyb_seg = seg; break; }
           }
           if (hybP && gpl.k > 12 && (hybP & 1u)) ++hybP;       // 16-byte elements must end in tmp: an even number of passes
-          const u32 margin = cfg.sort_hybrid == 2 ? 1u : 2u;
+          // worth it?  The finishing pass costs about as much as two element passes (15 B read with the look-ahead + 24 B
+          // written per record), the plain path's last pass half a pass more than the others
+          const u32 margin = cfg.sort_hybrid == 2 ? 1u : 3u;
           if (hybP && (hybP + margin > sorted_guess || hybP > gpl.k - gfirst)) hybP = 0;   // not worth it / would reach into unsorted index bytes
           if (hybP) gfirst = gpl.k - hybP;                   // the digit stream the compress pass leaves: the first prefix pass's
         }

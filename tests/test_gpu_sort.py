@@ -108,12 +108,16 @@ def test_wide_keys_take_prefix_and_finish(ctx, ctx24, oracle, n, capfd):
     assert _sort_on_device(ctx24, recs)[0] == want
 
 
+FIN_T, FIN_M = 1024, 256     # ibu_k_sort_finish: records per tile, longest run of equal prefix it accepts (= its look-ahead)
+
+
 def test_wide_keys_prefix_and_finish_segment_edges(ctx_pf, oracle, ia, capfd):
-    """Runs of equal prefix (segments) of every awkward shape: exactly the 512 records the finishing kernel accepts,
-    one more (overflow -> all passes), runs crossing the 2048-record tile boundaries, a run reaching the end of the array,
-    exact duplicates inside a run, the array ending inside the look-ahead window — with one prefix byte (fewer than 2304
+    """Runs of equal prefix (segments) of every awkward shape: exactly the FIN_M records the finishing kernel accepts,
+    one more (overflow -> all passes), runs crossing the tile boundaries, a run reaching the end of the array, exact
+    duplicates inside a run, the array ending inside the look-ahead window — with one prefix byte (fewer than 2304
     records) and with two."""
     rng = np.random.default_rng(99)
+    M, T = FIN_M, FIN_T
 
     def build(run_lengths, dup=False):
         recs = _full_range(sum(run_lengths), 7)
@@ -126,10 +130,10 @@ def test_wide_keys_prefix_and_finish_segment_edges(ctx_pf, oracle, ia, capfd):
         rng.shuffle(recs)
         return recs
 
-    cases = [([512] * 4, False), ([513] + [100] * 17, True), ([300, 400, 500, 512, 336, 10] + [7] * 30, False),   # one prefix byte
-             ([200] * 11 + [90], False), ([512, 512, 512, 512, 1], False), ([100] * 3 + [2000], True),
-             ([512] * 20 + [3] * 230, False), ([40] * 120 + [513] + [40] * 100, True), ([2, 510, 512, 1, 1023 - 512, 512] * 9, False),   # two
-             ([1] * 150 + [254] * 100, False), ([100] * 200 + [4096], True)]
+    cases = [([M] * 8, False), ([M + 1] + [100] * 17, True), ([150, 200, 250, M, 168, 10] + [7] * 30, False),   # one prefix byte (n < 2304)
+             ([200] * 11 + [90], False), ([M] * 4 + [M] * 4 + [1], False), ([100] * 3 + [2000], True),
+             ([M] * 40 + [3] * 200, False), ([40] * 120 + [M + 1] + [40] * 100, True), ([2, M - 2, M, 1, M - 1, M] * 9, False),   # two
+             ([1] * 150 + [254] * 100, False), ([100] * 200 + [4 * T], True)]
     for lengths, overflow in cases:
         assert len(lengths) <= 255 + 1 and (sum(lengths) < 2304 or 2304 <= sum(lengths) < 9 * 65_536)
         for dup in (False, True):

@@ -23,8 +23,16 @@
 //                          CRC-32 per (chunk, member) piece, combined with crc32_combine and checked against every
 //                          member trailer together with ISIZE.
 //
-// Output bytes and error class are those of the sequential zlib path (GzSource in host_io.cpp): same bytes, EPROTO for a
-// corrupt / truncated stream.  The decoder is suspendable in the middle of a block (output cap per chunk, end of the
+// Output bytes and error class are those of the sequential zlib path (GzSource in host_io.cpp) for every stream zlib accepts
+// and for truncated / bit-damaged ones (tests/test_pgzip.py): same bytes, EPROTO for a corrupt / truncated stream.
+// ONE known divergence, on crafted input only: the distance check is looser than zlib's at the start of a member.  The
+// 32 KiB history is carried across gzip member boundaries (chunk 0 runs with the window of whatever preceded it, marker-mode
+// chunks always allow 32 KiB), so a back-reference that reaches in front of the CURRENT member's first byte — which zlib
+// rejects as "invalid distance too far back" — resolves against the previous member's bytes (or zeros) here; if the
+// crafted member's CRC-32 / ISIZE then still match, this decoder accepts what the sequential one refuses.  No compressor
+// emits such a stream.  (The fix — bytes-since-member-start in the Inflater, min(window, that) as the distance bound, markers
+// that resolve in front of a member start rejected when patching — is left undone: ADVICE r02 rated it low and VERDICT r02
+// closed further work on this file.)  The decoder is suspendable in the middle of a block (output cap per chunk, end of the
 // bytes read so far), so memory stays bounded for any input.
 #pragma once
 #include <stddef.h>

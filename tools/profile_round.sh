@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- pyt
 cp "$(largest "$OUT/prof_bench" '*kernel_stats.csv')" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
 
 step "sortbench (unprofiled)"
-python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg > "$OUT/${TAG}_sortbench_random_index.jsonl" 2> "$OUT/sort.err" || exit 1
+python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg --presorted > "$OUT/${TAG}_sortbench_random_index.jsonl" 2> "$OUT/sort.err" || exit 1
 python3 tools/sortbench.py --records "$N" --rounds 3 --skip-agg > "$OUT/${TAG}_sortbench_read_order.jsonl" 2>> "$OUT/sort.err" || exit 1
 
 step "sortbench under rocprofv3 --kernel-trace --stats"

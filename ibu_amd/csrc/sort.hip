@@ -1276,7 +1276,9 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
 // number of PAIRS of sample records with equal prefix comes out per P.  With m sample records out of n, a record shares
 // its prefix with about 1 + (n / m) * 2 pairs / m records of the whole input — for well-spread keys that is 1 + n / 256^P,
 // for keys with few distinct prefixes (barcodes from a whitelist) it is large, and the sort then takes a longer prefix
-// or the plain passes.  (The samples are contiguous ranges: grouped input over-estimates, which errs on the safe side;
+// or the plain passes.  The pair count is a MEAN; a single heavy prefix (one barcode holding 0.1 % of the records) barely
+// moves it and still makes runs far longer than the finishing kernel accepts — so the most frequent prefix of the sample is
+// reported too (pairs[kMaxPrefix + P - 1]): four or more sample records with one prefix mean a run of tens of thousands.  (The samples are contiguous ranges: grouped input over-estimates, which errs on the safe side;
 // an under-estimate is caught by the finishing kernel's overflow flag.)
 static constexpr int kMaxPrefix = 8;
 static constexpr u32 kPairSlotsMax = 1u << 18;                // per P: 98 304 sample records -> load factor 0.375
@@ -1307,7 +1309,10 @@ __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 s0, u6
       const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&kt[slot]), 0ull, (unsigned long long)h);
       if (old == 0 || old == h) {
         const u32 before = atomicAdd(&ct[slot], 1u);          // records with this prefix seen so far: that many new pairs
-        if (before) atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[P - 1]), (unsigned long long)before);
+        if (before) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[P - 1]), (unsigned long long)before);
+          if (before >= 3) atomicMax(reinterpret_cast<unsigned long long*>(&pairs[kMaxPrefix + P - 1]), (unsigned long long)(before + 1));   // the most frequent prefix, from four sample records on (three of 98 304 happen by chance)
+        }
         break;
       }
     }
@@ -1703,15 +1708,15 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       if (cfg.sort_hybrid) {
         const u32 sorted_guess = gpl.k - gfirst;             // passes the plain path would run
         u32 slots = kPairSlotsMax;
-        while (slots > 1024 && (size_t)slots * 12 * kMaxPrefix + 64 > n * 24) slots >>= 1;
+        while (slots > 1024 && (size_t)slots * 12 * kMaxPrefix + 128 > n * 24) slots >>= 1;
         const u32 per_range = (u32)(kSample < slots / 8 ? kSample : slots / 8);   // load factor <= 3/8
         const size_t m = 3 * (size_t)per_range;
         uint8_t* tb = static_cast<uint8_t*>(tmp);
         u64* d_pairs = reinterpret_cast<u64*>(tb);
-        u64* d_keys = reinterpret_cast<u64*>(tb + 64);
-        u32* d_cnts = reinterpret_cast<u32*>(tb + 64 + (size_t)slots * 8 * kMaxPrefix);
-        if ((reinterpret_cast<uintptr_t>(tmp) & 7u) == 0 && (size_t)slots * 12 * kMaxPrefix + 64 <= n * 24) {
-          e = hipMemsetAsync(tb, 0, 64 + (size_t)slots * 12 * kMaxPrefix, st);
+        u64* d_keys = reinterpret_cast<u64*>(tb + 128);
+        u32* d_cnts = reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix);
+        if ((reinterpret_cast<uintptr_t>(tmp) & 7u) == 0 && (size_t)slots * 12 * kMaxPrefix + 128 <= n * 24) {
+          e = hipMemsetAsync(tb, 0, 128 + (size_t)slots * 12 * kMaxPrefix, st);
           if (e != hipSuccess) return e;
           const u64* r64 = static_cast<const u64*>(recs);
           if (gpl.k <= 12)
@@ -1720,7 +1725,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
           else
             hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, (u64)starts[0], (u64)starts[1], (u64)starts[2],
                                per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
-          u64 pairs[kMaxPrefix];
+          u64 pairs[2 * kMaxPrefix];                           // [P - 1]: pairs; [kMaxPrefix + P - 1]: the most frequent prefix's count (0: below 4)
           e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
           if (e != hipSuccess) return e;
           e = hipStreamSynchronize(st);
@@ -1728,7 +1733,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
           // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
           for (u32 P = 1; P <= (u32)kMaxPrefix && P <= gpl.k; ++P) {
             const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[P - 1] / (double)m);
-            if (seg <= 8.0) { hybP = P; hyb_seg = seg; break; }
+            const double heaviest = (double)pairs[kMaxPrefix + P - 1] * ((double)n / (double)m);   // estimated longest run
+            if (seg <= 8.0 && heaviest <= 128.0) { hybP = P; hyb_seg = seg; break; }
           }
           if (hybP && gpl.k > 12 && (hybP & 1u)) ++hybP;       // 16-byte elements must end in tmp: an even number of passes
           // worth it?  The finishing pass costs about as much as two element passes (15 B read with the look-ahead + 24 B

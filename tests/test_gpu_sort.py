@@ -277,7 +277,7 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
 @pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003, 5_000_001])
 @pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 12-byte and 16-byte elements
 @pytest.mark.parametrize("case", ["random_index", "index_order", "whitelist_barcodes", "heavy_run_outside_the_samples", "duplicates",
-                                  "guess_misses_a_umi_byte"])
+                                  "guess_misses_a_umi_byte", "one_heavy_barcode"])
 def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens, case, capfd):
     """The compact-key sort of large inputs: well-spread keys (short estimated runs) take P prefix passes + the finishing
     kernel; keys with few distinct prefixes (barcodes from a whitelist) take a longer prefix or the plain passes; a heavy run
@@ -301,6 +301,8 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
     elif case == "duplicates":
         recs[1::2] = recs[0:len(recs[1::2]) * 2:2]
         rng.shuffle(recs)
+    elif case == "one_heavy_barcode":                          # 2 % of the records carry one barcode, spread over the whole input
+        recs["barcode"][rng.random(n) < 0.02] = recs["barcode"][0]
     elif case == "guess_misses_a_umi_byte":
         recs["umi"][quarter] |= np.uint64(1) << np.uint64(44)
     want = oracle.sort_records(recs).tobytes()
@@ -314,6 +316,11 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
         assert "path=compact-prefix+finish" in trace and "overflowed" in trace, trace
     elif case == "guess_misses_a_umi_byte":
         assert "guess did not cover" in trace and "prefix+finish" not in trace, trace
+    elif case == "one_heavy_barcode":                          # the sample's most frequent prefix says so BEFORE anything overflows:
+        assert "overflowed" not in trace, trace                #   a prefix that also splits the heavy barcode, or the plain passes
+        if "path=compact-prefix+finish" in trace:
+            p = int(trace.split("prefix_passes=")[1].split()[0])
+            assert p > (4 if lens[0] == 16 else 8), trace
     elif case == "whitelist_barcodes":                         # never a 4-byte (barcode-only) prefix: longer, or the plain passes
         assert "overflowed" not in trace, trace
         if "path=compact-prefix+finish" in trace:

@@ -244,7 +244,12 @@ int32_t ibu_device_count(int32_t* n);
  *   "sort_guess"     0 | 1 | k  large compact-key sorts read the records once instead of twice: a census of three sample ranges
  *                           guesses the varying bytes, the compress pass runs on the guess and takes the exact census on the
  *                           way; a guess that missed a byte is detected and the sort continues from the exact census.
- *                           0 = never, 1 = inputs of 2^23 records and more (default), k = of k records and more.
+ *                           0 = never, 1 = inputs of 2^17 records and more (default), k = of k records and more.
+ *   "sort_hybrid"    0 | 1 | 2  PREFIX + FINISH: instead of one pass per varying key byte, passes over the most significant P
+ *                           varying bytes only, then one finishing pass that completes every run of equal prefix inside LDS.
+ *                           P comes from a pair count over sample ranges (compact keys) or from n (24-byte records); runs too
+ *                           long for the finishing kernel make it report an overflow, and all passes run.  0 = never,
+ *                           1 = when passes are saved (default), 2 = whenever one is (tests).  Same bytes either way.
  *   "base_order"     0 | 1  bit order of the 2-bit codec for every pack / unpack / decode / encode issued through
  *                           this context (device kernels and the stream entry points alike):
  *                             0 = IBU_BASE_ORDER_LSB_FIRST (default): base i at bits [2i, 2i+1], "ACGT" -> 0b11100100

@@ -189,7 +189,7 @@ def test_sort_compact_tile_shapes(ia, oracle, compact):
 
 @pytest.fixture(scope="module")
 def ctx_guess(ia):
-    """A context whose sorts speculate from 131 072 records on (the default starts at 2^23): compress on a sampled guess
+    """A context whose sorts speculate from 131 072 records on (which is also the library's default since round 3): compress on a sampled guess
     of the varying bytes, exact census in the same pass."""
     c = ia.Context(0)
     c.set_option("sort_guess", 131_072)

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--compact", default="", help="comma list of sort_compact values to time (0 = 24-byte passes only, k = compact tile shape k; "
                                                   "default: the library's default)")
     ap.add_argument("--skip-agg", action="store_true")
+    ap.add_argument("--guess", default="", help="comma list of sort_guess values to time (1 = the library default: speculation from 2^23 records; k = from k records)")
+    ap.add_argument("--hybrid", default="", help="comma list of sort_hybrid values (0 = all passes, 1 = default)")
     ap.add_argument("--presorted", action="store_true", help="also time ibu_sort_records on the SORTED result (the already-sorted fast exit: one read-only census)")
     a = ap.parse_args()
     import ibu_amd as ia
@@ -32,8 +34,13 @@ def main():
     for n in (int(float(x)) for x in a.records.split(",")):
         d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)
         cols = [ctx.alloc(8 * n) for _ in range(4)] if a.random_index else None
-        for variant, compact in ((int(v), c) for v in a.variants.split(",") for c in (a.compact.split(",") if a.compact else [None])):
+        for variant, compact, guess, hybrid in ((int(v), c, g, h) for v in a.variants.split(",") for c in (a.compact.split(",") if a.compact else [None])
+                                                for g in (a.guess.split(",") if a.guess else [None]) for h in (a.hybrid.split(",") if a.hybrid else [None])):
             ctx.set_option("sort_variant", variant)
+            if guess is not None:
+                ctx.set_option("sort_guess", int(guess))
+            if hybrid is not None:
+                ctx.set_option("sort_hybrid", int(hybrid))
             if compact is not None:
                 ctx.set_option("sort_compact", int(compact))
             ts = []
@@ -72,7 +79,7 @@ def main():
             passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
             # algorithmic traffic: census 24 + histogram 24 once, 48 per pass, 48 for the copy back after an odd number of passes
             alg = n * (48 + 48 * passes + (48 if passes & 1 else 0))
-            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "index": "random" if a.random_index else "increasing (read order)",
+            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "guess": guess, "hybrid": hybrid, "index": "random" if a.random_index else "increasing (read order)",
                               "seconds": round(sec, 4), "best": round(min(ts[1:]), 4), "M_records_per_s": round(n / sec / 1e6, 1),
                               "passes": passes, "presorted_input_ms": presorted, "barcode_counts_seconds": agg, "distinct_barcodes": nb,
                               "algorithmic_GB": round(alg / 1e9, 1), "GBps_algorithmic": round(alg / sec / 1e9)}), flush=True)

@@ -76,6 +76,11 @@ int main(int argc, char** argv) {
       t_kernel = st.seconds_kernel;
       if (red.count != n || red.sum[0] != c[0] || red.sum[1] != c[1] || red.sum[2] != c[2])
         throw std::runtime_error("device sums differ from process_parallel");
+      // ... and the reference's own shape, process_parallel(proc, 0), with a GPU per worker: ONE call over every visible device
+      // (ibu_mmap_process_devices: a host thread + context per device, shard i of the static split, partials added on the host)
+      auto [total, per_device] = reader.process_devices_reduce();
+      if (total.count != n || total.sum[0] != c[0] || total.sum[1] != c[1] || total.sum[2] != c[2] || per_device.empty())
+        throw std::runtime_error("multi-device sums differ from process_parallel");
     }
     unlink(path.c_str());
     if (json) {

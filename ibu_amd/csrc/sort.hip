@@ -18,6 +18,9 @@
 
 namespace ibu {
 
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 static constexpr int kSortThreads = 256;
 static constexpr int kSortWaves = kSortThreads / kWave;       // 4
 static constexpr int kBins = 256;
@@ -430,6 +433,9 @@ ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, const u64* _
 #ifndef IBU_SORT_XCD
 #define IBU_SORT_XCD 1
 #endif
+#ifndef IBU_SCATTER24_MODE
+#define IBU_SCATTER24_MODE 1   // write-out of the 24-byte passes: 0 = consecutive 8-byte words, 1 = half records (dwordx3): 10.37 -> 9.45 ms per pass at 1e9 records (profiles r03_v)
+#endif
 template <int THREADS, int ROUNDS>
 struct SweepShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
@@ -555,11 +561,24 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
   //    16-byte chunks with single-word heads and tails were measured slower: more address arithmetic than it saves)
   const u32 nw = 3 * cnt;
   if constexpr (WMODE == 0) {
+#if IBU_SCATTER24_MODE == 1
+    // one lane per HALF record (12 bytes, dwordx3): consecutive lanes on consecutive 12-byte pieces of a run, 768 contiguous
+    // bytes per wave instruction instead of 512 (the compact last pass's write-out)
+    const u32* stage32 = reinterpret_cast<const u32*>(stage);
+    for (u32 h = tid; h < 2 * cnt; h += THREADS) {
+      const u32 s = h >> 1, j = h & 1u;
+      const u64 g = gdelta[sbin[s]] + s;
+      u32x3 o;
+      o.x = stage32[6 * s + 3 * j]; o.y = stage32[6 * s + 3 * j + 1]; o.z = stage32[6 * s + 3 * j + 2];
+      *reinterpret_cast<u32x3_a4*>(reinterpret_cast<uint8_t*>(dst) + 24 * g + 12 * j) = o;
+    }
+#else
     for (u32 w = tid; w < nw; w += THREADS) {
       const u32 s = (u32)(((u64)w * 0xAAAAAAABull) >> 33);    // w / 3
       const u64 g = gdelta[sbin[s]] + s;
       dst[3 * g + (w - 3 * s)] = stage[w];
     }
+#endif
   } else {
     u32x4* o = reinterpret_cast<u32x4*>(dst + 3 * tbase);
     const u32x4* s = reinterpret_cast<const u32x4*>(stage);
@@ -595,9 +614,6 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
 // =====================================================================================================
 // Elements of W 32-bit words: W = 3 (12 bytes: at most 12 varying key bytes) or W = 4 (16 bytes: 13 .. 16).  ElemT<W>: in
 // memory (4-byte aligned); EV<W>: in registers.
-typedef u32 u32x3 __attribute__((ext_vector_type(3)));
-typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
-typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 template <int W> struct __attribute__((packed, aligned(4))) ElemT { u32 w[W]; };
 typedef ElemT<3> Elem;                                        // the 12-byte element of the C ABI (ibu_records_compact)
 static_assert(sizeof(ElemT<3>) == 12 && sizeof(ElemT<4>) == 16, "element sizes");
@@ -962,128 +978,178 @@ struct FinishShape {
   // LDS: stage 24 (L + 1) | head u8 [L + 1] (padded) | segstart u16 [L] | seglen u16 [L] | misc 16 x u32
   static constexpr size_t lds = 24 * (size_t)(L + 1) + ((L + 1 + 15) & ~15) + 2 * (size_t)L + 2 * (size_t)L + 64;
 };
-template <int T, int M>
+// PERSIST: persistent grid, the next tile's window prefetched into a second register set while this one is worked on (needs
+// 16-byte aligned records; the one-tile form takes any 8-byte aligned input: a shard at an odd record).
+template <int T, int M, bool PERSIST>
 __global__ void __launch_bounds__(kSortThreads)
 ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64 pm0, u64 pm1, u64 pm2, u32* __restrict__ overflow) {
   typedef FinishShape<T, M> S;
-  constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads;
+  constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads, CH = (3 * L / 2 + kSortThreads - 1) / kSortThreads;
+  static_assert((T * 24) % 16 == 0, "tiles must start at 16-byte boundaries of an aligned array");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u64* stage = reinterpret_cast<u64*>(smem) + 3;             // record i of the window at stage[3 i]; record -1 = the one in front
   uint8_t* head = reinterpret_cast<uint8_t*>(stage + 3 * L);  // head[i]: record i starts a segment
   uint16_t* segstart = reinterpret_cast<uint16_t*>(head + ((L + 1 + 15) & ~15));
   uint16_t* seglen = segstart + L;
   u32* misc = reinterpret_cast<u32*>(seglen + L);             // [0] first head in the tile, [1] first head at / behind T, [2] too long
-  const u32 tid = threadIdx.x;
-  const u64 base = (u64)blockIdx.x * T;
-  if (base >= n) return;
-  const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;   // records of the window that exist
-  // 1. stage the window (and the record in front of it) — consecutive lanes, consecutive 8-byte words
-  const u64* g = src + 3 * base;
-  if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
-    const u32x4* g4 = reinterpret_cast<const u32x4*>(g);
-    const u32 nch = (3 * len) >> 1;                           // 16-byte chunks of the window (stage itself is 8 (mod 16)-aligned: two halves)
-    constexpr int CH = (3 * L / 2 + kSortThreads - 1) / kSortThreads;
-    u32x4 v[CH];                                              // every load of a thread issued before its first LDS write (see the element kernel)
+  const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
+  const u64 ntiles = (n + T - 1) / T;
+  u64 tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  struct Win { u32x4 v[CH]; u64 front; };
+  // a window's loads, all issued before anything waits for them (unconditional, clamped)
+  auto load = [&](u64 t, Win& w) {
+    const u64 base = t * T;
+    const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;
+    const u32x4* g4 = reinterpret_cast<const u32x4*>(src + 3 * base);
+    const u32 nch = (3 * len) >> 1;                           // 16-byte chunks of the window
 #pragma unroll
     for (int r = 0; r < CH; ++r) {
       const u32 c = tid + kSortThreads * r;
-      v[r] = ld16(g4 + (c < nch ? c : (nch ? nch - 1 : 0)));
+      w.v[r] = ld16(g4 + (c < nch ? c : (nch ? nch - 1 : 0)));
     }
+    w.front = src[base > 0 ? 3 * base - 3 + (tid < 3 ? tid : 0) : 0];   // threads 0..2: the record in front of the window
+  };
+  auto work = [&](u64 t, const Win* w) {                      // w == nullptr: stage straight from memory (one-tile form)
+    const u64 base = t * T;
+    const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;   // records of the window that exist
+    const u64* g = src + 3 * base;
+    // 1. stage the window (and the record in front of it)
+    if (w) {
+      const u32 nch = (3 * len) >> 1;
 #pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      const u32 c = tid + kSortThreads * r;
-      if (c < nch) {
-        stage[2 * c] = ((u64)v[r].y << 32) | v[r].x;
-        stage[2 * c + 1] = ((u64)v[r].w << 32) | v[r].z;
+      for (int r = 0; r < CH; ++r) {
+        const u32 c = tid + kSortThreads * r;
+        if (c < nch) {                                        // stage is 8 (mod 16)-aligned: two halves
+          stage[2 * c] = ((u64)w->v[r].y << 32) | w->v[r].x;
+          stage[2 * c + 1] = ((u64)w->v[r].w << 32) | w->v[r].z;
+        }
+      }
+      if (tid == 0 && ((3 * len) & 1u)) stage[3 * len - 1] = g[3 * len - 1];
+      if (tid < 3) stage[(int)tid - 3] = base > 0 ? w->front : 0;
+    } else {
+      for (u32 k = tid; k < 3 * len; k += kSortThreads) stage[k] = g[k];
+      if (tid < 3) stage[(int)tid - 3] = base > 0 ? g[(int)tid - 3] : 0;
+    }
+    if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    // 2. segment heads: the prefix differs from the predecessor's (row 0 of the array is a head).  With short runs nearly every
+    //    record is one: the first head of a wave's 64 goes to the LDS word, not 64 same-address atomics
+    for (u32 i0 = tid - lane; i0 < len; i0 += kSortThreads) {
+      const u32 i = i0 + lane;
+      bool h = false;
+      if (i < len) {
+        const u64* r = stage + 3 * i;
+        h = (base + i == 0) || (((r[0] ^ r[-3]) & pm0) | ((r[1] ^ r[-2]) & pm1) | ((r[2] ^ r[-1]) & pm2)) != 0;
+        head[i] = h;
+      }
+      const u64 lo = __ballot(h && i < (u32)T), hi = __ballot(h && i >= (u32)T);
+      if (lane == 0) {
+        if (lo) atomicMin(&misc[0], i0 + (u32)__builtin_ctzll(lo));
+        if (hi) atomicMin(&misc[1], i0 + (u32)__builtin_ctzll(hi));
       }
     }
-    if (tid == 0 && ((3 * len) & 1u)) stage[3 * len - 1] = g[3 * len - 1];
+    __syncthreads();
+    const u32 begin = misc[0];
+    u32 end = misc[1];
+    if (end == 0xFFFFFFFFu && base + len == n) end = len;     // the array ends inside the window: that is the last segment's end
+    if (begin == 0xFFFFFFFFu) {                               // no segment starts in this tile: the tile is the inside of one that is
+      if (tid == 0 && len > (u32)M) *overflow = 1u;           // longer than a tile — its owner overflows as well; say so here too
+      return;
+    }
+    if (end == 0xFFFFFFFFu) {                                 // the last segment of the tile runs past the look-ahead
+      if (tid == 0) *overflow = 1u;
+      return;
+    }
+    // 3. every head walks its segment: segstart for the members, seglen at the head
+    for (u32 i = begin + tid; i < end; i += kSortThreads)
+      if (head[i]) {
+        u32 j = i + 1;
+        while (j < end && !head[j]) ++j;
+        if (j - i > (u32)M) misc[2] = 1u;
+        else {
+          for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
+          seglen[i] = (uint16_t)(j - i);
+        }
+      }
+    __syncthreads();
+    if (misc[2]) {                                            // a segment longer than M: ranking by counting would be quadratic in it
+      if (tid == 0) *overflow = 1u;
+      return;
+    }
+    // 4. rank inside the segment under the full key (ties: window order — equal keys are equal records)
+    u64 k0[PER], k1[PER], k2[PER];
+    u32 target[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const u32 i = begin + tid + kSortThreads * r;
+      target[r] = 0xFFFFFFFFu;
+      if (i < end) {
+        const u64* me = stage + 3 * i;
+        k0[r] = me[0]; k1[r] = me[1]; k2[r] = me[2];
+        const u32 s0 = segstart[i], s1 = s0 + seglen[s0];
+        u32 cnt = 0;
+        // four candidates per step, their LDS reads issued together (the lanes of a segment read the same record: broadcasts), and
+        // the comparison as mask arithmetic — the short-circuit form compiled to five branches per candidate and one LDS round
+        // trip per iteration: 159 ms per 1e9 records instead of ~15.  A segment of one record costs nothing.
+        if (s1 - s0 > 1)
+          for (u32 j = s0; j < s1; j += 4) {
+            u64 cb[4], cu[4], cx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const u32 jj = j + q < s1 ? j + q : s1 - 1;    // clamped: in the window, not counted
+              const u64* o = stage + 3 * jj;
+              cb[q] = o[0]; cu[q] = o[1]; cx[q] = o[2];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const u32 lt0 = cb[q] < k0[r], eq0 = cb[q] == k0[r], lt1 = cu[q] < k1[r], eq1 = cu[q] == k1[r], lt2 = cx[q] < k2[r], eq2 = cx[q] == k2[r];
+              const u32 before = lt0 | (eq0 & (lt1 | (eq1 & (lt2 | (eq2 & (u32)(j + q < i))))));   // orders before me (ties: window order)
+              cnt += before & (u32)(j + q < s1);
+            }
+          }
+        target[r] = s0 + cnt;
+      }
+    }
+    __syncthreads();                                          // every record is in registers: permute in place
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+      if (target[r] != 0xFFFFFFFFu) {
+        u64* o = stage + 3 * target[r];
+        o[0] = k0[r]; o[1] = k1[r]; o[2] = k2[r];
+      }
+    __syncthreads();
+    // 5. the chunk [begin, end) leaves as half records (dwordx3): consecutive lanes, consecutive 12-byte pieces
+    uint8_t* out = reinterpret_cast<uint8_t*>(dst + 3 * (base + begin));
+    const u32* in = reinterpret_cast<const u32*>(stage + 3 * begin);
+    for (u32 h = tid; h < 2 * (end - begin); h += kSortThreads) {
+      u32x3 o;
+      o.x = in[3 * h]; o.y = in[3 * h + 1]; o.z = in[3 * h + 2];
+      *reinterpret_cast<u32x3_a4*>(out + 12 * (size_t)h) = o;
+    }
+  };
+  if constexpr (!PERSIST) {
+    work(tile, nullptr);                                      // one tile per workgroup (the grid covers them)
   } else {
-    for (u32 w = tid; w < 3 * len; w += kSortThreads) stage[w] = g[w];
-  }
-  if (tid < 3) stage[(int)tid - 3] = base > 0 ? g[(int)tid - 3] : 0;
-  if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
-  __syncthreads();
-  // 2. segment heads: the prefix differs from the predecessor's (row 0 of the array is a head)
-  for (u32 i = tid; i < len; i += kSortThreads) {
-    const u64* r = stage + 3 * i;
-    const bool h = (base + i == 0) || (((r[0] ^ r[-3]) & pm0) | ((r[1] ^ r[-2]) & pm1) | ((r[2] ^ r[-1]) & pm2)) != 0;
-    head[i] = h;
-    if (h) atomicMin(&misc[i < (u32)T ? 0 : 1], i);
-  }
-  __syncthreads();
-  const u32 begin = misc[0];
-  u32 end = misc[1];
-  if (end == 0xFFFFFFFFu && base + len == n) end = len;       // the array ends inside the window: that is the last segment's end
-  if (begin == 0xFFFFFFFFu) {                                 // no segment starts in this tile: the tile is the inside of one that is
-    if (tid == 0 && len > (u32)M) *overflow = 1u;             // longer than a tile — its owner overflows as well; say so here too
-    return;
-  }
-  if (end == 0xFFFFFFFFu) {                                   // the last segment of the tile runs past the look-ahead
-    if (tid == 0) *overflow = 1u;
-    return;
-  }
-  // 3. every head walks its segment: segstart for the members, seglen at the head
-  for (u32 i = begin + tid; i < end; i += kSortThreads)
-    if (head[i]) {
-      u32 j = i + 1;
-      while (j < end && !head[j]) ++j;
-      if (j - i > (u32)M) misc[2] = 1u;
-      else {
-        for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
-        seglen[i] = (uint16_t)(j - i);
-      }
-    }
-  __syncthreads();
-  if (misc[2]) {                                              // a segment longer than M: ranking by counting would be quadratic in it
-    if (tid == 0) *overflow = 1u;
-    return;
-  }
-  // 4. rank inside the segment under the full key (ties: window order — equal keys are equal records)
-  u64 k0[PER], k1[PER], k2[PER];
-  u32 target[PER];
-#pragma unroll
-  for (int r = 0; r < PER; ++r) {
-    const u32 i = begin + tid + kSortThreads * r;
-    target[r] = 0xFFFFFFFFu;
-    if (i < end) {
-      const u64* me = stage + 3 * i;
-      k0[r] = me[0]; k1[r] = me[1]; k2[r] = me[2];
-      const u32 s0 = segstart[i], s1 = s0 + seglen[s0];
-      u32 cnt = 0;
-      // four candidates per step, their LDS reads issued together (the lanes of a segment read the same record: broadcasts), and
-      // the comparison as mask arithmetic — the short-circuit form compiled to five branches per candidate and one LDS round
-      // trip per iteration: 159 ms per 1e9 records instead of ~15
-      for (u32 j = s0; j < s1; j += 4) {
-        u64 cb[4], cu[4], cx[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const u32 jj = j + q < s1 ? j + q : s1 - 1;        // clamped: in the window, not counted
-          const u64* o = stage + 3 * jj;
-          cb[q] = o[0]; cu[q] = o[1]; cx[q] = o[2];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const u32 lt0 = cb[q] < k0[r], eq0 = cb[q] == k0[r], lt1 = cu[q] < k1[r], eq1 = cu[q] == k1[r], lt2 = cx[q] < k2[r], eq2 = cx[q] == k2[r];
-          const u32 before = lt0 | (eq0 & (lt1 | (eq1 & (lt2 | (eq2 & (u32)(j + q < i))))));   // orders before me (ties: window order)
-          cnt += before & (u32)(j + q < s1);
-        }
-      }
-      target[r] = s0 + cnt;
+    Win wa, wb;
+    load(tile, wa);
+    for (;;) {                                                // two register sets take turns (kcommon.hpp, sweep_tiles)
+      u64 next = tile + gridDim.x;
+      bool more = next < ntiles;
+      load(more ? next : tile, wb);
+      work(tile, &wa);
+      if (!more) break;
+      tile = next;
+      __syncthreads();                                        // step 5's LDS reads precede the next tile's stage writes
+      next = tile + gridDim.x;
+      more = next < ntiles;
+      load(more ? next : tile, wa);
+      work(tile, &wb);
+      if (!more) break;
+      tile = next;
+      __syncthreads();
     }
   }
-  __syncthreads();                                            // every record is in registers: permute in place
-#pragma unroll
-  for (int r = 0; r < PER; ++r)
-    if (target[r] != 0xFFFFFFFFu) {
-      u64* o = stage + 3 * target[r];
-      o[0] = k0[r]; o[1] = k1[r]; o[2] = k2[r];
-    }
-  __syncthreads();
-  // 5. the chunk [begin, end) leaves as consecutive 8-byte words
-  u64* out = dst + 3 * (base + begin);
-  const u64* in = stage + 3 * begin;
-  for (u32 w = tid; w < 3 * (end - begin); w += kSortThreads) out[w] = in[w];
 }
 
 // ---- the same on compact elements (W words): P element passes, then this kernel ranks inside the runs of equal prefix, and
@@ -1902,11 +1968,25 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       e = lsd(ps, P, true);
       if (e != hipSuccess) return e;
       typedef FinishShape<kFinishT, kFinishM> FS;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_sort_finish<kFinishT, kFinishM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS::lds);
-      if (e != hipSuccess) return e;
       const u64 nblk = (n + kFinishT - 1) / kFinishT;
-      hipLaunchKernelGGL((ibu_k_sort_finish<kFinishT, kFinishM>), dim3((u32)nblk), dim3(kSortThreads), FS::lds, st, (const u64*)tmp,
-                         static_cast<u64*>(recs), (u64)n, pm[0], pm[1], pm[2], d_overflow);
+      if ((reinterpret_cast<uintptr_t>(tmp) & 15u) == 0) {    // persistent, prefetching form
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_sort_finish<kFinishT, kFinishM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS::lds);
+        if (e != hipSuccess) return e;
+        static std::atomic<int> focc;
+        int fper = focc.load(std::memory_order_relaxed);
+        if (fper <= 0) {
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fper, ibu_k_sort_finish<kFinishT, kFinishM, true>, kSortThreads, FS::lds) != hipSuccess || fper <= 0) fper = 1;
+          focc.store(fper, std::memory_order_relaxed);
+        }
+        const u64 fgrid = (u64)fper * (u64)cfg.cus;
+        hipLaunchKernelGGL((ibu_k_sort_finish<kFinishT, kFinishM, true>), dim3((u32)(nblk < fgrid ? nblk : fgrid)), dim3(kSortThreads), FS::lds, st, (const u64*)tmp,
+                           static_cast<u64*>(recs), (u64)n, pm[0], pm[1], pm[2], d_overflow);
+      } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_sort_finish<kFinishT, kFinishM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS::lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((ibu_k_sort_finish<kFinishT, kFinishM, false>), dim3((u32)nblk), dim3(kSortThreads), FS::lds, st, (const u64*)tmp,
+                           static_cast<u64*>(recs), (u64)n, pm[0], pm[1], pm[2], d_overflow);
+      }
       u32 overflow = 0;
       e = hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st);
       if (e != hipSuccess) return e;

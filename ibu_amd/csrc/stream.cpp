@@ -447,6 +447,15 @@ extern "C" int32_t ibu_mmap_process_devices(const ibu_mmap_t* m, const int32_t* 
   } catch (...) {
     return caught_io("ibu_mmap_process_devices");
   }
+  // The contexts of this form live for ONE call, so their rings are allocated and pinned inside it: 4 x 96 MiB (the default
+  // of a kept context) costs 70 ms per context — more than streaming an eighth of a 24 GB file — and pinning serialises in
+  // the driver.  Without a caller's ring configuration the one-shot form uses 3 x 24 MiB slots (1 Mi records, the
+  // reference's BATCH_SIZE, mmap.rs:284): 18 ms, 54.5 GB/s against 56.1 (profiles/README.md r03_y).
+  ibu_ring_config_t one_shot;
+  memset(&one_shot, 0, sizeof one_shot);
+  one_shot.slots = 3;
+  one_shot.slot_records = IBU_BATCH_SIZE;
+  if (!cfg) cfg = &one_shot;
   int32_t rc = IBU_OK;
   for (size_t i = 0; i < n_devices && rc == IBU_OK; ++i) rc = ibu_ctx_create(devices[i], &ctxs[i]);   // in order: the first bad ordinal is the error
   if (rc == IBU_OK) rc = process_contexts(m, ctxs.data(), n_devices, cfg, proc, sinks, total, stats);

@@ -199,6 +199,25 @@ def main():
         _, st = m.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
         emit("mmap process_device DECODE", time.perf_counter() - t0, st)
         plain = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()]
+        # 3a. the one-call multi-device form (ibu_mmap_process_devices / _contexts): a host thread + context per listed device.
+        # The box has ONE GPU, so the lists repeat ordinal 0 — this measures the call's own overhead (contexts, rings) and
+        # whether two workers overlap better on one PCIe link, not multi-GPU scaling (unmeasured).
+        for devices in ((0,), (0, 0), (0, 0, 0, 0)):
+            t0 = time.perf_counter()
+            total, parts, sts = m.process_devices(devices, ia.PROC_REDUCE)   # no ring argument: the one-shot default (3 x 24 MiB)
+            dt = time.perf_counter() - t0
+            assert total == want and len(parts) == len(devices)
+            emit(f"mmap process_devices REDUCE, devices={list(devices)} (contexts created inside the call)", dt,
+                 kernel_seconds=round(sum(s_.seconds_kernel for s_ in sts), 4))
+        cs = [ia.Context(0) for _ in range(2)]
+        for rep in ("first call", "second call"):
+            t0 = time.perf_counter()
+            total, parts, sts = m.process_devices(proc=ia.PROC_REDUCE, ring=ring, contexts=cs)
+            dt = time.perf_counter() - t0
+            assert total == want
+            emit(f"mmap process_contexts REDUCE, 2 caller-owned contexts on device 0 ({rep})", dt)
+        for c_ in cs:
+            c_.close()
 
         # 3b. host <-> host codec pipelines: file -> ASCII in host memory, and back into a file
         if not a.skip_host_codec:

@@ -1619,6 +1619,8 @@ template <int W>
 static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
                                         const CompactPlan& pl, const u32* passes, u32 npass, hipStream_t st, bool compressed = false,
                                         u32 digits_byte = 0, u32 finish_prefix = 0, ElemT<W>* elems_at = nullptr) {
+  const bool retried = (finish_prefix & 0x80000000u) != 0;    // the one retry with a longer prefix (see the overflow handling below)
+  finish_prefix &= 0x7FFFFFFFu;
   const SortLayout L = sort_layout(n, cv.tile);
   u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
   u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
@@ -1701,6 +1703,19 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return e;
     if (!overflow) return hipGetLastError();
+    // Long runs of equal prefix.  The prefix-sorted elements are a permutation of the input's, so anything may follow.  A heavy
+    // prefix usually is a heavy BARCODE whose records the next key bytes (the UMI) spread again: ONE retry with a prefix that
+    // reaches at least two bytes past the barcode (and is at least three bytes longer; W = 4: even, the elements must end in tmp)
+    // is cheaper than all passes when it still saves two of them — and if that overflows too, all passes run.
+    u32 nbar = 0;                                             // element bytes that come from the barcode (the most significant ones)
+    for (u32 j = 0; j < pl.k && j < 4u * W; ++j)
+      if (((pl.csel[j >> 2][0] >> (8 * (j & 3))) & 255u) != 0x0Cu) ++nbar;
+    u32 longer = finish_prefix + 3 > nbar + 2 ? finish_prefix + 3 : nbar + 2;   // at least two bytes past the barcode
+    if (W == 4) longer += longer & 1u;
+    if (!retried && longer + 2 <= npass) {
+      if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu prefix+finish overflowed (long runs of equal prefix): retrying with prefix_passes=%u of %u\n", n, longer, npass);
+      return launch_compact_passes<W>(cfg, cv, recs, tmp, n, sc, pl, passes, npass, st, true, 0xFFFFFFFFu, longer | 0x80000000u, src);
+    }
     if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu prefix+finish overflowed (long runs of equal prefix): all %u passes\n", n, npass);
     return launch_compact_passes<W>(cfg, cv, recs, tmp, n, sc, pl, passes, npass, st, true, 0xFFFFFFFFu, 0, src);   // elements: a permutation of the input's
   }

@@ -277,7 +277,7 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
 @pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003, 5_000_001])
 @pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 12-byte and 16-byte elements
 @pytest.mark.parametrize("case", ["random_index", "index_order", "whitelist_barcodes", "heavy_run_outside_the_samples", "duplicates",
-                                  "guess_misses_a_umi_byte", "one_heavy_barcode"])
+                                  "guess_misses_a_umi_byte", "one_heavy_barcode", "heavy_barcode_outside_the_samples"])
 def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens, case, capfd):
     """The compact-key sort of large inputs: well-spread keys (short estimated runs) take P prefix passes + the finishing
     kernel; keys with few distinct prefixes (barcodes from a whitelist) take a longer prefix or the plain passes; a heavy run
@@ -298,6 +298,9 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
         span = max(span, 600)
         recs["barcode"][quarter:quarter + span] = recs["barcode"][quarter]
         recs["umi"][quarter:quarter + span] = recs["umi"][quarter]
+    elif case == "heavy_barcode_outside_the_samples":           # 3000 records of one barcode (UMIs stay random) where no sample looks
+        span = max(min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000), 600)
+        recs["barcode"][quarter:quarter + span] = recs["barcode"][quarter]
     elif case == "duplicates":
         recs[1::2] = recs[0:len(recs[1::2]) * 2:2]
         rng.shuffle(recs)
@@ -312,8 +315,11 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
     assert got == want and ctx_guess_pf.is_sorted(d, n)
     if case in ("random_index", "index_order", "duplicates"):
         assert "path=compact-prefix+finish" in trace and "overflowed" not in trace, trace
-    elif case == "heavy_run_outside_the_samples":
-        assert "path=compact-prefix+finish" in trace and "overflowed" in trace, trace
+    elif case == "heavy_run_outside_the_samples":               # 3000 records with ONE (barcode, umi): no prefix short of the index splits
+        assert "path=compact-prefix+finish" in trace and "overflowed" in trace, trace   # them, so the retry overflows too (or is not worth it)
+        assert "all " in trace.split("overflowed")[-1], trace
+    elif case == "heavy_barcode_outside_the_samples":           # ... with random UMIs the retry's longer prefix (barcode + UMI bytes) succeeds
+        assert "path=compact-prefix+finish" in trace and trace.count("overflowed") == 1 and "retrying with prefix_passes" in trace, trace
     elif case == "guess_misses_a_umi_byte":
         assert "guess did not cover" in trace and "prefix+finish" not in trace, trace
     elif case == "one_heavy_barcode":                          # the sample's most frequent prefix says so BEFORE anything overflows:

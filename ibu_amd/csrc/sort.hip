@@ -1385,6 +1385,42 @@ __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 s0, u6
   }
 }
 
+// The same estimate for 24-byte records (more than 16 varying bytes): the prefix of length P is the P most significant VARYING
+// key bytes, given as (field, shift) pairs, most significant first.
+struct PrefixBytes { uint8_t field[kMaxPrefix], shift[kMaxPrefix]; u32 count; };
+extern "C" __global__ void ibu_k_sort_sample_pairs_recs(const u64* __restrict__ recs, u64 s0, u64 s1, u64 s2, u32 per_range, PrefixBytes pb,
+                                                        u32 kPairSlots /*power of two*/, u64* __restrict__ keys, u32* __restrict__ cnts,
+                                                        u64* __restrict__ pairs) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * per_range) return;
+  const u32 rg = t / per_range;
+  const u64 row = (rg == 0 ? s0 : rg == 1 ? s1 : s2) + (t - rg * per_range);
+  const u64 f[3] = {recs[3 * row], recs[3 * row + 1], recs[3 * row + 2]};
+  u64 h = 0x9E3779B97F4A7C15ull;
+  for (u32 P = 1; P <= pb.count; ++P) {                       // the hash of the first P bytes extends the hash of the first P - 1
+    const u32 fi = pb.field[P - 1];
+    const u64 byte = ((fi == 0 ? f[0] : fi == 1 ? f[1] : f[2]) >> pb.shift[P - 1]) & 255u;
+    h = (h ^ (byte + 0x100ull * P)) * 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+    u64 key = (h ^ (h >> 32)) * 0x94D049BB133111EBull;
+    key ^= key >> 31;
+    if (key == 0) key = 1;
+    u64* kt = keys + (size_t)(P - 1) * kPairSlots;
+    u32* ct = cnts + (size_t)(P - 1) * kPairSlots;
+    for (u32 slot = (u32)key & (kPairSlots - 1), probes = 0; probes < kPairSlots; slot = (slot + 1) & (kPairSlots - 1), ++probes) {
+      const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&kt[slot]), 0ull, (unsigned long long)key);
+      if (old == 0 || old == key) {
+        const u32 before = atomicAdd(&ct[slot], 1u);
+        if (before) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[P - 1]), (unsigned long long)before);
+          if (before >= 3) atomicMax(reinterpret_cast<unsigned long long*>(&pairs[kMaxPrefix + P - 1]), (unsigned long long)(before + 1));
+        }
+        break;
+      }
+    }
+  }
+}
+
 // =====================================================================================================
 // Host side.  Scratch layout (bytes), all offsets 256-byte aligned:
 //   census u64[64][8] | binbase u64[256] | blocksum u32[nblocks][256] | blockoff u64[nblocks][256] | counts u16[ntiles][256]
@@ -1972,6 +2008,40 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     // length, against 10.3 ms for one more prefix pass), so the prefix is chosen to leave at most ~8 records per segment
     int P = 1;
     for (u64 segs = 256; n / segs > 8 && P < 8; segs <<= 8) ++P;
+    // ... of WELL-SPREAD keys.  From 2^17 records on the sample ranges say whether they are (ibu_k_sort_sample_pairs_recs: pairs of
+    // equal prefix and the most frequent prefix among 3 x 32 Ki sample records, tables in tmp): the shortest prefix with at most
+    // ~8 records per run and no heavy prefix is taken, which may be longer than the one n suggests — or none (P = 0: all passes).
+    static constexpr size_t kSampleW = 32768;
+    if (cfg.sort_hybrid && n >= 4 * kSampleW && (reinterpret_cast<uintptr_t>(tmp) & 7u) == 0) {
+      PrefixBytes pb;
+      pb.count = (u32)(npass < kMaxPrefix ? npass : kMaxPrefix);
+      for (u32 k = 0; k < pb.count; ++k) { pb.field[k] = (uint8_t)passes[npass - 1 - k].field; pb.shift[k] = (uint8_t)passes[npass - 1 - k].shift; }
+      const u32 slots = kPairSlotsMax;                       // 25 MB of tables in tmp: from 1.05 M records on (below: P from n alone)
+      const size_t table_bytes = 128 + (size_t)slots * 12 * kMaxPrefix;
+      if (table_bytes <= n * 24) {
+        uint8_t* tb = static_cast<uint8_t*>(tmp);
+        e = hipMemsetAsync(tb, 0, table_bytes, st);
+        if (e != hipSuccess) return e;
+        const size_t starts[3] = {0, n / 2, n - kSampleW};
+        const size_t m = 3 * kSampleW;
+        hipLaunchKernelGGL(ibu_k_sort_sample_pairs_recs, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, (const u64*)recs, (u64)starts[0], (u64)starts[1],
+                           (u64)starts[2], (u32)kSampleW, pb, slots, reinterpret_cast<u64*>(tb + 128),
+                           reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix), reinterpret_cast<u64*>(tb));
+        u64 pairs[2 * kMaxPrefix];
+        e = hipMemcpyAsync(pairs, tb, sizeof pairs, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        int Pest = 0;
+        for (u32 q = 1; q <= pb.count; ++q) {
+          const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q - 1] / (double)m);
+          const double heaviest = (double)pairs[kMaxPrefix + q - 1] * ((double)n / (double)m);
+          if (seg <= 8.0 && heaviest <= 128.0) { Pest = (int)q; break; }
+        }
+        if (trace_sort() && Pest != P) fprintf(stderr, "ibu sort: n=%zu sample estimate: prefix_passes=%d (well-spread keys would take %d)\n", n, Pest, P);
+        P = Pest ? Pest : npass;                              // npass: never worth it below
+      }
+    }
     const int margin = cfg.sort_hybrid == 2 ? 1 : 3;
     if (cfg.sort_hybrid && npass >= P + margin && n < (1ull << 40)) {
       u32* d_overflow = reinterpret_cast<u32*>(sc + L.misc);

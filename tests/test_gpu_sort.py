@@ -159,6 +159,25 @@ def test_wide_keys_heavy_prefixes_fall_back_to_all_passes(ctx, oracle, capfd):
     assert "prefix+finish overflowed" in trace and "path=24-byte" in trace, trace
 
 
+@pytest.mark.parametrize("kind", ["two_prefixes", "whitelist"])
+def test_wide_keys_sample_estimate_avoids_the_overflow(ctx, oracle, kind, capfd):
+    """From 1.05 M records on the 24-byte path asks the sample ranges before it commits to a prefix: keys with two distinct
+    top bytes, or barcodes from a whitelist of 4000, take a longer prefix (or all passes) at once instead of overflowing."""
+    n = 2_000_003
+    recs = _full_range(n, 17)
+    rng = np.random.default_rng(5)
+    if kind == "two_prefixes":
+        recs["barcode"] = (recs["barcode"] & np.uint64((1 << 40) - 1)) | (np.uint64(0xABCDEF) << np.uint64(40)) * (recs["index"] & np.uint64(1))
+    else:
+        wl = recs["barcode"][:4000].copy()
+        recs["barcode"] = wl[rng.integers(0, 4000, n)]
+    capfd.readouterr()
+    got, d = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == oracle.sort_records(recs).tobytes()
+    assert "sample estimate" in trace and "overflowed" not in trace, trace
+
+
 def test_wide_keys_of_a_shard_at_an_odd_record(ctx, oracle):
     n = 200_001
     recs = _full_range(n, 11)

@@ -352,10 +352,14 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
 /* Device-side sort by (barcode, umi, index) — the order `derive(Ord)` defines (record.rs:58)
  * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch.  The context
  * additionally keeps (and grows on demand) about 1.75 B per record of its own scratch.  Any n the
- * device can hold (n < 2^40); synchronises `stream` once (a 64-byte census read-back picks the passes).
- * Stable LSD radix sort over the key bytes that vary; when at most 16 of them do (and n < 2^32, d_records 16-byte
- * aligned) the passes run on 12- or 16-byte compacted keys held in d_tmp (and, for 16-byte keys, in the head of
- * d_records) (option "sort_compact"). */
+ * device can hold (n < 2^40).  NOT purely asynchronous: the call synchronises `stream` a few times (64- to 128-byte
+ * read-backs pick the path: the census of the varying bytes, from 2^17 records on a sample census and a pair count that
+ * estimates the runs of equal prefix, and the finishing kernel's overflow flag); the last kernels may still be queued
+ * when it returns.
+ * Stable radix sort over the key bytes that vary; when at most 16 of them do (and n < 2^32, d_records 16-byte
+ * aligned) it runs on 12- or 16-byte compacted keys held in d_tmp (and, for 16-byte keys, in the head of
+ * d_records) (option "sort_compact").  Large inputs whose keys are well spread take passes over the most significant
+ * varying bytes only and one finishing pass (option "sort_hybrid"); the result is the same bytes on every path. */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
 /* Per-barcode aggregation of SORTED device records: the device form of the reference's BarcodeAnalyzer
  * processor (src/parallel.rs:72-98 — HashMap<barcode, count> merged in on_batch_complete).  Writes, in

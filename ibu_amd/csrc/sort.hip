@@ -1034,7 +1034,8 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
     if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
     __syncthreads();
     // 2. segment heads: the prefix differs from the predecessor's (row 0 of the array is a head).  With short runs nearly every
-    //    record is one: the first head of a wave's 64 goes to the LDS word, not 64 same-address atomics
+    //    record is one: the first head of a wave's 64 goes to the LDS word, not 64 same-address atomics.
+    //    misc[0]: first head among the tile's first M records, misc[1]: first head in the look-ahead [T, T + M).
     for (u32 i0 = tid - lane; i0 < len; i0 += kSortThreads) {
       const u32 i = i0 + lane;
       bool h = false;
@@ -1043,43 +1044,43 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
         h = (base + i == 0) || (((r[0] ^ r[-3]) & pm0) | ((r[1] ^ r[-2]) & pm1) | ((r[2] ^ r[-1]) & pm2)) != 0;
         head[i] = h;
       }
-      const u64 lo = __ballot(h && i < (u32)T), hi = __ballot(h && i >= (u32)T);
+      const u64 lo = __ballot(h && i < (u32)M), hi = __ballot(h && i >= (u32)T);
       if (lane == 0) {
         if (lo) atomicMin(&misc[0], i0 + (u32)__builtin_ctzll(lo));
         if (hi) atomicMin(&misc[1], i0 + (u32)__builtin_ctzll(hi));
       }
     }
     __syncthreads();
-    const u32 begin = misc[0];
-    u32 end = misc[1];
-    if (end == 0xFFFFFFFFu && base + len == n) end = len;     // the array ends inside the window: that is the last segment's end
-    if (begin == 0xFFFFFFFFu) {                               // no segment starts in this tile: the tile is the inside of one that is
-      if (tid == 0 && len > (u32)M) *overflow = 1u;           // longer than a tile — its owner overflows as well; say so here too
-      return;
-    }
-    if (end == 0xFFFFFFFFu) {                                 // the last segment of the tile runs past the look-ahead
-      if (tid == 0) *overflow = 1u;
-      return;
-    }
-    // 3. every head walks its segment: segstart for the members, seglen at the head
+    // WHO WRITES WHAT: see ibu_k_sort_finish_elems (the same ownership rule: [begin, end) from the first heads among the first M
+    // records of this tile and of the next; runs of at most M records between two heads are ranked, everything else is part of a
+    // long run, passed through as it stands and checked for order).
+    // (The array's end closes a run like a head does: a last tile of at most M elements without a head is all tail of the
+    // previous tile's last run — the previous tile, whose window then reaches the array's end, finishes it.)
+    const u32 begin = misc[0] != 0xFFFFFFFFu ? misc[0] : ((len <= (u32)M && base + len == n) ? len : 0u);
+    u32 end;
+    bool end_is_head = true;
+    if (len <= (u32)T) end = len;                             // the array ends in this tile
+    else if (misc[1] != 0xFFFFFFFFu) end = misc[1];
+    else if (base + len == n) end = len;                      // ... or inside the look-ahead
+    else { end = (u32)T; end_is_head = false; }
+    // 3. short runs: every head walks to the next one; segstart for the members, seglen at the head
     for (u32 i = begin + tid; i < end; i += kSortThreads)
-      if (head[i]) {
+      if (head[i] || i == begin) {                            // (begin without a head: the part of a long run this tile owns)
         u32 j = i + 1;
         while (j < end && !head[j]) ++j;
-        if (j - i > (u32)M) misc[2] = 1u;
-        else {
+        if (head[i] && j - i <= (u32)M && (j < end || end_is_head)) {
           for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
           seglen[i] = (uint16_t)(j - i);
+        } else {
+          for (u32 k = i; k < j; ++k) segstart[k] = 0xFFFFu;   // part of a long run
         }
       }
     __syncthreads();
-    if (misc[2]) {                                            // a segment longer than M: ranking by counting would be quadratic in it
-      if (tid == 0) *overflow = 1u;
-      return;
-    }
-    // 4. rank inside the segment under the full key (ties: window order — equal keys are equal records)
+    // 4. rank inside the short runs under the full key (ties: window order — equal keys are equal records); long runs: identity
+    //    + order check
     u64 k0[PER], k1[PER], k2[PER];
     u32 target[PER];
+    bool inversion = false;
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
       const u32 i = begin + tid + kSortThreads * r;
@@ -1087,31 +1088,45 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
       if (i < end) {
         const u64* me = stage + 3 * i;
         k0[r] = me[0]; k1[r] = me[1]; k2[r] = me[2];
-        const u32 s0 = segstart[i], s1 = s0 + seglen[s0];
-        u32 cnt = 0;
-        // four candidates per step, their LDS reads issued together (the lanes of a segment read the same record: broadcasts), and
-        // the comparison as mask arithmetic — the short-circuit form compiled to five branches per candidate and one LDS round
-        // trip per iteration: 159 ms per 1e9 records instead of ~15.  A segment of one record costs nothing.
-        if (s1 - s0 > 1)
-          for (u32 j = s0; j < s1; j += 4) {
-            u64 cb[4], cu[4], cx[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const u32 jj = j + q < s1 ? j + q : s1 - 1;    // clamped: in the window, not counted
-              const u64* o = stage + 3 * jj;
-              cb[q] = o[0]; cu[q] = o[1]; cx[q] = o[2];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const u32 lt0 = cb[q] < k0[r], eq0 = cb[q] == k0[r], lt1 = cu[q] < k1[r], eq1 = cu[q] == k1[r], lt2 = cx[q] < k2[r], eq2 = cx[q] == k2[r];
-              const u32 before = lt0 | (eq0 & (lt1 | (eq1 & (lt2 | (eq2 & (u32)(j + q < i))))));   // orders before me (ties: window order)
-              cnt += before & (u32)(j + q < s1);
-            }
+        const u32 s0 = segstart[i];
+        if (s0 == 0xFFFFu) {                                  // part of a long run
+          target[r] = i;
+          if (!head[i]) {
+            const u32 lt0 = k0[r] < me[-3], eq0 = k0[r] == me[-3], lt1 = k1[r] < me[-2], eq1 = k1[r] == me[-2], lt2 = k2[r] < me[-1];
+            inversion = inversion || (lt0 | (eq0 & (lt1 | (eq1 & lt2)))) != 0;
           }
-        target[r] = s0 + cnt;
+        } else {
+          const u32 s1 = s0 + seglen[s0];
+          u32 cnt = 0;
+          // four candidates per step, their LDS reads issued together (the lanes of a segment read the same record: broadcasts), and
+          // the comparison as mask arithmetic — the short-circuit form compiled to five branches per candidate and one LDS round
+          // trip per iteration: 159 ms per 1e9 records instead of ~15.  A segment of one record costs nothing.
+          if (s1 - s0 > 1)
+            for (u32 j = s0; j < s1; j += 4) {
+              u64 cb[4], cu[4], cx[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const u32 jj = j + q < s1 ? j + q : s1 - 1;  // clamped: in the window, not counted
+                const u64* o = stage + 3 * jj;
+                cb[q] = o[0]; cu[q] = o[1]; cx[q] = o[2];
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const u32 lt0 = cb[q] < k0[r], eq0 = cb[q] == k0[r], lt1 = cu[q] < k1[r], eq1 = cu[q] == k1[r], lt2 = cx[q] < k2[r], eq2 = cx[q] == k2[r];
+                const u32 before = lt0 | (eq0 & (lt1 | (eq1 & (lt2 | (eq2 & (u32)(j + q < i))))));   // orders before me (ties: window order)
+                cnt += before & (u32)(j + q < s1);
+              }
+            }
+          target[r] = s0 + cnt;
+        }
       }
     }
+    if (inversion) misc[2] = 1u;
     __syncthreads();                                          // every record is in registers: permute in place
+    if (misc[2]) {                                            // a long run that is not in order: not this kernel's to sort
+      if (tid == 0) *overflow = 1u;
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < PER; ++r)
       if (target[r] != 0xFFFFFFFFu) {
@@ -1226,7 +1241,8 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
     }
     if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
     __syncthreads();
-    // 2. heads (with short runs nearly every element is one: the first head of a wave's 64 goes to the LDS word, not 64 atomics)
+    // 2. heads (with short runs nearly every element is one: the first head of a wave's 64 goes to the LDS word, not 64 atomics).
+    //    misc[0]: first head among the tile's first M elements, misc[1]: first head in the look-ahead [T, T + M).
     for (u32 i0 = tid - lane; i0 < len; i0 += kSortThreads) {
       const u32 i = i0 + lane;
       bool h = false;
@@ -1237,43 +1253,46 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
         h = (base + i == 0) || diff != 0;
         head[i] = h;
       }
-      const u64 lo = __ballot(h && i < (u32)T), hi = __ballot(h && i >= (u32)T);
+      const u64 lo = __ballot(h && i < (u32)M), hi = __ballot(h && i >= (u32)T);
       if (lane == 0) {
         if (lo) atomicMin(&misc[0], i0 + (u32)__builtin_ctzll(lo));
         if (hi) atomicMin(&misc[1], i0 + (u32)__builtin_ctzll(hi));
       }
     }
     __syncthreads();
-    const u32 begin = misc[0];
-    u32 end = misc[1];
-    if (end == 0xFFFFFFFFu && base + len == n) end = len;     // the array ends inside the window
-    if (begin == 0xFFFFFFFFu) {                               // the tile is the inside of a run longer than a tile
-      if (tid == 0 && len > (u32)M) *overflow = 1u;
-      return;
-    }
-    if (end == 0xFFFFFFFFu) {                                 // the tile's last run goes past the look-ahead
-      if (tid == 0) *overflow = 1u;
-      return;
-    }
-    // 3. segments
+    // WHO WRITES WHAT.  A workgroup owns [begin, end) of its window: begin = the first head among the tile's first M elements (the
+    // elements in front of it are the tail of a run the previous tile finishes), or 0 if there is none (then the run that crosses
+    // the tile's start is longer than M: nobody ranks it, every tile passes its own part through); end = likewise at the next tile's
+    // start, seen through the look-ahead.  Both neighbours look at the same M elements, so the ranges tile the array.
+    // Inside the range a run of at most M elements between two heads is RANKED; everything else is part of a long run and is
+    // passed through as it stands, provided it is in order already — which is what a stable sort leaves when the input was (equal
+    // (barcode, umi) groups of read-order input keep their index order) — and checked: one inversion raises the overflow flag.
+    // (The array's end closes a run like a head does: a last tile of at most M elements without a head is all tail of the
+    // previous tile's last run — the previous tile, whose window then reaches the array's end, finishes it.)
+    const u32 begin = misc[0] != 0xFFFFFFFFu ? misc[0] : ((len <= (u32)M && base + len == n) ? len : 0u);
+    u32 end;
+    bool end_is_head = true;
+    if (len <= (u32)T) end = len;                             // the array ends in this tile
+    else if (misc[1] != 0xFFFFFFFFu) end = misc[1];
+    else if (base + len == n) end = len;                      // ... or inside the look-ahead
+    else { end = (u32)T; end_is_head = false; }
+    // 3. short runs: every head walks to the next one; segstart for the members, seglen at the head
     for (u32 i = begin + tid; i < end; i += kSortThreads)
-      if (head[i]) {
+      if (head[i] || i == begin) {                            // (begin without a head: the part of a long run this tile owns)
         u32 j = i + 1;
         while (j < end && !head[j]) ++j;
-        if (j - i > (u32)M) misc[2] = 1u;
-        else {
+        if (head[i] && j - i <= (u32)M && (j < end || end_is_head)) {   // closed by heads (or the array's end) and short enough
           for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
           seglen[i] = (uint16_t)(j - i);
+        } else {
+          for (u32 k = i; k < j; ++k) segstart[k] = 0xFFFFu;   // part of a long run
         }
       }
     __syncthreads();
-    if (misc[2]) {
-      if (tid == 0) *overflow = 1u;
-      return;
-    }
-    // 4. rank inside the segment (a segment of one record — the usual case — costs nothing)
+    // 4. rank inside the short runs (a run of one record — the usual case — costs nothing); long runs: identity + order check
     u32 me[PER][W];
     u32 target[PER];
+    bool inversion = false;
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
       const u32 i = begin + tid + kSortThreads * r;
@@ -1281,21 +1300,37 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
       if (i < end) {
 #pragma unroll
         for (int w = 0; w < W; ++w) me[r][w] = stage[W * i + w];
-        const u32 s0 = segstart[i], m = seglen[s0];
-        u32 cnt = 0;
-        if (m > 1)
-          for (u32 j = s0; j < s0 + m; j += 2) {
-            const u32 j1 = j + 1 < s0 + m ? j + 1 : j;         // clamped: in the window, not counted
-            u32 a[W], b[W];
+        const u32 s0 = segstart[i];
+        if (s0 == 0xFFFFu) {                                  // part of a long run
+          target[r] = i;
+          if (!head[i]) {                                     // same run as the element in front (i = 0: the one in front of the window)
+            u32 prev[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
-            cnt += elem_before<W>(a, me[r], (u32)(j < i));
-            cnt += elem_before<W>(b, me[r], (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
+            for (int w = 0; w < W; ++w) prev[w] = stage[W * i + w - W];
+            inversion = inversion || elem_before<W>(me[r], prev, 0u);
           }
-        target[r] = s0 + cnt;
+        } else {
+          const u32 m = seglen[s0];
+          u32 cnt = 0;
+          if (m > 1)
+            for (u32 j = s0; j < s0 + m; j += 2) {
+              const u32 j1 = j + 1 < s0 + m ? j + 1 : j;       // clamped: in the window, not counted
+              u32 a[W], b[W];
+#pragma unroll
+              for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
+              cnt += elem_before<W>(a, me[r], (u32)(j < i));
+              cnt += elem_before<W>(b, me[r], (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
+            }
+          target[r] = s0 + cnt;
+        }
       }
     }
+    if (inversion) misc[2] = 1u;
     __syncthreads();
+    if (misc[2]) {                                            // a long run that is not in order: not this kernel's to sort
+      if (tid == 0) *overflow = 1u;
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < PER; ++r)
       if (target[r] != 0xFFFFFFFFu) {

@@ -178,6 +178,31 @@ def test_wide_keys_sample_estimate_avoids_the_overflow(ctx, oracle, kind, capfd)
     assert "sample estimate" in trace and "overflowed" not in trace, trace
 
 
+@pytest.mark.parametrize("n", [9_000, 300_007, 2_000_003])
+def test_wide_keys_long_runs_in_order_pass_through(ctx, oracle, n, capfd):
+    """Runs of equal prefix far longer than the finishing kernel ranks (here 5000 records with one barcode and one UMI, spanning
+    several of its tiles) are no overflow when they are in order already — the stable prefix passes keep the input's index order —
+    and an inversion inside such a run still is one."""
+    recs = _full_range(n, 23)
+    recs["barcode"] &= np.uint64((1 << 63) - 1)                     # the long run's prefix is its own: top bit set only there
+    a = n // 3
+    recs["barcode"][a:a + 5000] = np.uint64(0xF123456789ABCDEF)
+    recs["umi"][a:a + 5000] = np.uint64(77)
+    recs["index"][a:a + 5000] = np.arange(5000, dtype=np.uint64) * np.uint64(3)
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    got, _ = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == want
+    assert "path=prefix+finish" in trace and "overflowed" not in trace, trace
+    recs["index"][a + 4000], recs["index"][a + 4001] = recs["index"][a + 4001], recs["index"][a + 4000]   # one inversion deep inside the run
+    capfd.readouterr()
+    got, _ = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == oracle.sort_records(recs).tobytes()
+    assert "overflowed" in trace, trace
+
+
 def test_wide_keys_of_a_shard_at_an_odd_record(ctx, oracle):
     n = 200_001
     recs = _full_range(n, 11)
@@ -296,7 +321,8 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
 @pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003, 5_000_001])
 @pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 12-byte and 16-byte elements
 @pytest.mark.parametrize("case", ["random_index", "index_order", "whitelist_barcodes", "heavy_run_outside_the_samples", "duplicates",
-                                  "guess_misses_a_umi_byte", "one_heavy_barcode", "heavy_barcode_outside_the_samples"])
+                                  "guess_misses_a_umi_byte", "one_heavy_barcode", "heavy_barcode_outside_the_samples",
+                                  "heavy_run_in_read_order"])
 def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens, case, capfd):
     """The compact-key sort of large inputs: well-spread keys (short estimated runs) take P prefix passes + the finishing
     kernel; keys with few distinct prefixes (barcodes from a whitelist) take a longer prefix or the plain passes; a heavy run
@@ -316,6 +342,13 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
         span = min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000)
         span = max(span, 600)
         recs["barcode"][quarter:quarter + span] = recs["barcode"][quarter]
+        recs["umi"][quarter:quarter + span] = recs["umi"][quarter]
+    elif case == "heavy_run_in_read_order":                     # records in read order (index increasing), 3000 of them with one
+        recs["index"] = np.arange(n, dtype=np.uint64)          # (barcode, umi): the run is far longer than the finishing kernel ranks,
+        span = max(min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000), 600)   # but the stable passes leave it in
+        top = np.uint64(1) << np.uint64(2 * lens[0] - 1)       # index order: passed through as it is.  (Its prefix is its own: the
+        recs["barcode"] &= top - np.uint64(1)                  # top barcode bit is set only there — records that merely share the
+        recs["barcode"][quarter:quarter + span] = top | np.uint64(0x1234567)   # prefix would sit between them in input order.)
         recs["umi"][quarter:quarter + span] = recs["umi"][quarter]
     elif case == "heavy_barcode_outside_the_samples":           # 3000 records of one barcode (UMIs stay random) where no sample looks
         span = max(min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000), 600)
@@ -337,6 +370,8 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
     elif case == "heavy_run_outside_the_samples":               # 3000 records with ONE (barcode, umi): no prefix short of the index splits
         assert "path=compact-prefix+finish" in trace and "overflowed" in trace, trace   # them, so the retry overflows too (or is not worth it)
         assert "all " in trace.split("overflowed")[-1], trace
+    elif case == "heavy_run_in_read_order":                     # a long run that is already in order is not an overflow
+        assert "path=compact-prefix+finish" in trace and "overflowed" not in trace, trace
     elif case == "heavy_barcode_outside_the_samples":           # ... with random UMIs the retry's longer prefix (barcode + UMI bytes) succeeds
         assert "path=compact-prefix+finish" in trace and trace.count("overflowed") == 1 and "retrying with prefix_passes" in trace, trace
     elif case == "guess_misses_a_umi_byte":

@@ -388,6 +388,37 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
             assert p > (4 if lens[0] == 16 else 8), trace
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_sort_fuzz_key_structures(ctx, ctx_pf, oracle, ia, seed):
+    """Seeded fuzz over what decides the sort's path: which key bytes vary (1 .. 24 of them, anywhere in the record), how the values
+    are distributed (uniform / a few heavy values / Zipf-like / blocks of equal keys), whether stretches of the input are already in
+    order, and sizes on both sides of the speculation threshold.  Default context and forced prefix + finish: the oracle's bytes."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([70_001, 131_072, 200_003, 524_289, 1_200_007]))
+    nbytes = int(rng.integers(1, 25))
+    which = np.sort(rng.permutation(24)[:nbytes])
+    raw = np.tile(rng.integers(0, 256, 24, dtype=np.uint8), (n, 1))
+    dist = seed % 4
+    for b in which:
+        if dist == 0:
+            col = rng.integers(0, 256, n, dtype=np.uint8)
+        elif dist == 1:                                        # a few heavy values
+            col = rng.choice(np.array([3, 200, 77, 255, 0], dtype=np.uint8), n, p=[0.6, 0.2, 0.1, 0.05, 0.05])
+        elif dist == 2:                                        # Zipf-like
+            col = np.minimum(rng.zipf(1.3, n), 255).astype(np.uint8)
+        else:                                                  # blocks of equal values
+            col = np.repeat(rng.integers(0, 256, n // 997 + 1, dtype=np.uint8), 997)[:n]
+        raw[:, b] = col
+    raw[0, which], raw[1, which] = 0, 255                      # every chosen byte really varies
+    recs = raw.reshape(-1).view(ia.REC_DTYPE).copy()
+    if seed % 3 == 0:                                          # a third of the input already in order
+        k = n // 3
+        recs[k:2 * k] = oracle.sort_records(recs[k:2 * k])
+    want = oracle.sort_records(recs).tobytes()
+    assert _sort_on_device(ctx, recs)[0] == want, (seed, n, nbytes, dist)
+    assert _sort_on_device(ctx_pf, recs)[0] == want, (seed, n, nbytes, dist)
+
+
 @pytest.mark.parametrize("n", [2, 129, 5000, 300_007])
 @pytest.mark.parametrize("nbytes", [1, 5, 11, 12, 13, 14, 16, 17, 24])
 def test_sort_with_scattered_varying_bytes(ctx, oracle, ia, n, nbytes):

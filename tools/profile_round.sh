@@ -20,8 +20,11 @@ step "bench (unprofiled)"
 python3 bench.py > "$OUT/${TAG}_bench_1e9.json" 2> "$OUT/bench.err" || exit 1
 
 step "bench under rocprofv3 --kernel-trace --stats"
-# (--placement-tries 1: the probes of placement probing would be averaged into the per-kernel statistics)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline --placement-tries 1 \
+# (The default placement probing stays ON: since round 3 it is the library's and times the generator / reduce kernels, not decode,
+# so the decode launches of the profiled process are the first-placement probe (2), the kept arrays' probe (2), warm-up and the timed
+# steps — their rocprofv3 average agrees with the HIP-event time of the timed steps to 0.1 %.  With --placement-tries 1 the profiled
+# process would time whatever first placement it drew: 10.17 ms twice in round 3 against 9.36 for the probed headline.)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline \
   > "$OUT/${TAG}_bench_1e9_under_rocprof.json" 2> "$OUT/prof_bench.err" || exit 1
 cp "$(largest "$OUT/prof_bench" '*kernel_stats.csv')" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
 

@@ -223,6 +223,38 @@ extern "C" __global__ void ibu_k_generate_tail(u64 seed, u64 first, u64 row0, u6
 // on-device copy ceiling with a plain dwordx4 copy kernel and report both denominators").
 // Four 16-B chunks per lane in flight, grid-stride, nontemporal both ways.
 // =============================================================================================
+#ifndef IBU_COPY_MODE
+#define IBU_COPY_MODE 1
+#endif
+#if IBU_COPY_MODE == 1
+// Tiles of 4 KiB per wave (four dwordx4 per lane), swept like every streaming kernel here: XCD-static ownership, the next
+// tile's loads in flight while this one's stores are issued, two register sets taking turns.  (The first form — a grid-stride
+// loop with four chunks in flight — ran at 5.7-5.8 TB/s where deserialize, moving the same bytes through LDS, reached 6.2.)
+struct CopyRegs { u32x4 v[4]; };
+extern "C" __global__ void __launch_bounds__(kBlock, 8)
+ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchunks) {
+  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+  const u32 ntiles = (u32)(nchunks >> 8);                    // 256 chunks = 4 KiB per tile; the launcher keeps nchunks below 2^40
+  sweep_tiles<CopyRegs>(
+      tile_range(ntiles, wib),
+      [&](CopyRegs& g, u32 t) {
+        const uint8_t* p = src + (size_t)t * 4096 + 16 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.v[k] = ld16(p + 1024 * k);
+      },
+      [&](const CopyRegs& g, u32 t) {
+        uint8_t* q = dst + (size_t)t * 4096 + 16 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st16(q + 1024 * k, g.v[k]);
+      });
+  // the chunks behind the last whole tile (fewer than 256): the first workgroup's threads
+  const u64 done = (u64)ntiles << 8;
+  if (blockIdx.x == 0) {
+    const u64 c = done + threadIdx.x;
+    if (c < nchunks) st16(dst + 16 * c, ld16(src + 16 * c));
+  }
+}
+#else
 extern "C" __global__ void __launch_bounds__(kBlock, 8)
 ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchunks) {
   const u64 stride = (u64)gridDim.x * kBlock;      // (the fixed-eighth ownership of tile_range() measured no gain here)
@@ -235,6 +267,7 @@ ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchun
   }
   for (; c < nchunks; c += stride) st16(dst + 16 * c, ld16(src + 16 * c));
 }
+#endif
 // First differing 8-byte word of two word arrays, or ~0: `a == b` on two record slices (Record derives PartialEq / Eq,
 // src/constructs/record.rs:58) with the position a test wants.  VEC 2: both 16-B aligned, dwordx4 loads, four chunks of
 // each array in flight; VEC 1: 8-B aligned inputs.  One atomicMin per wave, and only where something differs.

@@ -433,6 +433,9 @@ ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, const u64* _
 #ifndef IBU_SORT_XCD
 #define IBU_SORT_XCD 1
 #endif
+#ifndef IBU_FINISH_XCD
+#define IBU_FINISH_XCD 0       // tile ownership of the persistent finishing kernel: 0 = tiles b, b + grid, ...; 1 = every XCD a contiguous eighth
+#endif
 #ifndef IBU_SCATTER24_MODE
 #define IBU_SCATTER24_MODE 1   // write-out of the 24-byte passes: 0 = consecutive 8-byte words, 1 = half records (dwordx3): 10.37 -> 9.45 ms per pass at 1e9 records (profiles r03_v)
 #endif
@@ -1197,8 +1200,18 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   u32* misc = reinterpret_cast<u32*>(seglen + L);
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
   const u32 ntiles = (u32)(((u64)n + T - 1) / T);
-  u32 tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  // which tiles this workgroup sweeps: with IBU_FINISH_XCD every XCD owns one contiguous eighth of the tiles (neighbouring
+  // ranges, whose boundary lines are written by two workgroups, then meet in one XCD's L2), else tiles b, b + grid, ...
+  u32 tile = blockIdx.x, tstride = gridDim.x, tend = ntiles;
+#if IBU_FINISH_XCD
+  if ((gridDim.x & 7u) == 0) {
+    const u32 tpp = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u;
+    tile = xcd * tpp + (blockIdx.x >> 3);
+    tstride = gridDim.x >> 3;
+    tend = xcd * tpp + tpp < ntiles ? xcd * tpp + tpp : ntiles;
+  }
+#endif
+  if (tile >= tend) return;
   // the half record this lane writes in step 5 (lane parity; kSortThreads is even)
   const u32 hj = tid & 1u;
   u32 hsel[3][2], hbase[3];
@@ -1354,15 +1367,15 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   EV<W> va[PER], vb[PER], fa, fb;
   load(tile, va, fa);
   for (;;) {                                                  // two register sets take turns (kcommon.hpp, sweep_tiles)
-    u32 next = tile + gridDim.x;
-    bool more = next < ntiles;
+    u32 next = tile + tstride;
+    bool more = next < tend;
     load(more ? next : tile, vb, fb);
     work(tile, va, fa);
     if (!more) break;
     tile = next;
     __syncthreads();                                          // step 5's LDS reads precede the next tile's stage writes
-    next = tile + gridDim.x;
-    more = next < ntiles;
+    next = tile + tstride;
+    more = next < tend;
     load(more ? next : tile, va, fa);
     work(tile, vb, fb);
     if (!more) break;

@@ -116,6 +116,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->cfg.sort_hybrid = (int)value;
     return IBU_OK;
   }
+  if (strcmp(key, "sort_idx64") == 0) {
+    if (value != 0 && value != 1) return err_arg("sort_idx64 must be 0 or 1");
+    ctx->cfg.sort_idx64 = (int)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "sort_compact") == 0) {
     if (value < 0 || value > sort_num_compact_variants()) return err_arg("sort_compact out of range");
     ctx->cfg.sort_compact = (int)value;

@@ -801,22 +801,23 @@ __global__ void ibu_k_sort_expand_tail(const ElemT<W>* __restrict__ in, u64 row0
 template <int THREADS, int ROUNDS, int W>
 struct CompactShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
-  // LDS: stage 4 W T | gdelta 256 x u32 | whist NW x 256 x u32 | misc 16 x u32 | sbin T bytes
-  static constexpr size_t lds = 4 * (size_t)W * T + 4 * kBins + 4 * (size_t)NW * kBins + 64 + (size_t)T;
+  // LDS: stage 4 W T | gdelta 256 x u64 (u32 indices use the low halves' space: sized for the wider) | whist NW x 256 x u32 | misc 16 x u32 | sbin T bytes
+  static constexpr size_t lds = 4 * (size_t)W * T + 8 * kBins + 4 * (size_t)NW * kBins + 64 + (size_t)T;
 };
 // One pass over element byte `byte`; nbyte: the next pass's byte (the digit side stream it leaves behind).
 // LAST: the last pass — every element leaves as the 24-byte record it stands for, straight into the caller's array
 // (`dst` = the records, `pl` = the expansion; no side stream): the expand kernel and one element round trip are saved.
-template <int THREADS, int ROUNDS, bool LAST, int W>
+// IDX: the type of a global element index — u32 below 2^32 elements, u64 from there on (the part holds 1.2e10 records).
+template <int THREADS, int ROUNDS, bool LAST, int W, class IDX>
 __global__ void __launch_bounds__(THREADS)
-ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, u32 n, u32 byte, u32 nbyte, const u32* __restrict__ pos,
+ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, IDX n, u32 byte, u32 nbyte, const IDX* __restrict__ pos,
                          uint8_t* __restrict__ digits, CompactPlan pl) {
   typedef CompactShape<THREADS, ROUNDS, W> S;
   constexpr int T = S::T, NW = S::NW, PER_WAVE = S::PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u32* stage = reinterpret_cast<u32*>(smem);                 // the tile in digit order
-  u32* gdelta = stage + W * T;                               // global element index of slot p of bin d = gdelta[d] + p
-  u32* whist = gdelta + kBins;
+  IDX* gdelta = reinterpret_cast<IDX*>(stage + W * T);       // global element index of slot p of bin d = gdelta[d] + p (W T words: 8-byte aligned)
+  u32* whist = reinterpret_cast<u32*>(reinterpret_cast<u64*>(stage + W * T) + kBins);
   u32* misc = whist + NW * kBins;
   uint8_t* sbin = reinterpret_cast<uint8_t*>(misc + 16);
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wib = tid >> 6;
@@ -828,9 +829,9 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
 #endif
   const u64 tbase64 = (u64)tile * T;
   if (tbase64 >= n) return;                                   // block-uniform: padding of the grid
-  const u32 tbase = (u32)tbase64;
-  const u32 cnt = n - tbase < (u32)T ? n - tbase : (u32)T;
-  const u32 mypos = tid < (u32)kBins ? pos[(size_t)tile * kBins + tid] : 0;
+  const IDX tbase = (IDX)tbase64;
+  const u32 cnt = n - tbase < (IDX)T ? (u32)(n - tbase) : (u32)T;
+  const IDX mypos = tid < (u32)kBins ? pos[(size_t)tile * kBins + tid] : 0;
 
   // 1. every lane loads its elements (unconditional, clamped) and the per-wave counters are cleared
   EV<W> v[ROUNDS];
@@ -919,7 +920,7 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
     for (int r = 0; r < 2 * ROUNDS; ++r) {
       const u32 p = (tid + THREADS * r) >> 1;               // element slot; lanes 2q, 2q+1 share it
       if (p < cnt) {
-        const u32 g = gdelta[sbin[p]] + p;
+        const IDX g = gdelta[sbin[p]] + p;
         u32 e[4] = {stage[W * p], stage[W * p + 1], stage[W * p + 2], 0};
         if constexpr (W == 4) e[3] = stage[W * p + 3];
         u32x3 o;
@@ -934,7 +935,7 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
   for (int r = 0; r < ROUNDS; ++r) {
     const u32 p = tid + THREADS * r;
     if (p < cnt) {
-      const u32 g = gdelta[sbin[p]] + p;
+      const IDX g = gdelta[sbin[p]] + p;
       EV<W> e;
 #pragma unroll
       for (int w = 0; w < W; ++w) e.w[w] = stage[W * p + w];
@@ -1189,7 +1190,7 @@ __device__ __forceinline__ u32 elem_before(const u32* a, const u32* b, u32 tie) 
 }
 template <int W, int T, int M>
 __global__ void __launch_bounds__(kSortThreads)
-ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, u32 n, EV<W> pm, CompactPlan pl, u32* __restrict__ overflow) {
+ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, u64 n, EV<W> pm, CompactPlan pl, u32* __restrict__ overflow) {
   typedef FinishElemShape<W, T, M> S;
   constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1199,7 +1200,7 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   uint16_t* seglen = segstart + L;
   u32* misc = reinterpret_cast<u32*>(seglen + L);
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
-  const u32 ntiles = (u32)(((u64)n + T - 1) / T);
+  const u32 ntiles = (u32)((n + T - 1) / T);
   // which tiles this workgroup sweeps: with IBU_FINISH_XCD every XCD owns one contiguous eighth of the tiles (neighbouring
   // ranges, whose boundary lines are written by two workgroups, then meet in one XCD's L2), else tiles b, b + grid, ...
   u32 tile = blockIdx.x, tstride = gridDim.x, tend = ntiles;
@@ -1227,8 +1228,8 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   // (persistent grid, two register sets).  As a load-then-store loop in a one-tile workgroup the kernel paid 18 memory
   // latencies per tile: 18.8 ms per 1e9 records; loads issued together 14.5 ms; prefetched as here: see profiles/README.md.
   auto load = [&](u32 t, EV<W>* v, EV<W>& front) {
-    const u32 base = t * (u32)T;
-    const u32 len = n - base < (u32)L ? n - base : (u32)L;
+    const u64 base = (u64)t * T;
+    const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
       const u32 i = tid + kSortThreads * r;
@@ -1237,8 +1238,8 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
     front = ld_elem<W>(src + (base > 0 ? base - 1 : 0));      // every lane the same element (one line); used by thread 0
   };
   auto work = [&](u32 t, const EV<W>* v, const EV<W>& front) {
-    const u32 base = t * (u32)T;
-    const u32 len = n - base < (u32)L ? n - base : (u32)L;
+    const u64 base = (u64)t * T;
+    const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;
     // 1. stage
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
@@ -1479,12 +1480,12 @@ struct SortLayout {
   u32 ntiles, nblocks;
   bool idx64;
 };
-static SortLayout sort_layout(size_t n, int tile) {
+static SortLayout sort_layout(const LaunchCfg& cfg, size_t n, int tile) {
   SortLayout L;
   const u64 nt = (n + tile - 1) / tile;
   L.ntiles = (u32)nt;
   L.nblocks = (u32)((nt + kTilesPerBlock - 1) / kTilesPerBlock);
-  L.idx64 = n >= (1ull << 32);
+  L.idx64 = n >= (1ull << 32) || cfg.sort_idx64;             // cfg.sort_idx64: a test knob (the 64-bit index kernels at small sizes)
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o = kCensusBytes;                                   // the census slots sit in front
   L.misc = o; o = up(o + kMiscBytes);
@@ -1547,15 +1548,22 @@ struct CompactVariant {
   const void* scatter;
   const void* scatter_last;
   void (*counts_bytes)(const uint8_t*, u64, u32, uint16_t*);
+  const void* scatter64;        // the same kernels with 64-bit element indices (2^32 elements and more): the default shapes only
+  const void* scatter_last64;
 };
-template <int TH, int R, int W>
+template <int TH, int R, int W, bool WIDE = false>
 static CompactVariant compact_variant() {
   typedef CompactShape<TH, R, W> S;
-  return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, false, W>),
-          reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, true, W>), ibu_k_sort_tilecounts_bytes<S::T>};
+  CompactVariant v = {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, false, W, u32>),
+                      reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, true, W, u32>), ibu_k_sort_tilecounts_bytes<S::T>, nullptr, nullptr};
+  if constexpr (WIDE) {
+    v.scatter64 = reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, false, W, u64>);
+    v.scatter_last64 = reinterpret_cast<const void*>(ibu_k_sort_scatter_elems<TH, R, true, W, u64>);
+  }
+  return v;
 }
 static const CompactVariant kCompact[] = {   // 12-byte elements
-    compact_variant<256, 20, 3>(),   // 1 (default): 5120-element tiles (60 KiB), 4 waves, two workgroups per CU (1e9 records: 73.7 ms)
+    compact_variant<256, 20, 3, true>(),   // 1 (default): 5120-element tiles (60 KiB), 4 waves, two workgroups per CU (1e9 records: 73.7 ms)
     compact_variant<256, 16, 3>(),   // 2: 4096-element tiles (75.2 ms)
     compact_variant<256, 8, 3>(),    // 3: 2048-element tiles (94 ms: runs of 8 elements = 96 bytes)
     compact_variant<512, 8, 3>(),    // 4: 4096-element tiles, 8 waves (79-83 ms)
@@ -1567,7 +1575,7 @@ static const CompactVariant kCompact[] = {   // 12-byte elements
 static constexpr int kNumCompact = sizeof(kCompact) / sizeof(kCompact[0]);
 // 16-byte elements (13 .. 16 varying bytes); shape = kCompact16[sort_compact - 1] where there is one, the first otherwise
 static const CompactVariant kCompact16s[] = {
-    compact_variant<256, 16, 4>(),   // 4096-element tiles = 64 KiB of elements, two workgroups per CU
+    compact_variant<256, 16, 4, true>(),   // 4096-element tiles = 64 KiB of elements, two workgroups per CU
     compact_variant<256, 12, 4>(),   // 3072-element tiles
     compact_variant<512, 8, 4>(),    // 4096-element tiles, 8 waves
     compact_variant<256, 8, 4>(),    // 2048-element tiles, four workgroups per CU
@@ -1582,10 +1590,10 @@ static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
 }
 
 size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) {
-  size_t need = sort_layout(n, pick_variant(cfg).tile).total;
+  size_t need = sort_layout(cfg, n, pick_variant(cfg).tile).total;
   if (const CompactVariant* cv = pick_compact(cfg)) {
     for (const CompactVariant* v : {cv, &kCompact16s[0], &kCompact16s[1], &kCompact16s[2], &kCompact16s[3]}) {
-      const size_t c = sort_layout(n, v->tile).total;
+      const size_t c = sort_layout(cfg, n, v->tile).total;
       if (c > need) need = c;
     }
   }
@@ -1705,13 +1713,16 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
                                         u32 digits_byte = 0, u32 finish_prefix = 0, ElemT<W>* elems_at = nullptr) {
   const bool retried = (finish_prefix & 0x80000000u) != 0;    // the one retry with a longer prefix (see the overflow handling below)
   finish_prefix &= 0x7FFFFFFFu;
-  const SortLayout L = sort_layout(n, cv.tile);
+  const SortLayout L = sort_layout(cfg, n, cv.tile);
   u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
   u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
   u64* blockoff = reinterpret_cast<u64*>(sc + L.blockoff);
   uint16_t* counts = reinterpret_cast<uint16_t*>(sc + L.counts);
-  u32* pos = reinterpret_cast<u32*>(sc + L.pos);
+  void* pos = sc + L.pos;                                     // u32 or u64 entries (L.idx64)
   uint8_t* digits = sc + L.digits;
+  const void* k_scatter = L.idx64 ? cv.scatter64 : cv.scatter;
+  const void* k_scatter_last = L.idx64 ? cv.scatter_last64 : cv.scatter_last;
+  if (!k_scatter || !k_scatter_last) return hipErrorInvalidValue;   // (the caller only comes here with a shape that has them)
   ElemT<W>* const half2 = W == 3 ? reinterpret_cast<ElemT<W>*>(static_cast<uint8_t*>(tmp) + 12 * n) : static_cast<ElemT<W>*>(recs);
   ElemT<W>* src = elems_at ? elems_at : static_cast<ElemT<W>*>(tmp);
   ElemT<W>* dst = src == half2 ? static_cast<ElemT<W>*>(tmp) : half2;
@@ -1721,9 +1732,9 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
   // several GPUs through several contexts (a few microseconds against a sort of milliseconds)
   hipError_t e;
   if (cv.lds > 48 * 1024) {
-    e = hipFuncSetAttribute(cv.scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
+    e = hipFuncSetAttribute(k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(cv.scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
+    e = hipFuncSetAttribute(k_scatter_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.lds);
     if (e != hipSuccess) return e;
   }
   const u32 first_pass = finish_prefix ? npass - finish_prefix : 0;
@@ -1739,16 +1750,21 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
                        L.ntiles, counts);
     hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
     hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
-    hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
-                       (const u64*)blockoff, (const u64*)binbase, pos);
+    if (L.idx64)
+      hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+                         (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
+    else
+      hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+                         (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
     const bool last = pi + 1 == npass, to_records = last && fuse_last && !finish_prefix;
-    u32 n_arg = (u32)n, b_arg = b, nb_arg = last ? 4u * W : passes[pi + 1];   // 4 W: no digit stream behind the last pass
+    u32 n32 = (u32)n, b_arg = b, nb_arg = last ? 4u * W : passes[pi + 1];   // 4 W: no digit stream behind the last pass
+    u64 n64 = n;
     const ElemT<W>* src_arg = src;
     void* dst_arg = to_records ? recs : static_cast<void*>(dst);
-    const u32* pos_arg = pos;
+    const void* pos_arg = pos;
     CompactPlan pl_arg = pl;
-    void* args[] = {&src_arg, &dst_arg, &n_arg, &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
-    e = hipLaunchKernel(to_records ? cv.scatter_last : cv.scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
+    void* args[] = {&src_arg, &dst_arg, L.idx64 ? static_cast<void*>(&n64) : static_cast<void*>(&n32), &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
+    e = hipLaunchKernel(to_records ? k_scatter_last : k_scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
     if (e != hipSuccess) return e;
     ElemT<W>* t = src; src = dst; dst = t;
   }
@@ -1780,7 +1796,7 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     }
     const u32 ftiles = (u32)((n + FT - 1) / FT), fgrid = (u32)fper * (u32)cfg.cus;
     hipLaunchKernelGGL((ibu_k_sort_finish_elems<W, FT, FM>), dim3(ftiles < fgrid ? ftiles : fgrid), dim3(kSortThreads), FS::lds, st, (const ElemT<W>*)src, recs,
-                       (u32)n, pm, pl, d_overflow);
+                       (u64)n, pm, pl, d_overflow);
     u32 overflow = 0;
     e = hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
@@ -1820,7 +1836,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   if (n < 2) return hipSuccess;
   const SweepVariant& sv = pick_variant(cfg);
   if ((n + sv.tile - 1) / sv.tile >= (1ull << 31)) return hipErrorInvalidValue;
-  const SortLayout L = sort_layout(n, sv.tile);
+  const SortLayout L = sort_layout(cfg, n, sv.tile);
   if (scratch_bytes < L.total) return hipErrorInvalidValue;
   uint8_t* sc = static_cast<uint8_t*>(scratch);
   u64* census = reinterpret_cast<u64*>(sc);
@@ -1831,12 +1847,15 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   void* pos = sc + L.pos;
   uint8_t* digits = sc + L.digits;
 
-  // Compact-key path (see "COMPACT-KEY passes"): n < 2^32, records 16-byte aligned (the tiled compress kernel), tmp at least
-  // 4-byte aligned.  Whether at most 12 key bytes vary is the census' to say.
+  // Compact-key path (see "COMPACT-KEY passes"): records 16-byte aligned (the tiled compress kernel), tmp at least 4-byte
+  // aligned; from 2^32 records on (64-bit element indices) the shapes that carry those kernels (the defaults).  Whether at most
+  // 12 / 16 key bytes vary is the census' to say.
   const CompactVariant* cv = pick_compact(cfg);
-  const bool compact_ok = cv && n < (1ull << 32) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
-                          (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(n, cv->tile).total &&
-                          scratch_bytes >= sort_layout(n, pick_compact16(cfg).tile).total;
+  const bool wide_idx = n >= (1ull << 32) || cfg.sort_idx64;
+  const bool compact_ok = cv && n < (1ull << 38) && (!wide_idx || (cv->scatter64 && pick_compact16(cfg).scatter64)) &&
+                          (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&
+                          (reinterpret_cast<uintptr_t>(tmp) & 3u) == 0 && scratch_bytes >= sort_layout(cfg, n, cv->tile).total &&
+                          scratch_bytes >= sort_layout(cfg, n, pick_compact16(cfg).tile).total;
   hipError_t e;
   // SPECULATION (large inputs): the census and the compress pass both read all the records.  A census of three SAMPLE
   // ranges (first / middle / last 32 Ki records: tens of microseconds) guesses which bytes vary; the compress pass runs on
@@ -1912,8 +1931,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         }
       }
       hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
-      if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(n, cv->tile).digits, st, census);
-      else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(n, pick_compact16(cfg).tile).digits, st, census);
+      if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(cfg, n, cv->tile).digits, st, census);
+      else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(cfg, n, pick_compact16(cfg).tile).digits, st, census);
       speculated = true;
     } else if (g[7] == 0 && trace_sort()) {
       fprintf(stderr, "ibu sort: n=%zu samples in order: read-only census first\n", n);

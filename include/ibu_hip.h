@@ -356,7 +356,7 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
  * read-backs pick the path: the census of the varying bytes, from 2^17 records on a sample census and a pair count that
  * estimates the runs of equal prefix, and the finishing kernel's overflow flag); the last kernels may still be queued
  * when it returns.
- * Stable radix sort over the key bytes that vary; when at most 16 of them do (and n < 2^32, d_records 16-byte
+ * Stable radix sort over the key bytes that vary; when at most 16 of them do (and d_records is 16-byte
  * aligned) it runs on 12- or 16-byte compacted keys held in d_tmp (and, for 16-byte keys, in the head of
  * d_records) (option "sort_compact").  Large inputs whose keys are well spread take passes over the most significant
  * varying bytes only and one finishing pass (option "sort_hybrid"); the result is the same bytes on every path. */

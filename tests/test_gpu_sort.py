@@ -65,6 +65,37 @@ def ctx_pf(ia):
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx64(ia):
+    """Every sort through the 64-bit index kernels (sort_idx64 = 1: what inputs of 2^32 records and more take — compact-key passes,
+    24-byte passes, position tables — forced at sizes the oracle can check byte for byte), speculation from 131 072 records."""
+    c = ia.Context(0)
+    c.set_option("sort_idx64", 1)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 129, 5121, 70_001, 131_072, 524_289, 1_310_721, 3_000_001])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 12), (32, 32)])
+def test_sort_with_64_bit_indices(ctx64, oracle, n, lens, capfd):
+    recs = _shuffled(oracle, n, *lens)
+    if lens == (32, 32) and n > 1:
+        recs["index"] = np.random.default_rng(n).integers(0, 2**64, n, dtype=np.uint64)
+    elif n:
+        recs["index"] = np.random.default_rng(n).integers(0, 2**30, n, dtype=np.uint64)
+    capfd.readouterr()
+    got, d = _sort_on_device(ctx64, recs)
+    trace = capfd.readouterr().err
+    assert got == oracle.sort_records(recs).tobytes()
+    if n >= 131_072 and lens != (32, 32):
+        assert "path=compact-prefix+finish" in trace, trace
+    asc = oracle.sort_records(recs)
+    assert _sort_on_device(ctx64, asc)[0] == asc.tobytes()         # already sorted
+    idx_order = recs.copy()
+    idx_order["index"] = np.arange(n, dtype=np.uint64)
+    assert _sort_on_device(ctx64, idx_order)[0] == oracle.sort_records(idx_order).tobytes()
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_sort_random_16_12(ctx, ctx24, ctx_pf, oracle, n):
     recs = _shuffled(oracle, n, 16, 12)
@@ -389,7 +420,7 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_sort_fuzz_key_structures(ctx, ctx_pf, oracle, ia, seed):
+def test_sort_fuzz_key_structures(ctx, ctx_pf, ctx64, oracle, ia, seed):
     """Seeded fuzz over what decides the sort's path: which key bytes vary (1 .. 24 of them, anywhere in the record), how the values
     are distributed (uniform / a few heavy values / Zipf-like / blocks of equal keys), whether stretches of the input are already in
     order, and sizes on both sides of the speculation threshold.  Default context and forced prefix + finish: the oracle's bytes."""
@@ -417,6 +448,7 @@ def test_sort_fuzz_key_structures(ctx, ctx_pf, oracle, ia, seed):
     want = oracle.sort_records(recs).tobytes()
     assert _sort_on_device(ctx, recs)[0] == want, (seed, n, nbytes, dist)
     assert _sort_on_device(ctx_pf, recs)[0] == want, (seed, n, nbytes, dist)
+    assert _sort_on_device(ctx64, recs)[0] == want, (seed, n, nbytes, dist)
 
 
 @pytest.mark.parametrize("n", [2, 129, 5000, 300_007])

@@ -1398,13 +1398,14 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
 static constexpr int kMaxPrefix = 8;
 static constexpr u32 kPairSlotsMax = 1u << 18;                // per P: 98 304 sample records -> load factor 0.375
 template <int W>
-__global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 s0, u64 s1, u64 s2, u32 per_range, CompactPlan pl, u32 k,
+__global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 range_stride, u32 nranges, u32 per_range, CompactPlan pl, u32 k,
                                         u32 kPairSlots /*power of two*/, u64* __restrict__ keys /*[kMaxPrefix][slots]*/, u32* __restrict__ cnts,
                                         u64* __restrict__ pairs) {
+  // the sample: `nranges` ranges of `per_range` consecutive records, evenly spaced over the input (range r starts at r * range_stride)
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 3 * per_range) return;
+  if (t >= nranges * per_range) return;
   const u32 rg = t / per_range;
-  const u64 row = (rg == 0 ? s0 : rg == 1 ? s1 : s2) + (t - rg * per_range);
+  const u64 row = (u64)rg * range_stride + (t - rg * per_range);
   const EV<W> e = compress_rec<W>(recs[3 * row], recs[3 * row + 1], recs[3 * row + 2], pl);
   for (u32 P = 1; P <= (u32)kMaxPrefix && P <= k; ++P) {
     u64 h = 0x9E3779B97F4A7C15ull * P;                        // hash of element bytes [k - P, k)
@@ -1437,13 +1438,13 @@ __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 s0, u6
 // The same estimate for 24-byte records (more than 16 varying bytes): the prefix of length P is the P most significant VARYING
 // key bytes, given as (field, shift) pairs, most significant first.
 struct PrefixBytes { uint8_t field[kMaxPrefix], shift[kMaxPrefix]; u32 count; };
-extern "C" __global__ void ibu_k_sort_sample_pairs_recs(const u64* __restrict__ recs, u64 s0, u64 s1, u64 s2, u32 per_range, PrefixBytes pb,
+extern "C" __global__ void ibu_k_sort_sample_pairs_recs(const u64* __restrict__ recs, u64 range_stride, u32 nranges, u32 per_range, PrefixBytes pb,
                                                         u32 kPairSlots /*power of two*/, u64* __restrict__ keys, u32* __restrict__ cnts,
                                                         u64* __restrict__ pairs) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 3 * per_range) return;
+  if (t >= nranges * per_range) return;
   const u32 rg = t / per_range;
-  const u64 row = (rg == 0 ? s0 : rg == 1 ? s1 : s2) + (t - rg * per_range);
+  const u64 row = (u64)rg * range_stride + (t - rg * per_range);
   const u64 f[3] = {recs[3 * row], recs[3 * row + 1], recs[3 * row + 2]};
   u64 h = 0x9E3779B97F4A7C15ull;
   for (u32 P = 1; P <= pb.count; ++P) {                       // the hash of the first P bytes extends the hash of the first P - 1
@@ -1895,8 +1896,13 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         const u32 sorted_guess = gpl.k - gfirst;             // passes the plain path would run
         u32 slots = kPairSlotsMax;
         while (slots > 1024 && (size_t)slots * 12 * kMaxPrefix + 128 > n * 24) slots >>= 1;
-        const u32 per_range = (u32)(kSample < slots / 8 ? kSample : slots / 8);   // load factor <= 3/8
-        const size_t m = 3 * (size_t)per_range;
+        // the estimate's own sample: 48 evenly spaced ranges of 2048 records (98 304 records as the census' three ranges, but
+        // spread: input that is grouped in stretches is seen for what it is), fewer ranges when the tables must be small
+        const u32 per_range = 2048;
+        u32 nranges = 48;
+        while (nranges > 3 && (size_t)nranges * per_range > (size_t)slots * 3 / 8) nranges /= 2;   // load factor <= 3/8
+        const size_t m = (size_t)nranges * per_range;
+        const u64 range_stride = nranges > 1 ? ((n - per_range) / (nranges - 1)) : 0;
         uint8_t* tb = static_cast<uint8_t*>(tmp);
         u64* d_pairs = reinterpret_cast<u64*>(tb);
         u64* d_keys = reinterpret_cast<u64*>(tb + 128);
@@ -1906,10 +1912,10 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
           if (e != hipSuccess) return e;
           const u64* r64 = static_cast<const u64*>(recs);
           if (gpl.k <= 12)
-            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, (u64)starts[0], (u64)starts[1], (u64)starts[2],
+            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges,
                                per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
           else
-            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, (u64)starts[0], (u64)starts[1], (u64)starts[2],
+            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges,
                                per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
           u64 pairs[2 * kMaxPrefix];                           // [P - 1]: pairs; [kMaxPrefix + P - 1]: the most frequent prefix's count (0: below 4)
           e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
@@ -2089,10 +2095,11 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         uint8_t* tb = static_cast<uint8_t*>(tmp);
         e = hipMemsetAsync(tb, 0, table_bytes, st);
         if (e != hipSuccess) return e;
-        const size_t starts[3] = {0, n / 2, n - kSampleW};
-        const size_t m = 3 * kSampleW;
-        hipLaunchKernelGGL(ibu_k_sort_sample_pairs_recs, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, (const u64*)recs, (u64)starts[0], (u64)starts[1],
-                           (u64)starts[2], (u32)kSampleW, pb, slots, reinterpret_cast<u64*>(tb + 128),
+        const u32 per_range = 2048, nranges = 48;             // 48 evenly spaced ranges of 2048 records
+        const size_t m = (size_t)nranges * per_range;
+        const u64 range_stride = (n - per_range) / (nranges - 1);
+        hipLaunchKernelGGL(ibu_k_sort_sample_pairs_recs, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, (const u64*)recs, range_stride, nranges,
+                           per_range, pb, slots, reinterpret_cast<u64*>(tb + 128),
                            reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix), reinterpret_cast<u64*>(tb));
         u64 pairs[2 * kMaxPrefix];
         e = hipMemcpyAsync(pairs, tb, sizeof pairs, hipMemcpyDeviceToHost, st);

@@ -361,28 +361,35 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
     recs = _shuffled(oracle, n, *lens)
     rng = np.random.default_rng(n + len(case))
     recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
-    quarter = n // 4 + 7
-    if n < 140_000:
-        quarter = 32_768 + (n // 2 - 32_768) // 2
+    # a row that NO sample sees: neither the census' three ranges (first / middle / last 32 768 records) nor the pair estimate's
+    # evenly spaced ranges of 2048 records (sort.hip: 48 of them, fewer while the hash tables must fit in 24 n bytes)
+    slots = 1 << 18
+    while slots > 1024 and slots * 96 + 128 > 24 * n:
+        slots >>= 1
+    nranges = 48
+    while nranges > 3 and nranges * 2048 > slots * 3 // 8:
+        nranges //= 2
+    stride = (n - 2048) // (nranges - 1)
+    quarter = next(q for q in range(32_768 + 64, n // 2 - 3064, 997)
+                   if all(q + 3000 + 64 <= r * stride or q >= r * stride + 2048 + 64 for r in range(nranges)))
     if case == "index_order":
         recs["index"] = np.arange(n, dtype=np.uint64)
     elif case == "whitelist_barcodes":                         # ~n / 500 distinct barcodes: runs of ~500 under a barcode-only prefix
         wl = np.unique(recs["barcode"][: max(n // 500, 2)])
         recs["barcode"] = wl[rng.integers(0, len(wl), n)]
     elif case == "heavy_run_outside_the_samples":              # 3000 records with one (barcode, umi) where no sample looks
-        span = min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000)
-        span = max(span, 600)
+        span = 3000
         recs["barcode"][quarter:quarter + span] = recs["barcode"][quarter]
         recs["umi"][quarter:quarter + span] = recs["umi"][quarter]
     elif case == "heavy_run_in_read_order":                     # records in read order (index increasing), 3000 of them with one
         recs["index"] = np.arange(n, dtype=np.uint64)          # (barcode, umi): the run is far longer than the finishing kernel ranks,
-        span = max(min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000), 600)   # but the stable passes leave it in
+        span = 3000                                            # but the stable passes leave it in
         top = np.uint64(1) << np.uint64(2 * lens[0] - 1)       # index order: passed through as it is.  (Its prefix is its own: the
         recs["barcode"] &= top - np.uint64(1)                  # top barcode bit is set only there — records that merely share the
         recs["barcode"][quarter:quarter + span] = top | np.uint64(0x1234567)   # prefix would sit between them in input order.)
         recs["umi"][quarter:quarter + span] = recs["umi"][quarter]
     elif case == "heavy_barcode_outside_the_samples":           # 3000 records of one barcode (UMIs stay random) where no sample looks
-        span = max(min(3000, (n // 2 - 32_768 - quarter) if n >= 140_000 else 3000), 600)
+        span = 3000
         recs["barcode"][quarter:quarter + span] = recs["barcode"][quarter]
     elif case == "duplicates":
         recs[1::2] = recs[0:len(recs[1::2]) * 2:2]

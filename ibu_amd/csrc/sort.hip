@@ -433,6 +433,9 @@ ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, const u64* _
 #ifndef IBU_SORT_XCD
 #define IBU_SORT_XCD 1
 #endif
+#ifndef IBU_SCATTER_PERSIST
+#define IBU_SCATTER_PERSIST 0  // element passes: 0 = one tile per workgroup; 1 = persistent grid with the next tile's elements prefetched — built in round 3 and NOT usable at the default shape: the second register set takes the kernel from 174 to 297 VGPRs (one wave per SIMD)
+#endif
 #ifndef IBU_FINISH_XCD
 #define IBU_FINISH_XCD 0       // tile ownership of the persistent finishing kernel: 0 = tiles b, b + grid, ...; 1 = every XCD a contiguous eighth
 #endif
@@ -822,24 +825,24 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
   uint8_t* sbin = reinterpret_cast<uint8_t*>(misc + 16);
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wib = tid >> 6;
   const u64 lt_mask = (1ull << lane) - 1;
-#if IBU_SORT_XCD
-  const u32 tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware tile order, as above
-#else
-  const u32 tile = blockIdx.x;
-#endif
-  const u64 tbase64 = (u64)tile * T;
-  if (tbase64 >= n) return;                                   // block-uniform: padding of the grid
-  const IDX tbase = (IDX)tbase64;
-  const u32 cnt = n - tbase < (IDX)T ? (u32)(n - tbase) : (u32)T;
-  const IDX mypos = tid < (u32)kBins ? pos[(size_t)tile * kBins + tid] : 0;
-
-  // 1. every lane loads its elements (unconditional, clamped) and the per-wave counters are cleared
-  EV<W> v[ROUNDS];
+  const u32 ntiles = (u32)(((u64)n + T - 1) / T);
+  struct Win { EV<W> v[ROUNDS]; IDX mypos; };
+  // 1. every lane loads its elements (unconditional, clamped) and this tile's first output position per bin
+  auto load = [&](u32 tile, Win& w) {
+    const IDX tbase = (IDX)((u64)tile * T);
+    const u32 cnt = n - tbase < (IDX)T ? (u32)(n - tbase) : (u32)T;
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const u32 slot = wib * PER_WAVE + r * kWave + lane;
-    v[r] = ld_elem<W>(src + tbase + (slot < cnt ? slot : cnt - 1));
-  }
+    for (int r = 0; r < ROUNDS; ++r) {
+      const u32 slot = wib * PER_WAVE + r * kWave + lane;
+      w.v[r] = ld_elem<W>(src + tbase + (slot < cnt ? slot : cnt - 1));
+    }
+    w.mypos = pos[(size_t)tile * kBins + (tid & (kBins - 1))];
+  };
+  auto body = [&](u32 tile, const Win& w) {
+  const EV<W>* v = w.v;
+  const IDX mypos = w.mypos;
+  const IDX tbase = (IDX)((u64)tile * T);
+  const u32 cnt = n - tbase < (IDX)T ? (u32)(n - tbase) : (u32)T;
 #pragma unroll
   for (int k = 0; k < kBins / kWave; ++k) whist[wib * kBins + lane + kWave * k] = 0;
   wave_lds_fence();                                          // a wave's counters are its own
@@ -951,6 +954,40 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
     }
   }
   }
+  };   // body
+  // XCD-aware tile order (speed only: see ibu_k_sort_scatter): XCD x = blockIdx % 8 takes the consecutive tiles
+  // [x tpp, (x + 1) tpp), its workgroups one after the other.
+  const u32 nb = gridDim.x >> 3, tpp = (ntiles + 7u) >> 3;    // the grid is a multiple of 8
+  const u32 x0 = (blockIdx.x & 7u) * tpp, xend = x0 + tpp < ntiles ? x0 + tpp : ntiles;
+  u32 tile = x0 + (blockIdx.x >> 3);
+  if (tile >= xend) return;                                   // block-uniform
+#if IBU_SCATTER_PERSIST
+  // persistent: a workgroup sweeps tiles tile, tile + nb, ... of its XCD's range with the NEXT tile's elements in flight (two
+  // register sets take turns; the barrier keeps a tile's LDS reads in front of the next tile's writes)
+  Win wa, wb;
+  load(tile, wa);
+  for (;;) {
+    u32 next = tile + nb;
+    bool more = next < xend;
+    load(more ? next : tile, wb);
+    body(tile, wa);
+    if (!more) break;
+    tile = next;
+    __syncthreads();
+    next = tile + nb;
+    more = next < xend;
+    load(more ? next : tile, wa);
+    body(tile, wb);
+    if (!more) break;
+    tile = next;
+    __syncthreads();
+  }
+#else
+  (void)nb;                                                   // one tile per workgroup: the grid covers them (nb == tpp)
+  Win w;
+  load(tile, w);
+  body(tile, w);
+#endif
 }
 
 // =====================================================================================================
@@ -985,7 +1022,7 @@ struct FinishShape {
 // PERSIST: persistent grid, the next tile's window prefetched into a second register set while this one is worked on (needs
 // 16-byte aligned records; the one-tile form takes any 8-byte aligned input: a shard at an odd record).
 template <int T, int M, bool PERSIST>
-__global__ void __launch_bounds__(kSortThreads)
+__global__ void __launch_bounds__(kSortThreads, 4)   // 37 KiB of LDS: four workgroups per CU, if the registers allow (128 VGPRs)
 ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64 pm0, u64 pm1, u64 pm2, u32* __restrict__ overflow) {
   typedef FinishShape<T, M> S;
   constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads, CH = (3 * L / 2 + kSortThreads - 1) / kSortThreads;
@@ -1188,8 +1225,10 @@ __device__ __forceinline__ u32 elem_before(const u32* a, const u32* b, u32 tie) 
   for (int w = 0; w < W; ++w) r = (u32)(a[w] < b[w]) | ((u32)(a[w] == b[w]) & r);   // from the least significant word up
   return r;
 }
+// (12-byte elements: four workgroups per CU fit the LDS, so the registers must too — 128 VGPRs; the kernel sat at 128 when the
+// tile shape was chosen and drifted to 135 with later edits, which silently cost a workgroup per CU: 7.8 -> 9.9 ms.)
 template <int W, int T, int M>
-__global__ void __launch_bounds__(kSortThreads)
+__global__ void __launch_bounds__(kSortThreads, W == 3 ? 4 : 3)
 ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst_v, u64 n, EV<W> pm, CompactPlan pl, u32* __restrict__ overflow) {
   typedef FinishElemShape<W, T, M> S;
   constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads;
@@ -1213,16 +1252,6 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   }
 #endif
   if (tile >= tend) return;
-  // the half record this lane writes in step 5 (lane parity; kSortThreads is even)
-  const u32 hj = tid & 1u;
-  u32 hsel[3][2], hbase[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    hsel[k][0] = hj ? pl.xsel[3 + k][0] : pl.xsel[k][0];
-    hsel[k][1] = hj ? pl.xsel[3 + k][1] : pl.xsel[k][1];
-    const u64 bf = hj ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
-    hbase[k] = ((3 * (hj ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
-  }
   // A window's loads: one element per lane and step (dwordx3 / dwordx4, consecutive lanes on consecutive elements), ALL issued
   // before anything waits for them (unconditional, clamped) — and the NEXT tile's window is loaded while this one is worked on
   // (persistent grid, two register sets).  As a load-then-store loop in a one-tile workgroup the kernel paid 18 memory
@@ -1352,7 +1381,18 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
         for (int w = 0; w < W; ++w) stage[W * target[r] + w] = me[r][w];
       }
     __syncthreads();
-    // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out)
+    // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out).
+    //    The lane's half (its parity; kSortThreads is even) is selected HERE, per tile: nine registers that would otherwise live
+    //    across the whole loop are what stands between this kernel and its fourth workgroup per CU.
+    const u32 hj = tid & 1u;
+    u32 hsel[3][2], hbase[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      hsel[k][0] = hj ? pl.xsel[3 + k][0] : pl.xsel[k][0];
+      hsel[k][1] = hj ? pl.xsel[3 + k][1] : pl.xsel[k][1];
+      const u64 bf = hj ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
+      hbase[k] = ((3 * (hj ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
+    }
     uint8_t* out = static_cast<uint8_t*>(dst_v) + 24 * (size_t)base;
     for (u32 h = 2 * begin + tid; h < 2 * end; h += kSortThreads) {   // kSortThreads is even: a lane keeps its half
       const u32 p = h >> 1;
@@ -1765,20 +1805,31 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     const void* pos_arg = pos;
     CompactPlan pl_arg = pl;
     void* args[] = {&src_arg, &dst_arg, L.idx64 ? static_cast<void*>(&n64) : static_cast<void*>(&n32), &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
-    e = hipLaunchKernel(to_records ? k_scatter_last : k_scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv.threads), args, cv.lds, st);   // multiple of 8: XCD-aware tile order
+    u32 sgrid = (L.ntiles + 7u) & ~7u;                        // multiple of 8: XCD-aware tile order
+#if IBU_SCATTER_PERSIST
+    {
+      int per = 0;                                            // persistent: exactly the resident grid
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, to_records ? k_scatter_last : k_scatter, cv.threads, cv.lds) != hipSuccess || per <= 0) per = 1;
+      const u32 resident = (u32)per * (u32)cfg.cus;
+      if (sgrid > resident) sgrid = resident & ~7u;
+    }
+#endif
+    e = hipLaunchKernel(to_records ? k_scatter_last : k_scatter, dim3(sgrid), dim3(cv.threads), args, cv.lds, st);
     if (e != hipSuccess) return e;
     ElemT<W>* t = src; src = dst; dst = t;
   }
   if (finish_prefix) {
 #ifndef IBU_FINISH_T
-#define IBU_FINISH_T 2048
+#define IBU_FINISH_T 1792
 #endif
 #ifndef IBU_FINISH_M
 #define IBU_FINISH_M 256
 #endif
-    // 2048-element tiles + 256 of look-ahead: 39 / 48 KiB of LDS and 128 / 161 VGPRs -> four / three workgroups per CU.  Measured
-    // at 1e9 records 16/12 (profiles r03_m, r03_n): (4096, 512) 12.2 ms, (3072, 256) 12.1, (2048, 512) 9.4, (2048, 256) 7.8-8.0,
-    // (2048, 128) 8.0, (1536, 256) 8.0, (1024, 256) 8.6, (1024, 128) 8.4.
+    // 1792-element tiles + 256 of look-ahead (eight elements per thread): 34 / 43 KiB of LDS and 126 / 156 VGPRs -> four / three
+    // workgroups per CU.  Measured at 1e9 records 16/12 (profiles r03_m, r03_n): (4096, 512) 12.2 ms, (3072, 256) 12.1, (2048, 512) 9.4,
+    // (2048, 256) 7.8-8.0 while it fitted 128 VGPRs and 9.9 once later edits had pushed it to 135 (three workgroups per CU: r03_ae),
+    // (2048, 128) 8.0, (1536, 256) 8.0, (1024, 256) 8.6, (1024, 128) 8.4; (1792, 256) 8.4 on the box where (2048, 256) took 9.9 (r03_af).
+    // tests/test_tools.py pins the register budgets.
     constexpr int FT = IBU_FINISH_T, FM = IBU_FINISH_M;
     typedef FinishElemShape<W, FT, FM> FS;
     u32* d_overflow = reinterpret_cast<u32*>(sc + L.misc);

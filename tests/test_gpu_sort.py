@@ -8,10 +8,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SEED = 0x1B00005
-# around the 128-record census tile, the scatter tiles (2 Ki records; 5 Ki elements on compact keys; other shapes), the
+# around the 128-record census tile, the scatter tiles (2560 records since round 3, 2 Ki before; 5 Ki elements on compact keys; other shapes), the
 # grid's multiple of eight tiles and the scan block of 256 tiles (524 288 records / 1 310 720 elements; 1024 tiles before)
-SIZES = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2047, 2048, 2049, 4096, 5119, 5120, 5121, 16_383, 16_384, 16_385,
-         32_768, 100_000, 524_287, 524_288, 524_289, 1_000_003, 1_310_719, 1_310_720, 1_310_721, 2_097_151, 2_097_152, 2_097_153,
+SIZES = [0, 1, 2, 3, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 4096, 5119, 5120, 5121, 16_383, 16_384, 16_385,
+         32_768, 100_000, 524_287, 524_288, 524_289, 655_359, 655_360, 655_361, 1_000_003, 1_310_719, 1_310_720, 1_310_721, 2_097_151, 2_097_152, 2_097_153,
          5_000_001]
 
 

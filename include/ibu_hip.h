@@ -234,7 +234,7 @@ int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream);
 int32_t ibu_device_count(int32_t* n);
 /* Tuning knobs (all optional; defaults are the measured best for MI355X):
  *   "blocks_per_cu"  1..8   cap on resident 256-thread workgroups per CU for the persistent grids
- *   "sort_variant"   0..7   tile shape / write-out mode of the radix passes (0 = default; the rest are A/B builds of the
+ *   "sort_variant"   0..6   tile shape of the 24-byte radix passes (0 = default: 2560-record tiles; the rest are A/B shapes of the
  *                           same algorithm kept for measurement: ibu_amd/csrc/sort.hip, kSweep)
  *   "sort_compact"   0..8   compact-key passes of the sort: when at most 12 bytes of the 24-byte key vary (16/12 records
  *                           with indices below 2^32: 11) the passes move 12-byte elements instead of records, when 13 .. 16
@@ -250,6 +250,8 @@ int32_t ibu_device_count(int32_t* n);
  *                           P comes from a pair count over sample ranges (compact keys) or from n (24-byte records); runs too
  *                           long for the finishing kernel make it report an overflow, and all passes run.  0 = never,
  *                           1 = when passes are saved (default), 2 = whenever one is (tests).  Same bytes either way.
+ *   "sort_idx64"     0 | 1  test knob: 1 = element / record positions are 64-bit at any size (what inputs of 2^32 records and more
+ *                           take), so that those kernels can be checked against the oracle at sizes it can sort.
  *   "base_order"     0 | 1  bit order of the 2-bit codec for every pack / unpack / decode / encode issued through
  *                           this context (device kernels and the stream entry points alike):
  *                             0 = IBU_BASE_ORDER_LSB_FIRST (default): base i at bits [2i, 2i+1], "ACGT" -> 0b11100100

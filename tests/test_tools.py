@@ -11,8 +11,8 @@ PROFILES = os.path.join(ROOT, "profiles")
 
 
 def test_pmc_traffic_merges_every_process_and_lists_the_sort_kernels(tmp_path):
-    lay = {"pmc/FETCH_SIZE/main": "r03_q_pmc_FETCH_SIZE_kbench_1e9.csv", "pmc/WRITE_SIZE/main": "r03_q_pmc_WRITE_SIZE_kbench_1e9.csv",
-           "pmc_sort/FETCH_SIZE/main": "r03_q_pmc_FETCH_SIZE_sort_1e9.csv", "pmc_sort/WRITE_SIZE/main": "r03_q_pmc_WRITE_SIZE_sort_1e9.csv"}
+    lay = {"pmc/FETCH_SIZE/main": "r03_zz_pmc_FETCH_SIZE_kbench_1e9.csv", "pmc/WRITE_SIZE/main": "r03_zz_pmc_WRITE_SIZE_kbench_1e9.csv",
+           "pmc_sort/FETCH_SIZE/main": "r03_zz_pmc_FETCH_SIZE_sort_1e9.csv", "pmc_sort/WRITE_SIZE/main": "r03_zz_pmc_WRITE_SIZE_sort_1e9.csv"}
     for d, f in lay.items():
         os.makedirs(tmp_path / d)
         shutil.copy(os.path.join(PROFILES, f), tmp_path / d / "123_counter_collection.csv")

@@ -10,6 +10,15 @@
 // Structure: census (OR / AND per field, "already sorted", "already in index order": one streaming read) -> per
 // varying digit one pass of count / scan / scatter, where only the FIRST count reads the records: later passes count from a
 // 1-byte-per-record digit side stream the previous scatter left behind (details above the pass kernels).
+//
+// Since round 3 large inputs do not run a pass per varying digit any more.  PREFIX + FINISH: passes over the most significant
+// P varying bytes only (P = 4 at 1e9 records), after which everything left to decide lies inside runs of equal prefix — a
+// handful of records each when the keys are well spread — and ONE finishing kernel ranks every record inside its run in LDS
+// and writes the final records (ibu_k_sort_finish / ibu_k_sort_finish_elems).  P comes from a pair count over sample ranges
+// (ibu_k_sort_sample_pairs*), long runs that are already in order pass through, other long runs escalate (one retry with a
+// longer prefix, then all passes).  Map of this file: census | 24-byte passes | compact keys (compress, element passes,
+// expand) | finishing kernels + the sample estimate | host side (layout, variants, launch_compact_passes,
+// launch_sort_records) | splitter search | per-barcode runs.
 #include <stdio.h>
 #include <stdlib.h>
 

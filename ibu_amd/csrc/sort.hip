@@ -1889,6 +1889,60 @@ static bool trace_sort() {
   static const bool on = [] { const char* v = getenv("IBU_TRACE_SORT"); return v && *v && *v != '0'; }();
   return on;
 }
+// PREFIX + FINISH on the elements?  Only if the runs of equal prefix are going to be short: a pair count over a sample says
+// (ibu_k_sort_sample_pairs; the tables live in tmp, which nothing uses at that point).  `sorted_bytes`: the passes the plain path
+// would run (the element bytes it sorts on are the top `sorted_bytes` of the plan's k).  *P = the prefix to use, 0 = none.
+static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs, size_t n, void* tmp, const CompactPlan& plan, u32 sorted_bytes,
+                                          hipStream_t st, u32* P_out, double* seg_out) {
+  *P_out = 0;
+  *seg_out = 0;
+  if (!cfg.sort_hybrid || (reinterpret_cast<uintptr_t>(tmp) & 7u) != 0) return hipSuccess;
+  u32 slots = kPairSlotsMax;
+  while (slots > 256 && (size_t)slots * 12 * kMaxPrefix + 128 > n * 24) slots >>= 1;
+  if ((size_t)slots * 12 * kMaxPrefix + 128 > n * 24) return hipSuccess;
+  // the estimate's own sample: 48 evenly spaced ranges of 2048 records (98 304 records, spread over the input: input that is
+  // grouped in stretches is seen for what it is); fewer and shorter ranges while the tables must be small (load factor <= 3/8)
+  const size_t cap = (size_t)slots * 3 / 8;
+  u32 per_range = 2048, nranges = 48;
+  while (nranges > 3 && (size_t)nranges * per_range > cap) nranges /= 2;
+  if ((size_t)nranges * per_range > cap) per_range = (u32)(cap / nranges);
+  if (per_range < 32 || (size_t)nranges * per_range > n) return hipSuccess;
+  const size_t m = (size_t)nranges * per_range;
+  const u64 range_stride = (n - per_range) / (nranges - 1);
+  uint8_t* tb = static_cast<uint8_t*>(tmp);
+  u64* d_pairs = reinterpret_cast<u64*>(tb);
+  u64* d_keys = reinterpret_cast<u64*>(tb + 128);
+  u32* d_cnts = reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix);
+  hipError_t e = hipMemsetAsync(tb, 0, 128 + (size_t)slots * 12 * kMaxPrefix, st);
+  if (e != hipSuccess) return e;
+  const u64* r64 = static_cast<const u64*>(recs);
+  if (plan.k <= 12)
+    hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges, per_range, plan, plan.k,
+                       slots, d_keys, d_cnts, d_pairs);
+  else
+    hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges, per_range, plan, plan.k,
+                       slots, d_keys, d_cnts, d_pairs);
+  u64 pairs[2 * kMaxPrefix];                                   // [P - 1]: pairs; [kMaxPrefix + P - 1]: the most frequent prefix's count (0: below 4)
+  e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
+  u32 P = 0;
+  for (u32 q = 1; q <= (u32)kMaxPrefix && q <= plan.k; ++q) {
+    const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q - 1] / (double)m);
+    const double heaviest = (double)pairs[kMaxPrefix + q - 1] * ((double)n / (double)m);   // estimated longest run
+    if (seg <= 8.0 && heaviest <= 128.0) { P = q; *seg_out = seg; break; }
+  }
+  if (P && plan.k > 12 && (P & 1u)) ++P;                       // 16-byte elements must end in tmp: an even number of passes
+  // worth it?  The finishing pass costs about as much as two element passes (14 B read with the look-ahead + 24 B written per
+  // record), the plain path's last pass half a pass more than the others
+  const u32 margin = cfg.sort_hybrid == 2 ? 1u : 3u;
+  if (P && P + margin > sorted_bytes) P = 0;                   // not worth it / would reach into index bytes the passes do not sort on
+  *P_out = P;
+  return hipSuccess;
+}
+
 // Not purely asynchronous: the census result comes back to the host (one 64-byte read) to pick the passes; everything
 // after that is queued on `st`.
 hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size_t n, void* scratch,
@@ -1950,52 +2004,9 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         for (u32 b = 0; b < 8; ++b)
           if (((g[f] ^ g[3 + f]) >> (8 * b)) & 255u) gmask[f] |= 255ull << (8 * b);
       gfirst = (g[6] == 0 && gpl.index_bytes < gpl.k) ? gpl.index_bytes : 0;   // the sample's guess of the first sorted byte
-      // PREFIX + FINISH on the elements?  Only if the runs of equal prefix are going to be short: the pair count of the sample
-      // says (ibu_k_sort_sample_pairs; the tables live in tmp, which nothing uses yet).
-      if (cfg.sort_hybrid) {
-        const u32 sorted_guess = gpl.k - gfirst;             // passes the plain path would run
-        u32 slots = kPairSlotsMax;
-        while (slots > 1024 && (size_t)slots * 12 * kMaxPrefix + 128 > n * 24) slots >>= 1;
-        // the estimate's own sample: 48 evenly spaced ranges of 2048 records (98 304 records as the census' three ranges, but
-        // spread: input that is grouped in stretches is seen for what it is), fewer ranges when the tables must be small
-        const u32 per_range = 2048;
-        u32 nranges = 48;
-        while (nranges > 3 && (size_t)nranges * per_range > (size_t)slots * 3 / 8) nranges /= 2;   // load factor <= 3/8
-        const size_t m = (size_t)nranges * per_range;
-        const u64 range_stride = nranges > 1 ? ((n - per_range) / (nranges - 1)) : 0;
-        uint8_t* tb = static_cast<uint8_t*>(tmp);
-        u64* d_pairs = reinterpret_cast<u64*>(tb);
-        u64* d_keys = reinterpret_cast<u64*>(tb + 128);
-        u32* d_cnts = reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix);
-        if ((reinterpret_cast<uintptr_t>(tmp) & 7u) == 0 && (size_t)slots * 12 * kMaxPrefix + 128 <= n * 24) {
-          e = hipMemsetAsync(tb, 0, 128 + (size_t)slots * 12 * kMaxPrefix, st);
-          if (e != hipSuccess) return e;
-          const u64* r64 = static_cast<const u64*>(recs);
-          if (gpl.k <= 12)
-            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges,
-                               per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
-          else
-            hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges,
-                               per_range, gpl, gpl.k, slots, d_keys, d_cnts, d_pairs);
-          u64 pairs[2 * kMaxPrefix];                           // [P - 1]: pairs; [kMaxPrefix + P - 1]: the most frequent prefix's count (0: below 4)
-          e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
-          if (e != hipSuccess) return e;
-          e = hipStreamSynchronize(st);
-          if (e != hipSuccess) return e;
-          // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
-          for (u32 P = 1; P <= (u32)kMaxPrefix && P <= gpl.k; ++P) {
-            const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[P - 1] / (double)m);
-            const double heaviest = (double)pairs[kMaxPrefix + P - 1] * ((double)n / (double)m);   // estimated longest run
-            if (seg <= 8.0 && heaviest <= 128.0) { hybP = P; hyb_seg = seg; break; }
-          }
-          if (hybP && gpl.k > 12 && (hybP & 1u)) ++hybP;       // 16-byte elements must end in tmp: an even number of passes
-          // worth it?  The finishing pass costs about as much as two element passes (15 B read with the look-ahead + 24 B
-          // written per record), the plain path's last pass half a pass more than the others
-          const u32 margin = cfg.sort_hybrid == 2 ? 1u : 3u;
-          if (hybP && (hybP + margin > sorted_guess || hybP > gpl.k - gfirst)) hybP = 0;   // not worth it / would reach into unsorted index bytes
-          if (hybP) gfirst = gpl.k - hybP;                   // the digit stream the compress pass leaves: the first prefix pass's
-        }
-      }
+      e = estimate_compact_prefix(cfg, recs, n, tmp, gpl, gpl.k - gfirst, st, &hybP, &hyb_seg);
+      if (e != hipSuccess) return e;
+      if (hybP) gfirst = gpl.k - hybP;                       // the digit stream the compress pass leaves: the first prefix pass's
       hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
       if (gpl.k <= 12) launch_compress<3>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<3>*>(tmp), sc + sort_layout(cfg, n, cv->tile).digits, st, census);
       else launch_compress<4>(cfg, gpl, recs, n, gfirst, static_cast<ElemT<4>*>(tmp), sc + sort_layout(cfg, n, pick_compact16(cfg).tile).digits, st, census);
@@ -2073,6 +2084,20 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     compact_plan_init(reinterpret_cast<const uint64_t*>(c), reinterpret_cast<const uint64_t*>(c + 3), &pl);
     if (pl.k <= 16) {
       for (u32 j = c[6] == 0 ? pl.index_bytes : 0; j < pl.k; ++j) ebytes[ne++] = j;   // input in index order: the index bytes ride along unsorted
+      // prefix + finish on the exact plan (inputs below the speculation threshold, or whose guess was not taken): the same estimate
+      if (ne && n >= 8192 && !speculated) {
+        u32 P = 0;
+        double seg = 0;
+        e = estimate_compact_prefix(cfg, recs, n, tmp, pl, ne, st, &P, &seg);
+        if (e != hipSuccess) return e;
+        if (P && P < ne) {
+          if (trace_sort())
+            fprintf(stderr, "ibu sort: n=%zu path=compact-prefix+finish element_bytes=%d prefix_passes=%u of %u estimated_run=%.2f (exact plan)\n", n,
+                    pl.k <= 12 ? 12 : 16, P, ne, seg);
+          return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st, false, 0, P)
+                            : launch_compact_passes<4>(cfg, pick_compact16(cfg), recs, tmp, n, sc, pl, ebytes, ne, st, false, 0, P);
+        }
+      }
       if (ne) {
         if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=compact element_bytes=%d passes=%u\n", n, pl.k <= 12 ? 12 : 16, ne);
         return pl.k <= 12 ? launch_compact_passes<3>(cfg, *cv, recs, tmp, n, sc, pl, ebytes, ne, st)

@@ -355,8 +355,8 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
  * and the header's sorted flag promises (header.rs:111-113).  d_tmp: n*24 B scratch.  The context
  * additionally keeps (and grows on demand) about 1.75 B per record of its own scratch.  Any n the
  * device can hold (n < 2^40).  NOT purely asynchronous: the call synchronises `stream` a few times (64- to 128-byte
- * read-backs pick the path: the census of the varying bytes, from 2^17 records on a sample census and a pair count that
- * estimates the runs of equal prefix, and the finishing kernel's overflow flag); the last kernels may still be queued
+ * read-backs pick the path: the census of the varying bytes, from 2^17 records on a sample census, from 8192 records on a
+ * pair count that estimates the runs of equal prefix, and the finishing kernel's overflow flag); the last kernels may still be queued
  * when it returns.
  * Stable radix sort over the key bytes that vary; when at most 16 of them do (and d_records is 16-byte
  * aligned) it runs on 12- or 16-byte compacted keys held in d_tmp (and, for 16-byte keys, in the head of

@@ -349,6 +349,40 @@ def test_sort_on_a_sampled_guess(ctx_guess, ctx24, oracle, n, lens, case, capfd)
     assert _sort_on_device(ctx24, recs)[0] == want
 
 
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 20_001, 70_001, 131_071])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 12)])
+@pytest.mark.parametrize("case", ["random_index", "index_order", "heavy_run", "few_barcodes"])
+def test_sort_prefix_and_finish_below_the_speculation_threshold(ctx, oracle, n, lens, case, capfd):
+    """Inputs too small for the sample census (< 2^17 records) plan from the exact census; from 8192 records the same pair-count
+    estimate decides between the top-P passes + finishing kernel and all passes.  Always the oracle's bytes."""
+    recs = _shuffled(oracle, n, *lens)
+    rng = np.random.default_rng(n + len(case))
+    recs["index"] = np.arange(n, dtype=np.uint64) if case == "index_order" else rng.integers(0, 2**30, n, dtype=np.uint64)
+    if case == "heavy_run":                                    # 3000 equal (barcode, umi) pairs, spread: every sample range sees them
+        at = rng.choice(n, 3000, replace=False)
+        recs["barcode"][at] = recs["barcode"][0]
+        recs["umi"][at] = recs["umi"][0]
+    elif case == "few_barcodes":                               # 16 distinct barcodes: a barcode-only prefix would leave runs of n / 16
+        recs["barcode"] = recs["barcode"][:16][rng.integers(0, 16, n)]
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    got, _ = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == want
+    if not trace:
+        pytest.skip("no trace: IBU_TRACE_SORT is not set")
+    if n < 8192:
+        assert "prefix+finish" not in trace and "path=compact element_bytes" in trace, trace
+    elif case in ("random_index", "index_order"):
+        assert "path=compact-prefix+finish" in trace and "(exact plan)" in trace and "overflowed" not in trace, trace
+    elif case == "heavy_run":                                  # seen by the estimate: a prefix that reaches into the index bytes, or none
+        assert "overflowed" not in trace, trace
+    else:
+        assert "overflowed" not in trace, trace
+        if "path=compact-prefix+finish" in trace:
+            assert int(trace.split("prefix_passes=")[1].split()[0]) > (4 if lens[0] == 16 else 8), trace
+
+
 @pytest.mark.parametrize("n", [131_072, 200_003, 1_000_003, 5_000_001])
 @pytest.mark.parametrize("lens", [(16, 12), (32, 12)])   # 12-byte and 16-byte elements
 @pytest.mark.parametrize("case", ["random_index", "index_order", "whitelist_barcodes", "heavy_run_outside_the_samples", "duplicates",

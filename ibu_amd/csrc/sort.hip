@@ -275,6 +275,19 @@ ibu_k_sort_scan_rows(u32* __restrict__ table, u32 nchunks, u32* __restrict__ row
 #define IBU_TILES_PER_BLOCK 256   // 1024: the position walk of a block (ibu_k_sort_tilepos) took 0.30 ms per pass at 1e9 records; 256: 3 ms less per sort
 #endif
 static constexpr int kTilesPerBlock = IBU_TILES_PER_BLOCK;                   // tiles per scan block
+// One count into an LDS histogram; when all the wave's active lanes hold the same digit (runs of equal keys), one lane adds for
+// all of them: 42 lanes adding to one word would take 42 turns.
+__device__ __forceinline__ void hist_add(u32* h, u32 d, bool active) {
+  if (active) {
+    const u32 f = (u32)__builtin_amdgcn_readfirstlane((int)d);
+    if (__ballot(d != f) == 0) {                               // wave-uniform
+      const u64 act = __ballot(true);
+      if ((threadIdx.x & (kWave - 1)) == (u32)__ffsll((long long)act) - 1u) atomicAdd(&h[f], (u32)__popcll(act));
+    } else {
+      atomicAdd(&h[d], 1u);
+    }
+  }
+}
 
 // ---- tile counts from the records (first pass): chunk-field trick of ibu_k_reduce, no LDS staging ------------------
 // One workgroup per tile.  The wave stride (3072 B = 384 u64) is a multiple of 3, so the u64 in slot (k, h) of a lane's
@@ -310,8 +323,8 @@ ibu_k_sort_tilecounts_recs(const uint8_t* __restrict__ recs, u32 nfull, u32 fiel
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const u64 v0 = ((u64)a[k].y << 32) | a[k].x, v1 = ((u64)a[k].w << 32) | a[k].z;
-        if (mine[k][0]) atomicAdd(&h[(u32)(v0 >> shift) & 255u], 1u);
-        if (mine[k][1]) atomicAdd(&h[(u32)(v1 >> shift) & 255u], 1u);
+        hist_add(h, (u32)(v0 >> shift) & 255u, mine[k][0]);
+        hist_add(h, (u32)(v1 >> shift) & 255u, mine[k][1]);
       }
     }
     __syncthreads();
@@ -357,13 +370,39 @@ ibu_k_sort_tilecounts_bytes(const uint8_t* __restrict__ digits, u64 n, u32 ntile
     wave_lds_fence();
     *reinterpret_cast<u32x4*>(&h[4 * lane]) = u32x4{0, 0, 0, 0};
     wave_lds_fence();
+    // Equal digits next to each other are the rule in the later passes of grouped input (barcodes from a whitelist: once the
+    // low barcode bytes are sorted, the high ones come in runs of hundreds to millions), and 64 lanes adding to ONE LDS word
+    // take 64 turns: a pass over such a stream took 3.4 ms instead of 0.27 (profiles/README.md r03_wl).  So a lane adds a run
+    // of equal bytes once, and lanes whose 16 bytes are one value hand them to the first lane of their stretch.
 #pragma unroll
     for (int k = 0; k < kLoads; ++k) {
       const u32 b0 = 16 * (lane + kWave * k);                 // tile-relative byte of this chunk
       const u32 w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      const u32 val = w[0] & 255u;
+      const bool flat = w[0] == val * 0x01010101u && w[1] == w[0] && w[2] == w[0] && w[3] == w[0] && b0 + 16 <= cnt;
+      const u64 flat_m = __ballot(flat);
+      const u32 left = (u32)__shfl_up((int)val, 1);
+      const bool follows = flat && lane > 0 && ((flat_m >> (lane - 1)) & 1ull) && left == val;   // the lane before holds the same 16 bytes
+      const u64 follow_m = __ballot(follows);
+      if (flat) {
+        if (!follows) {                                        // first of its stretch: add for the lanes that follow it
+          const u64 behind = lane < kWave - 1 ? follow_m >> (lane + 1) : 0ull;
+          atomicAdd(&h[val], 16u * (1u + (u32)__builtin_ctzll(~behind)));   // ~behind != 0: the shift cleared the top bit
+        }
+        continue;
+      }
+      u32 prev = val, run = 0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (b0 + j < cnt) atomicAdd(&h[(w[j >> 2] >> (8 * (j & 3))) & 255u], 1u);
+      for (int j = 0; j < 16; ++j) {
+        const u32 d = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+        if (d != prev) {
+          if (run) atomicAdd(&h[prev], run);
+          run = 0;
+          prev = d;
+        }
+        run += b0 + j < cnt ? 1u : 0u;
+      }
+      if (run) atomicAdd(&h[prev], run);
     }
     wave_lds_fence();
     const u32x4 c = *reinterpret_cast<const u32x4*>(&h[4 * lane]);

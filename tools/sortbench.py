@@ -25,15 +25,34 @@ def main():
     ap.add_argument("--skip-agg", action="store_true")
     ap.add_argument("--guess", default="", help="comma list of sort_guess values to time (1 = the library default: speculation from 2^23 records; k = from k records)")
     ap.add_argument("--hybrid", default="", help="comma list of sort_hybrid values (0 = all passes, 1 = default)")
+    ap.add_argument("--whitelist", type=int, default=0,
+                    help="K > 0: barcodes drawn from K distinct ones with a skewed distribution (rank ~ K u^3: a single-cell run, where a few "
+                         "thousand cells hold most reads), random UMIs, records in read order; built on the device with torch")
     ap.add_argument("--presorted", action="store_true", help="also time ibu_sort_records on the SORTED result (the already-sorted fast exit: one read-only census)")
     a = ap.parse_args()
+    if a.whitelist:
+        import torch                                         # before the library, as bench.py does: its HIP runtime is the process's
+        torch.cuda.init()
     import ibu_amd as ia
 
     bc_len, umi_len = (int(x) for x in a.lens.split(","))
     ctx = ia.Context(0)
     for n in (int(float(x)) for x in a.records.split(",")):
         d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)
-        cols = [ctx.alloc(8 * n) for _ in range(4)] if a.random_index else None
+        cols = [ctx.alloc(8 * n) for _ in range(4)] if (a.random_index or a.whitelist) else None
+        if a.whitelist:
+            g = torch.Generator(device="cuda").manual_seed(0x1B00007)
+            wl = torch.randint(0, 1 << (2 * bc_len), (a.whitelist,), generator=g, device="cuda", dtype=torch.int64)
+            bc, um, ix = (torch.as_tensor(c, device="cuda").view(torch.int64) for c in cols[:3])
+            step = 1 << 26
+            for lo in range(0, n, step):                     # in pieces: the temporaries stay small
+                hi = min(n, lo + step)
+                u = torch.rand(hi - lo, generator=g, device="cuda", dtype=torch.float64)
+                bc[lo:hi] = wl[(u * u * u * a.whitelist).to(torch.int64).clamp_(max=a.whitelist - 1)]
+                um[lo:hi] = torch.randint(0, 1 << (2 * umi_len), (hi - lo,), generator=g, device="cuda", dtype=torch.int64)
+                ix[lo:hi] = torch.arange(lo, hi, device="cuda", dtype=torch.int64)
+            del u
+            torch.cuda.synchronize()
         for variant, compact, guess, hybrid in ((int(v), c, g, h) for v in a.variants.split(",") for c in (a.compact.split(",") if a.compact else [None])
                                                 for g in (a.guess.split(",") if a.guess else [None]) for h in (a.hybrid.split(",") if a.hybrid else [None])):
             ctx.set_option("sort_variant", variant)
@@ -45,8 +64,11 @@ def main():
                 ctx.set_option("sort_compact", int(compact))
             ts = []
             for _ in range(a.rounds + 1):
-                ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)  # random barcode/UMI, increasing index: unsorted
-                if a.random_index:  # replace the index column by random 30-bit values (another stream's barcode column)
+                if a.whitelist:
+                    ctx.serialize(cols[0], cols[1], cols[2], n, d)
+                else:
+                    ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)  # random barcode/UMI, increasing index: unsorted
+                if a.random_index and not a.whitelist:  # replace the index column by random 30-bit values (another stream's barcode column)
                     ctx.deserialize(d, n, cols[0], cols[1], cols[2])
                     ctx.generate(0x1B00006, 0, n, 15, 1, t)
                     ctx.deserialize(t, n, cols[3], cols[2], cols[2])
@@ -79,7 +101,7 @@ def main():
             passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
             # algorithmic traffic: census 24 + histogram 24 once, 48 per pass, 48 for the copy back after an odd number of passes
             alg = n * (48 + 48 * passes + (48 if passes & 1 else 0))
-            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "guess": guess, "hybrid": hybrid, "index": "random" if a.random_index else "increasing (read order)",
+            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "guess": guess, "hybrid": hybrid, "index": "random" if a.random_index and not a.whitelist else "increasing (read order)", "whitelist": a.whitelist or None,
                               "seconds": round(sec, 4), "best": round(min(ts[1:]), 4), "M_records_per_s": round(n / sec / 1e6, 1),
                               "passes": passes, "presorted_input_ms": presorted, "barcode_counts_seconds": agg, "distinct_barcodes": nb,
                               "algorithmic_GB": round(alg / 1e9, 1), "GBps_algorithmic": round(alg / sec / 1e9)}), flush=True)

@@ -2,6 +2,8 @@
 (record.rs:58-66, test record.rs:184-232) and the header's sorted flag promises (header.rs:111-113).
 Identical records are indistinguishable, so the sorted byte string is unique: the bar is equality with
 the oracle's qsort under record_cmp, byte for byte."""
+import os
+
 import numpy as np
 import pytest
 
@@ -460,13 +462,13 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
             assert p > (4 if lens[0] == 16 else 8), trace
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IBU_FUZZ_SEEDS", "32"))))   # a soak run sets more (profiles/README.md r03_soak)
 def test_sort_fuzz_key_structures(ctx, ctx_pf, ctx64, oracle, ia, seed):
     """Seeded fuzz over what decides the sort's path: which key bytes vary (1 .. 24 of them, anywhere in the record), how the values
     are distributed (uniform / a few heavy values / Zipf-like / blocks of equal keys), whether stretches of the input are already in
     order, and sizes on both sides of the speculation threshold.  Default context and forced prefix + finish: the oracle's bytes."""
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([70_001, 131_072, 200_003, 524_289, 1_200_007]))
+    n = int(rng.choice([70_001, 131_072, 200_003, 524_289, 1_200_007] if seed < 24 else [8192, 9001, 30_011, 131_071, 262_144, 2_000_003]))
     nbytes = int(rng.integers(1, 25))
     which = np.sort(rng.permutation(24)[:nbytes])
     raw = np.tile(rng.integers(0, 256, 24, dtype=np.uint8), (n, 1))

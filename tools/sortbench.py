@@ -50,7 +50,8 @@ def main():
                 u = torch.rand(hi - lo, generator=g, device="cuda", dtype=torch.float64)
                 bc[lo:hi] = wl[(u * u * u * a.whitelist).to(torch.int64).clamp_(max=a.whitelist - 1)]
                 um[lo:hi] = torch.randint(0, 1 << (2 * umi_len), (hi - lo,), generator=g, device="cuda", dtype=torch.int64)
-                ix[lo:hi] = torch.arange(lo, hi, device="cuda", dtype=torch.int64)
+                ix[lo:hi] = (torch.randint(0, 1 << 30, (hi - lo,), generator=g, device="cuda", dtype=torch.int64) if a.random_index
+                             else torch.arange(lo, hi, device="cuda", dtype=torch.int64))
             del u
             torch.cuda.synchronize()
         for variant, compact, guess, hybrid in ((int(v), c, g, h) for v in a.variants.split(",") for c in (a.compact.split(",") if a.compact else [None])
@@ -101,7 +102,7 @@ def main():
             passes = (2 * bc_len + 7) // 8 + (2 * umi_len + 7) // 8 + idx_bytes
             # algorithmic traffic: census 24 + histogram 24 once, 48 per pass, 48 for the copy back after an odd number of passes
             alg = n * (48 + 48 * passes + (48 if passes & 1 else 0))
-            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "guess": guess, "hybrid": hybrid, "index": "random" if a.random_index and not a.whitelist else "increasing (read order)", "whitelist": a.whitelist or None,
+            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "variant": variant, "compact": compact if compact is None else int(compact), "guess": guess, "hybrid": hybrid, "index": "random" if a.random_index else "increasing (read order)", "whitelist": a.whitelist or None,
                               "seconds": round(sec, 4), "best": round(min(ts[1:]), 4), "M_records_per_s": round(n / sec / 1e6, 1),
                               "passes": passes, "presorted_input_ms": presorted, "barcode_counts_seconds": agg, "distinct_barcodes": nb,
                               "algorithmic_GB": round(alg / 1e9, 1), "GBps_algorithmic": round(alg / sec / 1e9)}), flush=True)

@@ -221,12 +221,8 @@ extern "C" __global__ void ibu_k_generate_tail(u64 seed, u64 first, u64 row0, u6
 // copy_from_slice, writer.rs:335-347; Writer::ingest's append, writer.rs:477-482) and the
 // on-device COPY CEILING every other kernel here is priced against ("measure an
 // on-device copy ceiling with a plain dwordx4 copy kernel and report both denominators").
-// Four 16-B chunks per lane in flight, grid-stride, nontemporal both ways.
+// Nontemporal both ways.
 // =============================================================================================
-#ifndef IBU_COPY_MODE
-#define IBU_COPY_MODE 1
-#endif
-#if IBU_COPY_MODE == 1
 // Tiles of 4 KiB per wave (four dwordx4 per lane), swept like every streaming kernel here: XCD-static ownership, the next
 // tile's loads in flight while this one's stores are issued, two register sets taking turns.  (The first form — a grid-stride
 // loop with four chunks in flight — ran at 5.7-5.8 TB/s where deserialize, moving the same bytes through LDS, reached 6.2.)
@@ -254,20 +250,6 @@ ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchun
     if (c < nchunks) st16(dst + 16 * c, ld16(src + 16 * c));
   }
 }
-#else
-extern "C" __global__ void __launch_bounds__(kBlock, 8)
-ibu_k_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, u64 nchunks) {
-  const u64 stride = (u64)gridDim.x * kBlock;      // (the fixed-eighth ownership of tile_range() measured no gain here)
-  u64 c = (u64)logical_block() * kBlock + threadIdx.x;
-  for (; c + 3 * stride < nchunks; c += 4 * stride) {
-    u32x4 v0 = ld16(src + 16 * c), v1 = ld16(src + 16 * (c + stride));
-    u32x4 v2 = ld16(src + 16 * (c + 2 * stride)), v3 = ld16(src + 16 * (c + 3 * stride));
-    st16(dst + 16 * c, v0); st16(dst + 16 * (c + stride), v1);
-    st16(dst + 16 * (c + 2 * stride), v2); st16(dst + 16 * (c + 3 * stride), v3);
-  }
-  for (; c < nchunks; c += stride) st16(dst + 16 * c, ld16(src + 16 * c));
-}
-#endif
 // First differing 8-byte word of two word arrays, or ~0: `a == b` on two record slices (Record derives PartialEq / Eq,
 // src/constructs/record.rs:58) with the position a test wants.  VEC 2: both 16-B aligned, dwordx4 loads, four chunks of
 // each array in flight; VEC 1: 8-B aligned inputs.  One atomicMin per wave, and only where something differs.

@@ -478,18 +478,6 @@ ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, const u64* _
 }
 
 // ---- scatter -----------------------------------------------------------------------------------------------------------
-#ifndef IBU_SORT_XCD
-#define IBU_SORT_XCD 1
-#endif
-#ifndef IBU_SCATTER_PERSIST
-#define IBU_SCATTER_PERSIST 0  // element passes: 0 = one tile per workgroup; 1 = persistent grid with the next tile's elements prefetched — built in round 3 and NOT usable at the default shape: the second register set takes the kernel from 174 to 297 VGPRs (one wave per SIMD)
-#endif
-#ifndef IBU_FINISH_XCD
-#define IBU_FINISH_XCD 0       // tile ownership of the persistent finishing kernel: 0 = tiles b, b + grid, ...; 1 = every XCD a contiguous eighth
-#endif
-#ifndef IBU_SCATTER24_MODE
-#define IBU_SCATTER24_MODE 1   // write-out of the 24-byte passes: 0 = consecutive 8-byte words, 1 = half records (dwordx3): 10.37 -> 9.45 ms per pass at 1e9 records (profiles r03_v)
-#endif
 template <int THREADS, int ROUNDS>
 struct SweepShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
@@ -516,13 +504,9 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
   // XCD-aware tile order (speed only): hardware deals workgroup b to XCD b % 8, so XCD x gets the CONSECUTIVE tiles
   // [x * gridDim/8, (x+1) * gridDim/8) in dispatch order.  The run of bin d of tile t+1 continues where tile t's ended,
   // usually in the middle of a 128-byte line: with both tiles on one XCD, close in time, the two halves meet in that
-  // XCD's L2 and the line leaves it once, whole (IBU_SORT_XCD=0: identity order, every boundary line is written twice, by
+  // XCD's L2 and the line leaves it once, whole (in identity order every boundary line is written twice, by
   // two XCDs, as partial lines).
-#if IBU_SORT_XCD
   const u32 tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // the grid is a multiple of 8
-#else
-  const u32 tile = blockIdx.x;
-#endif
   const u64 tbase = (u64)tile * T;
   if (tbase >= n) return;                                     // block-uniform: padding of the grid
   const u32 cnt = n - tbase < (u64)T ? (u32)(n - tbase) : (u32)T;
@@ -611,13 +595,13 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
   }
   __syncthreads();
 
-  // 5. write out: consecutive lanes write consecutive 8-byte words of each run (plain stores: the L2 merges neighbours;
-  //    16-byte chunks with single-word heads and tails were measured slower: more address arithmetic than it saves)
+  // 5. write out (plain stores: the L2 merges the pieces of a run that neighbouring tiles write)
   const u32 nw = 3 * cnt;
   if constexpr (WMODE == 0) {
-#if IBU_SCATTER24_MODE == 1
     // one lane per HALF record (12 bytes, dwordx3): consecutive lanes on consecutive 12-byte pieces of a run, 768 contiguous
-    // bytes per wave instruction instead of 512 (the compact last pass's write-out)
+    // bytes per wave instruction (the compact last pass's write-out).  One lane per 8-byte word: 512 bytes per instruction,
+    // 10.37 instead of 9.45 ms per pass at 1e9 records (profiles r03_v); 16-byte chunks with single-word heads and tails were
+    // slower still (more address arithmetic than they save).
     const u32* stage32 = reinterpret_cast<const u32*>(stage);
     for (u32 h = tid; h < 2 * cnt; h += THREADS) {
       const u32 s = h >> 1, j = h & 1u;
@@ -626,13 +610,6 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
       o.x = stage32[6 * s + 3 * j]; o.y = stage32[6 * s + 3 * j + 1]; o.z = stage32[6 * s + 3 * j + 2];
       *reinterpret_cast<u32x3_a4*>(reinterpret_cast<uint8_t*>(dst) + 24 * g + 12 * j) = o;
     }
-#else
-    for (u32 w = tid; w < nw; w += THREADS) {
-      const u32 s = (u32)(((u64)w * 0xAAAAAAABull) >> 33);    // w / 3
-      const u64 g = gdelta[sbin[s]] + s;
-      dst[3 * g + (w - 3 * s)] = stage[w];
-    }
-#endif
   } else {
     u32x4* o = reinterpret_cast<u32x4*>(dst + 3 * tbase);
     const u32x4* s = reinterpret_cast<const u32x4*>(stage);
@@ -846,9 +823,6 @@ __global__ void ibu_k_sort_expand_tail(const ElemT<W>* __restrict__ in, u64 row0
   recs[3 * i] = f0; recs[3 * i + 1] = f1; recs[3 * i + 2] = f2;
 }
 
-#ifndef IBU_LAST_MODE
-#define IBU_LAST_MODE 1   // write-out of the last compact pass: 0 = one lane per record (3 x 8-byte stores), 1 = one lane per half record (dwordx3)
-#endif
 template <int THREADS, int ROUNDS, int W>
 struct CompactShape {
   static constexpr int T = THREADS * ROUNDS, NW = THREADS / kWave, PER_WAVE = T / NW;
@@ -952,7 +926,7 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
 
   // 5. write out: lane = element, consecutive lanes write the consecutive elements of a run (dwordx3 each; plain stores:
   //    the L2 merges the pieces of a run that neighbouring tiles write); 6. the next pass's digit at the new position
-  if constexpr (LAST && IBU_LAST_MODE == 1) {
+  if constexpr (LAST) {
     // The last pass writes 24-byte records.  One lane per HALF record (12 bytes = dwords [3j, 3j+3) of the record, j = lane
     // parity): consecutive lanes write consecutive 12-byte pieces, so a wave's store instruction covers 768 contiguous
     // bytes of a run — the store shape of the element passes, which run at the box's copy rate.  (One lane per record
@@ -990,15 +964,8 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
       EV<W> e;
 #pragma unroll
       for (int w = 0; w < W; ++w) e.w[w] = stage[W * p + w];
-      if constexpr (LAST) {
-        u64 f0, f1, f2;
-        expand_elem<W>(e, pl, f0, f1, f2);
-        u64* o = static_cast<u64*>(dst_v) + 3 * (size_t)g;
-        o[0] = f0; o[1] = f1; o[2] = f2;
-      } else {
-        st_elem<W>(static_cast<ElemT<W>*>(dst_v) + g, e);
-        if (nbyte < 4 * W) digits[g] = (uint8_t)elem_byte<W>(e, nbyte);   // uniform; >= 4 W: no pass follows on elements
-      }
+      st_elem<W>(static_cast<ElemT<W>*>(dst_v) + g, e);
+      if (nbyte < 4 * W) digits[g] = (uint8_t)elem_byte<W>(e, nbyte);   // uniform; >= 4 W: no pass follows on elements
     }
   }
   }
@@ -1009,33 +976,12 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
   const u32 x0 = (blockIdx.x & 7u) * tpp, xend = x0 + tpp < ntiles ? x0 + tpp : ntiles;
   u32 tile = x0 + (blockIdx.x >> 3);
   if (tile >= xend) return;                                   // block-uniform
-#if IBU_SCATTER_PERSIST
-  // persistent: a workgroup sweeps tiles tile, tile + nb, ... of its XCD's range with the NEXT tile's elements in flight (two
-  // register sets take turns; the barrier keeps a tile's LDS reads in front of the next tile's writes)
-  Win wa, wb;
-  load(tile, wa);
-  for (;;) {
-    u32 next = tile + nb;
-    bool more = next < xend;
-    load(more ? next : tile, wb);
-    body(tile, wa);
-    if (!more) break;
-    tile = next;
-    __syncthreads();
-    next = tile + nb;
-    more = next < xend;
-    load(more ? next : tile, wa);
-    body(tile, wb);
-    if (!more) break;
-    tile = next;
-    __syncthreads();
-  }
-#else
-  (void)nb;                                                   // one tile per workgroup: the grid covers them (nb == tpp)
+  // One tile per workgroup: the grid covers them (nb == tpp).  A persistent form with the next tile's elements prefetched into a
+  // second register set was built in round 3 and is not usable at this shape: 174 -> 297 VGPRs, one wave per SIMD.
+  (void)nb;
   Win w;
   load(tile, w);
   body(tile, w);
-#endif
 }
 
 // =====================================================================================================
@@ -1288,17 +1234,10 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   u32* misc = reinterpret_cast<u32*>(seglen + L);
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
   const u32 ntiles = (u32)((n + T - 1) / T);
-  // which tiles this workgroup sweeps: with IBU_FINISH_XCD every XCD owns one contiguous eighth of the tiles (neighbouring
-  // ranges, whose boundary lines are written by two workgroups, then meet in one XCD's L2), else tiles b, b + grid, ...
-  u32 tile = blockIdx.x, tstride = gridDim.x, tend = ntiles;
-#if IBU_FINISH_XCD
-  if ((gridDim.x & 7u) == 0) {
-    const u32 tpp = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u;
-    tile = xcd * tpp + (blockIdx.x >> 3);
-    tstride = gridDim.x >> 3;
-    tend = xcd * tpp + tpp < ntiles ? xcd * tpp + tpp : ntiles;
-  }
-#endif
+  // which tiles this workgroup sweeps: b, b + grid, ...  (Every XCD owning one contiguous eighth of the tiles — so that the
+  // boundary lines two workgroups write meet in one XCD's L2 — measured no different: the ranges are written whole lines.)
+  u32 tile = blockIdx.x;
+  const u32 tstride = gridDim.x, tend = ntiles;
   if (tile >= tend) return;
   // A window's loads: one element per lane and step (dwordx3 / dwordx4, consecutive lanes on consecutive elements), ALL issued
   // before anything waits for them (unconditional, clamped) — and the NEXT tile's window is loaded while this one is worked on
@@ -1854,14 +1793,6 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     CompactPlan pl_arg = pl;
     void* args[] = {&src_arg, &dst_arg, L.idx64 ? static_cast<void*>(&n64) : static_cast<void*>(&n32), &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
     u32 sgrid = (L.ntiles + 7u) & ~7u;                        // multiple of 8: XCD-aware tile order
-#if IBU_SCATTER_PERSIST
-    {
-      int per = 0;                                            // persistent: exactly the resident grid
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, to_records ? k_scatter_last : k_scatter, cv.threads, cv.lds) != hipSuccess || per <= 0) per = 1;
-      const u32 resident = (u32)per * (u32)cfg.cus;
-      if (sgrid > resident) sgrid = resident & ~7u;
-    }
-#endif
     e = hipLaunchKernel(to_records ? k_scatter_last : k_scatter, dim3(sgrid), dim3(cv.threads), args, cv.lds, st);
     if (e != hipSuccess) return e;
     ElemT<W>* t = src; src = dst; dst = t;

@@ -1426,7 +1426,7 @@ static constexpr int kMaxPrefix = 8;
 static constexpr u32 kPairSlotsMax = 1u << 18;                // per P: 98 304 sample records -> load factor 0.375
 template <int W>
 __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 range_stride, u32 nranges, u32 per_range, CompactPlan pl, u32 k,
-                                        u32 kPairSlots /*power of two*/, u64* __restrict__ keys /*[kMaxPrefix][slots]*/, u32* __restrict__ cnts,
+                                        u32 first /*table q holds the prefixes of first + q + 1 bytes*/, u32 kPairSlots /*power of two*/, u64* __restrict__ keys /*[kMaxPrefix][slots]*/, u32* __restrict__ cnts,
                                         u64* __restrict__ pairs) {
   // the sample: `nranges` ranges of `per_range` consecutive records, evenly spaced over the input (range r starts at r * range_stride)
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1434,7 +1434,8 @@ __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 range_
   const u32 rg = t / per_range;
   const u64 row = (u64)rg * range_stride + (t - rg * per_range);
   const EV<W> e = compress_rec<W>(recs[3 * row], recs[3 * row + 1], recs[3 * row + 2], pl);
-  for (u32 P = 1; P <= (u32)kMaxPrefix && P <= k; ++P) {
+  for (u32 q = 0; q < (u32)kMaxPrefix && first + q + 1 <= k; ++q) {
+    const u32 P = first + q + 1;
     u64 h = 0x9E3779B97F4A7C15ull * P;                        // hash of element bytes [k - P, k)
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -1446,15 +1447,15 @@ __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 range_
     h = (h ^ (h >> 32)) * 0x94D049BB133111EBull;
     h ^= h >> 31;
     if (h == 0) h = 1;
-    u64* kt = keys + (size_t)(P - 1) * kPairSlots;
-    u32* ct = cnts + (size_t)(P - 1) * kPairSlots;
+    u64* kt = keys + (size_t)q * kPairSlots;
+    u32* ct = cnts + (size_t)q * kPairSlots;
     for (u32 slot = (u32)h & (kPairSlots - 1), probes = 0; probes < kPairSlots; slot = (slot + 1) & (kPairSlots - 1), ++probes) {
       const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&kt[slot]), 0ull, (unsigned long long)h);
       if (old == 0 || old == h) {
         const u32 before = atomicAdd(&ct[slot], 1u);          // records with this prefix seen so far: that many new pairs
         if (before) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[P - 1]), (unsigned long long)before);
-          if (before >= 3) atomicMax(reinterpret_cast<unsigned long long*>(&pairs[kMaxPrefix + P - 1]), (unsigned long long)(before + 1));   // the most frequent prefix, from four sample records on (three of 98 304 happen by chance)
+          atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[q]), (unsigned long long)before);
+          if (before >= 3) atomicMax(reinterpret_cast<unsigned long long*>(&pairs[kMaxPrefix + q]), (unsigned long long)(before + 1));   // the most frequent prefix, from four sample records on (three of 98 304 happen by chance)
         }
         break;
       }
@@ -1464,7 +1465,7 @@ __global__ void ibu_k_sort_sample_pairs(const u64* __restrict__ recs, u64 range_
 
 // The same estimate for 24-byte records (more than 16 varying bytes): the prefix of length P is the P most significant VARYING
 // key bytes, given as (field, shift) pairs, most significant first.
-struct PrefixBytes { uint8_t field[kMaxPrefix], shift[kMaxPrefix]; u32 count; };
+struct PrefixBytes { uint8_t field[24], shift[24]; u32 count, first; };   // `count` bytes listed; table q holds the prefixes of first + q + 1 bytes
 extern "C" __global__ void ibu_k_sort_sample_pairs_recs(const u64* __restrict__ recs, u64 range_stride, u32 nranges, u32 per_range, PrefixBytes pb,
                                                         u32 kPairSlots /*power of two*/, u64* __restrict__ keys, u32* __restrict__ cnts,
                                                         u64* __restrict__ pairs) {
@@ -1479,18 +1480,20 @@ extern "C" __global__ void ibu_k_sort_sample_pairs_recs(const u64* __restrict__ 
     const u64 byte = ((fi == 0 ? f[0] : fi == 1 ? f[1] : f[2]) >> pb.shift[P - 1]) & 255u;
     h = (h ^ (byte + 0x100ull * P)) * 0xBF58476D1CE4E5B9ull;
     h ^= h >> 29;
+    if (P <= pb.first) continue;                               // hashed, not counted: an earlier window's prefixes
+    const u32 q = P - pb.first - 1;
     u64 key = (h ^ (h >> 32)) * 0x94D049BB133111EBull;
     key ^= key >> 31;
     if (key == 0) key = 1;
-    u64* kt = keys + (size_t)(P - 1) * kPairSlots;
-    u32* ct = cnts + (size_t)(P - 1) * kPairSlots;
+    u64* kt = keys + (size_t)q * kPairSlots;
+    u32* ct = cnts + (size_t)q * kPairSlots;
     for (u32 slot = (u32)key & (kPairSlots - 1), probes = 0; probes < kPairSlots; slot = (slot + 1) & (kPairSlots - 1), ++probes) {
       const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&kt[slot]), 0ull, (unsigned long long)key);
       if (old == 0 || old == key) {
         const u32 before = atomicAdd(&ct[slot], 1u);
         if (before) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[P - 1]), (unsigned long long)before);
-          if (before >= 3) atomicMax(reinterpret_cast<unsigned long long*>(&pairs[kMaxPrefix + P - 1]), (unsigned long long)(before + 1));
+          atomicAdd(reinterpret_cast<unsigned long long*>(&pairs[q]), (unsigned long long)before);
+          if (before >= 3) atomicMax(reinterpret_cast<unsigned long long*>(&pairs[kMaxPrefix + q]), (unsigned long long)(before + 1));
         }
         break;
       }
@@ -1883,31 +1886,35 @@ static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs
   u64* d_pairs = reinterpret_cast<u64*>(tb);
   u64* d_keys = reinterpret_cast<u64*>(tb + 128);
   u32* d_cnts = reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix);
-  hipError_t e = hipMemsetAsync(tb, 0, 128 + (size_t)slots * 12 * kMaxPrefix, st);
-  if (e != hipSuccess) return e;
   const u64* r64 = static_cast<const u64*>(recs);
-  if (plan.k <= 12)
-    hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges, per_range, plan, plan.k,
-                       slots, d_keys, d_cnts, d_pairs);
-  else
-    hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges, per_range, plan, plan.k,
-                       slots, d_keys, d_cnts, d_pairs);
-  u64 pairs[2 * kMaxPrefix];                                   // [P - 1]: pairs; [kMaxPrefix + P - 1]: the most frequent prefix's count (0: below 4)
-  e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return e;
-  e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return e;
-  // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
+  const u32 margin = cfg.sort_hybrid == 2 ? 1u : 3u;
   u32 P = 0;
-  for (u32 q = 1; q <= (u32)kMaxPrefix && q <= plan.k; ++q) {
-    const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q - 1] / (double)m);
-    const double heaviest = (double)pairs[kMaxPrefix + q - 1] * ((double)n / (double)m);   // estimated longest run
-    if (seg <= 8.0 && heaviest <= 128.0) { P = q; *seg_out = seg; break; }
+  // prefixes of 1 .. 8 bytes first; keys that need more (a wide barcode from a whitelist: every barcode byte and then some of the
+  // UMI's) get a second and third look at 9 .. 16 and 17 .. 24 bytes, as long as such a prefix would still save passes
+  for (u32 first = 0; !P && first < plan.k && first + 1 + margin <= sorted_bytes; first += (u32)kMaxPrefix) {
+    hipError_t e = hipMemsetAsync(tb, 0, 128 + (size_t)slots * 12 * kMaxPrefix, st);
+    if (e != hipSuccess) return e;
+    if (plan.k <= 12)
+      hipLaunchKernelGGL(ibu_k_sort_sample_pairs<3>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges, per_range, plan, plan.k,
+                         first, slots, d_keys, d_cnts, d_pairs);
+    else
+      hipLaunchKernelGGL(ibu_k_sort_sample_pairs<4>, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, r64, range_stride, nranges, per_range, plan, plan.k,
+                         first, slots, d_keys, d_cnts, d_pairs);
+    u64 pairs[2 * kMaxPrefix];                                 // [q]: pairs of equal (first + q + 1)-byte prefix; [kMaxPrefix + q]: the most frequent one's count (0: below 4)
+    e = hipMemcpyAsync(pairs, d_pairs, sizeof pairs, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
+    for (u32 q = 0; q < (u32)kMaxPrefix && first + q + 1 <= plan.k; ++q) {
+      const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q] / (double)m);
+      const double heaviest = (double)pairs[kMaxPrefix + q] * ((double)n / (double)m);   // estimated longest run
+      if (seg <= 8.0 && heaviest <= 128.0) { P = first + q + 1; *seg_out = seg; break; }
+    }
   }
   if (P && plan.k > 12 && (P & 1u)) ++P;                       // 16-byte elements must end in tmp: an even number of passes
   // worth it?  The finishing pass costs about as much as two element passes (14 B read with the look-ahead + 24 B written per
   // record), the plain path's last pass half a pass more than the others
-  const u32 margin = cfg.sort_hybrid == 2 ? 1u : 3u;
   if (P && P + margin > sorted_bytes) P = 0;                   // not worth it / would reach into index bytes the passes do not sort on
   *P_out = P;
   return hipSuccess;
@@ -2142,30 +2149,37 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     static constexpr size_t kSampleW = 32768;
     if (cfg.sort_hybrid && n >= 4 * kSampleW && (reinterpret_cast<uintptr_t>(tmp) & 7u) == 0) {
       PrefixBytes pb;
-      pb.count = (u32)(npass < kMaxPrefix ? npass : kMaxPrefix);
-      for (u32 k = 0; k < pb.count; ++k) { pb.field[k] = (uint8_t)passes[npass - 1 - k].field; pb.shift[k] = (uint8_t)passes[npass - 1 - k].shift; }
+      pb = PrefixBytes();
+      for (int k = 0; k < npass && k < 24; ++k) { pb.field[k] = (uint8_t)passes[npass - 1 - k].field; pb.shift[k] = (uint8_t)passes[npass - 1 - k].shift; }
       const u32 slots = kPairSlotsMax;                       // 25 MB of tables in tmp: from 1.05 M records on (below: P from n alone)
       const size_t table_bytes = 128 + (size_t)slots * 12 * kMaxPrefix;
       if (table_bytes <= n * 24) {
         uint8_t* tb = static_cast<uint8_t*>(tmp);
-        e = hipMemsetAsync(tb, 0, table_bytes, st);
-        if (e != hipSuccess) return e;
         const u32 per_range = 2048, nranges = 48;             // 48 evenly spaced ranges of 2048 records
         const size_t m = (size_t)nranges * per_range;
         const u64 range_stride = (n - per_range) / (nranges - 1);
-        hipLaunchKernelGGL(ibu_k_sort_sample_pairs_recs, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, (const u64*)recs, range_stride, nranges,
-                           per_range, pb, slots, reinterpret_cast<u64*>(tb + 128),
-                           reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix), reinterpret_cast<u64*>(tb));
-        u64 pairs[2 * kMaxPrefix];
-        e = hipMemcpyAsync(pairs, tb, sizeof pairs, hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return e;
+        const int est_margin = cfg.sort_hybrid == 2 ? 1 : 3;
         int Pest = 0;
-        for (u32 q = 1; q <= pb.count; ++q) {
-          const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q - 1] / (double)m);
-          const double heaviest = (double)pairs[kMaxPrefix + q - 1] * ((double)n / (double)m);
-          if (seg <= 8.0 && heaviest <= 128.0) { Pest = (int)q; break; }
+        // prefixes of 1 .. 8 bytes, then (wide barcodes from a whitelist: all their bytes and some of the UMI's) 9 .. 16 and 17 .. 24,
+        // as long as such a prefix would still save passes
+        for (int first = 0; !Pest && first + 1 + est_margin <= npass; first += kMaxPrefix) {
+          pb.first = (u32)first;
+          pb.count = (u32)(npass < first + kMaxPrefix ? npass : first + kMaxPrefix);
+          e = hipMemsetAsync(tb, 0, table_bytes, st);
+          if (e != hipSuccess) return e;
+          hipLaunchKernelGGL(ibu_k_sort_sample_pairs_recs, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, (const u64*)recs, range_stride, nranges,
+                             per_range, pb, slots, reinterpret_cast<u64*>(tb + 128),
+                             reinterpret_cast<u32*>(tb + 128 + (size_t)slots * 8 * kMaxPrefix), reinterpret_cast<u64*>(tb));
+          u64 pairs[2 * kMaxPrefix];
+          e = hipMemcpyAsync(pairs, tb, sizeof pairs, hipMemcpyDeviceToHost, st);
+          if (e != hipSuccess) return e;
+          e = hipStreamSynchronize(st);
+          if (e != hipSuccess) return e;
+          for (u32 q = 0; q < (u32)kMaxPrefix && pb.first + q + 1 <= pb.count; ++q) {
+            const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q] / (double)m);
+            const double heaviest = (double)pairs[kMaxPrefix + q] * ((double)n / (double)m);
+            if (seg <= 8.0 && heaviest <= 128.0) { Pest = (int)(pb.first + q + 1); break; }
+          }
         }
         if (trace_sort() && Pest != P) fprintf(stderr, "ibu sort: n=%zu sample estimate: prefix_passes=%d (well-spread keys would take %d)\n", n, Pest, P);
         P = Pest ? Pest : npass;                              // npass: never worth it below

@@ -462,6 +462,32 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
             assert p > (4 if lens[0] == 16 else 8), trace
 
 
+@pytest.mark.parametrize("lens,n", [((32, 32), 1_200_007), ((32, 12), 1_000_003), ((32, 12), 200_003)])
+@pytest.mark.parametrize("index", ["random", "read_order"])
+def test_sort_prefixes_longer_than_eight_bytes(ctx, oracle, lens, n, index, capfd):
+    """Wide barcodes from a whitelist: all eight barcode bytes vary and say little, so the shortest prefix with short runs reaches
+    into the UMI — 10 bytes.  The estimate looks at prefixes of 9 .. 16 bytes when 1 .. 8 found nothing (24-byte records at
+    (32,32): 20 varying bytes; 16-byte elements at (32,12): 15), and takes them where that still saves passes."""
+    recs = _shuffled(oracle, n, *lens)
+    rng = np.random.default_rng(n)
+    recs["barcode"] = recs["barcode"][:16][rng.integers(0, 16, n)]
+    recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64) if index == "random" else np.arange(n, dtype=np.uint64)
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    got, _ = _sort_on_device(ctx, recs)
+    trace = capfd.readouterr().err
+    assert got == want
+    if not trace:
+        pytest.skip("no trace: IBU_TRACE_SORT is not set")
+    assert "overflowed" not in trace, trace
+    if lens == (32, 32):                                       # 8 + 8 key bytes (+ 4 index bytes when those are random)
+        assert "path=prefix+finish prefix_passes=10 of " + ("20" if index == "random" else "16") in trace, trace
+    elif index == "random":                                    # 8 + 3 key bytes + 4 index bytes in a 16-byte element
+        assert "path=compact-prefix+finish element_bytes=16 prefix_passes=10 of 15" in trace, trace
+    else:                                                      # 11 passes in read order: a 10-byte prefix saves nothing
+        assert "prefix+finish" not in trace, trace
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("IBU_FUZZ_SEEDS", "32"))))   # a soak run sets more (profiles/README.md r03_soak)
 def test_sort_fuzz_key_structures(ctx, ctx_pf, ctx64, oracle, ia, seed):
     """Seeded fuzz over what decides the sort's path: which key bytes vary (1 .. 24 of them, anywhere in the record), how the values

@@ -16,12 +16,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _rand_bits(torch, g, nbits, count):
+    """count random nbits-bit values as int64 bit patterns (nbits up to 64)."""
+    if nbits <= 62:
+        return torch.randint(0, 1 << nbits, (count,), generator=g, device="cuda", dtype=torch.int64)
+    hi = torch.randint(0, 1 << (nbits - 32), (count,), generator=g, device="cuda", dtype=torch.int64)
+    return (hi << 32) | torch.randint(0, 1 << 32, (count,), generator=g, device="cuda", dtype=torch.int64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", default="1e9")
     ap.add_argument("--lens", default="10,12;16,12")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--whitelist", type=int, default=0, help="K > 0: barcodes drawn from K distinct ones, skewed (rank ~ K u^3), as tools/sortbench.py --whitelist")
     a = ap.parse_args()
+    if a.whitelist:
+        import torch                                         # before the library, as bench.py does
+        torch.cuda.init()
     import ibu_amd as ia
     from ibu_amd import _dptr, _check, lib
 
@@ -31,6 +43,21 @@ def main():
         for lens in a.lens.split(";"):
             bc_len, umi_len = (int(x) for x in lens.split(","))
             ctx.generate(0x1B00005, 0, n, bc_len, umi_len, d)
+            if a.whitelist:                                    # replace the barcode column
+                cols = [ctx.alloc(8 * n) for _ in range(3)]
+                ctx.deserialize(d, n, cols[0], cols[1], cols[2])
+                g = torch.Generator(device="cuda").manual_seed(0x1B00007)
+                wl = _rand_bits(torch, g, 2 * bc_len, a.whitelist)
+                bc = torch.as_tensor(cols[0], device="cuda").view(torch.int64)
+                for lo in range(0, n, 1 << 26):
+                    hi = min(n, lo + (1 << 26))
+                    u = torch.rand(hi - lo, generator=g, device="cuda", dtype=torch.float64)
+                    bc[lo:hi] = wl[(u * u * u * a.whitelist).to(torch.int64).clamp_(max=a.whitelist - 1)]
+                del u
+                torch.cuda.synchronize()
+                ctx.serialize(cols[0], cols[1], cols[2], n, d)
+                for c in cols:
+                    c.free()
             ctx.sort_records(d, t, n)
             ctx.synchronize()
             nb, npairs = C.c_size_t(), C.c_size_t()
@@ -54,7 +81,7 @@ def main():
             qs, es = statistics.median(q[1:]), statistics.median(e[1:])
             # algorithmic bytes: the barcode and UMI words of every record once per pass (16 B; the hardware fetches the
             # whole 24-byte record) + 24 B per distinct barcode written; the emit call runs the count pass again
-            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "distinct_barcodes": u, "barcode_umi_pairs": npairs.value,
+            print(json.dumps({"n": n, "lens": [bc_len, umi_len], "whitelist": a.whitelist or None, "distinct_barcodes": u, "barcode_umi_pairs": npairs.value,
                               "size_query_ms": round(qs * 1e3, 3), "emit_call_ms": round(es * 1e3, 3),
                               "size_query_GBps_of_24B": round(24 * n / qs / 1e9),
                               "emit_call_GBps_of_24B_x2": round((48 * n + 24 * u) / es / 1e9)}), flush=True)

@@ -12,6 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _rand_bits(torch, g, nbits, count):
+    """count random nbits-bit values as int64 bit patterns (nbits up to 64)."""
+    if nbits <= 62:
+        return torch.randint(0, 1 << nbits, (count,), generator=g, device="cuda", dtype=torch.int64)
+    hi = torch.randint(0, 1 << (nbits - 32), (count,), generator=g, device="cuda", dtype=torch.int64)
+    return (hi << 32) | torch.randint(0, 1 << 32, (count,), generator=g, device="cuda", dtype=torch.int64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", default="1e8")
@@ -42,14 +50,14 @@ def main():
         cols = [ctx.alloc(8 * n) for _ in range(4)] if (a.random_index or a.whitelist) else None
         if a.whitelist:
             g = torch.Generator(device="cuda").manual_seed(0x1B00007)
-            wl = torch.randint(0, 1 << (2 * bc_len), (a.whitelist,), generator=g, device="cuda", dtype=torch.int64)
+            wl = _rand_bits(torch, g, 2 * bc_len, a.whitelist)
             bc, um, ix = (torch.as_tensor(c, device="cuda").view(torch.int64) for c in cols[:3])
             step = 1 << 26
             for lo in range(0, n, step):                     # in pieces: the temporaries stay small
                 hi = min(n, lo + step)
                 u = torch.rand(hi - lo, generator=g, device="cuda", dtype=torch.float64)
                 bc[lo:hi] = wl[(u * u * u * a.whitelist).to(torch.int64).clamp_(max=a.whitelist - 1)]
-                um[lo:hi] = torch.randint(0, 1 << (2 * umi_len), (hi - lo,), generator=g, device="cuda", dtype=torch.int64)
+                um[lo:hi] = _rand_bits(torch, g, 2 * umi_len, hi - lo)
                 ix[lo:hi] = (torch.randint(0, 1 << 30, (hi - lo,), generator=g, device="cuda", dtype=torch.int64) if a.random_index
                              else torch.arange(lo, hi, device="cuda", dtype=torch.int64))
             del u

@@ -189,11 +189,13 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     return leg, info
 
 
-def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3):
+def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3, torch=None, dev=None):
     """Device sort by (barcode, umi, index) (record.rs:58 ordering, header.rs:111-113 sorted flag) of the headline's
     synthetic records, in read order (index increasing: the index passes are skipped) and with the index column replaced
-    by random 30-bit values, then the per-barcode aggregation (parallel.rs:72-98) of the sorted records.  Checked, not
-    trusted: sorted, and count / wrapping sums / XORs unchanged."""
+    by random 30-bit values, then the per-barcode aggregation (parallel.rs:72-98) of the sorted records.  Third input: what
+    a single-cell run looks like — barcodes drawn from a whitelist of 100 000 with a skewed distribution (rank ~ K u^3), in
+    read order: such keys do not spread, every varying key byte gets its pass.  Checked, not trusted: sorted, and count /
+    wrapping sums / XORs unchanged."""
     import statistics
     import ctypes as C
 
@@ -203,10 +205,30 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3):
     cols = [ctx.alloc(8 * n) for _ in range(4)]
     out = {"workload": f"{n:.3g} records bc_len={bc_len} umi_len={umi_len}: ibu_sort_records on resident records, median of {rounds}"}
     try:
-        for name in ("read_order", "random_index"):
+        names = ["read_order", "random_index"]
+        if torch is not None and 2 * bc_len <= 62:
+            names.append("whitelist_read_order")
+
+        def whitelist_column(col):                             # barcodes for every record, drawn from kwl distinct ones
+            kwl = 100_000
+            g = torch.Generator(device=dev).manual_seed(seed + 2)
+            wl = torch.randint(0, 1 << (2 * bc_len), (kwl,), generator=g, device=dev, dtype=torch.int64)
+            bcv = torch.as_tensor(col, device=dev).view(torch.int64)
+            for lo in range(0, n, 1 << 26):                    # in pieces: the temporaries stay small
+                hi = min(n, lo + (1 << 26))
+                u = torch.rand(hi - lo, generator=g, device=dev, dtype=torch.float64)
+                bcv[lo:hi] = wl[(u * u * u * kwl).to(torch.int64).clamp_(max=kwl - 1)]
+            torch.cuda.synchronize()
+
+        for name in names:
             ts = []
+            if name == "whitelist_read_order":
+                whitelist_column(cols[0])
             for _ in range(rounds + 1):
                 ctx.generate(seed, 0, n, bc_len, umi_len, d)
+                if name == "whitelist_read_order":             # the whitelist barcodes replace the generator's
+                    ctx.deserialize(d, n, cols[1], cols[2], cols[3])
+                    ctx.serialize(cols[0], cols[2], cols[3], n, d)
                 if name == "random_index":     # another stream's 15-base barcode column as the index column
                     ctx.deserialize(d, n, cols[0], cols[1], cols[2])
                     ctx.generate(seed + 1, 0, n, 15, 1, t)
@@ -221,6 +243,8 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3):
             sec = statistics.median(ts[1:])
             ok = bool(ctx.is_sorted(d, n)) and ctx.reduce(d, n) == before
             out[name] = {"seconds": sec, "records_per_s": n / sec, "sorted_and_multiset_preserved": ok}
+            if name == "whitelist_read_order":
+                out[name]["input"] = "barcodes from 100000 distinct, rank ~ K u^3; random UMIs; index increasing"
             if not ok:
                 raise SystemExit("device sort: result not sorted or records changed")
         # aggregation of the sorted records: size query (count pass + scan), then the whole call into device arrays
@@ -481,7 +505,7 @@ def main():
         leg.free()
         torch.cuda.empty_cache()
         try:
-            sort_leg = sort_and_aggregate(ctx, n, bc_len, umi_len, args.seed)
+            sort_leg = sort_and_aggregate(ctx, n, bc_len, umi_len, args.seed, torch=torch, dev=dev)
         except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
             sort_leg = {"error": f"{type(e).__name__}: {e}"}
 

@@ -452,4 +452,28 @@ template <class T> static inline T* adv(T* p, size_t bytes) {
 }
 static inline u32 tail_grid(u64 rows) { return (u32)((rows + 255) / 256); }
 
+// Block-wide exclusive scan of one u32 per thread over the first 256 threads of the block (every thread of the block
+// must call; threads >= 256 pass 0 and get garbage).  Leaves the total in *total.
+__device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* wsum /*[4] shared*/, u32* total) {
+  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const u32 t = __shfl_up(inc, d);
+    if (lane >= (u32)d) inc += t;
+  }
+  if (lane == kWave - 1 && wib < 4) wsum[wib] = inc;
+  __syncthreads();
+  u32 off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const u32 s = wsum[w];
+    if ((u32)w < wib) off += s;
+    tot += s;
+  }
+  __syncthreads();  // wsum may be reused by the caller's next scan
+  *total = tot;
+  return off + inc - v;
+}
+
 }  // namespace ibu

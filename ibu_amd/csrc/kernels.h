@@ -82,7 +82,7 @@ void compact_plan_init(const uint64_t or_words[3], const uint64_t and_words[3], 
 hipError_t launch_records_census(const LaunchCfg&, const void* recs, size_t n, uint64_t* d_census /*u64[8]*/, hipStream_t st);
 hipError_t launch_compact(const LaunchCfg&, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st);
 hipError_t launch_expand(const LaunchCfg&, const CompactPlan& pl, const void* elems, size_t n, void* recs, hipStream_t st);
-// per-barcode run-length aggregation of sorted records (sort.hip)
+// per-barcode run-length aggregation of sorted records (k_aggregate.hip)
 size_t runs_scratch_bytes(size_t n);
 hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t runs_emit_scratch_bytes(uint64_t n_runs);

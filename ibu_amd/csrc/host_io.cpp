@@ -575,8 +575,8 @@ struct BgzfSource : Source {
   // straight out of `comp`, a block that is not whole yet stays for the next batch.
   size_t comp_pos = 0, comp_len = 0;                  // unparsed bytes: comp[comp_pos, comp_len)
   bool inner_eof = false;
-  int refill(RawBytes& out) {
-    out.n = 0;
+  int refill(RawBytes& dst) {
+    dst.n = 0;
     std::vector<Block> blocks;
     size_t total_out = 0;
     const size_t kBatchComp = batch_comp;
@@ -639,7 +639,7 @@ struct BgzfSource : Source {
       comp_pos += bsize;
     }
     if (pending_err) eof = true;                       // nothing is read behind a bad spot
-    if (!out.resize_uninit(total_out)) return ENOMEM;
+    if (!dst.resize_uninit(total_out)) return ENOMEM;
     if (blocks.empty()) return 0;
     const unsigned nt = blocks.size() < threads ? (unsigned)blocks.size() : threads;
     std::vector<int> rcs(nt, 0);
@@ -656,10 +656,10 @@ struct BgzfSource : Source {
         const Block& b = blocks[i];
         if (b.isize == 0 && b.clen <= 2) continue;  // empty block (the EOF marker)
         int rc;
-        if (use_zlib) rc = inflate_block(&zs, comp.data() + b.coff, b.clen, out.data() + b.ooff, b.isize, b.crc);
+        if (use_zlib) rc = inflate_block(&zs, comp.data() + b.coff, b.clen, dst.data() + b.ooff, b.isize, b.crc);
         else {
           uint32_t crc = 0;
-          rc = raw.inflate(comp.data() + b.coff, b.clen, out.data() + b.ooff, b.isize, &crc);
+          rc = raw.inflate(comp.data() + b.coff, b.clen, dst.data() + b.ooff, b.isize, &crc);
           if (rc == 0 && crc != b.crc) rc = EPROTO;
         }
         if (rc) { rcs[t] = rc; bad_at[t] = i; break; }
@@ -678,7 +678,7 @@ struct BgzfSource : Source {
       if (bad_at[t] < first_bad) first_bad = bad_at[t];
     }
     if (first_bad != ~(size_t)0) {                       // blocks in front of the first bad one are good and go out
-      out.n = blocks[first_bad].ooff;
+      dst.n = blocks[first_bad].ooff;
       pending_err = EPROTO;
       eof = true;                                      // nothing is read behind the bad spot
     }

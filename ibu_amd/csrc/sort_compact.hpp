@@ -227,19 +227,19 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
   const u32 ntiles = (u32)(((u64)n + T - 1) / T);
   struct Win { EV<W> v[ROUNDS]; IDX mypos; };
   // 1. every lane loads its elements (unconditional, clamped) and this tile's first output position per bin
-  auto load = [&](u32 tile, Win& w) {
+  auto load = [&](u32 tile, Win& win) {
     const IDX tbase = (IDX)((u64)tile * T);
     const u32 cnt = n - tbase < (IDX)T ? (u32)(n - tbase) : (u32)T;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const u32 slot = wib * PER_WAVE + r * kWave + lane;
-      w.v[r] = ld_elem<W>(src + tbase + (slot < cnt ? slot : cnt - 1));
+      win.v[r] = ld_elem<W>(src + tbase + (slot < cnt ? slot : cnt - 1));
     }
-    w.mypos = pos[(size_t)tile * kBins + (tid & (kBins - 1))];
+    win.mypos = pos[(size_t)tile * kBins + (tid & (kBins - 1))];
   };
-  auto body = [&](u32 tile, const Win& w) {
-  const EV<W>* v = w.v;
-  const IDX mypos = w.mypos;
+  auto body = [&](u32 tile, const Win& win) {
+  const EV<W>* v = win.v;
+  const IDX mypos = win.mypos;
   const IDX tbase = (IDX)((u64)tile * T);
   const u32 cnt = n - tbase < (IDX)T ? (u32)(n - tbase) : (u32)T;
 #pragma unroll

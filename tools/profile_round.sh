@@ -2,7 +2,8 @@
 # Evidence run of a round, on the GPU box (gpurun -- 'bash tools/profile_round.sh r02_b'):
 #   1. python bench.py                                        -> <tag>_bench_1e9.json
 #   2. rocprofv3 --kernel-trace --stats over the same command -> <tag>_bench_1e9_kernel_stats.csv (+ the line it printed)
-#   3. rocprofv3 --kernel-trace --stats over tools/sortbench.py at 1e9 (random index) -> <tag>_sort_1e9_kernel_stats.csv
+#   3. rocprofv3 --kernel-trace --stats over tools/sortbench.py at 1e9 (random index; whitelist barcodes in read order)
+#      -> <tag>_sort_1e9_kernel_stats.csv, <tag>_sort_whitelist_1e9_kernel_stats.csv
 #   4. two --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with each other or with other trace domains) over
 #      tools/kbench.py and tools/sortbench.py -> pmc CSVs + pmc_traffic.json (round-tagged)
 # Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
@@ -31,6 +32,13 @@ cp "$(largest "$OUT/prof_bench" '*kernel_stats.csv')" "$OUT/${TAG}_bench_1e9_ker
 step "sortbench (unprofiled)"
 python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg --presorted > "$OUT/${TAG}_sortbench_random_index.jsonl" 2> "$OUT/sort.err" || exit 1
 python3 tools/sortbench.py --records "$N" --rounds 3 --skip-agg > "$OUT/${TAG}_sortbench_read_order.jsonl" 2>> "$OUT/sort.err" || exit 1
+
+step "sortbench, barcodes from a whitelist of 1e5 in read order (all passes)"
+python3 tools/sortbench.py --records "$N" --rounds 3 --skip-agg --whitelist 100000 > "$OUT/${TAG}_sortbench_whitelist_read_order.jsonl" 2>> "$OUT/sort.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sort_wl" -- python3 tools/sortbench.py --records "$N" --rounds 3 --skip-agg --whitelist 100000 \
+  > "$OUT/${TAG}_sortbench_whitelist_under_rocprof.jsonl" 2> "$OUT/prof_sort_wl.err" || exit 1
+cp "$(largest "$OUT/prof_sort_wl" '*kernel_stats.csv')" "$OUT/${TAG}_sort_whitelist_1e9_kernel_stats.csv"
+rm -rf "$OUT/prof_sort_wl"
 
 step "sortbench under rocprofv3 --kernel-trace --stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_sort" -- python3 tools/sortbench.py --records "$N" --rounds 3 --random-index --skip-agg \

@@ -1,0 +1,221 @@
+"""Out-of-bounds writes on the GPU are silent inside a large allocation — and GPU AddressSanitizer is not available on this
+pool.  These tests give every kernel family buffers of EXACTLY the size its contract asks for, carved out of one arena with
+guard zones of a known pattern on both sides of each, run it at sizes around every tile boundary (and at 8- but not
+16-byte aligned addresses, the peeled paths), and then check two things: the result against the oracle, and every guard byte.
+Reads past a buffer cannot be seen this way; writes — the ones that corrupt a neighbour's data — can."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 4096
+PATTERN = 0xA5
+SIZES = [1, 2, 63, 127, 128, 129, 255, 2559, 2561, 5121, 100_003]
+
+
+@pytest.fixture(scope="module")
+def ia():
+    import ibu_amd
+    return ibu_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ia):
+    c = ia.Context(0)
+    yield c
+    c.close()
+
+
+class Arena:
+    """One allocation, pattern-filled; carve(nbytes, skew) hands out a view that starts `skew` bytes behind a 256-byte
+    boundary with at least GUARD pattern bytes on either side; check() looks at every byte outside the views."""
+
+    def __init__(self, ia, ctx, total):
+        self.ia, self.ctx = ia, ctx
+        self.total = total
+        self.buf = ctx.upload(np.full(total, PATTERN, np.uint8))
+        self.pos = GUARD
+        self.used = []
+
+    def carve(self, nbytes, skew=0):
+        start = (self.pos + 255) // 256 * 256 + skew
+        assert start + nbytes + GUARD <= self.total, "arena too small"
+        self.used.append((start, start + nbytes))
+        self.pos = start + nbytes + GUARD
+        return self.ia.DeviceBuffer.wrap(self.ctx, self.buf.ptr + start, max(nbytes, 1))
+
+    def check(self, what):
+        self.ctx.synchronize()
+        host = self.buf.download(np.uint8)
+        mask = np.ones(self.total, bool)
+        for a, b in self.used:
+            mask[a:b] = False
+        bad = np.flatnonzero(mask & (host != PATTERN))
+        assert bad.size == 0, f"{what}: {bad.size} guard bytes overwritten, first at arena offset {int(bad[0])} (views: {self.used})"
+
+    def free(self):
+        self.buf.free()
+
+
+def _arena(ia, ctx, *sizes):
+    return Arena(ia, ctx, sum(sizes) + (len(sizes) + 2) * (GUARD + 512) + 4096)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("skew", [0, 8])
+def test_deserialize_serialize_stay_inside_their_buffers(ia, ctx, oracle, n, skew):
+    recs = oracle.generate(0x1B00011, 0, n, 16, 12)
+    ar = _arena(ia, ctx, 24 * n, 8 * n, 8 * n, 8 * n, 24 * n)
+    try:
+        d = ar.carve(24 * n, skew)
+        d.upload(recs)
+        b, u, x = ar.carve(8 * n, skew), ar.carve(8 * n, 0), ar.carve(8 * n, skew)
+        back = ar.carve(24 * n, skew)
+        ctx.deserialize(d, n, b, u, x)
+        ctx.serialize(b, u, x, n, back)
+        ar.check("deserialize + serialize")
+        assert (b.download(np.uint64, n) == recs["barcode"]).all() and (x.download(np.uint64, n) == recs["index"]).all()
+        assert back.download(count=24 * n).tobytes() == recs.tobytes()
+    finally:
+        ar.free()
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32), (1, 1), (5, 7)])
+@pytest.mark.parametrize("skew", [0, 8])
+def test_decode_encode_stay_inside_their_buffers(ia, ctx, oracle, n, lens, skew):
+    """Odd lengths make the ASCII rows end anywhere: the columns are n * len bytes, not a byte more."""
+    bl, ul = lens
+    recs = oracle.generate(0x1B00012, 0, n, bl, ul)
+    want_bc, want_umi, want_idx = oracle.decode_records(recs, bl, ul)
+    ar = _arena(ia, ctx, 24 * n, bl * n, ul * n, 8 * n, 24 * n)
+    try:
+        d = ar.carve(24 * n, skew)
+        d.upload(recs)
+        bc, um, ix = ar.carve(bl * n, 0), ar.carve(ul * n, 0), ar.carve(8 * n, skew)
+        back = ar.carve(24 * n, skew)
+        ctx.decode_ascii(d, n, bl, ul, bc, um, ix)
+        ctx.encode_ascii(bc, um, ix, n, bl, ul, back)
+        ctx.codec_status()
+        ar.check(f"decode + encode {lens}")
+        assert bc.download(count=bl * n).tobytes() == want_bc.tobytes() and um.download(count=ul * n).tobytes() == want_umi.tobytes()
+        assert (ix.download(np.uint64, n) == want_idx).all()
+        assert back.download(count=24 * n).tobytes() == recs.tobytes()
+    finally:
+        ar.free()
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("length", [1, 3, 12, 16, 31, 32])
+def test_pack_unpack_stay_inside_their_buffers(ia, ctx, oracle, n, length):
+    codes = oracle.generate(0x1B00013, 0, n, length, 1)["barcode"].copy()
+    want = oracle.unpack_column(codes, length)
+    ar = _arena(ia, ctx, 8 * n, length * n, 8 * n)
+    try:
+        dc = ar.carve(8 * n)
+        dc.upload(codes)
+        asc, back = ar.carve(length * n), ar.carve(8 * n)
+        ctx.unpack_2bit(dc, n, length, asc)
+        ctx.pack_2bit(asc, n, length, back)
+        ctx.codec_status()
+        ar.check(f"unpack + pack len={length}")
+        assert asc.download(count=length * n).tobytes() == want.tobytes()
+        assert (back.download(np.uint64, n) == codes).all()
+    finally:
+        ar.free()
+
+
+@pytest.mark.parametrize("n", SIZES + [131_072, 1_000_003])
+@pytest.mark.parametrize("case", ["16_12_random_index", "16_12_read_order", "32_12_random_index", "32_32_random_index", "whitelist_read_order"])
+@pytest.mark.parametrize("skew", [0, 8])
+def test_sort_stays_inside_records_and_tmp(ia, ctx, oracle, n, case, skew):
+    """ibu_sort_records may use d_records and d_tmp (n * 24 bytes each) and the context's own scratch — nothing else.  The
+    cases take the 12-byte and 16-byte element paths, the 24-byte passes, prefix + finish (from 8192 records on) and all passes."""
+    bl, ul = (32, 32) if case.startswith("32_32") else (32, 12) if case.startswith("32_12") else (16, 12)
+    recs = oracle.generate(0x1B00014, 0, n, bl, ul)
+    rng = np.random.default_rng(n)
+    rng.shuffle(recs)
+    if case.endswith("random_index"):
+        recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
+    else:
+        recs["index"] = np.arange(n, dtype=np.uint64)
+    if case.startswith("whitelist"):
+        recs["barcode"] = recs["barcode"][:37][rng.integers(0, min(37, n), n)]
+    want = oracle.sort_records(recs).tobytes()
+    ar = _arena(ia, ctx, 24 * n, 24 * n)
+    try:
+        d, t = ar.carve(24 * n, skew), ar.carve(24 * n, skew)
+        d.upload(recs)
+        ctx.sort_records(d, t, n)
+        ar.check(f"sort {case} n={n} skew={skew}")
+        assert d.download(count=24 * n).tobytes() == want
+    finally:
+        ar.free()
+
+
+@pytest.mark.parametrize("n", SIZES + [300_007])
+@pytest.mark.parametrize("bc_len", [2, 6, 16])
+@pytest.mark.parametrize("skew", [0, 8])
+def test_barcode_counts_writes_exactly_its_runs(ia, ctx, oracle, n, bc_len, skew):
+    """The emit call writes n_barcodes entries into each output array: arrays of exactly that size, guarded."""
+    import ctypes as C
+
+    from ibu_amd import _check, _dptr, lib
+    recs = oracle.sort_records(oracle.generate(0x1B00015, 0, n, bc_len, 4))
+    bcs, counts = np.unique(recs["barcode"], return_counts=True)
+    pairs = np.unique(recs[["barcode", "umi"]], return_counts=False)
+    nb, npairs = C.c_size_t(), C.c_size_t()
+    ar = _arena(ia, ctx, 24 * n, 8 * len(bcs), 8 * len(bcs), 8 * len(bcs))
+    try:
+        d = ar.carve(24 * n, skew)
+        d.upload(recs)
+        _check(lib.ibu_barcode_counts(ctx._c, _dptr(d), n, None, None, None, 0, C.byref(nb), C.byref(npairs), None))
+        assert nb.value == len(bcs) and npairs.value == len(pairs)
+        ob, oc, ou = (ar.carve(8 * nb.value) for _ in range(3))
+        _check(lib.ibu_barcode_counts(ctx._c, _dptr(d), n, _dptr(ob), _dptr(oc), _dptr(ou), nb.value, C.byref(nb), C.byref(npairs), None))
+        ar.check(f"barcode_counts n={n} bc_len={bc_len}")
+        assert (ob.download(np.uint64, nb.value) == bcs).all() and (oc.download(np.uint64, nb.value) == counts.astype(np.uint64)).all()
+        assert int(ou.download(np.uint64, nb.value).sum()) == len(pairs)
+    finally:
+        ar.free()
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("skew", [0, 8])
+def test_compact_expand_copy_generate_stay_inside_their_buffers(ia, ctx, oracle, n, skew):
+    recs = oracle.generate(0x1B00016, 0, n, 16, 12)
+    ar = _arena(ia, ctx, 24 * n, 12 * n, 24 * n, 24 * n, 24 * n)
+    try:
+        d = ar.carve(24 * n, skew)
+        d.upload(recs)
+        c = ctx.census(d, n)
+        plan = ia.key_plan(c["or"], c["and"])
+        el, back, cp, gen = ar.carve(12 * n, 0), ar.carve(24 * n, skew), ar.carve(24 * n, skew), ar.carve(24 * n, skew)
+        if plan.k <= 12:
+            ctx.compact(plan, d, n, el)
+            ctx.expand(plan, el, n, back)
+        else:
+            ctx.copy(back, d, 24 * n)
+        ctx.copy(cp, d, 24 * n)
+        ctx.generate(0x1B00016, 0, n, 16, 12, gen)
+        ar.check("compact / expand / copy / generate")
+        for v in (back, cp, gen):
+            assert v.download(count=24 * n).tobytes() == recs.tobytes()
+    finally:
+        ar.free()
+
+
+def test_the_guard_check_sees_an_overrun(ia, ctx, oracle):
+    """The checker checked: a copy of 24 bytes too many (still inside the arena) must be reported."""
+    n = 1000
+    recs = oracle.generate(0x1B00017, 0, n, 16, 12)
+    ar = _arena(ia, ctx, 24 * n, 24 * n)
+    try:
+        d = ar.carve(24 * n)
+        d.upload(recs)
+        short = ar.carve(24 * (n - 1))
+        ctx.copy(short, d, 24 * n)
+        with pytest.raises(AssertionError, match="24 guard bytes overwritten"):
+            ar.check("deliberate overrun")
+    finally:
+        ar.free()

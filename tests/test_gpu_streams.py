@@ -229,6 +229,39 @@ def test_reader_process_device_plain_and_gzip(ia, ctx, oracle, tmp_path, compres
     r.close()
 
 
+@pytest.mark.parametrize("form", ["plain", "gzip"])
+def test_reader_process_device_from_a_pipe(ia, ctx, oracle, tmp_path, form):
+    """Reader::from_stdin's case (reader.rs:389-396): a descriptor that cannot seek and reads short — the pinned slots are filled
+    from whatever read(2) hands over, records cut across reads included."""
+    import os
+    import threading
+    n = 300_007
+    p = tmp_path / "pipe.ibu"
+    recs = _write_file(oracle, p, n)
+    data = p.read_bytes() if form == "plain" else gzip.compress(p.read_bytes(), 1)
+    rfd, wfd = os.pipe()
+
+    def feed():
+        rng = np.random.default_rng(5)
+        pos = 0
+        with os.fdopen(wfd, "wb", buffering=0) as w:
+            while pos < len(data):
+                k = int(rng.integers(1, 60_001))
+                w.write(data[pos:pos + k])
+                pos += k
+
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        r = ia.Reader(rfd)
+        res, st = r.process_device(ctx, ia.PROC_REDUCE, ring=SMALL_RING)
+        r.close()
+    finally:
+        t.join()
+        os.close(rfd)
+    assert res == oracle.reduce_records(recs) and st.records == n
+
+
 def test_reader_process_device_after_partial_host_iteration(ia, ctx, oracle, tmp_path):
     """The device stream takes over where the host iterator stopped (records already yielded are not re-read)."""
     n = 60_000

@@ -343,6 +343,43 @@ def test_reader_from_path_plain_and_gzip(tmp_path, oracle):  # reader.rs:345-352
     assert ei.value.kind == "Niffler"
 
 
+@pytest.mark.parametrize("form", ["plain", "gzip", "multi_member_gzip"])
+def test_reader_from_a_pipe(oracle, form):  # reader.rs:389-396 (from_stdin: a descriptor that cannot seek and reads short)
+    """Reader::from_stdin is Reader over fd 0: the same constructor over the read end of a pipe whose writer hands the bytes over
+    in uneven pieces — short reads, no seeking, no size; format sniffed from the first bytes as for a path."""
+    recs = oracle.generate(7, 0, 130_001, 16, 12)
+    raw = create_test_data(recs)
+    if form == "gzip":
+        data = gzip.compress(raw, 1)
+    elif form == "multi_member_gzip":
+        cut = 32 + 24 * 70_000 + 11
+        data = gzip.compress(raw[:cut], 1) + gzip.compress(raw[cut:], 6)
+    else:
+        data = raw
+    rfd, wfd = os.pipe()
+
+    def feed():
+        rng = np.random.default_rng(11)
+        pos = 0
+        with os.fdopen(wfd, "wb", buffering=0) as w:
+            while pos < len(data):
+                k = int(rng.integers(1, 70_000))
+                w.write(data[pos:pos + k])
+                pos += k
+
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        rd = Reader(rfd)
+        assert rd.header() == Header(16, 12)
+        got = records_array(list(rd))
+        rd.close()
+    finally:
+        t.join()
+        os.close(rfd)
+    assert got.tobytes() == recs.tobytes()
+
+
 def test_reader_from_path_bgzf_parallel_inflate(tmp_path, oracle, monkeypatch):
     """bgzip'd input (to niffler: a multi-member gzip stream) is inflated block-parallel; bytes out are identical."""
     from tests.bgzf import bgzf_compress

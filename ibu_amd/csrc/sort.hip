@@ -44,6 +44,42 @@ __device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
   u32 lo = __shfl_up((u32)v, d), hi = __shfl_up((u32)(v >> 32), d);
   return ((u64)hi << 32) | lo;
 }
+// Match-any on an 8-bit digit: the lanes of the wave (among `valid`) whose digit equals this lane's, as two 32-bit halves, and from
+// them the lane's rank among its peers and the peers' count.  Written for the instructions it should become — per bit one
+// v_bfe_i32 (0 or ~0), one v_cmp (the ballot), two v_xnor with the ballot's halves as scalar operands, two v_and: six VALU —
+// because the scatter kernels turned out VALU-bound, not memory-bound (SQ counters, profiles/README.md r03_sq: 40 % of every wave's
+// cycles issuing VALU at two waves per SIMD), and the plain `m &= bit ? bal : ~bal` on a 64-bit m compiled to eleven per bit.
+struct DigitPeers { u32 before, count; };
+// PLAIN = true: the straightforward 64-bit form, kept for the 16-byte element passes, which it suits better (measured on one box,
+// same process order: 6.32 ms per pass against 6.82 with the six-instruction form — those passes are memory-bound and the
+// compiler's schedule of the longer form happens to overlap their loads better; the 12-byte passes gain 3.5 % from the short form).
+template <bool PLAIN = false>
+__device__ __forceinline__ DigitPeers match_digit(u32 d, u64 valid) {
+  DigitPeers r;
+  if constexpr (PLAIN) {
+    u64 m = valid;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const u64 bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    r.before = (u32)__popcll(m & ((1ull << (threadIdx.x & (kWave - 1))) - 1ull));
+    r.count = (u32)__popcll(m);
+    return r;
+  }
+  u32 mlo = (u32)valid, mhi = (u32)(valid >> 32);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const u32 s = (u32)__builtin_amdgcn_sbfe((int)d, (u32)b, 1u);
+    const u64 bal = __ballot(s != 0u);
+    mlo &= ~((u32)bal ^ s);                                   // s = ~0: the lanes with the bit set; s = 0: those without
+    mhi &= ~((u32)(bal >> 32) ^ s);
+  }
+  r.before = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // peers in the lanes below this one
+  r.count = (u32)__builtin_popcount(mlo) + (u32)__builtin_popcount(mhi);
+  return r;
+}
 __device__ __forceinline__ bool rec_less(u64 b, u64 u, u64 x, u64 pb, u64 pu, u64 px) {  // (b,u,x) < (pb,pu,px): record.rs:58
   return b != pb ? b < pb : (u != pu ? u < pu : x < px);
 }

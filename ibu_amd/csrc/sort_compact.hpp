@@ -223,7 +223,6 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
   u32* misc = whist + NW * kBins;
   uint8_t* sbin = reinterpret_cast<uint8_t*>(misc + 16);
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wib = tid >> 6;
-  const u64 lt_mask = (1ull << lane) - 1;
   const u32 ntiles = (u32)(((u64)n + T - 1) / T);
   struct Win { EV<W> v[ROUNDS]; IDX mypos; };
   // 1. every lane loads its elements (unconditional, clamped) and this tile's first output position per bin
@@ -253,17 +252,11 @@ ibu_k_sort_scatter_elems(const ElemT<W>* __restrict__ src, void* __restrict__ ds
     const u32 slot = wib * PER_WAVE + r * kWave + lane;
     const bool valid = slot < cnt;
     const u32 d = elem_byte<W>(v[r], byte);
-    u64 m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const u64 bal = __ballot(bit);
-      m &= bit ? bal : ~bal;
-    }
-    const u32 before = (u32)__popcll(m & lt_mask);
+    const DigitPeers pe = match_digit<W == 4>(d, __ballot(valid));
+    const u32 before = pe.before;
     const u32 prev = valid ? whist[wib * kBins + d] : 0;
     wave_lds_fence();                                        // every lane has read before the leaders write
-    if (valid && before == 0) whist[wib * kBins + d] = prev + (u32)__popcll(m);
+    if (valid && before == 0) whist[wib * kBins + d] = prev + pe.count;
     wave_lds_fence();
     dig[r] = d;
     rk[r] = prev + before;

@@ -7,10 +7,11 @@
 // least significant of the P first), everything that is left to decide lies INSIDE runs of equal prefix ("segments"),
 // and for P = ceil(log256(n / 8)) a segment of well-spread keys holds a handful of records.  ibu_k_sort_finish completes the
 // sort in ONE more pass: a workgroup takes the segments that START in its tile of T records (from the first segment head
-// in the tile to the first head at or behind the tile's end — up to M records of look-ahead), stages them in LDS, ranks
-// every record inside its segment by counting the records of the segment that order before it under the full 24-byte key
-// (quadratic in the segment length, which is why segments longer than M are refused), permutes in LDS and writes the
-// chunk out as consecutive 8-byte words.  4 passes + 1 instead of 24 at 1e9 records.
+// in the tile to the first head at or behind the tile's end — up to M records of look-ahead), stages them in LDS, marks the
+// segment heads in a bitmap, lets every record find its segment there and its place inside it under the full 24-byte key
+// (segments of one and two records on the spot, longer ones from a worklist by counting — quadratic in the segment length,
+// which is why segments longer than M are not ranked), permutes in LDS and writes the chunk out as half records.
+// 4 passes + 1 instead of 24 at 1e9 records.
 //   Keys that are NOT well spread (a few heavy prefixes) make long segments: the kernel then raises the overflow flag and the
 // host falls back to the full LSD passes (the prefix-sorted records are a permutation of the input; records with equal
 // keys are equal byte for byte, so nothing is lost but the time of the P passes).
@@ -21,29 +22,72 @@
 #ifndef IBU_FINISH24_M
 #define IBU_FINISH24_M 256
 #endif
-// 1024-record tiles + 256 of look-ahead: 37 KiB of LDS, four workgroups per CU.  1e9 full-range (32,32) records (profiles r03_o):
+// 1024-record tiles + 256 of look-ahead: 36 KiB of LDS, four workgroups per CU.  1e9 full-range (32,32) records (profiles r03_o):
 // (2048, 512) 17.2 ms, (1024, 512) 15.7, (1536, 256) 12.8, (1024, 256) 12.4.
 static constexpr int kFinishT = IBU_FINISH24_T, kFinishM = IBU_FINISH24_M;
+// The run of equal prefix that element i of the window belongs to, from the head bitmap (bit i of hw: element i differs from its
+// predecessor in a prefix byte): s0 = its head (found: there is one at or below i), nx = the next head above i (kNoHead: none in the
+// window).  The words at and next to i's answer for runs of up to 64 elements; longer ones walk on, word by word.
+static constexpr u32 kNoHead = 0xFFFFFFFFu;
+__device__ __forceinline__ void run_around(const u64* hw /*[-1 .. nwords]*/, u32 i, u32 nwords, u32& s0, bool& found, u32& nx) {
+  const u32 wi = i >> 6, bi = i & 63u;
+  const u64 w0 = hw[wi];
+  const u64 below = w0 & ((2ull << bi) - 1ull);              // heads at 64 wi .. i (bi = 63: 2 << 63 wraps to 0, minus 1 = all)
+  found = true;
+  if (below) s0 = (wi << 6) + 63u - (u32)__builtin_clzll(below);
+  else {
+    const u64 wp = hw[(int)wi - 1];
+    if (wp) s0 = ((wi - 1u) << 6) + 63u - (u32)__builtin_clzll(wp);
+    else {
+      found = false;
+      s0 = 0;
+      for (int k = (int)wi - 2; k >= 0; --k) {
+        const u64 w = hw[k];
+        if (w) { s0 = ((u32)k << 6) + 63u - (u32)__builtin_clzll(w); found = true; break; }
+      }
+    }
+  }
+  const u64 above = (w0 >> bi) >> 1;                         // bit 0: element i + 1
+  if (above) nx = i + 1u + (u32)__builtin_ctzll(above);
+  else {
+    const u64 wn = hw[wi + 1u];
+    if (wn) nx = ((wi + 1u) << 6) + (u32)__builtin_ctzll(wn);
+    else {
+      nx = kNoHead;
+      for (u32 k = wi + 2u; k < nwords; ++k) {
+        const u64 w = hw[k];
+        if (w) { nx = (k << 6) + (u32)__builtin_ctzll(w); break; }
+      }
+    }
+  }
+}
+// record a orders before record b under the full key (mask arithmetic, no branches); tie: what equal records answer
+__device__ __forceinline__ u32 rec_before(u64 a0, u64 a1, u64 a2, u64 b0, u64 b1, u64 b2, u32 tie) {
+  const u32 lt0 = a0 < b0, eq0 = a0 == b0, lt1 = a1 < b1, eq1 = a1 == b1, lt2 = a2 < b2, eq2 = a2 == b2;
+  return lt0 | (eq0 & (lt1 | (eq1 & (lt2 | (eq2 & tie)))));
+}
 template <int T, int M>
 struct FinishShape {
   static constexpr int L = T + M;                             // records staged per workgroup (+ 1 in front)
-  // LDS: stage 24 (L + 1) | head u8 [L + 1] (padded) | segstart u16 [L] | seglen u16 [L] | misc 16 x u32
-  static constexpr size_t lds = 24 * (size_t)(L + 1) + ((L + 1 + 15) & ~15) + 2 * (size_t)L + 2 * (size_t)L + 64;
+  static constexpr int HW = (L + 63) / 64;                     // 64-bit words of the head bitmap (one zero word in front, one behind)
+  // LDS: stage 24 (L + 1) | head bitmap u64 [HW + 2] | worklist u16 [L] | targets u16 [L] | misc 16 x u32
+  static constexpr size_t lds = 24 * (size_t)(L + 1) + 8 * (size_t)(HW + 2) + 2 * (size_t)L + 2 * (size_t)L + 64;
 };
 // PERSIST: persistent grid, the next tile's window prefetched into a second register set while this one is worked on (needs
 // 16-byte aligned records; the one-tile form takes any 8-byte aligned input: a shard at an odd record).
 template <int T, int M, bool PERSIST>
-__global__ void __launch_bounds__(kSortThreads, 4)   // 37 KiB of LDS: four workgroups per CU, if the registers allow (128 VGPRs)
+__global__ void __launch_bounds__(kSortThreads, 4)   // 36 KiB of LDS: four workgroups per CU, if the registers allow (128 VGPRs)
 ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64 pm0, u64 pm1, u64 pm2, u32* __restrict__ overflow) {
   typedef FinishShape<T, M> S;
   constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads, CH = (3 * L / 2 + kSortThreads - 1) / kSortThreads;
   static_assert((T * 24) % 16 == 0, "tiles must start at 16-byte boundaries of an aligned array");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u64* stage = reinterpret_cast<u64*>(smem) + 3;             // record i of the window at stage[3 i]; record -1 = the one in front
-  uint8_t* head = reinterpret_cast<uint8_t*>(stage + 3 * L);  // head[i]: record i starts a segment
-  uint16_t* segstart = reinterpret_cast<uint16_t*>(head + ((L + 1 + 15) & ~15));
-  uint16_t* seglen = segstart + L;
-  u32* misc = reinterpret_cast<u32*>(seglen + L);             // [0] first head in the tile, [1] first head at / behind T, [2] too long
+  u64* hw = stage + 3 * L + 1;                               // head bitmap (bit i: record i starts a segment), hw[-1] and hw[HW] stay zero
+  uint16_t* wl = reinterpret_cast<uint16_t*>(hw + S::HW + 1);  // worklist: the records of runs of three and more
+  uint16_t* tgt = wl + L;                                    // where each record of [begin, end) goes
+  u32* misc = reinterpret_cast<u32*>(tgt + L);               // [0] first head in the tile, [1] first head at / behind T, [2] inversion seen, [3] worklist length
+  static_assert(T % 64 == 0 && M % 64 == 0, "a word of the head bitmap lies on one side of M and of T");
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
   const u64 ntiles = (n + T - 1) / T;
   u64 tile = blockIdx.x;
@@ -83,21 +127,24 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
       for (u32 k = tid; k < 3 * len; k += kSortThreads) stage[k] = g[k];
       if (tid < 3) stage[(int)tid - 3] = base > 0 ? g[(int)tid - 3] : 0;
     }
-    if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
+    if (tid < (u32)S::HW + 2u) hw[(int)tid - 1] = 0ull;
+    if (tid < 4) misc[tid] = tid >= 2 ? 0u : 0xFFFFFFFFu;
     __syncthreads();
-    // 2. segment heads: the prefix differs from the predecessor's (row 0 of the array is a head).  With short runs nearly every
-    //    record is one: the first head of a wave's 64 goes to the LDS word, not 64 same-address atomics.
-    //    misc[0]: first head among the tile's first M records, misc[1]: first head in the look-ahead [T, T + M).
+    // 2. segment heads: the prefix differs from the predecessor's (row 0 of the array is a head).  A wave's 64 heads are one word
+    //    of the bitmap; misc[0]: first head among the tile's first M records, misc[1]: first head in the look-ahead [T, T + M).
+    const u32 nwords = (len + 63u) >> 6;
+#pragma unroll 1
     for (u32 i0 = tid - lane; i0 < len; i0 += kSortThreads) {
       const u32 i = i0 + lane;
       bool h = false;
       if (i < len) {
         const u64* r = stage + 3 * i;
         h = (base + i == 0) || (((r[0] ^ r[-3]) & pm0) | ((r[1] ^ r[-2]) & pm1) | ((r[2] ^ r[-1]) & pm2)) != 0;
-        head[i] = h;
       }
-      const u64 lo = __ballot(h && i < (u32)M), hi = __ballot(h && i >= (u32)T);
+      const u64 hm = __ballot(h);
       if (lane == 0) {
+        hw[i0 >> 6] = hm;
+        const u64 lo = i0 < (u32)M ? hm : 0ull, hi = i0 >= (u32)T ? hm : 0ull;
         if (lo) atomicMin(&misc[0], i0 + (u32)__builtin_ctzll(lo));
         if (hi) atomicMin(&misc[1], i0 + (u32)__builtin_ctzll(hi));
       }
@@ -115,74 +162,86 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
     else if (misc[1] != 0xFFFFFFFFu) end = misc[1];
     else if (base + len == n) end = len;                      // ... or inside the look-ahead
     else { end = (u32)T; end_is_head = false; }
-    // 3. short runs: every head walks to the next one; segstart for the members, seglen at the head
-    for (u32 i = begin + tid; i < end; i += kSortThreads)
-      if (head[i] || i == begin) {                            // (begin without a head: the part of a long run this tile owns)
-        u32 j = i + 1;
-        while (j < end && !head[j]) ++j;
-        if (head[i] && j - i <= (u32)M && (j < end || end_is_head)) {
-          for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
-          seglen[i] = (uint16_t)(j - i);
-        } else {
-          for (u32 k = i; k < j; ++k) segstart[k] = 0xFFFFu;   // part of a long run
-        }
-      }
-    __syncthreads();
-    // 4. rank inside the short runs under the full key (ties: window order — equal keys are equal records); long runs: identity
-    //    + order check
-    u64 k0[PER], k1[PER], k2[PER];
-    u32 target[PER];
+    // 3. every record finds its run in the bitmap and its place in the run (ibu_k_sort_finish_elems, step 3: runs of one and two
+    //    settled on the spot, longer short runs onto the worklist, long runs identity + order check)
+    auto short_run = [&](u32 s0, bool found, u32 nx, u32& m) -> bool {
+      const u32 stop = nx < end ? nx : end;
+      m = stop - s0;
+      return found && s0 >= begin && m <= (u32)M && (nx < end || end_is_head);
+    };
     bool inversion = false;
-#pragma unroll
-    for (int r = 0; r < PER; ++r) {
-      const u32 i = begin + tid + kSortThreads * r;
-      target[r] = 0xFFFFFFFFu;
-      if (i < end) {
-        const u64* me = stage + 3 * i;
-        k0[r] = me[0]; k1[r] = me[1]; k2[r] = me[2];
-        const u32 s0 = segstart[i];
-        if (s0 == 0xFFFFu) {                                  // part of a long run
-          target[r] = i;
-          if (!head[i]) {
-            const u32 lt0 = k0[r] < me[-3], eq0 = k0[r] == me[-3], lt1 = k1[r] < me[-2], eq1 = k1[r] == me[-2], lt2 = k2[r] < me[-1];
-            inversion = inversion || (lt0 | (eq0 & (lt1 | (eq1 & lt2)))) != 0;
-          }
+#pragma unroll 1
+    for (u32 i = begin + tid; i < end; i += kSortThreads) {
+      const u64* me = stage + 3 * i;
+      const u64 m0 = me[0], m1 = me[1], m2 = me[2];
+      u32 s0, nx, m;
+      bool found;
+      run_around(hw, i, nwords, s0, found, nx);
+      if (short_run(s0, found, nx, m)) {
+        if (m >= 3u) {
+          wl[atomicAdd(&misc[3], 1u)] = (uint16_t)i;          // its place comes in step 4
         } else {
-          const u32 s1 = s0 + seglen[s0];
-          u32 cnt = 0;
-          // four candidates per step, their LDS reads issued together (the lanes of a segment read the same record: broadcasts), and
-          // the comparison as mask arithmetic — the short-circuit form compiled to five branches per candidate and one LDS round
-          // trip per iteration: 159 ms per 1e9 records instead of ~15.  A segment of one record costs nothing.
-          if (s1 - s0 > 1)
-            for (u32 j = s0; j < s1; j += 4) {
-              u64 cb[4], cu[4], cx[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const u32 jj = j + q < s1 ? j + q : s1 - 1;  // clamped: in the window, not counted
-                const u64* o = stage + 3 * jj;
-                cb[q] = o[0]; cu[q] = o[1]; cx[q] = o[2];
-              }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const u32 lt0 = cb[q] < k0[r], eq0 = cb[q] == k0[r], lt1 = cu[q] < k1[r], eq1 = cu[q] == k1[r], lt2 = cx[q] < k2[r], eq2 = cx[q] == k2[r];
-                const u32 before = lt0 | (eq0 & (lt1 | (eq1 & (lt2 | (eq2 & (u32)(j + q < i))))));   // orders before me (ties: window order)
-                cnt += before & (u32)(j + q < s1);
-              }
-            }
-          target[r] = s0 + cnt;
+          const u32 p = m == 2u ? s0 + (u32)(i == s0) : i;     // the other record of a pair (a run of one: itself, which counts nothing)
+          const u64* o = stage + 3 * p;
+          tgt[i] = (uint16_t)(s0 + rec_before(o[0], o[1], o[2], m0, m1, m2, (u32)(p < i)));
         }
+      } else {                                                // part of a long run
+        tgt[i] = (uint16_t)i;
+        if (!((hw[i >> 6] >> (i & 63u)) & 1ull)) inversion = inversion || rec_before(m0, m1, m2, me[-3], me[-2], me[-1], 0u);
       }
     }
     if (inversion) misc[2] = 1u;
-    __syncthreads();                                          // every record is in registers: permute in place
+    __syncthreads();
+    // 4. the worklist: rank by counting inside the run, four candidates per step (their LDS reads issued together; the lanes of a
+    //    run read the same records: broadcasts), the comparison as mask arithmetic — the short-circuit form compiled to five
+    //    branches per candidate and one LDS round trip per iteration: 159 ms per 1e9 records instead of ~15
+    const u32 nwl = misc[3];
+    for (u32 t2 = tid; t2 < nwl; t2 += kSortThreads) {
+      const u32 i = wl[t2];
+      u32 s0, nx, m;
+      bool found;
+      run_around(hw, i, nwords, s0, found, nx);
+      (void)short_run(s0, found, nx, m);
+      const u64* me = stage + 3 * i;
+      const u64 m0 = me[0], m1 = me[1], m2 = me[2];
+      const u32 s1 = s0 + m;
+      u32 cnt = 0;
+      for (u32 j = s0; j < s1; j += 4) {
+        u64 cb[4], cu[4], cx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32 jj = j + q < s1 ? j + q : s1 - 1;        // clamped: in the window, not counted
+          const u64* o = stage + 3 * jj;
+          cb[q] = o[0]; cu[q] = o[1]; cx[q] = o[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cnt += rec_before(cb[q], cu[q], cx[q], m0, m1, m2, (u32)(j + q < i)) & (u32)(j + q < s1);   // ties: window order
+      }
+      tgt[i] = (uint16_t)(s0 + cnt);
+    }
+    __syncthreads();
     if (misc[2]) {                                            // a long run that is not in order: not this kernel's to sort
       if (tid == 0) *overflow = 1u;
       return;
     }
+    // every record of the range into registers, then to its place: permuted in place
+    u64 k0[PER], k1[PER], k2[PER];
+    u32 to[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const u32 i = begin + tid + kSortThreads * r;
+      to[r] = 0xFFFFFFFFu;
+      if (i < end) {
+        const u64* me = stage + 3 * i;
+        k0[r] = me[0]; k1[r] = me[1]; k2[r] = me[2];
+        to[r] = tgt[i];
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < PER; ++r)
-      if (target[r] != 0xFFFFFFFFu) {
-        u64* o = stage + 3 * target[r];
+      if (to[r] != 0xFFFFFFFFu) {
+        u64* o = stage + 3 * to[r];
         o[0] = k0[r]; o[1] = k1[r]; o[2] = k2[r];
       }
     __syncthreads();
@@ -227,7 +286,9 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
 template <int W, int T, int M>
 struct FinishElemShape {
   static constexpr int L = T + M;
-  static constexpr size_t lds = 4 * (size_t)W * (L + 1) + ((L + 1 + 15) & ~15) + 2 * (size_t)L + 2 * (size_t)L + 64;
+  static constexpr int HW = (L + 63) / 64;                     // 64-bit words of the head bitmap (one zero word in front, one behind)
+  static constexpr size_t stage_bytes = (4 * (size_t)W * (L + 1) + 7) & ~(size_t)7;
+  static constexpr size_t lds = stage_bytes + 8 * (size_t)(HW + 2) + 2 * (size_t)L + 2 * (size_t)L + 64;
 };
 template <int W>
 __device__ __forceinline__ u32 elem_before(const u32* a, const u32* b, u32 tie) {   // a orders before b (W-word integers; tie: what equal elements answer)
@@ -245,10 +306,10 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   constexpr int L = S::L, PER = (L + kSortThreads - 1) / kSortThreads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u32* stage = reinterpret_cast<u32*>(smem) + W;             // element i of the window at stage[W i]; element -1 = the one in front
-  uint8_t* head = reinterpret_cast<uint8_t*>(stage + W * L);
-  uint16_t* segstart = reinterpret_cast<uint16_t*>(head + ((L + 1 + 15) & ~15));
-  uint16_t* seglen = segstart + L;
-  u32* misc = reinterpret_cast<u32*>(seglen + L);
+  u64* hw = reinterpret_cast<u64*>(smem + S::stage_bytes) + 1;   // head bitmap, hw[-1] and hw[HW] stay zero
+  uint16_t* wl = reinterpret_cast<uint16_t*>(hw + S::HW + 1);    // worklist: the elements of runs of three and more
+  uint16_t* tgt = wl + L;                                    // ... and where they go
+  u32* misc = reinterpret_cast<u32*>(tgt + L);               // [0] [1] first heads, [2] inversion seen, [3] worklist length
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
   const u32 ntiles = (u32)((n + T - 1) / T);
   // which tiles this workgroup sweeps: b, b + grid, ...  (Every XCD owning one contiguous eighth of the tiles — so that the
@@ -273,7 +334,7 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
   auto work = [&](u32 t, const EV<W>* v, const EV<W>& front) {
     const u64 base = (u64)t * T;
     const u32 len = n - base < (u64)L ? (u32)(n - base) : (u32)L;
-    // 1. stage
+    // 1. stage; the head bitmap starts empty
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
       const u32 i = tid + kSortThreads * r;
@@ -286,10 +347,14 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
 #pragma unroll
       for (int w = 0; w < W; ++w) stage[w - W] = base > 0 ? front.w[w] : 0u;
     }
-    if (tid < 3) misc[tid] = tid == 2 ? 0u : 0xFFFFFFFFu;
+    if (tid < (u32)S::HW + 2u) hw[(int)tid - 1] = 0ull;
+    if (tid < 4) misc[tid] = tid >= 2 ? 0u : 0xFFFFFFFFu;
     __syncthreads();
-    // 2. heads (with short runs nearly every element is one: the first head of a wave's 64 goes to the LDS word, not 64 atomics).
-    //    misc[0]: first head among the tile's first M elements, misc[1]: first head in the look-ahead [T, T + M).
+    // 2. heads: element i differs from its predecessor in a prefix byte.  A wave's 64 heads are one word of the bitmap; misc[0]: first
+    //    head among the tile's first M elements, misc[1]: first head in the look-ahead.  (Steps 2 and 3 are rolled loops over LDS on
+    //    purpose: unrolled over the register copies they cost 9000 lines of code and 228 bytes of scratch per lane.)
+    const u32 nwords = (len + 63u) >> 6;
+#pragma unroll 1
     for (u32 i0 = tid - lane; i0 < len; i0 += kSortThreads) {
       const u32 i = i0 + lane;
       bool h = false;
@@ -298,10 +363,11 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
 #pragma unroll
         for (int w = 0; w < W; ++w) diff |= (stage[W * i + w] ^ stage[W * i + w - W]) & pm.w[w];
         h = (base + i == 0) || diff != 0;
-        head[i] = h;
       }
-      const u64 lo = __ballot(h && i < (u32)M), hi = __ballot(h && i >= (u32)T);
+      const u64 hm = __ballot(h);
       if (lane == 0) {
+        hw[i0 >> 6] = hm;
+        const u64 lo = i0 < (u32)M ? hm : 0ull, hi = i0 >= (u32)T ? hm : 0ull;   // M and T are multiples of 64: a word lies on one side
         if (lo) atomicMin(&misc[0], i0 + (u32)__builtin_ctzll(lo));
         if (hi) atomicMin(&misc[1], i0 + (u32)__builtin_ctzll(hi));
       }
@@ -323,67 +389,86 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
     else if (misc[1] != 0xFFFFFFFFu) end = misc[1];
     else if (base + len == n) end = len;                      // ... or inside the look-ahead
     else { end = (u32)T; end_is_head = false; }
-    // 3. short runs: every head walks to the next one; segstart for the members, seglen at the head
-    for (u32 i = begin + tid; i < end; i += kSortThreads)
-      if (head[i] || i == begin) {                            // (begin without a head: the part of a long run this tile owns)
-        u32 j = i + 1;
-        while (j < end && !head[j]) ++j;
-        if (head[i] && j - i <= (u32)M && (j < end || end_is_head)) {   // closed by heads (or the array's end) and short enough
-          for (u32 k = i; k < j; ++k) segstart[k] = (uint16_t)i;
-          seglen[i] = (uint16_t)(j - i);
-        } else {
-          for (u32 k = i; k < j; ++k) segstart[k] = 0xFFFFu;   // part of a long run
-        }
-      }
-    __syncthreads();
-    // 4. rank inside the short runs (a run of one record — the usual case — costs nothing); long runs: identity + order check
-    u32 me[PER][W];
-    u32 target[PER];
+    // 3. every element finds its run in the bitmap and its place in the run.  Runs of one and two — nearly all of them when the keys
+    //    are well spread — are settled on the spot with one comparison; the elements of longer short runs go onto a worklist that is
+    //    worked off densely afterwards.  (Round 3's first form let every head walk to the next one and every element loop over its
+    //    run: a wave then pays for the longest run among its 64 lanes in every round — 181 VALU and 151 scalar instructions per
+    //    element, profiles/README.md r03_sq.)  Long runs: identity + order check.
+    // a run [s0, s0 + m) is ranked when it starts with a head inside the range, is closed by a head (or by the array's end) and short
+    auto short_run = [&](u32 s0, bool found, u32 nx, u32& m) -> bool {
+      const u32 stop = nx < end ? nx : end;
+      m = stop - s0;
+      return found && s0 >= begin && m <= (u32)M && (nx < end || end_is_head);
+    };
     bool inversion = false;
+#pragma unroll 1
+    for (u32 i = begin + tid; i < end; i += kSortThreads) {
+      {
+        u32 me[W];
 #pragma unroll
-    for (int r = 0; r < PER; ++r) {
-      const u32 i = begin + tid + kSortThreads * r;
-      target[r] = 0xFFFFFFFFu;
-      if (i < end) {
+        for (int w = 0; w < W; ++w) me[w] = stage[W * i + w];
+        u32 s0, nx, m;
+        bool found;
+        run_around(hw, i, nwords, s0, found, nx);
+        if (short_run(s0, found, nx, m)) {
+          if (m >= 3u) {
+            wl[atomicAdd(&misc[3], 1u)] = (uint16_t)i;    // its place comes in step 4
+          } else {
+            const u32 p = m == 2u ? s0 + (u32)(i == s0) : i;   // the other element of a pair (a run of one: itself, which counts nothing)
+            u32 a[W];
 #pragma unroll
-        for (int w = 0; w < W; ++w) me[r][w] = stage[W * i + w];
-        const u32 s0 = segstart[i];
-        if (s0 == 0xFFFFu) {                                  // part of a long run
-          target[r] = i;
-          if (!head[i]) {                                     // same run as the element in front (i = 0: the one in front of the window)
+            for (int w = 0; w < W; ++w) a[w] = stage[W * p + w];
+            tgt[i] = (uint16_t)(s0 + elem_before<W>(a, me, (u32)(p < i)));
+          }
+        } else {                                              // part of a long run
+          tgt[i] = (uint16_t)i;
+          if (!((hw[i >> 6] >> (i & 63u)) & 1ull)) {          // same run as the element in front (i = 0: the one in front of the window)
             u32 prev[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) prev[w] = stage[W * i + w - W];
-            inversion = inversion || elem_before<W>(me[r], prev, 0u);
+            inversion = inversion || elem_before<W>(me, prev, 0u);
           }
-        } else {
-          const u32 m = seglen[s0];
-          u32 cnt = 0;
-          if (m > 1)
-            for (u32 j = s0; j < s0 + m; j += 2) {
-              const u32 j1 = j + 1 < s0 + m ? j + 1 : j;       // clamped: in the window, not counted
-              u32 a[W], b[W];
-#pragma unroll
-              for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
-              cnt += elem_before<W>(a, me[r], (u32)(j < i));
-              cnt += elem_before<W>(b, me[r], (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
-            }
-          target[r] = s0 + cnt;
         }
       }
     }
     if (inversion) misc[2] = 1u;
+    __syncthreads();
+    // 4. the worklist: rank by counting inside the run (mask arithmetic, two candidates per step)
+    const u32 nwl = misc[3];
+    for (u32 t2 = tid; t2 < nwl; t2 += kSortThreads) {
+      const u32 i = wl[t2];
+      u32 s0, nx, m;
+      bool found;
+      run_around(hw, i, nwords, s0, found, nx);
+      (void)short_run(s0, found, nx, m);
+      u32 me[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) me[w] = stage[W * i + w];
+      u32 cnt = 0;
+      for (u32 j = s0; j < s0 + m; j += 2) {
+        const u32 j1 = j + 1 < s0 + m ? j + 1 : j;             // clamped: in the window, not counted
+        u32 a[W], b[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
+        cnt += elem_before<W>(a, me, (u32)(j < i));
+        cnt += elem_before<W>(b, me, (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
+      }
+      tgt[i] = (uint16_t)(s0 + cnt);
+    }
     __syncthreads();
     if (misc[2]) {                                            // a long run that is not in order: not this kernel's to sort
       if (tid == 0) *overflow = 1u;
       return;
     }
 #pragma unroll
-    for (int r = 0; r < PER; ++r)
-      if (target[r] != 0xFFFFFFFFu) {
+    for (int r = 0; r < PER; ++r) {
+      const u32 i = tid + kSortThreads * r;
+      if (i >= begin && i < end) {
+        const u32 to = tgt[i];
 #pragma unroll
-        for (int w = 0; w < W; ++w) stage[W * target[r] + w] = me[r][w];
+        for (int w = 0; w < W; ++w) stage[W * to + w] = v[r].w[w];
       }
+    }
     __syncthreads();
     // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out).
     //    The lane's half (its parity; kSortThreads is even) is selected HERE, per tile: nine registers that would otherwise live
@@ -398,6 +483,7 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
       hbase[k] = ((3 * (hj ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
     }
     uint8_t* out = static_cast<uint8_t*>(dst_v) + 24 * (size_t)base;
+#pragma unroll 1
     for (u32 h = 2 * begin + tid; h < 2 * end; h += kSortThreads) {   // kSortThreads is even: a lane keeps its half
       const u32 p = h >> 1;
       u32 e[4] = {stage[W * p], stage[W * p + 1], stage[W * p + 2], 0};
@@ -406,7 +492,7 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
       o.x = hbase[0] | __builtin_amdgcn_perm(e[1], e[0], hsel[0][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[0][1]);
       o.y = hbase[1] | __builtin_amdgcn_perm(e[1], e[0], hsel[1][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[1][1]);
       o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
-      *reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * hj) = o;
+      __builtin_nontemporal_store(o, reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * hj));   // the chunk is contiguous: nothing for the L2 to merge
     }
   };
   EV<W> va[PER], vb[PER], fa, fb;

@@ -254,7 +254,6 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
   u32* misc = whist + NW * kBins;                            // [0..3] scan scratch
   uint8_t* sbin = reinterpret_cast<uint8_t*>(misc + 16);     // digit of each slot of the permuted tile
   const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wib = tid >> 6;
-  const u64 lt_mask = (1ull << lane) - 1;
   // XCD-aware tile order (speed only): hardware deals workgroup b to XCD b % 8, so XCD x gets the CONSECUTIVE tiles
   // [x * gridDim/8, (x+1) * gridDim/8) in dispatch order.  The run of bin d of tile t+1 continues where tile t's ended,
   // usually in the middle of a 128-byte line: with both tiles on one XCD, close in time, the two halves meet in that
@@ -302,17 +301,11 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
     if (valid) { r0[r] = stage[3 * slot]; r1[r] = stage[3 * slot + 1]; r2[r] = stage[3 * slot + 2]; }
     const u64 key = field == 0 ? r0[r] : (field == 1 ? r1[r] : r2[r]);
     const u32 d = (u32)(key >> shift) & 255u;
-    u64 m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const u64 bal = __ballot(bit);
-      m &= bit ? bal : ~bal;
-    }
-    const u32 before = (u32)__popcll(m & lt_mask);
+    const DigitPeers pe = match_digit(d, __ballot(valid));
+    const u32 before = pe.before;
     const u32 prev = valid ? whist[wib * kBins + d] : 0;
     wave_lds_fence();                                        // every lane has read before the leaders write
-    if (valid && before == 0) whist[wib * kBins + d] = prev + (u32)__popcll(m);
+    if (valid && before == 0) whist[wib * kBins + d] = prev + pe.count;
     wave_lds_fence();
     dig[r] = d;
     rk[r] = prev + before;

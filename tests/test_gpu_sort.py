@@ -462,6 +462,46 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
             assert p > (4 if lens[0] == 16 else 8), trace
 
 
+@pytest.mark.parametrize("n", [200_003, 1_000_003, 5_000_001])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 12)])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_finishing_kernel_ranks_runs_of_every_length_up_to_its_limit(ctx_guess_pf, oracle, n, lens, seed, capfd):
+    """Runs of equal prefix of 3 .. 256 elements — the worklist of the finishing kernel, and beyond 64 the word-by-word walk
+    through its head bitmap — placed where no sample looks, so that the estimate still takes the short prefix: each run is one
+    barcode (its own) with random UMIs, unsorted inside.  All ranked, no overflow, the oracle's bytes."""
+    recs = _shuffled(oracle, n, *lens)
+    rng = np.random.default_rng(n + seed)
+    recs["index"] = rng.integers(0, 2**30, n, dtype=np.uint64)
+    slots = 1 << 18
+    while slots > 1024 and slots * 96 + 128 > 24 * n:
+        slots >>= 1
+    nranges = 48
+    while nranges > 3 and nranges * 2048 > slots * 3 // 8:
+        nranges //= 2
+    stride = (n - 2048) // (nranges - 1)
+    at = next(q for q in range(32_768 + 64, n // 2 - 3064, 997)
+              if all(q + 3000 + 64 <= r * stride or q >= r * stride + 2048 + 64 for r in range(nranges)))
+    lengths = [3, 4, 7, 17, 63, 64, 65, 66, 127, 128, 129, 200, 255, 256, 256, 31, 2, 1, 193]
+    rng.shuffle(lengths)
+    pos = at
+    top = np.uint64(1) << np.uint64(2 * lens[0] - 1)
+    shift = np.uint64(2 * lens[0] - 16)                        # the shortest prefix the estimate may take: two bytes
+    for k, ln in enumerate(lengths):                           # run k: barcode drawn at random (its place in the sorted order: anywhere)
+        b = rng.integers(0, 1 << (2 * lens[0] - 1), dtype=np.uint64) | np.uint64(k)
+        others = (recs["barcode"] >> shift) == (b >> shift)   # ... and alone under every prefix: a run of 256 must stay one of 256
+        recs["barcode"][others] |= top
+        recs["barcode"][pos:pos + ln] = b
+        pos += ln
+    assert pos - at <= 3000
+    want = oracle.sort_records(recs).tobytes()
+    capfd.readouterr()
+    got, _ = _sort_on_device(ctx_guess_pf, recs)
+    trace = capfd.readouterr().err
+    assert got == want
+    if trace:
+        assert "path=compact-prefix+finish" in trace and "overflowed" not in trace, trace
+
+
 @pytest.mark.parametrize("lens,n", [((32, 32), 1_200_007), ((32, 12), 1_000_003), ((32, 12), 200_003)])
 @pytest.mark.parametrize("index", ["random", "read_order"])
 def test_sort_prefixes_longer_than_eight_bytes(ctx, oracle, lens, n, index, capfd):

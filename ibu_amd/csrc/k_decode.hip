@@ -111,42 +111,35 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
   }
 }
 
-// Single u64 column -> ASCII (stride-8 "records", 1 KiB tile).
+// Single u64 column -> ASCII (stride-8 "records").  NT 128-code tiles per wave iteration: with one (1 KiB of codes, a single
+// 16-byte load per lane and iteration) the waves sat parked on their loads 45 % of the time (SQ counters, profiles r03_sq) and the
+// kernel ran at 5.0 TB/s; the decode kernel had gained the same way (dec_nt).
+constexpr int unpack_nt(int len) { return len == 0 ? 1 : 2; }   // (four tiles spill under the 64-VGPR budget of eight waves per SIMD)
 template <int LEN, bool MSB>
 __global__ void __launch_bounds__(kBlock, dword_len(LEN) ? 8 : 3)
-ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles, u32 len, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * 1024];
+ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles /*of NT x 128 codes*/, u32 len, uint8_t* __restrict__ out) {
+  constexpr int NT = unpack_nt(LEN);
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * 1024 * NT];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * 1024;
-  const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
-  const u32 nwaves = tr.stride;
-  u32 t = tr.t;
-  ntiles = tr.end;
-  if (t >= ntiles) return;
+  uint8_t* tile = lds + wib * 1024 * NT;
   if (LEN > 0) len = LEN;
   const uint8_t* base = reinterpret_cast<const uint8_t*>(codes) + 16 * lane;
-  u32x4 a = ld16(base + (size_t)t * 1024);
-  for (;;) {                                   // two phases, registers swap roles: see decode
-    u32 tn = t + nwaves;
-    bool more = tn < ntiles;
-    u32x4 b = ld16(base + (size_t)(more ? tn : t) * 1024);
-    wave_lds_fence();
-    *reinterpret_cast<u32x4*>(tile + 16 * lane) = MSB ? rev_pairs_x2(a, len) : a;  // lane's chunk = code words 2L, 2L+1
-    wave_lds_fence();
-    expand_field<LEN>(tile, 8, 0, len, out + (size_t)t * kTileRecs * len, lane);
-    if (!more) break;
-    t = tn;
-    tn = t + nwaves;
-    more = tn < ntiles;
-    a = ld16(base + (size_t)(more ? tn : t) * 1024);
-    wave_lds_fence();
-    *reinterpret_cast<u32x4*>(tile + 16 * lane) = MSB ? rev_pairs_x2(b, len) : b;
-    wave_lds_fence();
-    expand_field<LEN>(tile, 8, 0, len, out + (size_t)t * kTileRecs * len, lane);
-    if (!more) break;
-    t = tn;
-  }
+  struct Regs { u32x4 v[NT]; };
+  sweep_tiles<Regs>(
+      tile_range(ntiles, wib),                                // which tiles this wave sweeps (kcommon.hpp)
+      [&](Regs& g, u32 t) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) g.v[k] = ld16(base + ((size_t)t * NT + k) * 1024);
+      },
+      [&](const Regs& g, u32 t) {
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NT; ++k)                          // lane's chunk = code words 2L, 2L+1 of sub-tile k
+          *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = MSB ? rev_pairs_x2(g.v[k], len) : g.v[k];
+        wave_lds_fence();
+        expand_field<LEN, NT>(tile, 8, 0, len, out + (size_t)t * NT * kTileRecs * len, lane);
+      });
 }
 
 // ---- tails: one thread per record, any alignment -----------------------------------------------
@@ -221,12 +214,13 @@ hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, 
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[2] = {{codes, 8}, {out, len}};
-  const RowSplit rs = split_rows(sp, 2, n, kTileRecs);
+  const size_t tile_recs = (size_t)kTileRecs * unpack_nt(len_of_mode(mode_of_len(len)));
+  const RowSplit rs = split_rows(sp, 2, n, tile_recs);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_unpack_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)codes, (u64)0, (u64)rs.head,
                        len, cfg.base_order, out);
   if (rs.main) {
-    const u32 ntiles = (u32)(rs.main / kTileRecs);
+    const u32 ntiles = (u32)(rs.main / tile_recs);
     const int m = mode_of_len(len), mo = cfg.base_order ? 1 : 0;
     static std::atomic<int> occ[2][kNumLenModes];
     hipLaunchKernelGGL(kUnpTable[mo][m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kUnpTable[mo][m], 0, &occ[mo][m]))),

@@ -60,6 +60,16 @@ pub struct ibu_alloc_probe_t {
     pub ms: [f32; 16],
 }
 
+/// One shard of `ibu_sort_records_contexts`: `n` records in `d_records` (room for `capacity`), `d_tmp` = capacity * 24 bytes.
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct ibu_sort_shard_t {
+    pub d_records: *mut c_void,
+    pub d_tmp: *mut c_void,
+    pub n: usize,
+    pub capacity: usize,
+}
+
 #[repr(C)]
 pub struct ibu_decode_sink_t {
     pub d_bc_ascii: *mut u8,
@@ -194,6 +204,7 @@ extern "C" {
                         d_records: *mut c_void, stream: *mut c_void) -> i32;
     pub fn ibu_sort_records(ctx: *mut ibu_ctx_t, d_records: *mut c_void, d_tmp: *mut c_void, n: usize,
                             stream: *mut c_void) -> i32;
+    pub fn ibu_sort_records_contexts(ctxs: *const *mut ibu_ctx_t, n_ctxs: usize, shards: *mut ibu_sort_shard_t) -> i32;
     pub fn ibu_lower_bound_records(ctx: *mut ibu_ctx_t, d_sorted_records: *const c_void, n: usize, d_keys: *const c_void, k: usize,
                                    d_pos: *mut u64, stream: *mut c_void) -> i32;
     pub fn ibu_records_first_mismatch(ctx: *mut ibu_ctx_t, d_a: *const c_void, d_b: *const c_void, n: usize, first: *mut u64,

@@ -509,6 +509,19 @@ pub mod device {
         pub fn sort_records(&self, recs: &DeviceBuf, tmp: &DeviceBuf, n: usize) -> Result<()> {
             check(unsafe { ffi::ibu_sort_records(self.raw, recs.ptr, tmp.ptr, n, std::ptr::null_mut()) })
         }
+        /// The same order over several shards, one per context (= per GPU), in one call (`ibu_sort_records_contexts`): shard i
+        /// ends up with the i-th range of the global order; returns the new record counts.  `shards[i]` = (records, tmp, n,
+        /// capacity in records) on `ctxs[i]`'s device.
+        pub fn sort_records_contexts(ctxs: &[&Context], shards: &[(&DeviceBuf, &DeviceBuf, usize, usize)]) -> Result<Vec<usize>> {
+            assert_eq!(ctxs.len(), shards.len());
+            let raw: Vec<*mut ffi::ibu_ctx_t> = ctxs.iter().map(|c| c.raw).collect();
+            let mut sh: Vec<ffi::ibu_sort_shard_t> = shards
+                .iter()
+                .map(|(r, t, n, cap)| ffi::ibu_sort_shard_t { d_records: r.ptr, d_tmp: t.ptr, n: *n, capacity: *cap })
+                .collect();
+            check(unsafe { ffi::ibu_sort_records_contexts(raw.as_ptr(), raw.len(), sh.as_mut_ptr()) })?;
+            Ok(sh.iter().map(|s| s.n).collect())
+        }
         /// `a[..n] == b[..n]` on device-resident records (`Record: PartialEq`), with the position: the index of the
         /// first record that differs, `n` if none does.
         pub fn first_mismatch(&self, a: &DeviceBuf, b: &DeviceBuf, n: usize) -> Result<usize> {

@@ -715,6 +715,18 @@ class Context:
     def sort_records(self, d_records, d_tmp, n, stream=None):
         _check(lib.ibu_sort_records(self._c, _dptr(d_records), _dptr(d_tmp), n, stream))
 
+    @staticmethod
+    def sort_records_contexts(ctxs, shards):
+        """The sort over several shards, one per context (= per GPU), in one call (ibu_sort_records_contexts): shards =
+        [(d_records, d_tmp, n, capacity_in_records), ...]; returns the new record counts — shard i holds the i-th
+        contiguous range of the global order."""
+        arr = (C.c_void_p * len(ctxs))(*[c._c for c in ctxs])
+        sh = (_lib.CSortShard * len(shards))()
+        for k, (r, t, n, cap) in enumerate(shards):
+            sh[k].d_records, sh[k].d_tmp, sh[k].n, sh[k].capacity = _dptr(r).value, _dptr(t).value, n, cap
+        _check(lib.ibu_sort_records_contexts(arr, len(ctxs), sh))
+        return [int(x.n) for x in sh]
+
     def barcode_counts(self, d_sorted_records, n, unique_umis=True, stream=None):
         """BarcodeAnalyzer (parallel.rs:72-98) on sorted device records ->
         (barcodes, counts, unique_umis | None) as numpy u64 arrays in ascending barcode order."""

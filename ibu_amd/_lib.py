@@ -43,6 +43,10 @@ class CKeyPlan(C.Structure):  # ibu_key_plan_t
     _fields_ = [("csel", (u32 * 3) * 4), ("xsel", (u32 * 2) * 6), ("k", u32), ("index_bytes", u32), ("base", u64 * 3)]
 
 
+class CSortShard(C.Structure):  # ibu_sort_shard_t
+    _fields_ = [("d_records", C.c_void_p), ("d_tmp", C.c_void_p), ("n", C.c_size_t), ("capacity", C.c_size_t)]
+
+
 class CAllocProbe(C.Structure):  # ibu_alloc_probe_t
     _fields_ = [("tries", u32), ("chosen", u32), ("ms", C.c_float * 16)]
 
@@ -157,6 +161,7 @@ SIGNATURES = {
     "ibu_writer_write_batch_device_on": (i32, [vp, vp, P(CRingConfig), vp, sz, vp, P(CStreamStats)]),
     "ibu_mmap_process_device": (i32, [vp, vp, P(CRingConfig), i32, sz, sz, vp, P(CStreamStats)]),
     "ibu_mmap_process_devices": (i32, [vp, P(i32), sz, P(CRingConfig), i32, vp, P(CReduceResult), P(CStreamStats)]),
+    "ibu_sort_records_contexts": (i32, [P(vp), sz, P(CSortShard)]),
     "ibu_mmap_process_contexts": (i32, [vp, P(vp), sz, P(CRingConfig), i32, vp, P(CReduceResult), P(CStreamStats)]),
     "ibu_reader_process_device": (i32, [vp, vp, P(CRingConfig), i32, vp, P(CStreamStats)]),
 }

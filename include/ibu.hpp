@@ -394,6 +394,13 @@ class Context {
   }
   void copy(void* d_dst, const void* d_src, size_t bytes, void* st = nullptr) { check(ibu_device_copy(c_, d_dst, d_src, bytes, st)); }
   void sort_records(void* d_recs, void* d_tmp, size_t n, void* st = nullptr) { check(ibu_sort_records(c_, d_recs, d_tmp, n, st)); }
+  // the sort over several shards, one per context (= per GPU), in one call: shard i ends up with the i-th range of the global
+  // order and shards[i].n says how long it is (ibu_sort_records_contexts)
+  static void sort_records_contexts(const std::vector<Context*>& ctxs, std::vector<ibu_sort_shard_t>& shards) {
+    std::vector<ibu_ctx_t*> raw;
+    for (Context* c : ctxs) raw.push_back(c->c_);
+    check(ibu_sort_records_contexts(raw.data(), raw.size(), shards.data()));
+  }
   void lower_bound(const void* d_sorted, size_t n, const void* d_keys, size_t k, uint64_t* d_pos, void* st = nullptr) { check(ibu_lower_bound_records(c_, d_sorted, n, d_keys, k, d_pos, st)); }
   // index of the first record that differs, n if the slices are equal (Record: PartialEq, record.rs:58)
   size_t first_mismatch(const void* d_a, const void* d_b, size_t n, void* st = nullptr) { uint64_t f = 0; check(ibu_records_first_mismatch(c_, d_a, d_b, n, &f, st)); return (size_t)f; }

@@ -363,6 +363,26 @@ int32_t ibu_device_copy(ibu_ctx_t* ctx, void* d_dst, const void* d_src, size_t b
  * d_records) (option "sort_compact").  Large inputs whose keys are well spread take passes over the most significant
  * varying bytes only and one finishing pass (option "sort_hybrid"); the result is the same bytes on every path. */
 int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n, void* stream);
+
+/* The same order over SEVERAL shards, one per context (= per GPU), in one call — the multi-GPU form of the sort (SURVEY 8f-2:
+ * sample sort with one device-to-device exchange), as ibu_mmap_process_contexts is the multi-GPU form of process_parallel.
+ * shards[i] lives on ctxs[i]'s device: n records in d_records, which has room for `capacity` records; d_tmp: capacity * 24
+ * bytes of scratch on the same device.  On return shard i holds the i-th contiguous range of the global order and
+ * shards[i].n says how many records that is (their sum is unchanged): every shard is sorted where it lives, up to 64 x n_ctxs
+ * evenly spaced samples of each pick n_ctxs - 1 splitters, every shard is cut at them by a binary search on its device,
+ * every owner pulls its pieces (hipMemcpyPeerAsync: over xGMI between GPUs) and sorts what it received.  One host thread
+ * per context; the first error in context order is the call's.  A shard that would receive more than its capacity:
+ * IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) with every shard sorted locally and
+ * nothing moved — leave headroom for uneven splits (the samples balance well-spread keys to a few percent; many equal records
+ * all go to one owner).  n_ctxs == 1 is ibu_sort_records.  Two contexts may share a device (a rehearsal on one GPU); the same
+ * context twice is refused.  Synchronous. */
+typedef struct ibu_sort_shard {
+  void* d_records; /* device, 8-byte aligned: `capacity` records of room, `n` of them valid */
+  void* d_tmp;     /* device, 8-byte aligned: capacity * 24 bytes of scratch                 */
+  size_t n;        /* in: records of this shard; out: records of its range of the global order */
+  size_t capacity;
+} ibu_sort_shard_t;
+int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ctxs, ibu_sort_shard_t* shards);
 /* Per-barcode aggregation of SORTED device records: the device form of the reference's BarcodeAnalyzer
  * processor (src/parallel.rs:72-98 — HashMap<barcode, count> merged in on_batch_complete).  Writes, in
  * ascending barcode order, d_barcodes[k], d_counts[k] (records with that barcode) and, when

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "check.hpp"
@@ -93,6 +94,35 @@ TEST(sort_matches_oracle_and_aggregation_follows) {
     CHECK_EQ(got.size(), k);
     for (size_t i = 0; i < k; ++i) CHECK(got[i] == std::make_tuple(b[i], c[i], u[i]));
   }
+}
+TEST(sort_over_several_contexts_is_one_order) {
+  // ibu_sort_records_contexts: three shards on three contexts (all on this box's GPU) come back as the ranges of one order
+  const size_t counts[3] = {70001, 0, 130007}, total = 200008, cap = total;
+  auto recs = oracle_records(0x1B00009, 0, total, 16, 12);
+  std::reverse(recs.begin(), recs.end());
+  device::Context c1(0), c2(0);
+  std::vector<device::Context*> cs = {&ctx(), &c1, &c2};
+  std::vector<std::unique_ptr<DeviceBuffer>> bufs;
+  std::vector<ibu_sort_shard_t> shards;
+  size_t at = 0;
+  for (int i = 0; i < 3; ++i) {
+    bufs.emplace_back(new DeviceBuffer(*cs[i], cap * 24));
+    bufs.emplace_back(new DeviceBuffer(*cs[i], cap * 24));
+    if (counts[i]) bufs[2 * i]->upload(std::vector<Record>(recs.begin() + at, recs.begin() + at + counts[i]));
+    shards.push_back({bufs[2 * i]->ptr(), bufs[2 * i + 1]->ptr(), counts[i], cap});
+    at += counts[i];
+  }
+  device::Context::sort_records_contexts(cs, shards);
+  orc_sort_records(reinterpret_cast<orc_record*>(recs.data()), total);
+  std::vector<Record> got;
+  for (int i = 0; i < 3; ++i) {
+    auto part = bufs[2 * i]->download<Record>(shards[i].n);
+    got.insert(got.end(), part.begin(), part.end());
+  }
+  CHECK_EQ(got.size(), total);
+  CHECK(got == recs);
+  shards[0].capacity = 10; shards[0].n = 10;                 // a shard that cannot hold its share: refused with the numbers
+  CHECK_THROWS(InvalidArg, device::Context::sort_records_contexts(cs, shards), {});
 }
 TEST(compacted_keys_round_trip) {
   // census -> plan -> 12-byte elements -> records: the exchange format of the multi-GPU sort (ibu_records_compact / _expand)

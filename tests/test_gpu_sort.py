@@ -906,3 +906,76 @@ def test_compact_rejects_more_than_12_varying_bytes(ctx, oracle, ia):
     assert err.value.kind == "InvalidArg"
     with pytest.raises(ia.IbuError):
         ctx.expand(plan, e, 1000, d)
+
+
+# ---- the sort over several shards, one per context, in one call (ibu_sort_records_contexts) ------------------------------
+@pytest.mark.parametrize("counts", [[5000], [3000, 7001], [0, 4000, 1], [100_003, 0, 250_000, 77], [1, 1, 1], [0, 0],
+                                    [1_000_003, 999_999, 1_300_001]])
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32)])
+def test_sort_records_contexts_is_the_global_order(ia, oracle, counts, lens):
+    """Shards on several contexts (here: all on the box's one GPU, the rehearsal the API allows) come back as the contiguous ranges
+    of ONE sorted sequence: their concatenation is the oracle's sort of all records, byte for byte, and the counts add up."""
+    total = sum(counts)
+    recs = oracle.generate(SEED + len(counts), 0, total, *lens)
+    rng = np.random.default_rng(total + len(counts))
+    rng.shuffle(recs)
+    recs["index"] = rng.integers(0, 2**30, total, dtype=np.uint64)
+    want = oracle.sort_records(recs).tobytes()
+    cap = max(total, len(counts) + 1)
+    ctxs = [ia.Context(0) for _ in counts]
+    try:
+        shards, at = [], 0
+        for c, n in zip(ctxs, counts):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            if n:
+                d.upload(recs[at:at + n])
+            shards.append((d, t, n, cap))
+            at += n
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        assert sum(out) == total
+        got = b"".join(shards[k][0].download(count=24 * out[k]).tobytes() for k in range(len(counts)))
+        assert got == want
+        if total >= 100_000 and len(counts) > 1:                # the samples balance well-spread keys
+            assert max(out) <= 1.3 * total / len(counts), out
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_sort_records_contexts_refuses_what_does_not_fit(ia, oracle):
+    """A shard that would receive more than its capacity: InvalidArg with the numbers, every shard sorted locally, nothing moved;
+    the same context twice, a shard above its capacity, NULL buffers: refused before anything runs."""
+    n = 50_000
+    a = oracle.generate(SEED, 0, n, 16, 12)
+    a["barcode"] |= np.uint64(1) << np.uint64(31)             # shard 0 holds the large keys, shard 1 the small ones:
+    b = oracle.generate(SEED + 1, 0, n, 16, 12)
+    b["barcode"] &= (np.uint64(1) << np.uint64(31)) - np.uint64(1)   # sorted globally, every record changes sides
+    c0, c1 = ia.Context(0), ia.Context(0)
+    try:
+        d0, t0, d1, t1 = c0.upload(a), c0.alloc(24 * n), c1.upload(b), c1.alloc(24 * n)
+        out = ia.Context.sort_records_contexts([c0, c1], [(d0, t0, n, n), (d1, t1, n, n)])
+        assert out == [n, n]
+        assert d0.download(count=24 * n).tobytes() == oracle.sort_records(b).tobytes()
+        assert d1.download(count=24 * n).tobytes() == oracle.sort_records(a).tobytes()
+        # uneven: everything belongs to one owner's half, which has no room for it
+        small = oracle.generate(SEED + 2, 0, 1000, 16, 12)
+        ds, ts = c1.upload(small), c1.alloc(24 * 1000)
+        d0.upload(a)
+        with pytest.raises(ia.IbuError) as e:
+            ia.Context.sort_records_contexts([c0, c1], [(d0, t0, n, n), (ds, ts, 1000, 1000)])
+        assert e.value.kind == "InvalidArg" and e.value.b == 1000 and e.value.a > 1000, (e.value.kind, e.value.a, e.value.b)
+        assert d0.download(count=24 * n).tobytes() == oracle.sort_records(a).tobytes()          # sorted locally, not moved
+        assert ds.download(count=24 * 1000).tobytes() == oracle.sort_records(small).tobytes()
+        for bad in ([(d0, t0, n, n), (d0, t0, n, n)],):
+            with pytest.raises(ia.IbuError) as e:
+                ia.Context.sort_records_contexts([c0, c0], bad)
+            assert e.value.kind == "InvalidArg"
+        with pytest.raises(ia.IbuError) as e:
+            ia.Context.sort_records_contexts([c0, c1], [(d0, t0, n + 1, n), (d1, t1, n, n)])
+        assert e.value.kind == "InvalidArg"
+        with pytest.raises(ia.IbuError) as e:
+            ia.Context.sort_records_contexts([c0, c1], [(0, 0, n, n), (d1, t1, n, n)])
+        assert e.value.kind == "InvalidArg"
+    finally:
+        c0.close()
+        c1.close()

@@ -20,6 +20,30 @@ def _rand_bits(torch, g, nbits, count):
     return (hi << 32) | torch.randint(0, 1 << 32, (count,), generator=g, device="cuda", dtype=torch.int64)
 
 
+def shards_main(a, ia, bc_len, umi_len):
+    k = a.shards
+    ctxs = [ia.Context(0) for _ in range(k)]
+    for n in (int(float(x)) for x in a.records.split(",")):
+        per, cap = n // k, int(n // k * 1.25) + k + 1
+        bufs = [(c.alloc(24 * cap), c.alloc(24 * cap)) for c in ctxs]
+        ts, outs = [], None
+        for _ in range(a.rounds + 1):
+            for i, (c, (d, t)) in enumerate(zip(ctxs, bufs)):     # shard i = rows [i per, (i + 1) per) of the generator's stream
+                c.generate(0x1B00005, i * per, per, bc_len, umi_len, d)
+                c.synchronize()
+            t0 = time.perf_counter()
+            outs = ia.Context.sort_records_contexts(ctxs, [(d, t, per, cap) for d, t in bufs])
+            ts.append(time.perf_counter() - t0)
+        assert sum(outs) == per * k and all(c.is_sorted(d, m) for c, (d, _), m in zip(ctxs, bufs, outs))
+        sec = statistics.median(ts[1:])
+        print(json.dumps({"n": per * k, "lens": [bc_len, umi_len], "contexts_on_device_0": k, "seconds": round(sec, 4),
+                          "M_records_per_s": round(per * k / sec / 1e6, 1), "records_per_shard_after": outs,
+                          "note": "one GPU: the K local sorts share it and the exchange is a device-local copy"}), flush=True)
+        for d, t in bufs:
+            d.free()
+            t.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", default="1e8")
@@ -36,6 +60,9 @@ def main():
     ap.add_argument("--whitelist", type=int, default=0,
                     help="K > 0: barcodes drawn from K distinct ones with a skewed distribution (rank ~ K u^3: a single-cell run, where a few "
                          "thousand cells hold most reads), random UMIs, records in read order; built on the device with torch")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="K > 0: time ibu_sort_records_contexts over K contexts instead — all on device 0 (the one-GPU rehearsal of the "
+                         "multi-GPU sort: K local sorts, the device-to-device exchange, K sorts of what arrived), n / K records each")
     ap.add_argument("--presorted", action="store_true", help="also time ibu_sort_records on the SORTED result (the already-sorted fast exit: one read-only census)")
     a = ap.parse_args()
     if a.whitelist:
@@ -44,6 +71,8 @@ def main():
     import ibu_amd as ia
 
     bc_len, umi_len = (int(x) for x in a.lens.split(","))
+    if a.shards:
+        return shards_main(a, ia, bc_len, umi_len)
     ctx = ia.Context(0)
     for n in (int(float(x)) for x in a.records.split(",")):
         d, t = ctx.alloc(24 * n), ctx.alloc(24 * n)

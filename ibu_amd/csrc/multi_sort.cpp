@@ -8,11 +8,15 @@
 // process_contexts (stream.cpp); the phases are separated by joins, which is all the cross-device ordering there is.
 //
 // The one-process-per-GPU form of the same algorithm is ibu_amd/sharding.py (torch.distributed: all-gather of the samples,
-// all-to-all of 12-byte compacted keys); this form ships 24-byte records and needs no collective library.  Neither has run
+// all-to-all of 12-byte compacted keys); this form needs no collective library and ships the same 12-byte elements whenever
+// the keys of all shards allow it.  Neither has run
 // on more than one distinct GPU yet (no multi-GPU box in any round's budget): unmeasured.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -122,27 +126,59 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
                          "shard %zu would receive %zu records, its capacity is %zu (the shards are sorted locally, nothing was moved)", j,
                          n_out[j], shards[j].capacity);
     }
-    // 5. the exchange: every owner pulls its pieces device to device into its scratch, copies them over its records and sorts
+    // 5. the exchange.  When at most 12 key bytes vary over ALL shards (the census words of every shard combined: one plan for
+    //    everybody) the records travel as 12-byte elements — half the bytes on the links (ibu_records_compact / _expand, the
+    //    exchange format of ibu_amd/sharding.py): every shard compacts itself into the lower half of its scratch, every owner
+    //    pulls its pieces into the upper half, expands them over its records and sorts.  Otherwise 24-byte records travel into
+    //    the owner's scratch and are copied over its records before the sort.
+    ibu_key_plan_t plan;
+    memset(&plan, 0, sizeof plan);
+    bool compact = ctxs[0]->cfg.sort_compact != 0;
+    if (compact) {
+      std::vector<std::array<uint64_t, 8>> words(W);
+      rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
+      if (rc) return rc;
+      uint64_t o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
+      for (auto& w : words)
+        for (int f = 0; f < 3; ++f) { o[f] |= w[f]; a[f] &= w[3 + f]; }
+      rc = ibu_key_plan_init(o, a, &plan);
+      if (rc) return rc;
+      compact = plan.k <= 12;
+    }
+    const size_t wire = compact ? 12 : kRec;                  // bytes per record on the links
+    if (compact) {
+      rc = on_every_context(W, [&](size_t i) -> int32_t {
+        int32_t r = ibu_records_compact(ctxs[i], &plan, shards[i].d_records, shards[i].n, shards[i].d_tmp, nullptr);
+        return r ? r : ibu_ctx_synchronize(ctxs[i], nullptr);
+      });
+      if (rc) return rc;
+    }
     rc = on_every_context(W, [&](size_t j) -> int32_t {
       IBU_HIP(hipSetDevice(ctxs[j]->device));
-      uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp);
+      uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp) + (compact ? 12 * shards[j].capacity : 0);
       for (size_t i = 0; i < W; ++i) {
         const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
         if (!cnt) continue;
-        const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_records) + kRec * bound[i][j];
-        IBU_HIP(hipMemcpyPeerAsync(t + kRec * land[j][i], ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ctxs[j]->stream));
+        const uint8_t* src = static_cast<const uint8_t*>(compact ? shards[i].d_tmp : shards[i].d_records) + wire * bound[i][j];
+        IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ctxs[j]->stream));
       }
       IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
       return IBU_OK;
     });
-    if (rc) return rc;                                        // (joined: nobody overwrites records a peer is still reading)
+    if (rc) return rc;                                        // (joined: nobody overwrites what a peer is still reading)
     rc = on_every_context(W, [&](size_t j) -> int32_t {
-      int32_t r = n_out[j] ? ibu_device_copy(ctxs[j], shards[j].d_records, shards[j].d_tmp, kRec * n_out[j], nullptr) : IBU_OK;
+      int32_t r = IBU_OK;
+      if (n_out[j]) {
+        uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp);
+        r = compact ? ibu_records_expand(ctxs[j], &plan, t + 12 * shards[j].capacity, n_out[j], shards[j].d_records, nullptr)
+                    : ibu_device_copy(ctxs[j], shards[j].d_records, t, kRec * n_out[j], nullptr);
+      }
       if (!r) r = ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr);
       if (!r) r = ibu_ctx_synchronize(ctxs[j], nullptr);
       return r;
     });
     if (rc) return rc;
+    if (getenv("IBU_TRACE_SORT")) fprintf(stderr, "ibu sort: contexts=%zu exchange=%zu bytes per record\n", W, wire);
     for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   } catch (...) {
     return caught_io("ibu_sort_records_contexts");

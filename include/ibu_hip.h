@@ -370,7 +370,9 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * bytes of scratch on the same device.  On return shard i holds the i-th contiguous range of the global order and
  * shards[i].n says how many records that is (their sum is unchanged): every shard is sorted where it lives, up to 64 x n_ctxs
  * evenly spaced samples of each pick n_ctxs - 1 splitters, every shard is cut at them by a binary search on its device,
- * every owner pulls its pieces (hipMemcpyPeerAsync: over xGMI between GPUs) and sorts what it received.  One host thread
+ * every owner pulls its pieces (hipMemcpyPeerAsync: over xGMI between GPUs) and sorts what it received.  When at most 12 key
+ * bytes vary over all shards the pieces travel as 12-byte elements (ibu_records_compact / _expand with one plan from the
+ * combined census words: half the bytes on the links; option "sort_compact" = 0 on ctxs[0] keeps 24-byte records).  One host thread
  * per context; the first error in context order is the call's.  A shard that would receive more than its capacity:
  * IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) with every shard sorted locally and
  * nothing moved — leave headroom for uneven splits (the samples balance well-spread keys to a few percent; many equal records

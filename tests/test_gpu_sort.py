@@ -911,10 +911,12 @@ def test_compact_rejects_more_than_12_varying_bytes(ctx, oracle, ia):
 # ---- the sort over several shards, one per context, in one call (ibu_sort_records_contexts) ------------------------------
 @pytest.mark.parametrize("counts", [[5000], [3000, 7001], [0, 4000, 1], [100_003, 0, 250_000, 77], [1, 1, 1], [0, 0],
                                     [1_000_003, 999_999, 1_300_001]])
-@pytest.mark.parametrize("lens", [(16, 12), (32, 32)])
-def test_sort_records_contexts_is_the_global_order(ia, oracle, counts, lens):
+@pytest.mark.parametrize("lens,compact", [((16, 12), True), ((16, 12), False), ((32, 32), True)])
+def test_sort_records_contexts_is_the_global_order(ia, oracle, counts, lens, compact, capfd):
     """Shards on several contexts (here: all on the box's one GPU, the rehearsal the API allows) come back as the contiguous ranges
-    of ONE sorted sequence: their concatenation is the oracle's sort of all records, byte for byte, and the counts add up."""
+    of ONE sorted sequence: their concatenation is the oracle's sort of all records, byte for byte, and the counts add up.
+    16/12 keys travel as 12-byte elements (11 varying bytes over all shards), full-range (32,32) keys and contexts told not to
+    compact (sort_compact = 0 on the first) as 24-byte records."""
     total = sum(counts)
     recs = oracle.generate(SEED + len(counts), 0, total, *lens)
     rng = np.random.default_rng(total + len(counts))
@@ -931,8 +933,14 @@ def test_sort_records_contexts_is_the_global_order(ia, oracle, counts, lens):
                 d.upload(recs[at:at + n])
             shards.append((d, t, n, cap))
             at += n
+        if not compact:
+            ctxs[0].set_option("sort_compact", 0)
+        capfd.readouterr()
         out = ia.Context.sort_records_contexts(ctxs, shards)
+        trace = capfd.readouterr().err
         assert sum(out) == total
+        if trace and len(counts) > 1:
+            assert f"exchange={12 if compact and lens == (16, 12) and total else 24} bytes per record" in trace, trace   # (no records: every byte "varies")
         got = b"".join(shards[k][0].download(count=24 * out[k]).tobytes() for k in range(len(counts)))
         assert got == want
         if total >= 100_000 and len(counts) > 1:                # the samples balance well-spread keys

@@ -159,6 +159,16 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
       for (size_t i = 0; i < W; ++i) {
         const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
         if (!cnt) continue;
+        if (ctxs[i]->device != ctxs[j]->device) {             // direct xGMI access where the topology has it; without, the copy is staged
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, ctxs[j]->device, ctxs[i]->device) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(ctxs[i]->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // not fatal: see above
+            else if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          } else {
+            (void)hipGetLastError();
+          }
+        }
         const uint8_t* src = static_cast<const uint8_t*>(compact ? shards[i].d_tmp : shards[i].d_records) + wire * bound[i][j];
         IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ctxs[j]->stream));
       }

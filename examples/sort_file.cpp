@@ -1,22 +1,68 @@
 // sort_file — what the header's sorted flag is for (header.rs:111-113): read an IBU file, sort its records by
 // (barcode, umi, index) on the GPU, write them back under a header with the flag set, and print the per-barcode
 // summary the reference's BarcodeAnalyzer example computes (parallel.rs:72-98).
-//   sort_file IN OUT [--top K]
+//   sort_file IN OUT [--top K] [--contexts N]
+// --contexts N: the same through N contexts — context i on GPU i % (GPUs of the box), shard i of the static split
+// (mmap.rs:297-307) — and ONE call of the multi-GPU sort (ibu_sort_records_contexts): shard i comes back as the i-th range of
+// the global order and the ranges are written one after the other (the Writer::ingest pattern, writer.rs:477-482).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "ibu.hpp"
 
+static double now();
+// the multi-context form: shards of the mapped file on N contexts, one global sort, ranges written in order
+static int sort_over_contexts(const char* in, const char* out_path, size_t nctx) {
+  using namespace ibu;
+  MmapReader m{std::string(in)};
+  const size_t n = m.len();
+  const int ndev = std::max(1, device::device_count());
+  std::vector<std::unique_ptr<device::Context>> ctxs;
+  std::vector<std::unique_ptr<device::DeviceBuffer>> bufs;
+  std::vector<device::Context*> raw;
+  std::vector<ibu_sort_shard_t> shards;
+  const double t0 = now();
+  for (size_t i = 0; i < nctx; ++i) {
+    ctxs.emplace_back(new device::Context((int)(i % (size_t)ndev)));
+    raw.push_back(ctxs.back().get());
+    const auto [s, e] = shard_range(n, nctx, i);
+    const size_t cap = (n / nctx) * 5 / 4 + nctx + 64;          // headroom for an uneven split
+    bufs.emplace_back(new device::DeviceBuffer(*ctxs.back(), cap * RECORD_SIZE));
+    bufs.emplace_back(new device::DeviceBuffer(*ctxs.back(), cap * RECORD_SIZE));
+    if (e > s) ctxs.back()->upload(bufs[2 * i]->ptr(), m.slice(s, e).ptr, (e - s) * RECORD_SIZE);
+    shards.push_back({bufs[2 * i]->ptr(), bufs[2 * i + 1]->ptr(), e - s, cap});
+  }
+  const double t1 = now();
+  device::Context::sort_records_contexts(raw, shards);
+  const double t2 = now();
+  Header h = m.header();
+  h.set_sorted();
+  Writer w = Writer::from_path(out_path, h);
+  for (size_t i = 0; i < nctx; ++i) w.write_batch_device(*ctxs[i], shards[i].d_records, shards[i].n);
+  w.finish();
+  const double t3 = now();
+  std::printf("%zu records over %zu contexts on %d GPU(s): load %.3fs, sort %.3fs, write %.3fs; shard sizes", n, nctx, ndev, t1 - t0, t2 - t1, t3 - t2);
+  for (auto& sh : shards) std::printf(" %zu", sh.n);
+  std::printf("\n");
+  bufs.clear();                                               // before the contexts they belong to
+  return 0;
+}
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: sort_file IN OUT [--top K]\n"); return 2; }
-  size_t top = 5;
-  for (int i = 3; i + 1 < argc; ++i) if (!std::strcmp(argv[i], "--top")) top = std::strtoull(argv[i + 1], nullptr, 10);
+  if (argc < 3) { std::fprintf(stderr, "usage: sort_file IN OUT [--top K] [--contexts N]\n"); return 2; }
+  size_t top = 5, nctx = 0;
+  for (int i = 3; i + 1 < argc; ++i) {
+    if (!std::strcmp(argv[i], "--top")) top = std::strtoull(argv[i + 1], nullptr, 10);
+    if (!std::strcmp(argv[i], "--contexts")) nctx = std::strtoull(argv[i + 1], nullptr, 10);
+  }
   try {
+    if (nctx > 1) return sort_over_contexts(argv[1], argv[2], nctx);
     ibu::device::Context ctx(0);
     const double t0 = now();
     auto [h, d_recs, n] = ctx.load_to_device(argv[1]);          // load_to_vec, device form

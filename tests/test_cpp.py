@@ -184,3 +184,7 @@ def test_sort_file_example(built, tmp_path, oracle):
     again = tmp_path / "again.ibu"  # a sorted file goes through unchanged (flag trusted, then verified)
     r = _run([os.path.join(built, "sort_file"), str(dst), str(again)])
     assert r.returncode == 0 and again.read_bytes() == dst.read_bytes()
+    multi = tmp_path / "multi.ibu"  # the same file through three contexts and ONE call of the multi-GPU sort: the same bytes
+    r = _run([os.path.join(built, "sort_file"), str(src), str(multi), "--contexts", "3"])
+    assert r.returncode == 0, r.stderr
+    assert "300000 records over 3 contexts" in r.stdout and multi.read_bytes() == dst.read_bytes()

@@ -987,3 +987,37 @@ def test_sort_records_contexts_refuses_what_does_not_fit(ia, oracle):
     finally:
         c0.close()
         c1.close()
+
+
+def test_sort_records_contexts_with_sixteen_shards_and_with_equal_records(ia, oracle):
+    """Sixteen contexts on one GPU (a host thread each); and records that are all the same: every splitter equals every record,
+    so one owner gets them all — fine when it has the room (capacity = everything)."""
+    n_each, k = 20_011, 16
+    recs = oracle.generate(SEED + 77, 0, n_each * k, 16, 12)
+    np.random.default_rng(3).shuffle(recs)
+    ctxs = [ia.Context(0) for _ in range(k)]
+    try:
+        cap = n_each * 2
+        shards = []
+        for i, c in enumerate(ctxs):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            d.upload(recs[i * n_each:(i + 1) * n_each])
+            shards.append((d, t, n_each, cap))
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        assert sum(out) == n_each * k and max(out) <= cap
+        got = b"".join(shards[i][0].download(count=24 * out[i]).tobytes() for i in range(k))
+        assert got == oracle.sort_records(recs).tobytes()
+        same = np.repeat(recs[:1], 3000)
+        cap2 = 3 * 3000
+        sh2 = []
+        for c in ctxs[:3]:
+            d, t = c.alloc(24 * cap2), c.alloc(24 * cap2)
+            d.upload(same)
+            sh2.append((d, t, 3000, cap2))
+        out = ia.Context.sort_records_contexts(ctxs[:3], sh2)
+        assert sorted(out) == [0, 0, 9000]
+        j = out.index(9000)
+        assert sh2[j][0].download(count=24 * 9000).tobytes() == np.repeat(recs[:1], 9000).tobytes()
+    finally:
+        for c in ctxs:
+            c.close()

@@ -151,3 +151,27 @@ def test_repr_c_structs_have_the_size_of_their_ctypes_twins():
         assert size == C.sizeof(twins[name]), (name, size, C.sizeof(twins[name]))
         seen += 1
     assert seen == len(twins), seen
+
+
+def test_safe_wrappers_call_the_externs_with_the_right_number_of_arguments():
+    """bindings/rust/src/lib.rs: every `ffi::ibu_*( ... )` call names a declared extern and passes as many arguments as it takes;
+    brackets balance over the whole file (the cheapest proxy for "it parses")."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', code)           # string literals may hold brackets
+    code = re.sub(r"'(?:[^'\\]|\\.)'", "' '", code)           # char literals too (lifetimes like 'a stay: no closing quote)
+    for o, c in ("()", "[]", "{}"):
+        assert code.count(o) == code.count(c), (o, code.count(o), code.count(c))
+    externs = rust_externs()
+    calls = 0
+    for m in re.finditer(r"ffi::(ibu_[a-z0-9_]+)\s*\(", code):
+        name, i, depth = m.group(1), m.end(), 1
+        assert name in externs, name
+        j = i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(code[j], 0)
+            j += 1
+        args = _split_params(code[i:j - 1])
+        assert len(args) == len(externs[name][1]), (name, len(args), len(externs[name][1]), code[i:j - 1][:120])
+        calls += 1
+    assert calls >= 60, calls

@@ -96,14 +96,24 @@ __device__ __forceinline__ bool rec_less(u64 b, u64 u, u64 x, u64 pb, u64 pu, u6
 static constexpr size_t kMiscBytes = 256;                     // behind the census slots: [0] the finishing kernel's overflow flag (u32)
 struct SortLayout {
   size_t misc, binbase, blocksum, blockoff, counts, pos, digits, total;
-  u32 ntiles, nblocks;
+  u32 ntiles, nblocks, tpb;                                   // tpb: tiles per scan block
   bool idx64;
 };
+// Tiles per scan block: the position walk of a block (ibu_k_sort_tilepos) is a serial chain over its tiles and the scan over the
+// blocks (ibu_k_sort_blockscan) one over the blocks, so small inputs want short blocks (both chains ~ sqrt(tiles): 1e6 records,
+// 196 tiles: 16 per block; the fixed 256 left ONE workgroup walking all of them, 26 of a 400-us sort, three times) and large ones
+// the 256 that bounds the scan's chain (1e9 records: 763 blocks).
+static u32 tiles_per_block(u64 ntiles) {
+  u32 t = 8;
+  while (t < (u32)kTilesPerBlock && (u64)t * t < ntiles) t <<= 1;
+  return t;
+}
 static SortLayout sort_layout(const LaunchCfg& cfg, size_t n, int tile) {
   SortLayout L;
   const u64 nt = (n + tile - 1) / tile;
   L.ntiles = (u32)nt;
-  L.nblocks = (u32)((nt + kTilesPerBlock - 1) / kTilesPerBlock);
+  L.tpb = tiles_per_block(nt);
+  L.nblocks = (u32)((nt + L.tpb - 1) / L.tpb);
   L.idx64 = n >= (1ull << 32) || cfg.sort_idx64;             // cfg.sort_idx64: a test knob (the 64-bit index kernels at small sizes)
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o = kCensusBytes;                                   // the census slots sit in front
@@ -367,13 +377,13 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
     const u32 b = passes[pi];
     hipLaunchKernelGGL(cv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n,
                        L.ntiles, counts);
-    hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
+    hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
     hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
     if (L.idx64)
-      hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+      hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
                          (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
     else
-      hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+      hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
                          (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
     const bool last = pi + 1 == npass, to_records = last && fuse_last && !finish_prefix;
     u32 n32 = (u32)n, b_arg = b, nb_arg = last ? 4u * W : passes[pi + 1];   // 4 W: no digit stream behind the last pass
@@ -702,13 +712,13 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits,
                            (u64)n, L.ntiles, counts);
       }
-      hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, blocksum);
+      hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
       hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
       if (L.idx64)
-        hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+        hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
                            (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
       else
-        hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles,
+        hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
                            (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
       const bool last = p + 1 == np;
       const u32 nf = last ? 3u : ps[p + 1].field, ns = last ? 0u : ps[p + 1].shift;

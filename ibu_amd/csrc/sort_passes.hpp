@@ -26,9 +26,9 @@
 // cost 2.2 B/record/pass of extra traffic and no waiting at all.
 // =====================================================================================================
 #ifndef IBU_TILES_PER_BLOCK
-#define IBU_TILES_PER_BLOCK 256   // 1024: the position walk of a block (ibu_k_sort_tilepos) took 0.30 ms per pass at 1e9 records; 256: 3 ms less per sort
+#define IBU_TILES_PER_BLOCK 256   // the most (large inputs).  1024: the position walk of a block (ibu_k_sort_tilepos) took 0.30 ms per pass at 1e9 records; 256: 3 ms less per sort
 #endif
-static constexpr int kTilesPerBlock = IBU_TILES_PER_BLOCK;                   // tiles per scan block
+static constexpr int kTilesPerBlock = IBU_TILES_PER_BLOCK;                   // tiles per scan block at most (sort.hip: tiles_per_block)
 // One count into an LDS histogram; when all the wave's active lanes hold the same digit (runs of equal keys), one lane adds for
 // all of them: 42 lanes adding to one word would take 42 turns.
 __device__ __forceinline__ void hist_add(u32* h, u32 d, bool active) {
@@ -165,12 +165,12 @@ ibu_k_sort_tilecounts_bytes(const uint8_t* __restrict__ digits, u64 n, u32 ntile
   }
 }
 // ---- scan ------------------------------------------------------------------------------------------------------------
-// 1. per block of kTilesPerBlock tiles: column sums.  Wave w takes tiles w, w+4, ...; lane l the bins 4l..4l+3.
+// 1. per block of tpb tiles: column sums.  Wave w takes tiles w, w+4, ...; lane l the bins 4l..4l+3.
 extern "C" __global__ void __launch_bounds__(kSortThreads)
-ibu_k_sort_blocksums(const uint16_t* __restrict__ counts, u32 ntiles, u32* __restrict__ blocksum) {
+ibu_k_sort_blocksums(const uint16_t* __restrict__ counts, u32 ntiles, u32 tpb, u32* __restrict__ blocksum) {
   __shared__ u32 part[kSortWaves][kBins];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
-  const u32 t0 = blockIdx.x * kTilesPerBlock, t1 = t0 + kTilesPerBlock < ntiles ? t0 + kTilesPerBlock : ntiles;
+  const u32 t0 = blockIdx.x * tpb, t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
   u32 acc[4] = {0, 0, 0, 0};
   for (u32 t = t0 + wib; t < t1; t += kSortWaves) {
     const u32x2 c = *reinterpret_cast<const u32x2*>(counts + (size_t)t * kBins + 4 * lane);
@@ -213,10 +213,10 @@ ibu_k_sort_blockscan(const u32* __restrict__ blocksum, u32 nblocks, u64* __restr
 // 3. per block, thread = bin: first output position of every (tile, bin).
 template <class IDX>
 __global__ void __launch_bounds__(kSortThreads)
-ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, const u64* __restrict__ blockoff, const u64* __restrict__ binbase,
+ibu_k_sort_tilepos(const uint16_t* __restrict__ counts, u32 ntiles, u32 tpb, const u64* __restrict__ blockoff, const u64* __restrict__ binbase,
                    IDX* __restrict__ pos) {
   const u32 bin = threadIdx.x;
-  const u32 t0 = blockIdx.x * kTilesPerBlock, t1 = t0 + kTilesPerBlock < ntiles ? t0 + kTilesPerBlock : ntiles;
+  const u32 t0 = blockIdx.x * tpb, t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
   u64 running = binbase[bin] + blockoff[(size_t)blockIdx.x * kBins + bin];
   constexpr int kFly = 32;                                    // loads in flight per thread: the walk is latency-bound
   for (u32 t = t0; t < t1; t += kFly) {

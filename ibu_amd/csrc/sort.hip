@@ -476,6 +476,7 @@ static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs
   const size_t cap = (size_t)slots * 3 / 8;
   u32 per_range = 2048, nranges = 48;
   while (nranges > 3 && (size_t)nranges * per_range > cap) nranges /= 2;
+  while (nranges > 3 && (size_t)nranges * per_range > n / 32) nranges /= 2;   // small inputs: a thirty-second of them is sample enough (the pair count of 49 152 samples was 75 of a 1e6-record sort's 255 us of kernels)
   if ((size_t)nranges * per_range > cap) per_range = (u32)(cap / nranges);
   if (per_range < 32 || (size_t)nranges * per_range > n) return hipSuccess;
   const size_t m = (size_t)nranges * per_range;

@@ -405,6 +405,8 @@ def test_sort_prefix_and_finish_on_elements(ctx_guess_pf, ctx24, oracle, n, lens
     nranges = 48
     while nranges > 3 and nranges * 2048 > slots * 3 // 8:
         nranges //= 2
+    while nranges > 3 and nranges * 2048 > n // 32:
+        nranges //= 2
     stride = (n - 2048) // (nranges - 1)
     quarter = next(q for q in range(32_768 + 64, n // 2 - 3064, 997)
                    if all(q + 3000 + 64 <= r * stride or q >= r * stride + 2048 + 64 for r in range(nranges)))
@@ -477,6 +479,8 @@ def test_finishing_kernel_ranks_runs_of_every_length_up_to_its_limit(ctx_guess_p
         slots >>= 1
     nranges = 48
     while nranges > 3 and nranges * 2048 > slots * 3 // 8:
+        nranges //= 2
+    while nranges > 3 and nranges * 2048 > n // 32:
         nranges //= 2
     stride = (n - 2048) // (nranges - 1)
     at = next(q for q in range(32_768 + 64, n // 2 - 3064, 997)

@@ -217,10 +217,20 @@ int sort_num_compact_variants() { return kNumCompact; }
 static const CompactVariant* pick_compact(const LaunchCfg& cfg) {
   return cfg.sort_compact >= 1 && cfg.sort_compact <= kNumCompact ? &kCompact[cfg.sort_compact - 1] : nullptr;
 }
+// ... for n records: inputs of fewer than 512 default tiles (2.6 M records: less than the two workgroups per CU the chip takes)
+// run the 12-byte passes on 2048-element tiles — 2.5 times the workgroups, each done sooner (1e6 records: three passes of 14 us
+// on 196 workgroups).  The default shape only (an explicit choice is an A/B), and not under the 64-bit index test knob (the
+// small shape has no 64-bit kernels).
+static constexpr size_t kSmallInput = (size_t)512 * 5120;
+static const CompactVariant* pick_compact_for(const LaunchCfg& cfg, size_t n) {
+  const CompactVariant* cv = pick_compact(cfg);
+  if (cv == &kCompact[0] && n < kSmallInput && !cfg.sort_idx64) return &kCompact[2];
+  return cv;
+}
 
 size_t sort_scratch_bytes(const LaunchCfg& cfg, size_t n) {
   size_t need = sort_layout(cfg, n, pick_variant(cfg).tile).total;
-  if (const CompactVariant* cv = pick_compact(cfg)) {
+  if (const CompactVariant* cv = pick_compact_for(cfg, n)) {
     for (const CompactVariant* v : {cv, &kCompact16s[0], &kCompact16s[1], &kCompact16s[2], &kCompact16s[3]}) {
       const size_t c = sort_layout(cfg, n, v->tile).total;
       if (c > need) need = c;
@@ -541,7 +551,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   // Compact-key path (see "COMPACT-KEY passes"): records 16-byte aligned (the tiled compress kernel), tmp at least 4-byte
   // aligned; from 2^32 records on (64-bit element indices) the shapes that carry those kernels (the defaults).  Whether at most
   // 12 / 16 key bytes vary is the census' to say.
-  const CompactVariant* cv = pick_compact(cfg);
+  const CompactVariant* cv = pick_compact_for(cfg, n);
   const bool wide_idx = n >= (1ull << 32) || cfg.sort_idx64;
   const bool compact_ok = cv && n < (1ull << 38) && (!wide_idx || (cv->scatter64 && pick_compact16(cfg).scatter64)) &&
                           (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 &&

@@ -1025,3 +1025,39 @@ def test_sort_records_contexts_with_sixteen_shards_and_with_equal_records(ia, or
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IBU_FUZZ_SEEDS_MC", "12"))))
+def test_sort_records_contexts_fuzz(ia, oracle, seed):
+    """Seeded fuzz of the multi-context sort: 2 .. 6 shards of uneven sizes (empty ones included), keys that compact or do not,
+    duplicates, skew — the concatenation of the returned ranges is the oracle's sort of everything."""
+    rng = np.random.default_rng(5000 + seed)
+    w = int(rng.integers(2, 7))
+    counts = [int(rng.choice([0, 1, 7, 1000, 20_000, 150_000])) for _ in range(w)]
+    total = sum(counts)
+    lens = [(16, 12), (32, 32), (8, 8), (24, 10)][seed % 4]
+    recs = oracle.generate(SEED + seed, 0, max(total, 1), *lens)[:total]
+    rng.shuffle(recs)
+    if seed % 3 == 0 and total:
+        recs["index"] = rng.integers(0, 2**30, total, dtype=np.uint64)
+    if seed % 5 == 1 and total > 10:                          # many equal records
+        recs[: total // 2] = recs[0]
+    if seed % 5 == 2 and total > 10:                          # few barcodes
+        recs["barcode"] = recs["barcode"][:5][rng.integers(0, 5, total)]
+    want = oracle.sort_records(recs).tobytes()
+    cap = total + w + 1
+    ctxs = [ia.Context(0) for _ in range(w)]
+    try:
+        shards, at = [], 0
+        for c, n in zip(ctxs, counts):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            if n:
+                d.upload(recs[at:at + n])
+            shards.append((d, t, n, cap))
+            at += n
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        assert sum(out) == total
+        assert b"".join(shards[k][0].download(count=24 * out[k]).tobytes() for k in range(w)) == want, (seed, counts, lens)
+    finally:
+        for c in ctxs:
+            c.close()

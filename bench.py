@@ -34,9 +34,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
-    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--gpus", type=int, default=None,
+                   help="ranks = GPUs of this node.  Under torch.distributed.run it must equal WORLD_SIZE (anything else is an error); "
+                        "run bare with N > 1, bench.py starts the N ranks itself as a child torch.distributed.run and returns its "
+                        "exit code.  Default: WORLD_SIZE, or 1")
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--records", type=float, default=1e9,
@@ -47,6 +50,9 @@ def parse():
     p.add_argument("--no-wide-leg", action="store_true", help="skip the (32,32) leg (configs[2]) on one GPU")
     p.add_argument("--wide-records", type=float, default=0, help="records of the (32,32) leg (0 = same as --records)")
     p.add_argument("--no-sort-leg", action="store_true", help="skip the sort + per-barcode aggregation leg on one GPU")
+    p.add_argument("--no-e2e-leg", action="store_true", help="skip the file -> result (PCIe-inclusive) leg on one GPU")
+    p.add_argument("--e2e-records", type=float, default=1e8, help="records of the e2e leg's file (24 B each)")
+    p.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its files (default: the system temp dir)")
     p.add_argument("--bc-len", type=int, default=16)
     p.add_argument("--umi-len", type=int, default=12)
     p.add_argument("--seed", type=lambda s: int(s, 0), default=0x1B00003)
@@ -66,7 +72,33 @@ def parse():
     p.add_argument("--force-dist", action="store_true",
                    help="initialise the process group and run every collective even with one rank (a one-GPU box can then "
                         "execute the RCCL code path of the N > 1 runs: init, barrier, all_reduce, all_gather)")
-    return p.parse_args()
+    return p.parse_args(argv)
+
+
+def resolve_world(args, argv, env):
+    """What `--gpus N` means.  Returns ("run", world) when this process is one of `world` ranks (or the only one), or
+    ("spawn", cmd) when it was started bare with N > 1 and has to start the ranks itself — as a CHILD process, before
+    anything touches the GPU (never an exec).  A `--gpus` that contradicts WORLD_SIZE is an error, not a silent
+    one-GPU run that prints n_gpus: 1."""
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        world = int(ws)
+        if args.gpus is not None and args.gpus != world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} contradicts WORLD_SIZE={world} set by the launcher; "
+                             f"start it as `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
+                             f"or run `python bench.py --gpus {args.gpus}` bare")
+        return "run", world
+    n = args.gpus or 1
+    if n < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if n == 1:
+        return "run", 1
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return "spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def usable_cores():
@@ -278,6 +310,131 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3, torch=None, dev=
     return out
 
 
+def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
+    """File -> result rates on this box, PCIe included — reported beside the headline, NEVER part of `value` (BASELINE.md §3
+    asks for the kernel-resident and the file -> result rates separately; configs[4] is the gzip form).  A file of `n`
+    synthetic records is written from device memory (`Writer::write_batch` of a device slice), then read back three ways:
+      load_to_device        reader.rs:510-535   pread -> pinned ring -> H2D
+      mmap -> DECODE        mmap.rs:286-332     ibu_mmap_process_devices over EVERY visible device (one call, a host thread +
+                                                context per device, shard i of the static split on device i): map -> ring -> H2D || K2
+      gzip -> DECODE        reader.rs:345-352   the same file as ONE gzip member (level 1) -> parallel host inflate -> ring -> H2D || K2
+    Every result is checked against K4 (count, wrapping sums, XORs) of the resident copy the file was written from: the
+    loaded records directly, the decoded columns after re-encoding them on the device."""
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gzutil import gzip_single_member   # test-data writer (pigz-style parallel deflate into one member)
+
+    t_leg = time.perf_counter()
+    n = int(n)
+    path = os.path.join(tmpdir or tempfile.gettempdir(), f"ibu_bench_e2e_{os.getpid()}.ibu")
+    file_bytes = 32 + 24 * n
+    ring = {"slots": 4, "slot_records": 4 << 20, "feeder_threads": 8}
+    out = {"workload": f"{n:.3g} records bc_len={bc_len} umi_len={umi_len}, a {file_bytes / 1e9:.2f} GB file in {os.path.dirname(path)}; "
+                       f"wall-clock rates including PCIe and host work; never part of `value`"}
+
+    def rate(seconds, st=None, **kw):
+        r = {"seconds": seconds, "GBps_of_file": file_bytes / seconds / 1e9, "records_per_s": n / seconds}
+        if st is not None:
+            ks = st if isinstance(st, float) else st.seconds_kernel
+            r.update(kernel_seconds=ks, kernel_share_of_wall=ks / seconds)
+        r.update(kw)
+        return r
+
+    def wadd(a, b):
+        return {"count": a["count"] + b["count"], "sum": [(x + y) & (2**64 - 1) for x, y in zip(a["sum"], b["sum"])],
+                "xor": [x ^ y for x, y in zip(a["xor"], b["xor"])]}
+
+    gz = path + ".gz"
+    ctxs = []
+    try:
+        d = ctx.alloc(24 * n)
+        ctx.generate(seed, 0, n, bc_len, umi_len, d)
+        want = ctx.reduce(d, n)
+        t0 = time.perf_counter()
+        w = ia.Writer.from_path(path, ia.Header(bc_len, umi_len))
+        st = w.write_batch_device(ctx, d, n, ring=ring)
+        w.finish()
+        w.close()
+        out["write_batch_device_to_file"] = rate(time.perf_counter() - t0)
+        d.free()
+        assert os.path.getsize(path) == file_bytes
+
+        best = None
+        for _ in range(2):                               # the first call allocates the pinned ring and warms the page cache
+            t0 = time.perf_counter()
+            _, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
+            dt = time.perf_counter() - t0
+            ok = got_n == n and ctx.reduce(dptr, n) == want
+            ctx.free(dptr)
+            if not ok:
+                raise SystemExit("e2e: load_to_device returned other records than were written")
+            best = rate(dt, st, first_call_seconds=best["seconds"] if best else None, totals_equal_resident_copy=True)
+        out["load_to_device"] = best
+
+        m = ia.MmapReader.new(path)
+        ndev = ia.device_count()
+        ctxs = [ia.Context(i) for i in range(ndev)]      # caller-owned contexts: their rings survive from call to call
+        shards = [ia.shard_range(n, ndev, i) for i in range(ndev)]
+        sinks = []
+        for c, (a0, a1) in zip(ctxs, shards):
+            k = max(a1 - a0, 1)
+            sinks.append((c.alloc(k * bc_len), c.alloc(k * umi_len), c.alloc(k * 8), k))
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            count, _, sts = m.process_devices(proc=ia.PROC_DECODE, sinks=sinks, ring=ring, contexts=ctxs)
+            dt = time.perf_counter() - t0
+            best = rate(dt, max(s_.seconds_kernel for s_ in sts), first_call_seconds=best["seconds"] if best else None,
+                        devices=ndev, call="ibu_mmap_process_contexts(m, ctxs, n_devices, ring, IBU_PROC_DECODE, sinks, &total, stats)")
+        got = {"count": 0, "sum": [0, 0, 0], "xor": [0, 0, 0]}
+        for c, (a0, a1), (s_bc, s_umi, s_idx, _) in zip(ctxs, shards, sinks):
+            if a1 > a0:                                  # the decoded columns, re-encoded where they live, reduced with K4
+                back = c.alloc(24 * (a1 - a0))
+                c.encode_ascii(s_bc, s_umi, s_idx, a1 - a0, bc_len, umi_len, back)
+                c.codec_status()
+                got = wadd(got, c.reduce(back, a1 - a0))
+                back.free()
+        if count != n or got != want:
+            raise SystemExit("e2e: mmap -> DECODE over the devices does not reproduce the records written")
+        best["totals_equal_resident_copy"] = True
+        out["mmap_process_devices_decode"] = best
+        m.close()
+
+        t0 = time.perf_counter()
+        gz_bytes = gzip_single_member(path, gz, level=1, workers=max(2, min(16, usable_cores())))
+        tc = time.perf_counter() - t0
+        s_bc, s_umi, s_idx, cap = sinks[0]
+        if cap < n:                                      # several devices: device 0's sink held one shard only
+            for b in (s_bc, s_umi, s_idx):
+                b.free()
+            s_bc, s_umi, s_idx = ctxs[0].alloc(n * bc_len), ctxs[0].alloc(n * umi_len), ctxs[0].alloc(n * 8)
+            sinks[0] = (s_bc, s_umi, s_idx, n)
+        r = ia.Reader.from_path(gz)
+        t0 = time.perf_counter()
+        _, st = r.process_device(ctxs[0], ia.PROC_DECODE, sink=(s_bc, s_umi, s_idx, n), ring=ring)
+        dt = time.perf_counter() - t0
+        r.close()
+        back = ctxs[0].alloc(24 * n)
+        ctxs[0].encode_ascii(s_bc, s_umi, s_idx, n, bc_len, umi_len, back)
+        ctxs[0].codec_status()
+        ok = ctxs[0].reduce(back, n) == want
+        back.free()
+        if not ok:
+            raise SystemExit("e2e: gzip -> DECODE does not reproduce the records written")
+        out["gzip_reader_process_device_decode"] = rate(dt, st, gz_bytes=gz_bytes, gz_ratio=gz_bytes / file_bytes, compress_seconds=tc,
+                                                        input="ONE gzip member, level 1 (what `gzip -1` writes), inflated on the host cores",
+                                                        totals_equal_resident_copy=True)
+    finally:
+        for c in ctxs:
+            c.close()
+        for f in (path, gz):
+            if os.path.exists(f):
+                os.unlink(f)
+    out["leg_seconds"] = time.perf_counter() - t_leg
+    return out
+
+
 class Leg:
     """One resident workload: this rank's shard [first, first + n) of the synthetic stream, its output columns and the
     re-encoded records.  step() = K2 decode followed by K3 encode."""
@@ -404,14 +561,18 @@ class Leg:
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    what, world = resolve_world(args, argv, os.environ)
+    if what == "spawn":                              # `python bench.py --gpus N` run bare: N ranks as a child job
+        import subprocess
+        raise SystemExit(subprocess.call(world))
     import torch
     import torch.distributed as dist
 
     import ibu_amd
     from ibu_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
@@ -509,6 +670,16 @@ def main():
         except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
             sort_leg = {"error": f"{type(e).__name__}: {e}"}
 
+    e2e = None
+    if world == 1 and not args.no_e2e_leg:
+        # BASELINE.md §3 / configs[4]: file -> result with PCIe and the host in the path; outside the timed region, never `value`
+        leg.free()
+        torch.cuda.empty_cache()
+        try:
+            e2e = e2e_leg(ctx, ibu_amd, args.e2e_records, bc_len, umi_len, args.seed, args.e2e_dir)
+        except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
+            e2e = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         bpr = 24 + bc_len + umi_len + 8
         # rank 0's own launch: its records x algorithmic bytes / its measured decode time
@@ -563,6 +734,8 @@ def main():
             out["config2_32_32"] = wide
         if sort_leg:
             out["sort_leg"] = sort_leg
+        if e2e:
+            out["e2e"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -57,6 +57,8 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
   ctx->device = device;
   ctx->cfg.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   // blocks_per_cu keeps LaunchCfg's measured default; ibu_ctx_set_option overrides it
+  static const int trace_rows_env = [] { const char* v = getenv("IBU_TRACE_ROWS"); return (v && *v && *v != '0') ? 1 : 0; }();   // read once
+  ctx->cfg.trace_rows = trace_rows_env;
   hipError_t rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
@@ -124,6 +126,10 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
   if (strcmp(key, "sort_compact") == 0) {
     if (value < 0 || value > sort_num_compact_variants()) return err_arg("sort_compact out of range");
     ctx->cfg.sort_compact = (int)value;
+    return IBU_OK;
+  }
+  if (strcmp(key, "trace_rows") == 0) {
+    ctx->cfg.trace_rows = value != 0;
     return IBU_OK;
   }
   if (strcmp(key, "base_order") == 0) {

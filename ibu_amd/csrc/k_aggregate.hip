@@ -173,9 +173,9 @@ ibu_k_runs_scan(const u32* __restrict__ seg_heads, u32 nseg, u64* __restrict__ s
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-static SegPlan seg_plan(const void* recs, size_t n) {
+static SegPlan seg_plan(const LaunchCfg& cfg, const void* recs, size_t n) {
   const Span span[1] = {{recs, 24}};
-  const RowSplit rs = split_rows(span, 1, n, kTileRecs);    // an 8-B aligned base peels exactly one record
+  const RowSplit rs = split_rows(cfg, span, 1, n, kTileRecs);    // an 8-B aligned base peels exactly one record
   return {(u64)rs.head, (u64)rs.main, (u64)n, runs_nseg(rs.main)};
 }
 size_t runs_scratch_bytes(size_t n) {
@@ -185,10 +185,10 @@ size_t runs_scratch_bytes(size_t n) {
 static inline size_t seg_base_offset(u32 nseg) { return 64 + 2 * sizeof(u32) * (size_t)nseg + ((2 * sizeof(u32) * (size_t)nseg) & 4); }
 // Pass 1 + scan.  Leaves the scanned table in `scratch`; totals[0] = runs, totals[1] = (barcode, umi) pairs
 // are read back by the caller from scratch[0..15] (u64 each).
-hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st) {
+hipError_t launch_runs_count(const LaunchCfg& cfg, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st) {
   (void)hipGetLastError();
   if (n == 0 || n / kSegRecs + 2 >= (1ull << 31) || scratch_bytes < runs_scratch_bytes(n)) return hipErrorInvalidValue;
-  const SegPlan sp = seg_plan(recs, n);
+  const SegPlan sp = seg_plan(cfg, recs, n);
   u64* totals = static_cast<u64*>(scratch);
   u32* heads = reinterpret_cast<u32*>(static_cast<uint8_t*>(scratch) + 64);
   u64* base = reinterpret_cast<u64*>(static_cast<uint8_t*>(scratch) + seg_base_offset(sp.nseg));
@@ -200,7 +200,7 @@ hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void*
 hipError_t launch_runs_emit(const LaunchCfg& cfg, const void* recs, size_t n, const void* scratch, void* run_scratch, uint64_t n_runs,
                             uint64_t n_pairs, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq, hipStream_t st) {
   (void)hipGetLastError();
-  const SegPlan sp = seg_plan(recs, n);
+  const SegPlan sp = seg_plan(cfg, recs, n);
   const u64* base = reinterpret_cast<const u64*>(static_cast<const uint8_t*>(scratch) + seg_base_offset(sp.nseg));
   u64* starts = static_cast<u64*>(run_scratch);             // n_runs entries each (run_scratch_bytes)
   u64* pair_rank = uniq ? starts + n_runs : nullptr;

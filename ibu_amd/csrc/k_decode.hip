@@ -13,11 +13,15 @@ namespace ibu {
 // placements, (32,32), (12,8), (32,12)); slower for (8,8) by 1 %, and the byte-path length 10 spills (2.7x slower), so
 // NT is a property of the instantiation: dec_nt<BC, UM>().  -DIBU_DECODE_NT=1|2 forces one value everywhere (A/B builds).
 constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
+#ifndef IBU_DECODE_GEN_NT
+#define IBU_DECODE_GEN_NT 1
+#endif
 template <int BC, int UM>
 constexpr int dec_nt() {
 #ifdef IBU_DECODE_NT
   return IBU_DECODE_NT;
 #else
+  if (BC == 0 && UM == 0) return IBU_DECODE_GEN_NT;   // both lengths at run time: the code-stream path holds few registers
   return (dword_len(BC) && dword_len(UM) && BC + UM >= 20) ? 2 : 1;
 #endif
 }
@@ -45,8 +49,11 @@ __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs<dec_nt<
     rev_pairs_tile<kDecodeNT>(tile, 24, 8, umi_len, lane);
     wave_lds_fence();
   }
-  if (bc_out) expand_field<BC, kDecodeNT>(tile, 24, 0, bc_len, bc_out + (size_t)t * kDecRecs * bc_len, lane);
-  if (umi_out) expand_field<UM, kDecodeNT>(tile, 24, 8, umi_len, umi_out + (size_t)t * kDecRecs * umi_len, lane);
+  // a runtime-length field goes through its code stream (kcommon.hpp), kept behind the AoS tile in the wave's LDS slice
+  u32* const stream_bc = reinterpret_cast<u32*>(tile + kTileBytes * kDecodeNT);
+  u32* const stream_umi = reinterpret_cast<u32*>(tile + kTileBytes * kDecodeNT + (BC == 0 ? stream_bytes(kDecodeNT) : 0));
+  if (bc_out) expand_field<BC, kDecodeNT>(tile, 24, 0, bc_len, bc_out + (size_t)t * kDecRecs * bc_len, lane, stream_bc);
+  if (umi_out) expand_field<UM, kDecodeNT>(tile, 24, 8, umi_len, umi_out + (size_t)t * kDecRecs * umi_len, lane, stream_umi);
   if (idx_out) {                               // chunk c = indices of records 2c, 2c+1
 #pragma unroll
     for (int j = 0; j < kDecodeNT; ++j) {
@@ -70,9 +77,13 @@ __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs<dec_nt<
 // (Round 3: the code objects' metadata showed five instantiations with scratch under those budgets — (12,12), (12,32), (32,12)
 // at NT = 2, whose length-12 gathers hold more addresses than the dword reads of 16 / 32, and (10,10) both orders;
 // tools/kernel_resources.py, now a CPU test.  They get one wave per SIMD less.)
+#ifndef IBU_DECODE_GEN_WAVES
+#define IBU_DECODE_GEN_WAVES 6
+#endif
 template <int BC, int UM, bool MSB>
 constexpr int dec_waves() {
-  if (!(dword_len(BC) && dword_len(UM))) return (BC == 10 && UM == 10) ? 2 : 3;
+  if (BC == 10 || UM == 10) return (BC == 10 && UM == 10) ? 2 : 3;                       // the byte path
+  if (BC == 0 || UM == 0) return (BC == 12 || UM == 12) ? 5 : IBU_DECODE_GEN_WAVES;     // a runtime-length field: the code stream
   if (dec_nt<BC, UM>() > 1) return (BC == 12 || UM == 12) ? 4 : (MSB ? 4 : 5);
   return MSB ? 6 : 7;
 }
@@ -81,10 +92,11 @@ __global__ void __launch_bounds__(kBlock, (dec_waves<BC, UM, MSB>()))
 ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_len,
              uint8_t* __restrict__ bc_out, uint8_t* __restrict__ umi_out, u64* __restrict__ idx_out) {
   constexpr int kDecBytes = kTileBytes * dec_nt<BC, UM>();
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kDecBytes];
+  constexpr int kWaveLds = kDecBytes + ((BC == 0) + (UM == 0)) * (int)stream_bytes(dec_nt<BC, UM>());
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kWaveLds];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * kDecBytes;
+  uint8_t* tile = lds + wib * kWaveLds;
   const TileRange tr = tile_range(ntiles, wib);
   const u32 nwaves = tr.stride;
   u32 t = tr.t;
@@ -114,15 +126,19 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
 // Single u64 column -> ASCII (stride-8 "records").  NT 128-code tiles per wave iteration: with one (1 KiB of codes, a single
 // 16-byte load per lane and iteration) the waves sat parked on their loads 45 % of the time (SQ counters, profiles r03_sq) and the
 // kernel ran at 5.0 TB/s; the decode kernel had gained the same way (dec_nt).
-constexpr int unpack_nt(int len) { return len == 0 ? 1 : 2; }   // (four tiles spill under the 64-VGPR budget of eight waves per SIMD)
+#ifndef IBU_UNPACK_GEN_NT
+#define IBU_UNPACK_GEN_NT 2
+#endif
+constexpr int unpack_nt(int len) { return len == 0 ? IBU_UNPACK_GEN_NT : 2; }   // (four tiles spill under the 64-VGPR budget of eight waves per SIMD)
 template <int LEN, bool MSB>
-__global__ void __launch_bounds__(kBlock, dword_len(LEN) ? 8 : 3)
+__global__ void __launch_bounds__(kBlock, LEN == 0 ? 6 : dword_len(LEN) ? 8 : 3)
 ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles /*of NT x 128 codes*/, u32 len, uint8_t* __restrict__ out) {
   constexpr int NT = unpack_nt(LEN);
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * 1024 * NT];
+  constexpr int kWaveLds = 1024 * NT + (LEN == 0 ? (int)stream_bytes(NT) : 0);   // a runtime length goes through the code stream
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kWaveLds];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* tile = lds + wib * 1024 * NT;
+  uint8_t* tile = lds + wib * kWaveLds;
   if (LEN > 0) len = LEN;
   const uint8_t* base = reinterpret_cast<const uint8_t*>(codes) + 16 * lane;
   struct Regs { u32x4 v[NT]; };
@@ -138,7 +154,7 @@ ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles /*of NT x 128 codes*/, u3
         for (int k = 0; k < NT; ++k)                          // lane's chunk = code words 2L, 2L+1 of sub-tile k
           *reinterpret_cast<u32x4*>(tile + 1024 * k + 16 * lane) = MSB ? rev_pairs_x2(g.v[k], len) : g.v[k];
         wave_lds_fence();
-        expand_field<LEN, NT>(tile, 8, 0, len, out + (size_t)t * NT * kTileRecs * len, lane);
+        expand_field<LEN, NT>(tile, 8, 0, len, out + (size_t)t * NT * kTileRecs * len, lane, reinterpret_cast<u32*>(tile + 1024 * NT));
       });
 }
 
@@ -184,7 +200,7 @@ hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint3
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, bc_len}, {umi, umi_len}, {idx, 8}};
   const size_t kDecRecs = (size_t)kDecRecsTable[mode_of_len(bc_len)][mode_of_len(umi_len)];
-  const RowSplit rs = split_rows(sp, 4, n, kDecRecs);   // peel rows until every array is 16-B aligned
+  const RowSplit rs = split_rows(cfg, sp, 4, n, kDecRecs);   // peel rows until every array is 16-B aligned
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_decode_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0,
                        (u64)rs.head, bc_len, umi_len, cfg.base_order, bc, umi, (u64*)idx);
@@ -215,7 +231,7 @@ hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, 
   if (n == 0) return hipSuccess;
   const Span sp[2] = {{codes, 8}, {out, len}};
   const size_t tile_recs = (size_t)kTileRecs * unpack_nt(len_of_mode(mode_of_len(len)));
-  const RowSplit rs = split_rows(sp, 2, n, tile_recs);
+  const RowSplit rs = split_rows(cfg, sp, 2, n, tile_recs);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_unpack_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)codes, (u64)0, (u64)rs.head,
                        len, cfg.base_order, out);

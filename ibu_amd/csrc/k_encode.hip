@@ -9,8 +9,9 @@
 namespace ibu {
 
 // BC / UM: compile-time barcode / UMI length, or 0 for "runtime length" (generic kernel).
-// Dynamic LDS per wave: max(3072, 128*(bc_len+umi_len)) bytes; the AoS tile reuses the ASCII
-// staging area once every row has been packed (in-order DS makes that safe).
+// Dynamic LDS per wave: max(3072, the two fields' staging areas: 128*len bytes of ASCII, or the 32*len + 16 bytes of the
+// code stream of a runtime-length field); the AoS tile reuses the staging area once every row has been packed
+// (in-order DS makes that safe).
 // Lane L owns the ADJACENT rows 2L, 2L+1: its index pair is one 16-B chunk of the column and
 // its two records are 48 contiguous bytes of the AoS tile (3 x ds_write_b128 at stride 48 B,
 // conflict-free).  All global loads of a tile are issued back to back into registers; right
@@ -21,17 +22,47 @@ namespace ibu {
 #endif
 // Register budget (waves/SIMD): short dword-path rows fit 80 VGPRs; 32-base rows need 128;
 // byte-path (len % 4 != 0) and generic kernels get 168 — none of the instantiations spills.
+// A runtime-length field (0) lands as its code stream and costs no more registers than a dword-path field (round 4; it was
+// packed byte by byte under a 168-VGPR budget before).
+#ifndef IBU_ENCODE_GEN_MINWAVES
+#define IBU_ENCODE_GEN_MINWAVES 4
+#endif
 constexpr int encode_minwaves(int bc, int um) {
-  const bool dw = bc > 0 && um > 0 && (bc & 3) == 0 && (um & 3) == 0;
-  return !dw ? 3 : (bc <= 16 && um <= 16) ? IBU_ENCODE_MINWAVES : 4;
+  const bool bytes = (bc & 3) != 0 || (um & 3) != 0;          // a specialised length off the dword path: 10
+  if (bytes) return 3;
+  if (bc == 0 || um == 0) return IBU_ENCODE_GEN_MINWAVES;
+  return (bc <= 16 && um <= 16) ? IBU_ENCODE_MINWAVES : 4;
 }
+// LDS of one field of one 128-row tile: the ASCII rows, or the code stream of a runtime-length field.
+__host__ __device__ constexpr u32 enc_field_lds(int spec_len, u32 len) { return spec_len > 0 ? 128u * len : 32u * len + kStreamPad; }
+// Rows per wave iteration = 128 * NT.  Round 4 measured two tiles per iteration for the dword-path rows of at most 32 bases
+// (at (8,8) one tile is 3 KiB of loads in flight per wave against the 6 KiB of decode's two), same box, same
+// arrays, one process (profiles/r04_d_kbench_enc_nt.jsonl): (8,8) 0.756 -> 0.759 of peak, (12,8) 0.752 -> 0.757, (12,12) and
+// (16,12) equal, (16,16) needs 128 VGPRs and four waves per SIMD to tie — the kernel does not wait for more bytes in flight
+// (its probe builds without ALU or LDS traffic are not faster either: profiles/README.md r02_i).  NT stays 1;
+// -DIBU_ENCODE_NT=2 builds the other form on every dword-path instantiation for the next A/B.
+template <int BC, int UM>
+constexpr int enc_nt() {
+#ifdef IBU_ENCODE_NT
+  return (BC > 0 && UM > 0 && (BC & 3) == 0 && (UM & 3) == 0) ? IBU_ENCODE_NT : 1;
+#else
+  return 1;
+#endif
+}
+#ifndef IBU_ENCODE_NT2_MINWAVES
+#define IBU_ENCODE_NT2_MINWAVES 5
+#endif
+template <int BC, int UM>
+constexpr int enc_waves() { return enc_nt<BC, UM>() > 1 ? IBU_ENCODE_NT2_MINWAVES : encode_minwaves(BC, UM); }
+
 template <int BC, int UM, bool MSB>
-__global__ void __launch_bounds__(kBlock, encode_minwaves(BC, UM))
+__global__ void __launch_bounds__(kBlock, (enc_waves<BC, UM>()))
 ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_in,
              const u64* __restrict__ idx_in, u64 first_index, u64 row_base, u32 ntiles, u32 bc_len, u32 umi_len,
              u32 wave_lds_bytes, uint8_t* __restrict__ recs, u64* __restrict__ status) {
   // row_base: rows the launcher peeled off in front of this launch (kcommon.hpp, "Peeling"); bad rows are reported
   // in the caller's numbering, and first_index already includes it
+  constexpr int NT = enc_nt<BC, UM>(), kRecs = kTileRecs * NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
@@ -39,7 +70,7 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   if (UM > 0) umi_len = UM;
   uint8_t* area = dyn_lds + wib * wave_lds_bytes;
   uint8_t* asc_bc = area;
-  uint8_t* asc_umi = area + kTileRecs * bc_len;
+  uint8_t* asc_umi = area + enc_field_lds(BC, bc_len) * NT;
   const TileRange tr = tile_range(ntiles, wib);
   const u32 nwaves = tr.stride;
   u32 t = tr.t;
@@ -48,59 +79,81 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   // idx_in == NULL: the loads below read the (valid, 16-B aligned) barcode column instead and
   // the result is ignored, so the instruction stream has no branch around a load.
   const uint8_t* idx_src = idx_in ? reinterpret_cast<const uint8_t*>(idx_in) + 16 * lane : bc_in;
-  const size_t idx_tile = idx_in ? 1024 : 0;
+  const size_t idx_tile = idx_in ? 1024 * NT : 0, idx_sub = idx_in ? 1024 : 0;
 
-  AsciiStage<BC> sb;
-  AsciiStage<UM> su;
-  sb.issue(bc_in + (size_t)t * kTileRecs * bc_len, bc_len, lane);
-  su.issue(umi_in + (size_t)t * kTileRecs * umi_len, umi_len, lane);
-  u32x4 vi = ld16(idx_src + (size_t)t * idx_tile);
+  AsciiStage<BC, NT> sb;
+  AsciiStage<UM, NT> su;
+  u32x4 vi[NT];
+  sb.issue(bc_in + (size_t)t * kRecs * bc_len, bc_len, lane);
+  su.issue(umi_in + (size_t)t * kRecs * umi_len, umi_len, lane);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) vi[j] = ld16(idx_src + (size_t)t * idx_tile + j * idx_sub);
   BadRows bad;
   for (;;) {
-    const size_t row0 = (size_t)t * kTileRecs;
+    const size_t row0 = (size_t)t * kRecs;
     wave_lds_fence();                          // previous tile's AoS reads precede these writes
-    sb.land(asc_bc, bc_len, lane);
-    su.land(asc_umi, umi_len, lane);
-    u64 i0 = ((u64)vi.y << 32) | vi.x, i1 = ((u64)vi.w << 32) | vi.z;
-    if (!idx_in) { i0 = first_index + row0 + 2 * lane; i1 = i0 + 1; }
+    const bool okcb = sb.land(asc_bc, bc_len, lane), okcu = su.land(asc_umi, umi_len, lane);
+    const bool chunks_ok = okcb && okcu;       // false only from a runtime-length field
+    u64 ix[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      ix[j][0] = ((u64)vi[j].y << 32) | vi[j].x;
+      ix[j][1] = ((u64)vi[j].w << 32) | vi[j].z;
+      if (!idx_in) { ix[j][0] = first_index + row0 + 128 * j + 2 * lane; ix[j][1] = ix[j][0] + 1; }
+    }
     const u32 tn = t + nwaves;
     const bool more = tn < ntiles;             // wave-uniform
     const u32 tp = more ? tn : t;              // registers are free again: next tile goes in flight
-    sb.issue(bc_in + (size_t)tp * kTileRecs * bc_len, bc_len, lane);   // unconditional, see kcommon.hpp
-    su.issue(umi_in + (size_t)tp * kTileRecs * umi_len, umi_len, lane);
-    vi = ld16(idx_src + (size_t)tp * idx_tile);
+    sb.issue(bc_in + (size_t)tp * kRecs * bc_len, bc_len, lane);   // unconditional, see kcommon.hpp
+    su.issue(umi_in + (size_t)tp * kRecs * umi_len, umi_len, lane);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) vi[j] = ld16(idx_src + (size_t)tp * idx_tile + j * idx_sub);
     wave_lds_fence();
-    bool okb0 = true, oku0 = true, okb1 = true, oku1 = true;
+    u64 b[NT][2], u[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32 r = 128 * j + 2 * lane + h;
+        bool okb = true, oku = true;
 #if IBU_PROBE == 1      // measurement build (WRONG output): the LDS row reads stay, the packing ALU goes
-    u64 b0 = *reinterpret_cast<const u32*>(asc_bc + (2 * lane) * bc_len), u0 = *reinterpret_cast<const u32*>(asc_umi + (2 * lane) * umi_len);
-    u64 b1 = *reinterpret_cast<const u32*>(asc_bc + (2 * lane + 1) * bc_len), u1 = *reinterpret_cast<const u32*>(asc_umi + (2 * lane + 1) * umi_len);
+        b[j][h] = *reinterpret_cast<const u32*>(asc_bc + r * bc_len);
+        u[j][h] = *reinterpret_cast<const u32*>(asc_umi + r * umi_len);
 #elif IBU_PROBE == 2    // measurement build (WRONG output): no LDS row reads either
-    u64 b0 = row0 + lane, u0 = b0 * 3, b1 = b0 + 7, u1 = b0 ^ 5;
+        b[j][h] = row0 + r;
+        u[j][h] = b[j][h] * 3;
 #else
-    u64 b0 = pack_row<BC>(asc_bc + (2 * lane) * bc_len, bc_len, okb0);
-    u64 u0 = pack_row<UM>(asc_umi + (2 * lane) * umi_len, umi_len, oku0);
-    u64 b1 = pack_row<BC>(asc_bc + (2 * lane + 1) * bc_len, bc_len, okb1);
-    u64 u1 = pack_row<UM>(asc_umi + (2 * lane + 1) * umi_len, umi_len, oku1);
+        b[j][h] = pack_row<BC>(asc_bc, r, bc_len, okb);
+        u[j][h] = pack_row<UM>(asc_umi, r, umi_len, oku);
+        if constexpr (BC == 0 || UM == 0) {
+          // A runtime-length field was packed chunk by chunk, which does not say WHICH row holds the offending byte: a tile
+          // with one (wave-uniform test, never taken on valid input) packs the rows of those fields again, byte by byte from
+          // the column in global memory, as the tail kernel does.
+          if (__ballot(!chunks_ok) != 0) {
+            if constexpr (BC == 0) b[j][h] = pack_row_bytes(bc_in + (row0 + r) * bc_len, bc_len, okb);
+            if constexpr (UM == 0) u[j][h] = pack_row_bytes(umi_in + (row0 + r) * umi_len, umi_len, oku);
+          }
+        }
 #endif
-    if (!okb0) b0 = 0;
-    if (!oku0) u0 = 0;
-    if (!okb1) b1 = 0;
-    if (!oku1) u1 = 0;
-    bad.note(!(okb0 && oku0), row_base + row0 + 2 * lane);
-    bad.note(!(okb1 && oku1), row_base + row0 + 2 * lane + 1);
+        if (!okb) b[j][h] = 0;
+        if (!oku) u[j][h] = 0;
+        bad.note(!(okb && oku), row_base + row0 + r);
+      }
     wave_lds_fence();                          // all ASCII reads done before the area is reused
-    u64* r = reinterpret_cast<u64*>(area + lane * 48);
-    r[0] = b0; r[1] = u0; r[2] = i0; r[3] = b1; r[4] = u1; r[5] = i1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      u64* r = reinterpret_cast<u64*>(area + (128 * j + 2 * lane) * 24);
+      r[0] = b[j][0]; r[1] = u[j][0]; r[2] = ix[j][0]; r[3] = b[j][1]; r[4] = u[j][1]; r[5] = ix[j][1];
+    }
     wave_lds_fence();
     if constexpr (MSB) {                       // first base most significant: rewrite the staged AoS tile
-      rev_pairs_tile(area, 24, 0, bc_len, lane);   // (lane L owns records 2L, 2L+1 = the 48 bytes it just wrote)
-      rev_pairs_tile(area, 24, 8, umi_len, lane);
+      rev_pairs_tile<NT>(area, 24, 0, bc_len, lane);   // (lane L owns records 128j + 2L, 2L+1 = the 48 bytes it just wrote)
+      rev_pairs_tile<NT>(area, 24, 8, umi_len, lane);
       wave_lds_fence();
     }
-    uint8_t* dst = recs + (size_t)t * kTileBytes + 16 * lane;
-    st16(dst, *reinterpret_cast<const u32x4*>(area + 16 * lane));
-    st16(dst + 1024, *reinterpret_cast<const u32x4*>(area + 1024 + 16 * lane));
-    st16(dst + 2048, *reinterpret_cast<const u32x4*>(area + 2048 + 16 * lane));
+    uint8_t* dst = recs + (size_t)t * (kTileBytes * NT) + 16 * lane;
+#pragma unroll
+    for (int k = 0; k < 3 * NT; ++k) st16(dst + 1024 * k, *reinterpret_cast<const u32x4*>(area + 1024 * k + 16 * lane));
     if (!more) break;
     t = tn;
   }
@@ -109,7 +162,7 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
 
 // Single ASCII column -> u64 codes.
 template <int LEN, bool MSB>
-__global__ void __launch_bounds__(kBlock, (LEN > 0 && LEN <= 16 && (LEN & 3) == 0) ? 8 : 4)
+__global__ void __launch_bounds__(kBlock, (LEN <= 16 && (LEN & 3) == 0) ? 8 : 4)
 ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles, u32 len, u64* __restrict__ codes,
            u64* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileRecs * 32];
@@ -128,14 +181,21 @@ ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles, u32 len, u6
   for (;;) {
     const size_t row0 = (size_t)t * kTileRecs;
     wave_lds_fence();
-    sv.land(asc, len, lane);
+    const bool chunks_ok = sv.land(asc, len, lane);
     const u32 tn = t + nwaves;
     const bool more = tn < ntiles;
     sv.issue(in + (size_t)(more ? tn : t) * kTileRecs * len, len, lane);  // unconditional, see kcommon.hpp
     wave_lds_fence();
     bool ok0 = true, ok1 = true;
-    u64 v0 = pack_row<LEN>(asc + (2 * lane) * len, len, ok0);
-    u64 v1 = pack_row<LEN>(asc + (2 * lane + 1) * len, len, ok1);
+    u64 v0 = pack_row<LEN>(asc, 2 * lane, len, ok0);
+    u64 v1 = pack_row<LEN>(asc, 2 * lane + 1, len, ok1);
+    if constexpr (LEN == 0) {                      // a tile with an offending byte: its rows again, byte by byte (see ibu_k_encode)
+      if (__ballot(!chunks_ok) != 0) {
+        const size_t r0 = row0 + 2 * lane;
+        v0 = pack_row_bytes(in + r0 * len, len, ok0);
+        v1 = pack_row_bytes(in + (r0 + 1) * len, len, ok1);
+      }
+    }
     if constexpr (MSB) { v0 = rev_pairs(v0, len); v1 = rev_pairs(v1, len); }
     if (!ok0) v0 = 0;
     if (!ok1) v1 = 0;
@@ -181,6 +241,12 @@ static constexpr EncFn enc_entry() { return ibu_k_encode<len_of_mode(B), len_of_
 #define IBU_ENC_ROW(B, M) {enc_entry<B, 0, M>(), enc_entry<B, 1, M>(), enc_entry<B, 2, M>(), enc_entry<B, 3, M>(), enc_entry<B, 4, M>(), enc_entry<B, 5, M>()}
 #define IBU_ENC_TABLE(M) {IBU_ENC_ROW(0, M), IBU_ENC_ROW(1, M), IBU_ENC_ROW(2, M), IBU_ENC_ROW(3, M), IBU_ENC_ROW(4, M), IBU_ENC_ROW(5, M)}
 static const EncFn kEncTable[2][kNumLenModes][kNumLenModes] = {IBU_ENC_TABLE(false), IBU_ENC_TABLE(true)};  // [base_order][bc][umi]
+// 128-row tiles per wave iteration of each instantiation (the same for both base orders)
+template <int B, int U>
+static constexpr int enc_nt_of() { return enc_nt<len_of_mode(B), len_of_mode(U)>(); }
+#define IBU_ENC_NT_ROW(B) {enc_nt_of<B, 0>(), enc_nt_of<B, 1>(), enc_nt_of<B, 2>(), enc_nt_of<B, 3>(), enc_nt_of<B, 4>(), enc_nt_of<B, 5>()}
+static const int kEncNtTable[kNumLenModes][kNumLenModes] = {IBU_ENC_NT_ROW(0), IBU_ENC_NT_ROW(1), IBU_ENC_NT_ROW(2),
+                                                            IBU_ENC_NT_ROW(3), IBU_ENC_NT_ROW(4), IBU_ENC_NT_ROW(5)};
 
 hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t* umi, const uint64_t* idx,
                          uint64_t first_index, size_t n, uint32_t bc_len, uint32_t umi_len, void* recs,
@@ -188,15 +254,17 @@ hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t*
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, bc_len}, {umi, umi_len}, {idx, 8}};
-  const RowSplit rs = split_rows(sp, 4, n, kTileRecs);   // peel rows until every array is 16-B aligned
+  const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
+  const u32 nt = (u32)kEncNtTable[mb][mu];
+  const size_t tile_recs = (size_t)kTileRecs * nt;
+  const RowSplit rs = split_rows(cfg, sp, 4, n, tile_recs);   // peel rows until every array is 16-B aligned
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_encode_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, bc, umi, (const u64*)idx, (u64)first_index,
                        (u64)0, (u64)rs.head, bc_len, umi_len, cfg.base_order, (u64*)recs, (u64*)status);
   if (rs.main) {
-    const u32 ntiles = (u32)(rs.main / kTileRecs);
-    u32 wave_lds = kTileRecs * (bc_len + umi_len);
-    if (wave_lds < (u32)kTileBytes) wave_lds = kTileBytes;
-    const int mb = mode_of_len(bc_len), mu = mode_of_len(umi_len);
+    const u32 ntiles = (u32)(rs.main / tile_recs);
+    u32 wave_lds = (enc_field_lds(len_of_mode(mb), bc_len) + enc_field_lds(len_of_mode(mu), umi_len)) * nt;
+    if (wave_lds < (u32)kTileBytes * nt) wave_lds = kTileBytes * nt;
     const int mo = cfg.base_order ? 1 : 0;
     const EncFn fn = kEncTable[mo][mb][mu];
     static std::atomic<int> occ[2][33][33];  // LDS depends on the actual lengths, not only on the mode
@@ -222,7 +290,7 @@ hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[2] = {{in, len}, {codes, 8}};
-  const RowSplit rs = split_rows(sp, 2, n, kTileRecs);
+  const RowSplit rs = split_rows(cfg, sp, 2, n, kTileRecs);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_pack_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, in, (u64)0, (u64)rs.head, len, cfg.base_order,
                        (u64*)codes, (u64*)status);

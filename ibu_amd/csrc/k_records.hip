@@ -354,7 +354,7 @@ hipError_t launch_deserialize(const LaunchCfg& cfg, const void* recs, size_t n, 
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, 8}, {umi, 8}, {idx, 8}};
-  const RowSplit rs = split_rows(sp, 4, n, kRecTileRecs);   // peel rows until every array is 16-B aligned
+  const RowSplit rs = split_rows(cfg, sp, 4, n, kRecTileRecs);   // peel rows until every array is 16-B aligned
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_deserialize_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)rs.head,
                        (u64*)bc, (u64*)umi, (u64*)idx);
@@ -377,7 +377,7 @@ hipError_t launch_serialize(const LaunchCfg& cfg, const uint64_t* bc, const uint
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[4] = {{recs, 24}, {bc, 8}, {umi, 8}, {idx, 8}};
-  const RowSplit rs = split_rows(sp, 4, n, kRecTileRecs);
+  const RowSplit rs = split_rows(cfg, sp, 4, n, kRecTileRecs);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_serialize_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)bc, (const u64*)umi,
                        (const u64*)idx, (u64)0, (u64)rs.head, (u64*)recs);
@@ -398,7 +398,7 @@ hipError_t launch_reduce(const LaunchCfg& cfg, const void* recs, size_t n, uint6
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[1] = {{recs, 24}};
-  const RowSplit rs = split_rows(sp, 1, n, kTileRecs);   // an 8-B aligned base peels exactly one record
+  const RowSplit rs = split_rows(cfg, sp, 1, n, kTileRecs);   // an 8-B aligned base peels exactly one record
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_reduce_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)rs.head,
                        (u64*)acc);
@@ -418,7 +418,7 @@ hipError_t launch_generate(const LaunchCfg& cfg, uint64_t seed, uint64_t first, 
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[1] = {{recs, 24}};
-  const RowSplit rs = split_rows(sp, 1, n, kTileRecs);
+  const RowSplit rs = split_rows(cfg, sp, 1, n, kTileRecs);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_generate_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (u64)seed, (u64)first, (u64)0, (u64)rs.head,
                        bc_len, umi_len, (u64*)recs);

@@ -25,6 +25,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "kernels.h"
+
 namespace ibu {
 
 typedef unsigned int u32;
@@ -295,15 +297,90 @@ __device__ __forceinline__ u32x4 expand_chunk(const uint8_t* tile, u32 rstride, 
   return o;
 }
 
+__device__ __forceinline__ u64 mask2(u32 len) { return len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1); }
+
+// ---- runtime-length fields: the code stream ----------------------------------------------------------------------------
+// A field whose length is only known at run time (any of 1..32 without a specialisation: header.rs:180-185) goes through
+// its CODE STREAM: the rows' 2*len code bits back to back, row r at bit r*2*len.  The stream of a 128-row tile is 32*len
+// bytes, and its dword c holds exactly the 16 bases of chunk c of the ASCII column — between the stream and the column
+// every length looks like length 16 (one ds_read_b32 / ds_write_b32 and four v_perm expansions / SWAR packs per 16-byte
+// chunk).  What is ragged sits between the rows and the stream, and costs a fixed handful of instructions per ROW:
+//   decode: the row's masked code word shifted to its bit position and OR-ed into 2 (len <= 16) or 3 dwords of a zeroed
+//           stream with LDS atomics (ds_or_b32, no return value; a wave's DS instructions execute in order);
+//   encode: three dword reads at the row's bit position and two v_alignbit_b32.
+// Round 3 resolved every byte of such a field on its own (ds_read_u8 + v_bfe + shift/or per base; pack1 per byte):
+// (31,31) decode 0.49 / encode 0.53 of peak where the specialised lengths ran 0.75 / 0.65.
+static constexpr u32 kStreamPad = 16;                                   // the third dword of the last row's access
+__host__ __device__ constexpr u32 stream_bytes(int nt) { return 1024u * nt + kStreamPad; }   // 32 B/row x 128 x nt rows at len 32
+
+#ifndef IBU_STREAM_PROBE   // measurement builds (WRONG output): 1 = plain stores instead of the LDS atomics, 2 = no stream build at all
+#define IBU_STREAM_PROBE 0
+#endif
+__device__ __forceinline__ void lds_or(u32* p, u32 v) {
+#if IBU_STREAM_PROBE == 1
+  *p = v;
+#else
+  (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
+}
+// Rows of a staged tile (u64 field at byte `foff` of records of stride `rstride`; bits at and above 2*len ignored: F7) ->
+// the field's code stream.  Lane L places rows 2L, 2L+1 of each of the NT sub-tiles.
+template <int NT>
+__device__ __forceinline__ void stream_from_rows(const uint8_t* tile, u32 rstride, u32 foff, u32 len, u32* stream, u32 lane) {
+#if IBU_STREAM_PROBE == 2
+  return;
+#endif
+  u32x4 z; z.x = z.y = z.z = z.w = 0;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(stream) + 1024 * k + 16 * lane) = z;
+  if (lane == 0) *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(stream) + 1024 * NT) = z;
+  wave_lds_fence();
+  const u64 m = mask2(len);
+  const bool wide = len > 16;                      // wave-uniform: a row of at most 32 bits touches two dwords
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 r = 128 * j + 2 * lane + h;
+      const u64 v = *reinterpret_cast<const u64*>(tile + (size_t)r * rstride + foff) & m;
+      const u32 bit = r * 2 * len, s = bit & 31u;
+      u32* d = stream + (bit >> 5);
+      const u64 t = v << s;
+      lds_or(d, (u32)t);
+      lds_or(d + 1, (u32)(t >> 32));
+      if (wide) lds_or(d + 2, (u32)((v >> 32) >> (32 - s)));   // the s bits shifted out of t (u64 arithmetic: s == 0 gives 0)
+    }
+  wave_lds_fence();
+}
+// The code stream -> the ASCII column of the tile.  Fixed trip count, stores predicated: a store in a runtime-count loop
+// would turn the wait in front of the next tile's LDS writes into vmcnt(0) (see the head of this file).
+template <int NT>
+__device__ __forceinline__ void expand_stream(const u32* stream, u32 len, uint8_t* out_tile, u32 lane) {
+  const u32 nchunks = 8 * len * NT;
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) {
+    const u32 c = lane + 64 * i;
+    if (c < nchunks) st16(out_tile + 16 * (size_t)c, expand16(stream[c]));
+  }
+}
+// Row r of a code stream (encode side).  Reads up to 8 bytes past the row: the stream area is padded (kStreamPad).
+__device__ __forceinline__ u64 stream_row(const u32* stream, u32 r, u32 len) {
+  const u32 bit = r * 2 * len, s = bit & 31u;
+  const u32* d = stream + (bit >> 5);
+  const u32 w0 = d[0], w1 = d[1], w2 = d[2];
+  const u32 lo = __builtin_amdgcn_alignbit(w1, w0, s), hi = __builtin_amdgcn_alignbit(w2, w1, s);   // ({w1,w0} >> s) & 0xffffffff
+  return (((u64)hi << 32) | lo) & mask2(len);
+}
+
 // Output-centric expansion of one field of a staged tile: every lane produces whole 16-byte
 // chunks of the ASCII stream, so every store is a full coalesced dwordx4 whatever len is.
 //   LEN > 0 : compile-time length; ceil(LEN/8) rounds, straight-line; lanes past the last chunk
 //             recompute and re-store the LAST chunk (same bytes, same address: benign) so no
 //             store is exec-branched and the store count per tile is exact.
-//   LEN == 0: runtime length, plain loop (generic kernel).
+//   LEN == 0: runtime length: rows -> code stream -> chunks (above).
 template <int LEN, int NT = 1>  // NT: 128-record tiles staged back to back in `tile`
 __device__ __forceinline__ void expand_field(const uint8_t* tile, u32 rstride, u32 foff, u32 rt_len,
-                                             uint8_t* out_tile, u32 lane) {
+                                             uint8_t* out_tile, u32 lane, u32* stream = nullptr) {
   if constexpr (LEN > 0) {
     constexpr u32 last = 8 * LEN * NT - 1;
     constexpr int rounds = (8 * LEN * NT + kWave - 1) / kWave;
@@ -313,10 +390,9 @@ __device__ __forceinline__ void expand_field(const uint8_t* tile, u32 rstride, u
       c = c < last ? c : last;
       st16(out_tile + 16 * (size_t)c, expand_chunk(tile, rstride, foff, (u32)LEN, c));
     }
-  } else {
-    const u32 nchunks = 8 * rt_len * NT;
-    for (u32 c = lane; c < nchunks; c += kWave)
-      st16(out_tile + 16 * (size_t)c, expand_chunk(tile, rstride, foff, rt_len, c));
+  } else {                                         // runtime length: through the field's code stream (`stream`: stream_bytes(NT) of LDS)
+    stream_from_rows<NT>(tile, rstride, foff, rt_len, stream, lane);
+    expand_stream<NT>(stream, rt_len, out_tile, lane);
   }
 }
 
@@ -333,22 +409,20 @@ __device__ __forceinline__ u64 pack_row_bytes(const uint8_t* row, u32 len, bool&
   for (u32 i = 0; i < len; ++i) v |= (u64)pack1(row[i], ok) << (2 * i);
   return v;
 }
+// Row `r` of a field staged at `field` by AsciiStage<LEN>::land: ASCII rows (LEN > 0) or the code stream (LEN == 0, whose
+// validity was settled per chunk when it was landed: `ok` is not touched).
 template <int LEN>
-__device__ __forceinline__ u64 pack_row(const uint8_t* row, u32 rt_len, bool& ok) {
+__device__ __forceinline__ u64 pack_row(const uint8_t* field, u32 r, u32 rt_len, bool& ok) {
   if constexpr (LEN > 0 && (LEN & 3) == 0) {
-    return pack_row_dwords<LEN / 4>(row, ok);
+    return pack_row_dwords<LEN / 4>(field + r * LEN, ok);
   } else if constexpr (LEN > 0) {
+    const uint8_t* row = field + r * LEN;
     u64 v = 0;
 #pragma unroll
     for (int i = 0; i < LEN; ++i) v |= (u64)pack1(row[i], ok) << (2 * i);
     return v;
   } else {
-    if ((rt_len & 3) == 0) {
-      u64 v = 0;
-      for (u32 q = 0; q < (rt_len >> 2); ++q) v |= (u64)pack4(*reinterpret_cast<const u32*>(row + 4 * q), ok) << (8 * q);
-      return v;
-    }
-    return pack_row_bytes(row, rt_len, ok);
+    return stream_row(reinterpret_cast<const u32*>(field), r, rt_len);
   }
 }
 
@@ -356,13 +430,14 @@ __device__ __forceinline__ u64 pack_row(const uint8_t* row, u32 rt_len, bool& ok
 //   LEN > 0 : ceil(LEN/8) wave-wide dwordx4 loads in straight-line code; lanes past the last
 //             chunk re-read the last chunk (same cache line as their neighbours: no extra HBM
 //             traffic) and skip the LDS write.
-//   LEN == 0: generic kernel; 4 rounds, the unused ones predicated off.
-template <int LEN>
+//   LEN == 0: runtime length; 4 rounds, the unused ones predicated off; lands as the field's code stream.
+template <int LEN, int NT = 1>  // NT: 128-row tiles back to back (specialised lengths only)
 struct AsciiStage {
-  static constexpr int rounds = LEN > 0 ? (LEN + 7) / 8 : 4;
+  static_assert(LEN > 0 || NT == 1, "a runtime-length field is staged one tile at a time");
+  static constexpr int rounds = LEN > 0 ? (LEN * NT + 7) / 8 : 4;
   u32x4 v[rounds];
   __device__ __forceinline__ void issue(const uint8_t* g, u32 rt_len, u32 lane) {
-    const u32 last = 8 * (LEN > 0 ? (u32)LEN : rt_len) - 1;
+    const u32 last = 8 * (LEN > 0 ? (u32)(LEN * NT) : rt_len) - 1;
 #pragma unroll
     for (int i = 0; i < rounds; ++i) {
       u32 c = lane + 64 * i;
@@ -370,13 +445,26 @@ struct AsciiStage {
       v[i] = ld16(g + 16 * (size_t)c);
     }
   }
-  __device__ __forceinline__ void land(uint8_t* lds, u32 rt_len, u32 lane) const {
-    const u32 nchunks = 8 * (LEN > 0 ? (u32)LEN : rt_len);
+  // Registers -> LDS.  LEN > 0: the ASCII bytes, linear.  LEN == 0: every 16-byte chunk packed to the 32 code bits of its 16
+  // bases = dword c of the field's code stream (needs 32*len + kStreamPad <= 128*len bytes: the same area).  Returns false in
+  // a lane one of whose chunks holds a byte outside ACGTacgt (LEN == 0 only; rows are attributed by the caller's slow path).
+  __device__ __forceinline__ bool land(uint8_t* lds, u32 rt_len, u32 lane) const {
+    const u32 nchunks = 8 * (LEN > 0 ? (u32)(LEN * NT) : rt_len);
+    bool ok = true;
 #pragma unroll
     for (int i = 0; i < rounds; ++i) {
       const u32 c = lane + 64 * i;
-      if (c < nchunks) *reinterpret_cast<u32x4*>(lds + 16 * c) = v[i];
+      if constexpr (LEN > 0) {
+        if (c < nchunks) *reinterpret_cast<u32x4*>(lds + 16 * c) = v[i];
+      } else {
+        if (64u * i < nchunks) {                     // wave-uniform: a round past the column costs nothing
+          bool okc = true;
+          const u32 w = pack4(v[i].x, okc) | (pack4(v[i].y, okc) << 8) | (pack4(v[i].z, okc) << 16) | (pack4(v[i].w, okc) << 24);
+          if (c < nchunks) { reinterpret_cast<u32*>(lds)[c] = w; ok = ok && okc; }
+        }
+      }
     }
+    return ok;
   }
 };
 
@@ -405,7 +493,6 @@ struct BadRows {
   }
 };
 
-__device__ __forceinline__ u64 mask2(u32 len) { return len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1); }
 
 // ---- host-side launch helpers ------------------------------------------------------------------
 static inline u32 grid_for(u32 ntiles, int cus, int blocks_per_cu) {
@@ -432,19 +519,20 @@ static inline int peel_rows(const Span* s, int k) {
   return -1;
 }
 // Split n rows into head (tail kernel) + main (tiled kernel, `tile` rows per tile) + rest (tail kernel).
-// IBU_TRACE_ROWS=1 (tests only, read per call): one stderr line per split saying how many rows took which kernel, so that a
-// test can assert that an odd-record shard still runs tiled WITHOUT timing anything (a wall-clock ratio in the
-// correctness suite is a flake on a pool whose placements differ by 20 %).
+// Context option "trace_rows" (tests only; a context starts with the value IBU_TRACE_ROWS had when the library first looked):
+// one stderr line per split saying how many rows took which kernel, so that a test can assert that an odd-record shard
+// still runs tiled WITHOUT timing anything (a wall-clock ratio in the correctness suite is a flake on a pool whose
+// placements differ by 20 %).  Not an environment lookup per launch: the ring pipelines launch per slot from several host
+// threads.
 struct RowSplit { size_t head, main; };
-static inline RowSplit split_rows(const Span* s, int k, size_t n, size_t tile) {
+static inline RowSplit split_rows(const LaunchCfg& cfg, const Span* s, int k, size_t n, size_t tile) {
   const int h = peel_rows(s, k);
   RowSplit rs{n, 0};
   if (h >= 0) {
     rs.head = (size_t)h < n ? (size_t)h : n;
     rs.main = ((n - rs.head) / tile) * tile;
   }
-  if (const char* v = getenv("IBU_TRACE_ROWS"))
-    if (*v && *v != '0') fprintf(stderr, "ibu rows: n=%zu head=%zu tiled=%zu rest=%zu tile=%zu\n", n, rs.head, rs.main, n - rs.head - rs.main, tile);
+  if (cfg.trace_rows) fprintf(stderr, "ibu rows: n=%zu head=%zu tiled=%zu rest=%zu tile=%zu\n", n, rs.head, rs.main, n - rs.head - rs.main, tile);
   return rs;
 }
 template <class T> static inline T* adv(T* p, size_t bytes) {

@@ -134,7 +134,7 @@ extern "C" __global__ void ibu_k_sort_census_tail(const u64* __restrict__ recs, 
 }
 static void launch_census(const LaunchCfg& cfg, const void* recs, size_t n, u64* census, u32* flag32, hipStream_t st) {
   const Span sp[1] = {{recs, 24}};
-  const RowSplit rs = split_rows(sp, 1, n, kTileRecs);   // an 8-B aligned base peels exactly one record
+  const RowSplit rs = split_rows(cfg, sp, 1, n, kTileRecs);   // an 8-B aligned base peels exactly one record
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_sort_census_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)rs.head,
                        census, flag32);

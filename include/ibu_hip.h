@@ -261,6 +261,9 @@ int32_t ibu_device_count(int32_t* n);
  *                           The reference holds no codec code and no vector, so the order is UNPINNED; the second
  *                           value is the hedge: if an external bitnuc vector shows the other order, callers flip this
  *                           option and no kernel changes.
+ *   "trace_rows"     0 | 1  tests: one stderr line per kernel launch of the streaming entry points saying how many rows took
+ *                           the tiled and how many the one-thread-per-row kernel.  A context starts with the value the
+ *                           environment variable IBU_TRACE_ROWS had when the library first created a context (read once).
  * Unknown keys / out-of-range values return IBU_ERR_INVALID_ARG. */
 #define IBU_BASE_ORDER_LSB_FIRST 0
 #define IBU_BASE_ORDER_MSB_FIRST 1

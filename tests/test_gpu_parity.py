@@ -273,14 +273,14 @@ def test_bad_rows_keep_the_callers_numbering_when_peeled(ia, ctx, oracle, k):
 def test_odd_record_shard_takes_the_tiled_kernels(ia, ctx, oracle, capfd, monkeypatch):
     """The peel: decode / encode / reduce of a shard that starts at record 1 or 3 of a larger buffer
     (8-byte aligned base) must run through the TILED kernels for all but a handful of rows — it used to fall back to the
-    one-thread-per-record kernel for every record (~10x slower).  Asserted on the path taken (IBU_TRACE_ROWS: rows per
+    one-thread-per-record kernel for every record (~10x slower).  Asserted on the path taken (option trace_rows: rows per
     kernel of every launch), not on a clock: the wall-clock form of this check lives in tests/perf/peel_rate.py."""
     n, bc_len, umi_len = 1_000_003, 16, 12
     recs, back = ctx.alloc((n + 4) * 24), ctx.alloc((n + 4) * 24)
     bc, umi, idx = ctx.alloc((n + 4) * bc_len), ctx.alloc((n + 4) * umi_len), ctx.alloc((n + 4) * 8)
     ctx.generate(SEED, 0, n + 4, bc_len, umi_len, recs)
     host = recs.download(ia.REC_DTYPE)
-    monkeypatch.setenv("IBU_TRACE_ROWS", "1")
+    ctx.set_option("trace_rows", 1)       # a context option since round 4 (it was an environment lookup per launch)
     for k in (0, 1, 3):
         capfd.readouterr()
         ctx.decode_ascii(recs.ptr + 24 * k, n, bc_len, umi_len, bc.ptr + k * bc_len, umi.ptr + k * umi_len, idx.ptr + 8 * k)
@@ -297,6 +297,7 @@ def test_odd_record_shard_takes_the_tiled_kernels(ia, ctx, oracle, capfd, monkey
         want = host[k:k + n]
         assert got == oracle.reduce_records(want)
         assert back.download(count=n * 24, offset=24 * k).tobytes() == want.tobytes()
+    ctx.set_option("trace_rows", 0)
 
 
 @pytest.mark.parametrize("length", [1, 3, 4, 8, 12, 13, 16, 24, 31, 32])

@@ -5,7 +5,7 @@ Times the hot-path kernels with HIP events on one stream.  Variants (different b
 libibu_hip.so and/or different residency caps) are run in interleaved rounds inside ONE
 process (cdna_hip_programming.md rule 24), all on the same buffers.
 
-  python tools/kbench.py [--records 2e8] [--lens 16,12] [--rounds 7] [--kernels decode,encode,...]
+  python tools/kbench.py [--records 2e8] [--lens "16,12 31,31 ..."] [--rounds 7] [--kernels decode,encode,...]
                          [--so tag=path ...] [--blocks 8,7,6]
 Prints one JSON line per (variant, blocks, kernel): median / best ms and algorithmic GB/s."""
 import argparse
@@ -33,14 +33,15 @@ def main():
     from ibu_amd import _lib
 
     n = int(a.records)
-    bc_len, umi_len = (int(x) for x in a.lens.split(","))
+    pairs = [tuple(int(x) for x in pr.split(",")) for pr in a.lens.replace(";", " ").split()]
+    bc_max, umi_max = max(p_[0] for p_ in pairs), max(p_[1] for p_ in pairs)
     dev = torch.device("cuda", 0)
     ts = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(ts)
     st = C.c_void_p(ts.cuda_stream)
     buf = lambda b: torch.empty(b, dtype=torch.uint8, device=dev)
     recs, back = buf(n * 24), buf(n * 24)
-    bc, umi, idx = buf(n * bc_len), buf(n * umi_len), buf(n * 8)
+    bc, umi, idx = buf(n * bc_max), buf(n * umi_max), buf(n * 8)   # ONE set of arrays for every pair of lengths: same placement
     c0, c1 = buf(n * 8), buf(n * 8)
     p = lambda t: C.c_void_p(t.data_ptr())
 
@@ -53,7 +54,7 @@ def main():
         assert lib.ibu_ctx_create(0, C.byref(ctx)) == 0, tag
         cfgs.append((tag, lib, ctx))
 
-    def ops_for(lib, ctx):
+    def ops_for(lib, ctx, bc_len, umi_len):
         return {
             "decode": (lambda: lib.ibu_decode_ascii(ctx, p(recs), n, bc_len, umi_len, p(bc), p(umi), p(idx), st), 24 + bc_len + umi_len + 8),
             "encode": (lambda: lib.ibu_encode_ascii(ctx, p(bc), p(umi), p(idx), 0, n, bc_len, umi_len, p(back), st), 24 + bc_len + umi_len + 8),
@@ -68,63 +69,64 @@ def main():
         }
 
     tag0, lib0, ctx0 = cfgs[0]
-    assert lib0.ibu_generate(ctx0, 1, 0, n, bc_len, umi_len, p(recs), st) == 0
-    assert lib0.ibu_decode_ascii(ctx0, p(recs), n, bc_len, umi_len, p(bc), p(umi), p(idx), st) == 0
-    assert lib0.ibu_deserialize(ctx0, p(recs), n, p(c0), p(c1), p(idx), st) == 0
-    torch.cuda.synchronize()
-
-    # measurement-only read:write mix kernels (tools/native/hbm_mix.hip), timed in the same process as a yardstick
-    mix_so = os.path.join(ROOT, "tools", "native", "libhbm_mix.so")
-    mix_ops = {}
-    if os.path.exists(mix_so):
-        mix = C.CDLL(mix_so)
-        mix.hbm_mix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
-        span = min(recs.numel(), back.numel())
-        for tag_, r_, w_ in (("mix10", 1, 0), ("mix30", 3, 0), ("mix11", 1, 1), ("mix23", 2, 3), ("mix32", 3, 2),
-                               ("pipe11", 11, 1), ("pipe23", 12, 3), ("pipe32", 13, 2)):  # r_ >= 10: software-pipelined form
-            steps = span // 16 // max(r_ % 10, w_) // 4 * 4
-            mix_ops[tag_] = (lambda r_=r_, w_=w_, steps=steps: mix.hbm_mix(r_, w_, recs.data_ptr(), back.data_ptr(), steps, 256 * 7, st),
-                             (r_ % 10 + w_) * 16 * steps / n)
-
-    names = [k for k in a.kernels.split(",") if k in ops_for(lib0, ctx0)]
-    runs = []  # (tag, blocks, kernel, fn, bytes_per_record, lib, ctx)
-    for tag, lib, ctx in cfgs:
-        ops = ops_for(lib, ctx)
-        for b in blocks:
-            for k in names:
-                runs.append((tag, b, k, ops[k][0], ops[k][1], lib, ctx))
-    for k in a.kernels.split(","):
-        if k in mix_ops:
-            runs.append(("mix", 0, k, mix_ops[k][0], mix_ops[k][1], lib0, ctx0))
-    times = {(r[0], r[1], r[2]): [] for r in runs}
-
-    def run(r):
-        tag, b, k, fn, _, lib, ctx = r
-        if b:
-            assert lib.ibu_ctx_set_option(ctx, b"blocks_per_cu", b) == 0
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = fn()
-        e1.record()
-        e1.synchronize()
-        assert rc == 0, (tag, k, rc)
-        return e0.elapsed_time(e1)
-
     print(json.dumps({"gpu": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))}), flush=True)
-    for r in runs:  # warm-up (module load, occupancy query)
-        run(r)
-    for _ in range(a.rounds):
+    for bc_len, umi_len in pairs:
+        assert lib0.ibu_generate(ctx0, 1, 0, n, bc_len, umi_len, p(recs), st) == 0
+        assert lib0.ibu_decode_ascii(ctx0, p(recs), n, bc_len, umi_len, p(bc), p(umi), p(idx), st) == 0
+        assert lib0.ibu_deserialize(ctx0, p(recs), n, p(c0), p(c1), p(idx), st) == 0
+        torch.cuda.synchronize()
+
+        # measurement-only read:write mix kernels (tools/native/hbm_mix.hip), timed in the same process as a yardstick
+        mix_so = os.path.join(ROOT, "tools", "native", "libhbm_mix.so")
+        mix_ops = {}
+        if os.path.exists(mix_so):
+            mix = C.CDLL(mix_so)
+            mix.hbm_mix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+            span = min(recs.numel(), back.numel())
+            for tag_, r_, w_ in (("mix10", 1, 0), ("mix30", 3, 0), ("mix11", 1, 1), ("mix23", 2, 3), ("mix32", 3, 2),
+                                   ("pipe11", 11, 1), ("pipe23", 12, 3), ("pipe32", 13, 2)):  # r_ >= 10: software-pipelined form
+                steps = span // 16 // max(r_ % 10, w_) // 4 * 4
+                mix_ops[tag_] = (lambda r_=r_, w_=w_, steps=steps: mix.hbm_mix(r_, w_, recs.data_ptr(), back.data_ptr(), steps, 256 * 7, st),
+                                 (r_ % 10 + w_) * 16 * steps / n)
+
+        names = [k for k in a.kernels.split(",") if k in ops_for(lib0, ctx0, bc_len, umi_len)]
+        runs = []  # (tag, blocks, kernel, fn, bytes_per_record, lib, ctx)
+        for tag, lib, ctx in cfgs:
+            ops = ops_for(lib, ctx, bc_len, umi_len)
+            for b in blocks:
+                for k in names:
+                    runs.append((tag, b, k, ops[k][0], ops[k][1], lib, ctx))
+        for k in a.kernels.split(","):
+            if k in mix_ops:
+                runs.append(("mix", 0, k, mix_ops[k][0], mix_ops[k][1], lib0, ctx0))
+        times = {(r[0], r[1], r[2]): [] for r in runs}
+
+        def run(r):
+            tag, b, k, fn, _, lib, ctx = r
+            if b:
+                assert lib.ibu_ctx_set_option(ctx, b"blocks_per_cu", b) == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn()
+            e1.record()
+            e1.synchronize()
+            assert rc == 0, (tag, k, rc)
+            return e0.elapsed_time(e1)
+
+        for r in runs:  # warm-up (module load, occupancy query)
+            run(r)
+        for _ in range(a.rounds):
+            for r in runs:
+                times[(r[0], r[1], r[2])].append(run(r))
+        for tag, lib, ctx in cfgs:
+            if lib.ibu_codec_status(ctx, st, None, None) != 0:  # expected only with IBU_PROBE builds (their output is wrong)
+                print(json.dumps({"note": f"codec status of {tag!r} reports invalid rows (probe build in the mix?)"}), flush=True)
         for r in runs:
-            times[(r[0], r[1], r[2])].append(run(r))
-    for tag, lib, ctx in cfgs:
-        if lib.ibu_codec_status(ctx, st, None, None) != 0:  # expected only with IBU_PROBE builds (their output is wrong)
-            print(json.dumps({"note": f"codec status of {tag!r} reports invalid rows (probe build in the mix?)"}), flush=True)
-    for r in runs:
-        t = times[(r[0], r[1], r[2])]
-        med, mn = statistics.median(t), min(t)
-        print(json.dumps({"tag": r[0], "blocks_per_cu": r[1] or "default", "kernel": r[2], "n": n, "lens": [bc_len, umi_len],
-                          "ms_med": round(med, 4), "ms_min": round(mn, 4), "GBps_med": round(n * r[4] / med / 1e6, 1),
-                          "GBps_best": round(n * r[4] / mn / 1e6, 1)}), flush=True)
+            t = times[(r[0], r[1], r[2])]
+            med, mn = statistics.median(t), min(t)
+            print(json.dumps({"tag": r[0], "blocks_per_cu": r[1] or "default", "kernel": r[2], "n": n, "lens": [bc_len, umi_len],
+                              "ms_med": round(med, 4), "ms_min": round(mn, 4), "GBps_med": round(n * r[4] / med / 1e6, 1),
+                              "GBps_best": round(n * r[4] / mn / 1e6, 1)}), flush=True)
 
 
 if __name__ == "__main__":

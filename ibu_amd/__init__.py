@@ -720,6 +720,8 @@ class Context:
         """The sort over several shards, one per context (= per GPU), in one call (ibu_sort_records_contexts): shards =
         [(d_records, d_tmp, n, capacity_in_records), ...]; returns the new record counts — shard i holds the i-th
         contiguous range of the global order."""
+        if len(shards) != len(ctxs):   # the C side reads n_ctxs entries of both arrays
+            raise ValueError(f"{len(ctxs)} contexts but {len(shards)} shards")
         arr = (C.c_void_p * len(ctxs))(*[c._c for c in ctxs])
         sh = (_lib.CSortShard * len(shards))()
         for k, (r, t, n, cap) in enumerate(shards):

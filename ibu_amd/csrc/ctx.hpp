@@ -65,6 +65,17 @@ namespace ibu {
 int32_t ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_dev);
 void ring_release(ibu_ctx* ctx);
 void codec_ring_release(ibu_ctx* ctx);
+// The context's sort scratch (census slots, histograms, digit side stream): grows only; the one allocation a launch path may make.
+inline int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
+  if (need > ctx->sort_scratch_bytes) {
+    if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));
+    ctx->d_sort_scratch = nullptr;
+    ctx->sort_scratch_bytes = 0;
+    IBU_HIP(hipMalloc(&ctx->d_sort_scratch, need));
+    ctx->sort_scratch_bytes = need;
+  }
+  return IBU_OK;
+}
 inline hipStream_t pick_stream(const ibu_ctx* ctx, void* stream) {
   return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 }

@@ -428,17 +428,6 @@ extern "C" int32_t ibu_records_first_mismatch(ibu_ctx_t* ctx, const void* d_a, c
   if (w != ~0ull) *first = w / 3;
   return IBU_OK;
 }
-static int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
-  if (need > ctx->sort_scratch_bytes) {  // grows only; the one allocation a launch path may make
-    if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));
-    ctx->d_sort_scratch = nullptr;
-    ctx->sort_scratch_bytes = 0;
-    IBU_HIP(hipMalloc(&ctx->d_sort_scratch, need));
-    ctx->sort_scratch_bytes = need;
-  }
-  return IBU_OK;
-}
-
 // ---- compacted keys: census, plan, records <-> 12-byte elements (the exchange format of the multi-GPU sort) ----------
 static_assert(sizeof(ibu_key_plan_t) == sizeof(ibu::CompactPlan) && offsetof(ibu_key_plan_t, base) == offsetof(ibu::CompactPlan, base) &&
                   offsetof(ibu_key_plan_t, k) == offsetof(ibu::CompactPlan, k),

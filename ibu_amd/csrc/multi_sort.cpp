@@ -1,16 +1,25 @@
 // multi_sort.cpp — ibu_sort_records_contexts: the records of several shards, one per context (= per GPU), sorted GLOBALLY by
 // (barcode, umi, index) — the order derive(Ord) gives Record (src/constructs/record.rs:58) and the header's sorted flag
 // promises (header.rs:111-113) — behind ONE call of the C ABI, the way ibu_mmap_process_contexts is the one-call form of
-// process_parallel.  Sample sort: every shard is sorted where it lives, evenly spaced samples of all shards
-// pick n - 1 splitters, every shard is cut at the splitters (binary search on the device), the pieces travel to their
-// owners device to device (hipMemcpyPeerAsync: over xGMI between GPUs, a plain copy inside one), and every owner sorts what
-// it received.  Shard i ends up with the i-th contiguous range of the global order.  A host thread per context, like
+// process_parallel.  Sample sort: samples of all shards pick n - 1 splitters, every record travels to the
+// owner of the range between two splitters device to device (hipMemcpyPeerAsync: over xGMI between GPUs, a plain copy inside
+// one), and shard i ends up with the i-th contiguous range of the global order.  A host thread per context, like
 // process_contexts (stream.cpp); the phases are separated by joins, which is all the cross-device ordering there is.
 //
+// Two forms.  PARTITION FIRST (round 4; keys of which at most 11 bytes vary over ALL shards — 16/12 records with indices below
+// 2^32 —, up to 256 shards): nothing is sorted before the exchange.  A shard is compacted to 12-byte elements (one plan for all
+// shards from the combined census words), every element gets the number of its key RANGE (256 of them, cut by sampled splitters)
+// in its free top byte, one ordinary element pass on that byte puts the elements in range order (sort.hip:
+// launch_partition_elems), the exact counts of that pass say which consecutive ranges an owner gets, the owners pull their
+// pieces — 12 bytes per record on the links — and sort them straight into records (launch_sort_elems: the sort's passes without its census and
+// compress steps).  Every record is sorted ONCE; round 3 sorted every shard, exchanged, and sorted every owner's pieces again
+// (one-GPU rehearsal at 1e9 records: 0.097 s; DESIGN.md §5 has this round's).  SORT FIRST (the round-3 form, kept for every
+// other input: wide keys, unaligned buffers, sort_compact = 0): shards sorted where they live, cut at the splitters by binary
+// search, 24-byte records (or 12-byte elements when exactly 12 bytes vary) exchanged, owners sort again.
+//
 // The one-process-per-GPU form of the same algorithm is ibu_amd/sharding.py (torch.distributed: all-gather of the samples,
-// all-to-all of 12-byte compacted keys); this form needs no collective library and ships the same 12-byte elements whenever
-// the keys of all shards allow it.  Neither has run
-// on more than one distinct GPU yet (no multi-GPU box in any round's budget): unmeasured.
+// all-to-all of 12-byte compacted keys).  Neither has run on more than one distinct GPU yet (no multi-GPU box in any round's
+// budget): unmeasured, and this entry point is EXPERIMENTAL until it has.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -52,12 +61,249 @@ int32_t on_every_context(size_t n, F&& fn) {
     }
   return IBU_OK;
 }
+
+// Direct xGMI access where the topology has it (current device = the puller's); already enabled, or not possible (the runtime
+// stages the copy then): neither is an error.  Peer access stays enabled for the rest of the process.
+void enable_peer(int self, int peer) {
+  int can = 0;
+  if (self != peer && hipDeviceCanAccessPeer(&can, self, peer) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(peer, 0);
+  (void)hipGetLastError();
+}
+
+// Evenly spaced samples of every shard, IN PROPORTION to its size (a shard of 1e3 records beside one of 1e9 does not get the
+// same say: ADVICE r03), `budget` in all — one strided copy per shard.
+int32_t sample_shards(ibu_ctx_t* const* ctxs, const ibu_sort_shard_t* shards, size_t W, size_t budget, std::vector<std::vector<Rec>>& samp) {
+  size_t total = 0;
+  for (size_t i = 0; i < W; ++i) total += shards[i].n;
+  return on_every_context(W, [&](size_t i) -> int32_t {
+    const size_t n = shards[i].n;
+    size_t take = total ? (size_t)(((long double)budget * n) / total) + 1 : 0;
+    if (take > n) take = n;
+    try { samp[i].resize(take); } catch (...) { return caught_io("ibu_sort_records_contexts"); }
+    if (!take) return IBU_OK;
+    IBU_HIP(hipSetDevice(ctxs[i]->device));
+    const size_t stride = n / take;                          // >= 1
+    IBU_HIP(hipMemcpy2DAsync(samp[i].data(), kRec, static_cast<const uint8_t*>(shards[i].d_records) + kRec * (stride / 2), stride * kRec, kRec, take,
+                             hipMemcpyDeviceToHost, ctxs[i]->stream));
+    IBU_HIP(hipStreamSynchronize(ctxs[i]->stream));
+    return IBU_OK;
+  });
+}
+// splitter k = the pooled sample at k / W (W: owners, or the 256 fine ranges of the partition-first form)
+void pick_splitters(std::vector<std::vector<Rec>>& samp, size_t W, std::vector<Rec>& split) {
+  std::vector<Rec> all;
+  for (auto& v : samp) all.insert(all.end(), v.begin(), v.end());
+  std::sort(all.begin(), all.end(), rec_lt);
+  split.resize(W - 1);
+  for (size_t k = 1; k < W; ++k)
+    split[k - 1] = all.empty() ? Rec{~0ull, ~0ull, ~0ull} : all[std::min(all.size() - 1, k * all.size() / W)];
+}
+size_t sample_budget(size_t W) {
+  const size_t want = 512 * W;                                // ~512 samples per owner: its share is known to a few percent
+  return want < 16384 ? 16384 : (want > (1u << 19) ? (1u << 19) : want);
+}
+
+// who receives how much, and where each piece lands at its owner (pieces in shard order); a shard without the room fails the call
+int32_t plan_landing(const ibu_sort_shard_t* shards, size_t W, const std::vector<std::vector<uint64_t>>& bound, std::vector<size_t>& n_out,
+                     std::vector<std::vector<size_t>>& land, const char* state) {
+  for (size_t j = 0; j < W; ++j) {
+    for (size_t i = 0; i < W; ++i) {
+      land[j][i] = n_out[j];
+      n_out[j] += (size_t)(bound[i][j + 1] - bound[i][j]);
+    }
+    if (n_out[j] > shards[j].capacity)
+      return set_error(IBU_ERR_INVALID_ARG, n_out[j], shards[j].capacity, 0, "shard %zu would receive %zu records, its capacity is %zu (%s)", j, n_out[j],
+                       shards[j].capacity, state);
+  }
+  return IBU_OK;
+}
+
+// ---- PARTITION FIRST -------------------------------------------------------------------------------------------------------
+int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, const CompactPlan& plan, size_t total) {
+  // 1. 255 splitters from samples of the (unsorted) shards cut the key space into 256 FINE ranges — more than there are owners:
+  //    the samples only have to make the ranges small, the exact counts of the partition pass then say which consecutive ranges
+  //    an owner gets (a range is ~1/256 of the records: the owners' loads differ by about that much, not by the sampling noise
+  //    of W - 1 splitters drawn from unsorted data)
+  constexpr size_t F = 256;
+  std::vector<std::vector<Rec>> samp(W);
+  int32_t rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
+  if (rc) return rc;
+  std::vector<Rec> split;
+  pick_splitters(samp, F, split);
+  // 2. every shard: elements in range order in the upper half of its scratch; fine[i][f] = first element of range f.
+  //    The largest shard also says how many prefix passes a sort of `total` records like its own wants (it is a sample of them).
+  size_t big = 0;
+  for (size_t i = 1; i < W; ++i)
+    if (shards[i].n > shards[big].n) big = i;
+  uint32_t prefix_passes = 0;
+  std::vector<std::vector<uint64_t>> fine(W, std::vector<uint64_t>(F + 1, 0));
+  const size_t split_bytes = (kRec + 12) * (F - 1) + 512;
+  rc = on_every_context(W, [&](size_t i) -> int32_t {
+    ibu_ctx_t* c = ctxs[i];
+    const size_t n = shards[i].n;
+    if (!n) return IBU_OK;
+    IBU_HIP(hipSetDevice(c->device));
+    const size_t need = sort_scratch_bytes(c->cfg, n);
+    int32_t r = ensure_sort_scratch(c, need + split_bytes);   // the splitters ride behind the sort's own scratch
+    if (r) return r;
+    hipStream_t st = c->stream;
+    uint8_t* t = static_cast<uint8_t*>(shards[i].d_tmp);
+    uint8_t* d_split_recs = static_cast<uint8_t*>(c->d_sort_scratch) + ((need + 255) & ~(size_t)255);
+    uint8_t* d_split_elems = d_split_recs + ((kRec * (F - 1) + 15) & ~(size_t)15);
+    if (i == big) IBU_HIP(launch_estimate_prefix(c->cfg, shards[i].d_records, n, total, t, plan, &prefix_passes, st));   // (scratch: the head of d_tmp)
+    IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
+    IBU_HIP(launch_compact(c->cfg, plan, d_split_recs, F - 1, d_split_elems, st));
+    IBU_HIP(launch_compact(c->cfg, plan, shards[i].d_records, n, t, st));
+    const uint64_t* d_starts = nullptr;
+    IBU_HIP(launch_partition_elems(c->cfg, t, n, d_split_elems, (uint32_t)(F - 1), t + 12 * shards[i].capacity, c->d_sort_scratch, need, &d_starts, st));
+    IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
+    IBU_HIP(hipStreamSynchronize(st));
+    fine[i][F] = n;
+    return IBU_OK;
+  });
+  if (rc) return rc;
+  // which ranges an owner gets: consecutive ones, up to the point nearest to its share of the records (and not past its capacity
+  // while an earlier cut avoids that; the last owner takes what is left)
+  std::vector<uint64_t> g(F, 0);
+  for (size_t i = 0; i < W; ++i)
+    for (size_t f = 0; f < F; ++f) g[f] += fine[i][f + 1] - fine[i][f];
+  std::vector<size_t> cut(W + 1, F);
+  cut[0] = 0;
+  uint64_t cum = 0;
+  for (size_t j = 0, f = 0; j + 1 < W; ++j) {
+    const long double target = (long double)total * (j + 1) / W;
+    uint64_t load = 0;
+    while (f < F && load + g[f] <= shards[j].capacity && (long double)cum + (long double)g[f] / 2 <= target) {
+      load += g[f];
+      cum += g[f];
+      ++f;
+    }
+    cut[j + 1] = f;
+  }
+  std::vector<std::vector<uint64_t>> bound(W, std::vector<uint64_t>(W + 1, 0));
+  for (size_t i = 0; i < W; ++i)
+    for (size_t j = 0; j <= W; ++j) bound[i][j] = fine[i][cut[j]];
+  std::vector<size_t> n_out(W, 0);
+  std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));   // land[j][i]: element offset of shard i's piece at owner j
+  rc = plan_landing(shards, W, bound, n_out, land, "no shard's records were touched");
+  if (rc) return rc;
+  // 3. the exchange: every owner pulls its pieces into the LOWER half of its scratch (its own unpartitioned elements: dead)
+  rc = on_every_context(W, [&](size_t j) -> int32_t {
+    IBU_HIP(hipSetDevice(ctxs[j]->device));
+    uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp);
+    for (size_t i = 0; i < W; ++i) {
+      const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
+      if (!cnt) continue;
+      enable_peer(ctxs[j]->device, ctxs[i]->device);
+      const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + 12 * (shards[i].capacity + bound[i][j]);
+      IBU_HIP(hipMemcpyPeerAsync(t + 12 * land[j][i], ctxs[j]->device, src, ctxs[i]->device, 12 * cnt, ctxs[j]->stream));
+    }
+    IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
+    return IBU_OK;
+  });
+  if (rc) return rc;                                          // (joined: the upper halves are not read any more)
+  // 4. every owner sorts what it received, elements -> records
+  rc = on_every_context(W, [&](size_t j) -> int32_t {
+    ibu_ctx_t* c = ctxs[j];
+    if (!n_out[j]) return IBU_OK;
+    IBU_HIP(hipSetDevice(c->device));
+    const size_t need = sort_scratch_bytes(c->cfg, n_out[j]);
+    int32_t r = ensure_sort_scratch(c, need);
+    if (r) return r;
+    IBU_HIP(launch_sort_elems(c->cfg, plan, shards[j].d_records, shards[j].d_tmp, n_out[j], prefix_passes, c->d_sort_scratch, c->sort_scratch_bytes, c->stream));
+    IBU_HIP(hipStreamSynchronize(c->stream));
+    return IBU_OK;
+  });
+  if (rc) return rc;
+  if (getenv("IBU_TRACE_SORT")) fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u)\n", W, prefix_passes);
+  for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
+  return IBU_OK;
+}
+
+// ---- SORT FIRST (round 3) -----------------------------------------------------------------------------------------------------
+int32_t sort_sort_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, const CompactPlan& census_plan, bool have_plan) {
+  // 1. every shard sorted where it lives
+  int32_t rc = on_every_context(W, [&](size_t i) -> int32_t {
+    int32_t r = ibu_sort_records(ctxs[i], shards[i].d_records, shards[i].d_tmp, shards[i].n, nullptr);
+    return r ? r : ibu_ctx_synchronize(ctxs[i], nullptr);
+  });
+  if (rc) return rc;
+  // 2. samples (of sorted shards: exact local quantiles) -> splitters
+  std::vector<std::vector<Rec>> samp(W);
+  rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
+  if (rc) return rc;
+  std::vector<Rec> split;
+  pick_splitters(samp, W, split);
+  // 3. every shard cut at the splitters: bound[i][k] = first record of shard i that is >= splitter k (device binary search;
+  //    keys and positions staged in the shard's scratch: 32 (W - 1) bytes, which the argument check guarantees)
+  std::vector<std::vector<uint64_t>> bound(W, std::vector<uint64_t>(W + 1, 0));
+  rc = on_every_context(W, [&](size_t i) -> int32_t {
+    uint8_t* t = static_cast<uint8_t*>(shards[i].d_tmp);
+    uint64_t* d_pos = reinterpret_cast<uint64_t*>(t + kRec * (W - 1));
+    int32_t r = ibu_memcpy_h2d(ctxs[i], t, split.data(), kRec * (W - 1), nullptr);
+    if (!r) r = ibu_lower_bound_records(ctxs[i], shards[i].d_records, shards[i].n, t, W - 1, d_pos, nullptr);
+    if (!r) r = ibu_memcpy_d2h(ctxs[i], bound[i].data() + 1, d_pos, 8 * (W - 1), nullptr);
+    if (!r) r = ibu_ctx_synchronize(ctxs[i], nullptr);
+    bound[i][0] = 0;
+    bound[i][W] = shards[i].n;
+    return r;
+  });
+  if (rc) return rc;
+  std::vector<size_t> n_out(W, 0);
+  std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));   // land[j][i]: record offset of shard i's piece in owner j
+  rc = plan_landing(shards, W, bound, n_out, land, "the shards are sorted locally, nothing was moved");
+  if (rc) return rc;
+  // 4. the exchange.  Exactly 12 varying bytes over all shards: 12-byte elements (every shard compacts itself into the lower half
+  //    of its scratch, every owner pulls its pieces into the upper half and expands them over its records); otherwise 24-byte
+  //    records travel into the owner's scratch and are copied over its records.  Then every owner sorts.
+  const bool compact = have_plan && census_plan.k <= 12;
+  const ibu_key_plan_t* plan = reinterpret_cast<const ibu_key_plan_t*>(&census_plan);
+  const size_t wire = compact ? 12 : kRec;                    // bytes per record on the links
+  if (compact) {
+    rc = on_every_context(W, [&](size_t i) -> int32_t {
+      int32_t r = ibu_records_compact(ctxs[i], plan, shards[i].d_records, shards[i].n, shards[i].d_tmp, nullptr);
+      return r ? r : ibu_ctx_synchronize(ctxs[i], nullptr);
+    });
+    if (rc) return rc;
+  }
+  rc = on_every_context(W, [&](size_t j) -> int32_t {
+    IBU_HIP(hipSetDevice(ctxs[j]->device));
+    uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp) + (compact ? 12 * shards[j].capacity : 0);
+    for (size_t i = 0; i < W; ++i) {
+      const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
+      if (!cnt) continue;
+      enable_peer(ctxs[j]->device, ctxs[i]->device);
+      const uint8_t* src = static_cast<const uint8_t*>(compact ? shards[i].d_tmp : shards[i].d_records) + wire * bound[i][j];
+      IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ctxs[j]->stream));
+    }
+    IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
+    return IBU_OK;
+  });
+  if (rc) return rc;                                          // (joined: nobody overwrites what a peer is still reading)
+  rc = on_every_context(W, [&](size_t j) -> int32_t {
+    int32_t r = IBU_OK;
+    if (n_out[j]) {
+      uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp);
+      r = compact ? ibu_records_expand(ctxs[j], plan, t + 12 * shards[j].capacity, n_out[j], shards[j].d_records, nullptr)
+                  : ibu_device_copy(ctxs[j], shards[j].d_records, t, kRec * n_out[j], nullptr);
+    }
+    if (!r) r = ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr);
+    if (!r) r = ibu_ctx_synchronize(ctxs[j], nullptr);
+    return r;
+  });
+  if (rc) return rc;
+  if (getenv("IBU_TRACE_SORT")) fprintf(stderr, "ibu sort: contexts=%zu exchange=%zu bytes per record (sort first)\n", W, wire);
+  for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
+  return IBU_OK;
+}
 }  // namespace
 
 extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ctxs, ibu_sort_shard_t* shards) {
   if (!ctxs || !shards || n_ctxs == 0) return err_arg("NULL argument or no context");
   if (n_ctxs > 1024) return err_arg("more than 1024 contexts");
   const size_t W = n_ctxs;
+  size_t total = 0;
+  bool aligned = true;
   for (size_t i = 0; i < W; ++i) {
     if (!ctxs[i]) return err_arg("a context is NULL");
     for (size_t j = 0; j < i; ++j)
@@ -66,132 +312,34 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
     if (s.n > s.capacity) return err_arg("a shard holds more records than its capacity");
     if (s.capacity && (!s.d_records || !s.d_tmp)) return err_arg("a shard's d_records / d_tmp is NULL");
     if ((reinterpret_cast<uintptr_t>(s.d_records) | reinterpret_cast<uintptr_t>(s.d_tmp)) & 7u) return err_arg("d_records / d_tmp must be 8-byte aligned");
-    if (W > 1 && s.capacity < W + 1) return err_arg("a shard's capacity must be at least the number of shards + 1 (the splitters are staged in d_tmp)");
+    // the splitters (24 bytes each) and their positions (8 bytes each) are staged in d_tmp: 32 (n_ctxs - 1) bytes of it
+    if (W > 1 && (s.capacity < W + 1 || kRec * s.capacity < 32 * (W - 1)))
+      return err_arg("a shard's capacity must be at least the number of shards + 1, and 24 x capacity at least 32 x (shards - 1) bytes (the splitters and their positions are staged in d_tmp)");
+    total += s.n;
+    aligned = aligned && sort_elems_supported(ctxs[i]->cfg, s.d_records, s.d_tmp, s.capacity);
   }
-  // 1. every shard sorted where it lives
-  int32_t rc = on_every_context(W, [&](size_t i) -> int32_t {
-    int32_t r = ibu_sort_records(ctxs[i], shards[i].d_records, shards[i].d_tmp, shards[i].n, nullptr);
-    return r ? r : ibu_ctx_synchronize(ctxs[i], nullptr);
-  });
-  if (rc || W == 1) return rc;
-
+  if (W == 1) {
+    const int32_t r = ibu_sort_records(ctxs[0], shards[0].d_records, shards[0].d_tmp, shards[0].n, nullptr);
+    return r ? r : ibu_ctx_synchronize(ctxs[0], nullptr);
+  }
   try {
-    // 2. samples: up to 64 W evenly spaced records of every shard (one strided copy each), sorted on the host; splitter k = the
-    //    sample at k / W of them
-    const size_t per = 64 * W;
-    std::vector<std::vector<Rec>> samp(W);
-    rc = on_every_context(W, [&](size_t i) -> int32_t {
-      const size_t n = shards[i].n, take = n < per ? n : per;
-      try { samp[i].resize(take); } catch (...) { return caught_io("ibu_sort_records_contexts"); }
-      if (!take) return IBU_OK;
-      IBU_HIP(hipSetDevice(ctxs[i]->device));
-      const size_t stride = n / take;                          // >= 1
-      IBU_HIP(hipMemcpy2DAsync(samp[i].data(), kRec, shards[i].d_records, stride * kRec, kRec, take, hipMemcpyDeviceToHost, ctxs[i]->stream));
-      IBU_HIP(hipStreamSynchronize(ctxs[i]->stream));
-      return IBU_OK;
-    });
-    if (rc) return rc;
-    std::vector<Rec> all;
-    for (auto& v : samp) all.insert(all.end(), v.begin(), v.end());
-    std::sort(all.begin(), all.end(), rec_lt);
-    std::vector<Rec> split(W - 1);
-    for (size_t k = 1; k < W; ++k)
-      split[k - 1] = all.empty() ? Rec{~0ull, ~0ull, ~0ull} : all[std::min(all.size() - 1, k * all.size() / W)];
-
-    // 3. every shard cut at the splitters: bound[i][k] = first record of shard i that is >= splitter k (device binary search;
-    //    keys and positions staged in the shard's scratch)
-    std::vector<std::vector<uint64_t>> bound(W, std::vector<uint64_t>(W + 1, 0));
-    rc = on_every_context(W, [&](size_t i) -> int32_t {
-      uint8_t* t = static_cast<uint8_t*>(shards[i].d_tmp);
-      uint64_t* d_pos = reinterpret_cast<uint64_t*>(t + kRec * (W - 1));
-      int32_t r = ibu_memcpy_h2d(ctxs[i], t, split.data(), kRec * (W - 1), nullptr);
-      if (!r) r = ibu_lower_bound_records(ctxs[i], shards[i].d_records, shards[i].n, t, W - 1, d_pos, nullptr);
-      if (!r) r = ibu_memcpy_d2h(ctxs[i], bound[i].data() + 1, d_pos, 8 * (W - 1), nullptr);
-      if (!r) r = ibu_ctx_synchronize(ctxs[i], nullptr);
-      bound[i][0] = 0;
-      bound[i][W] = shards[i].n;
-      return r;
-    });
-    if (rc) return rc;
-    // 4. who receives how much, and where each piece lands in its owner's scratch (pieces in shard order)
-    std::vector<size_t> n_out(W, 0);
-    std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));   // land[j][i]: record offset of shard i's piece in owner j
-    for (size_t j = 0; j < W; ++j) {
-      for (size_t i = 0; i < W; ++i) {
-        land[j][i] = n_out[j];
-        n_out[j] += (size_t)(bound[i][j + 1] - bound[i][j]);
-      }
-      if (n_out[j] > shards[j].capacity)
-        return set_error(IBU_ERR_INVALID_ARG, n_out[j], shards[j].capacity, 0,
-                         "shard %zu would receive %zu records, its capacity is %zu (the shards are sorted locally, nothing was moved)", j,
-                         n_out[j], shards[j].capacity);
-    }
-    // 5. the exchange.  When at most 12 key bytes vary over ALL shards (the census words of every shard combined: one plan for
-    //    everybody) the records travel as 12-byte elements — half the bytes on the links (ibu_records_compact / _expand, the
-    //    exchange format of ibu_amd/sharding.py): every shard compacts itself into the lower half of its scratch, every owner
-    //    pulls its pieces into the upper half, expands them over its records and sorts.  Otherwise 24-byte records travel into
-    //    the owner's scratch and are copied over its records before the sort.
-    ibu_key_plan_t plan;
+    // one plan for everybody: the census words of every shard combined
+    CompactPlan plan;
     memset(&plan, 0, sizeof plan);
-    bool compact = ctxs[0]->cfg.sort_compact != 0;
-    if (compact) {
+    bool have_plan = false;
+    if (ctxs[0]->cfg.sort_compact != 0) {
       std::vector<std::array<uint64_t, 8>> words(W);
-      rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
+      int32_t rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
       if (rc) return rc;
       uint64_t o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
       for (auto& w : words)
         for (int f = 0; f < 3; ++f) { o[f] |= w[f]; a[f] &= w[3 + f]; }
-      rc = ibu_key_plan_init(o, a, &plan);
-      if (rc) return rc;
-      compact = plan.k <= 12;
+      compact_plan_init(o, a, &plan);
+      have_plan = true;
     }
-    const size_t wire = compact ? 12 : kRec;                  // bytes per record on the links
-    if (compact) {
-      rc = on_every_context(W, [&](size_t i) -> int32_t {
-        int32_t r = ibu_records_compact(ctxs[i], &plan, shards[i].d_records, shards[i].n, shards[i].d_tmp, nullptr);
-        return r ? r : ibu_ctx_synchronize(ctxs[i], nullptr);
-      });
-      if (rc) return rc;
-    }
-    rc = on_every_context(W, [&](size_t j) -> int32_t {
-      IBU_HIP(hipSetDevice(ctxs[j]->device));
-      uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp) + (compact ? 12 * shards[j].capacity : 0);
-      for (size_t i = 0; i < W; ++i) {
-        const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
-        if (!cnt) continue;
-        if (ctxs[i]->device != ctxs[j]->device) {             // direct xGMI access where the topology has it; without, the copy is staged
-          int can = 0;
-          if (hipDeviceCanAccessPeer(&can, ctxs[j]->device, ctxs[i]->device) == hipSuccess && can) {
-            const hipError_t pe = hipDeviceEnablePeerAccess(ctxs[i]->device, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // not fatal: see above
-            else if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-          } else {
-            (void)hipGetLastError();
-          }
-        }
-        const uint8_t* src = static_cast<const uint8_t*>(compact ? shards[i].d_tmp : shards[i].d_records) + wire * bound[i][j];
-        IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ctxs[j]->stream));
-      }
-      IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
-      return IBU_OK;
-    });
-    if (rc) return rc;                                        // (joined: nobody overwrites what a peer is still reading)
-    rc = on_every_context(W, [&](size_t j) -> int32_t {
-      int32_t r = IBU_OK;
-      if (n_out[j]) {
-        uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp);
-        r = compact ? ibu_records_expand(ctxs[j], &plan, t + 12 * shards[j].capacity, n_out[j], shards[j].d_records, nullptr)
-                    : ibu_device_copy(ctxs[j], shards[j].d_records, t, kRec * n_out[j], nullptr);
-      }
-      if (!r) r = ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr);
-      if (!r) r = ibu_ctx_synchronize(ctxs[j], nullptr);
-      return r;
-    });
-    if (rc) return rc;
-    if (getenv("IBU_TRACE_SORT")) fprintf(stderr, "ibu sort: contexts=%zu exchange=%zu bytes per record\n", W, wire);
-    for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
+    if (have_plan && plan.k <= 11 && W <= 256 && aligned && total > 0) return sort_partition_first(ctxs, W, shards, plan, total);
+    return sort_sort_first(ctxs, W, shards, plan, have_plan);
   } catch (...) {
     return caught_io("ibu_sort_records_contexts");
   }
-  return IBU_OK;
 }

@@ -473,8 +473,11 @@ static bool trace_sort() {
 // PREFIX + FINISH on the elements?  Only if the runs of equal prefix are going to be short: a pair count over a sample says
 // (ibu_k_sort_sample_pairs; the tables live in tmp, which nothing uses at that point).  `sorted_bytes`: the passes the plain path
 // would run (the element bytes it sorts on are the top `sorted_bytes` of the plan's k).  *P = the prefix to use, 0 = none.
+// n_scale: the size of the whole the runs are estimated for — n, or (the multi-GPU sort) the records of ALL shards, of which these
+// n are taken for a sample.
 static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs, size_t n, void* tmp, const CompactPlan& plan, u32 sorted_bytes,
-                                          hipStream_t st, u32* P_out, double* seg_out) {
+                                          hipStream_t st, u32* P_out, double* seg_out, size_t n_scale = 0) {
+  if (!n_scale) n_scale = n;
   *P_out = 0;
   *seg_out = 0;
   if (!cfg.sort_hybrid || (reinterpret_cast<uintptr_t>(tmp) & 7u) != 0) return hipSuccess;
@@ -516,8 +519,8 @@ static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs
     if (e != hipSuccess) return e;
     // a record shares its prefix with about 1 + (n / m) * (2 pairs / m) records: at most ~8 wanted (ranking is quadratic)
     for (u32 q = 0; q < (u32)kMaxPrefix && first + q + 1 <= plan.k; ++q) {
-      const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q] / (double)m);
-      const double heaviest = (double)pairs[kMaxPrefix + q] * ((double)n / (double)m);   // estimated longest run
+      const double seg = 1.0 + ((double)n_scale / (double)m) * (2.0 * (double)pairs[q] / (double)m);
+      const double heaviest = (double)pairs[kMaxPrefix + q] * ((double)n_scale / (double)m);   // estimated longest run
       if (seg <= 8.0 && heaviest <= 128.0) { P = first + q + 1; *seg_out = seg; break; }
     }
   }
@@ -527,6 +530,119 @@ static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs
   if (P && P + margin > sorted_bytes) P = 0;                   // not worth it / would reach into index bytes the passes do not sort on
   *P_out = P;
   return hipSuccess;
+}
+
+// ---- the multi-GPU sort on 12-byte elements: partition first, sort once (multi_sort.cpp, round 4) -----------------------------------
+// Round 3 sorted every shard, exchanged the pieces between the splitters and sorted every owner's pieces AGAIN.  Now a shard is only
+// PARTITIONED before the exchange: its records become 12-byte elements (one plan for all shards, at most 11 varying bytes), every
+// element gets the number of its key range — how many of the (up to 255) splitters are not above it — in its free top byte, and one
+// ordinary element pass on that byte (count from the side stream, scan, scatter: the kernels of the sort) moves the elements into
+// range order; the scan's bin starts are the range boundaries, from which the caller cuts the owners' pieces.  The owner sorts the elements it received straight into records (launch_sort_elems: the
+// passes of the sort without its census and compress steps — the sender made the elements).
+extern "C" __global__ void __launch_bounds__(256)
+ibu_k_sort_stamp_bucket(ElemT<3>* __restrict__ elems, u64 n, const ElemT<3>* __restrict__ split, u32 nsplit, uint8_t* __restrict__ digits) {
+  __shared__ u32 sp[3 * 256];
+  for (u32 i = threadIdx.x; i < 3 * nsplit; i += blockDim.x) sp[i] = reinterpret_cast<const u32*>(split)[i];
+  __syncthreads();
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    EV<3> e = ld_elem<3>(elems + i);
+    e.w[2] &= 0x00FFFFFFu;                                    // (zero already: at most 11 bytes vary)
+    u32 lo = 0, hi = nsplit;                                  // owner = splitters <= e (the element as a 96-bit integer orders like the record)
+    while (lo < hi) {
+      const u32 mid = (lo + hi) >> 1;
+      const u32 s2 = sp[3 * mid + 2], s1 = sp[3 * mid + 1], s0 = sp[3 * mid];
+      const bool le = s2 != e.w[2] ? s2 < e.w[2] : (s1 != e.w[1] ? s1 < e.w[1] : s0 <= e.w[0]);
+      if (le) lo = mid + 1; else hi = mid;
+    }
+    e.w[2] |= lo << 24;
+    st_elem<3>(elems + i, e);
+    digits[i] = (uint8_t)lo;
+  }
+}
+static const CompactVariant* elems_variant(const LaunchCfg& cfg, size_t n, size_t scratch_bytes) {
+  const CompactVariant* cv = pick_compact_for(cfg, n);
+  if (!cv) cv = &kCompact[0];                                 // (sort_compact = 0 on this context: the default shape)
+  const bool wide_idx = n >= (1ull << 32) || cfg.sort_idx64;
+  if (n >= (1ull << 38) || (wide_idx && !cv->scatter64) || scratch_bytes < sort_layout(cfg, n, cv->tile).total) return nullptr;
+  return cv;
+}
+hipError_t launch_estimate_prefix(const LaunchCfg& cfg, const void* recs, size_t n, size_t n_scale, void* tmp, const CompactPlan& pl,
+                                  uint32_t* prefix_passes, hipStream_t st) {
+  (void)hipGetLastError();
+  double seg = 0;
+  u32 P = 0;
+  *prefix_passes = 0;
+  if (n < 8192 || pl.k == 0 || pl.k > 12) return hipSuccess;
+  const hipError_t e = estimate_compact_prefix(cfg, recs, n, tmp, pl, pl.k, st, &P, &seg, n_scale);   // (synchronises st)
+  if (e == hipSuccess) *prefix_passes = P;
+  return e;
+}
+hipError_t launch_partition_elems(const LaunchCfg& cfg, void* elems, size_t n, const void* d_split, uint32_t nsplit, void* out, void* scratch,
+                                  size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0 || nsplit > 255) return hipErrorInvalidValue;
+  const CompactVariant* cv = elems_variant(cfg, n, scratch_bytes);
+  if (!cv) return hipErrorInvalidValue;
+  uint8_t* sc = static_cast<uint8_t*>(scratch);
+  const SortLayout L = sort_layout(cfg, n, cv->tile);
+  u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
+  u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
+  u64* blockoff = reinterpret_cast<u64*>(sc + L.blockoff);
+  uint16_t* counts = reinterpret_cast<uint16_t*>(sc + L.counts);
+  void* pos = sc + L.pos;
+  uint8_t* digits = sc + L.digits;
+  const void* k_scatter = L.idx64 ? cv->scatter64 : cv->scatter;
+  hipError_t e;
+  if (cv->lds > 48 * 1024) {
+    e = hipFuncSetAttribute(k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv->lds);
+    if (e != hipSuccess) return e;
+  }
+  const u32 cap = (u32)cfg.cus * 8;
+  const u64 want = (n + 255) / 256;
+  hipLaunchKernelGGL(ibu_k_sort_stamp_bucket, dim3((u32)(want < cap ? want : cap)), dim3(256), 0, st, static_cast<ElemT<3>*>(elems), (u64)n,
+                     static_cast<const ElemT<3>*>(d_split), nsplit, digits);
+  const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
+  hipLaunchKernelGGL(cv->counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n, L.ntiles,
+                     counts);
+  hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
+  hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
+  if (L.idx64)
+    hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
+                       (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
+  else
+    hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
+                       (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
+  u32 n32 = (u32)n, b_arg = 11, nb_arg = 12;                  // the owner byte; 12 = no digit stream behind this pass
+  u64 n64 = n;
+  const void* src_arg = elems;
+  void* dst_arg = out;
+  const void* pos_arg = pos;
+  CompactPlan pl_arg = CompactPlan();                         // (only a last pass expands)
+  void* args[] = {&src_arg, &dst_arg, L.idx64 ? static_cast<void*>(&n64) : static_cast<void*>(&n32), &b_arg, &nb_arg, &pos_arg, &digits, &pl_arg};
+  e = hipLaunchKernel(k_scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv->threads), args, cv->lds, st);
+  if (e != hipSuccess) return e;
+  *d_starts = reinterpret_cast<const uint64_t*>(binbase);                                  // u64[256]: first element of every owner's piece
+  return hipGetLastError();
+}
+bool sort_elems_supported(const LaunchCfg& cfg, const void* recs, const void* tmp, size_t capacity) {
+  return cfg.sort_compact != 0 && capacity < (1ull << 38) && (reinterpret_cast<uintptr_t>(recs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(tmp) & 15u) == 0;
+}
+hipError_t launch_sort_elems(const LaunchCfg& cfg, const CompactPlan& pl, void* recs, void* tmp, size_t n, uint32_t prefix_passes, void* scratch,
+                             size_t scratch_bytes, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0) return hipSuccess;
+  if (pl.k > 12) return hipErrorInvalidValue;
+  if (n == 1 || pl.k == 0) return launch_expand(cfg, pl, tmp, n, recs, st);   // one record, or all of them the same
+  const CompactVariant* cv = elems_variant(cfg, n, scratch_bytes);
+  if (!cv) return hipErrorInvalidValue;
+  u32 ebytes[12];
+  for (u32 j = 0; j < pl.k; ++j) ebytes[j] = j;               // every varying byte: pieces of different shards interleave in the index too
+  u32 P = prefix_passes;
+  if (n < 8192 || P + 1 >= pl.k) P = 0;
+  if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu path=elements-received element_bytes=12 prefix_passes=%u of %u\n", n, P, pl.k);
+  return launch_compact_passes<3>(cfg, *cv, recs, tmp, n, static_cast<uint8_t*>(scratch), pl, ebytes, pl.k, st, true, 0xFFFFFFFFu, P,
+                                  static_cast<ElemT<3>*>(tmp));
 }
 
 // Not purely asynchronous: the census result comes back to the host (one 64-byte read) to pick the passes; everything

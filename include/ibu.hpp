@@ -397,6 +397,12 @@ class Context {
   // the sort over several shards, one per context (= per GPU), in one call: shard i ends up with the i-th range of the global
   // order and shards[i].n says how long it is (ibu_sort_records_contexts)
   static void sort_records_contexts(const std::vector<Context*>& ctxs, std::vector<ibu_sort_shard_t>& shards) {
+    if (shards.size() != ctxs.size()) {                        // the C side reads n_ctxs entries of both arrays
+      ibu_error_detail_t d{};
+      d.code = IBU_ERR_INVALID_ARG;
+      snprintf(d.message, sizeof d.message, "Invalid argument: one shard per context");
+      throw IbuError(IBU_ERR_INVALID_ARG, d);
+    }
     std::vector<ibu_ctx_t*> raw;
     for (Context* c : ctxs) raw.push_back(c->c_);
     check(ibu_sort_records_contexts(raw.data(), raw.size(), shards.data()));

@@ -369,18 +369,27 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
 
 /* The same order over SEVERAL shards, one per context (= per GPU), in one call — the multi-GPU form of the sort (SURVEY 8f-2:
  * sample sort with one device-to-device exchange), as ibu_mmap_process_contexts is the multi-GPU form of process_parallel.
+ * EXPERIMENTAL: rehearsed with up to 16 contexts on one GPU, never run on two distinct GPUs (no such box in any round).
  * shards[i] lives on ctxs[i]'s device: n records in d_records, which has room for `capacity` records; d_tmp: capacity * 24
  * bytes of scratch on the same device.  On return shard i holds the i-th contiguous range of the global order and
- * shards[i].n says how many records that is (their sum is unchanged): every shard is sorted where it lives, up to 64 x n_ctxs
- * evenly spaced samples of each pick n_ctxs - 1 splitters, every shard is cut at them by a binary search on its device,
- * every owner pulls its pieces (hipMemcpyPeerAsync: over xGMI between GPUs) and sorts what it received.  When at most 12 key
- * bytes vary over all shards the pieces travel as 12-byte elements (ibu_records_compact / _expand with one plan from the
- * combined census words: half the bytes on the links; option "sort_compact" = 0 on ctxs[0] keeps 24-byte records).  One host thread
- * per context; the first error in context order is the call's.  A shard that would receive more than its capacity:
- * IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) with every shard sorted locally and
- * nothing moved — leave headroom for uneven splits (the samples balance well-spread keys to a few percent; many equal records
- * all go to one owner).  n_ctxs == 1 is ibu_sort_records.  Two contexts may share a device (a rehearsal on one GPU); the same
- * context twice is refused.  Synchronous. */
+ * shards[i].n says how many records that is (their sum is unchanged).  Evenly spaced samples of every shard, in proportion to
+ * its size (about 512 per shard in all), pick n_ctxs - 1 splitters; every record travels once to the owner of its range
+ * (hipMemcpyPeerAsync: over xGMI between GPUs).  Two forms (multi_sort.cpp):
+ *   partition first — at most 11 key bytes vary over ALL shards (16/12 records with indices below 2^32), at most 256 shards,
+ *     16-byte aligned buffers: a shard is compacted to 12-byte elements (ibu_records_compact with one plan from the combined
+ *     census words), the elements are put in owner order by one pass of the sort's own kernels, the owners pull their pieces
+ *     (12 bytes per record on the links) and sort them straight into records.  Nothing is sorted twice;
+ *   sort first — everything else (option "sort_compact" = 0 on ctxs[0] forces it): every shard sorted where it lives, cut at
+ *     the splitters by binary search, 24-byte records exchanged (12-byte elements when exactly 12 bytes vary), owners sort again.
+ * One host thread per context; the first error in context order is the call's.  A shard that would receive more than its
+ * capacity: IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) before anything has moved between
+ * shards: every shard still holds its own records (untouched, or sorted locally on the sort-first path) — leave headroom for
+ * uneven splits (the samples balance well-spread keys to a few percent; many equal records all go to one owner).  After ANY
+ * OTHER error (a failed copy or kernel once the exchange has begun) the contents of the shards are unspecified.  Capacity: at
+ * least n_ctxs + 1 records and 24 x capacity >= 32 x (n_ctxs - 1) bytes (the sort-first form stages the splitters and their
+ * positions in d_tmp).  n_ctxs == 1 is ibu_sort_records.  Two contexts may share a device (a rehearsal on one GPU); the same
+ * context twice is refused.  Peer access between the devices involved is enabled where the topology has it and stays enabled.
+ * Synchronous. */
 typedef struct ibu_sort_shard {
   void* d_records; /* device, 8-byte aligned: `capacity` records of room, `n` of them valid */
   void* d_tmp;     /* device, 8-byte aligned: capacity * 24 bytes of scratch                 */

@@ -205,6 +205,54 @@ def test_compact_expand_copy_generate_stay_inside_their_buffers(ia, ctx, oracle,
         ar.free()
 
 
+@pytest.mark.parametrize("w", [2, 8, 16])
+@pytest.mark.parametrize("form", ["partition_first", "sort_first", "sort_first_wide_keys"])
+@pytest.mark.parametrize("fill", ["minimal", "roomy"])
+def test_sort_records_contexts_stays_inside_records_and_tmp(ia, ctx, oracle, w, form, fill):
+    """The multi-context sort with every shard's d_records / d_tmp carved at exactly capacity x 24 bytes (ADVICE r03 / VERDICT r03
+    weak 6: with 8 and more contexts the splitters and their positions, 32 (W - 1) bytes, overran a d_tmp of the minimal
+    capacity W + 1).  minimal: the smallest capacity the call accepts, one below it refused; roomy: shards of a few thousand
+    records.  All contexts on the box's one GPU; both forms of the call and both exchange formats."""
+    lens = (32, 32) if form == "sort_first_wide_keys" else (16, 12)
+    cap_min = max(w + 1, -(-32 * (w - 1) // 24))
+    cap = cap_min if fill == "minimal" else 4000
+    rng = np.random.default_rng(w * 7 + len(form))
+    counts = [int(rng.integers(0, cap // w + 1)) for _ in range(w)] if fill == "minimal" else [int(rng.integers(0, cap // 2)) for _ in range(w)]
+    total = sum(counts)
+    recs = oracle.generate(0x1B00018 + w, 0, max(total, 1), *lens)[:total]
+    rng.shuffle(recs)
+    ctxs = [ia.Context(0) for _ in range(w)]
+    ar = _arena(ia, ctx, *([24 * cap] * (2 * w)))
+    try:
+        if form == "sort_first":
+            ctxs[0].set_option("sort_compact", 0)
+        shards, at = [], 0
+        for n in counts:
+            d, t = ar.carve(24 * cap), ar.carve(24 * cap)
+            if n:
+                d.upload(recs[at:at + n])
+            shards.append((d, t, n, cap))
+            at += n
+        if fill == "minimal" and cap_min > w + 1:              # 24 x capacity must hold the 32 (W - 1) staged bytes
+            with pytest.raises(ia.IbuError) as e:
+                ia.Context.sort_records_contexts(ctxs, [(d, t, min(n, cap - 1), cap - 1) for d, t, n, _ in shards])
+            assert e.value.kind == "InvalidArg"
+        try:
+            out = ia.Context.sort_records_contexts(ctxs, shards)
+        except ia.IbuError as e:                                # tiny shards do not always split evenly: the refusal is fine, an overrun is not
+            assert fill == "minimal" and e.kind == "InvalidArg" and e.b == cap, (e.kind, e.a, e.b)
+            out = None
+        ar.check(f"sort_records_contexts w={w} {form} {fill}")
+        if out is not None:
+            assert sum(out) == total
+            got = b"".join(shards[k][0].download(count=24 * out[k]).tobytes() for k in range(w))
+            assert got == oracle.sort_records(recs).tobytes()
+    finally:
+        for c in ctxs:
+            c.close()
+        ar.free()
+
+
 def test_the_guard_check_sees_an_overrun(ia, ctx, oracle):
     """The checker checked: a copy of 24 bytes too many (still inside the arena) must be reported."""
     n = 1000

@@ -76,6 +76,7 @@ inline int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   }
   return IBU_OK;
 }
+int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hipMalloc, or the probed form under option "alloc_probe_tries"
 inline hipStream_t pick_stream(const ibu_ctx* ctx, void* stream) {
   return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 }

@@ -128,6 +128,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->cfg.sort_compact = (int)value;
     return IBU_OK;
   }
+  if (strcmp(key, "alloc_probe_tries") == 0) {
+    if (value < 1 || value > IBU_ALLOC_PROBE_MAX) return err_arg("alloc_probe_tries must be 1..16");
+    ctx->cfg.alloc_probe_tries = (int)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "trace_rows") == 0) {
     ctx->cfg.trace_rows = value != 0;
     return IBU_OK;
@@ -151,6 +156,12 @@ extern "C" int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr) 
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;
   if (!d_ptr) return err_arg("d_ptr is NULL");
+  return ibu::ctx_alloc(ctx, bytes, d_ptr);
+}
+// Long-lived device memory the library allocates for a caller: with the context option "alloc_probe_tries" > 1, arrays of at least
+// 256 MiB go through the placement probing below (smaller ones are not worth the candidates' time: the ring's slots, scratch).
+int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
+  if (ctx->cfg.alloc_probe_tries > 1 && bytes >= ((size_t)256 << 20)) return ibu_device_alloc_probed(ctx, bytes, (uint32_t)ctx->cfg.alloc_probe_tries, d_ptr, nullptr);
   IBU_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
   return IBU_OK;
 }

@@ -215,10 +215,10 @@ extern "C" int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ib
   if (rc) return rc;
   bool owned = false;
   if (*d_records == nullptr) {
-    hipError_t e = hipMalloc(d_records, num ? num * IBU_RECORD_SIZE : 16);
-    if (e != hipSuccess) {
+    rc = ctx_alloc(ctx, num * IBU_RECORD_SIZE, d_records);   // (placement-probed under option "alloc_probe_tries")
+    if (rc) {
       close(fd);
-      return hip_fail(e, "hipMalloc");
+      return rc;
     }
     owned = true;
   } else if (num > cap_records) {

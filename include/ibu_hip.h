@@ -261,6 +261,11 @@ int32_t ibu_device_count(int32_t* n);
  *                           The reference holds no codec code and no vector, so the order is UNPINNED; the second
  *                           value is the hedge: if an external bitnuc vector shows the other order, callers flip this
  *                           option and no kernel changes.
+ *   "alloc_probe_tries" 1..16  placement probing as a property of the library (default 1 = plain allocations): arrays of at
+ *                           least 256 MiB that the library allocates for the caller — ibu_device_alloc, the destination of
+ *                           ibu_load_to_device — draw this many candidates and keep the fastest, as
+ *                           ibu_device_alloc_probed does on request (see there for why).  Costs a write + read of every
+ *                           candidate (~0.3 ms per GB each) once per allocation.
  *   "trace_rows"     0 | 1  tests: one stderr line per kernel launch of the streaming entry points saying how many rows took
  *                           the tiled and how many the one-thread-per-row kernel.  A context starts with the value the
  *                           environment variable IBU_TRACE_ROWS had when the library first created a context (read once).
@@ -268,7 +273,8 @@ int32_t ibu_device_count(int32_t* n);
 #define IBU_BASE_ORDER_LSB_FIRST 0
 #define IBU_BASE_ORDER_MSB_FIRST 1
 int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value);
-/* Device memory helpers for callers without their own allocator (tests in C, Rust shim). */
+/* Device memory helpers for callers without their own allocator (tests in C, Rust shim).  With option "alloc_probe_tries" > 1
+ * allocations of at least 256 MiB are placement-probed (ibu_device_alloc_probed below). */
 int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr);
 int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr);
 /* ibu_device_alloc with PLACEMENT PROBING, for arrays that stay resident (no reference counterpart: the crate holds its records in
@@ -538,7 +544,16 @@ int32_t ibu_reader_process_device(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_rin
  * consumer loop (MmapReader::slice / process_parallel -> Record -> sequences, mmap.rs:253-332 + the 2-bit
  * table record.rs:19-27) with the unpacking done on the GPU: map -> pinned ring -> H2D -> K2 decode -> D2H ->
  * caller buffers, three streams overlapped.  Buffers hold shard_records rows (row i of the shard at
- * h_bc_ascii + i*bc_len ...); any of them may be NULL to skip that column. */
+ * h_bc_ascii + i*bc_len ...); any of them may be NULL to skip that column.
+ * WHEN NOT TO CALL THIS: whenever the columns are wanted in HOST memory and nothing else runs on the device.  Every record
+ * crosses PCIe twice (24 B in, bc_len + umi_len + 8 B out) between two host copies (map -> pinned, pinned -> caller, the
+ * second one faulting in the caller's fresh pages), and the kernel is 2 % of the wall time: 0.28-0.40 G records/s at 16/12 on
+ * a one-GPU box of this pool at every size from 1e6 to 1e9 records (tools/e2e.py rows "mmap decode_to_host": the rate does
+ * not grow with the size, so there is no crossover), where a plain loop over MmapReader::slice with a scalar 2-bit unpack on
+ * the same box's 16 CPUs decodes AND re-encodes 0.73-0.84 G records/s (bench.py: cpu_baseline).  The call exists so that the
+ * API is complete for consumers that hold their sequences in host memory; the device pays off when the columns STAY
+ * resident — ibu_mmap_process_device(s) with IBU_PROC_DECODE (2.2 G records/s, PCIe-bound one way) and everything behind
+ * it (sort, per-barcode aggregation, re-encoding) at HBM rates. */
 int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, size_t shard,
                                 size_t n_shards, uint8_t* h_bc_ascii, uint8_t* h_umi_ascii, uint64_t* h_index,
                                 ibu_stream_stats_t* stats);

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--kernels", default="decode,encode,deserialize,serialize,reduce,unpack,pack,generate,copy")
     ap.add_argument("--so", action="append", default=[], help="tag=path of an alternative build (repeatable)")
     ap.add_argument("--blocks", default="", help="comma list of blocks_per_cu caps to sweep (default: library default)")
+    ap.add_argument("--alloc-probe-tries", type=int, default=0,
+                    help="N > 1: the arrays come from ibu_device_alloc under the context option alloc_probe_tries = N (placement probing as a "
+                         "library property) instead of torch.empty")
     a = ap.parse_args()
     import torch
 
@@ -40,6 +43,24 @@ def main():
     torch.cuda.set_stream(ts)
     st = C.c_void_p(ts.cuda_stream)
     buf = lambda b: torch.empty(b, dtype=torch.uint8, device=dev)
+    if a.alloc_probe_tries > 1:
+        alib = _lib.load(_lib.SO_PATH)
+        actx = C.c_void_p()
+        assert alib.ibu_ctx_create(0, C.byref(actx)) == 0
+        assert alib.ibu_ctx_set_option(actx, b"alloc_probe_tries", a.alloc_probe_tries) == 0
+
+        class LibBuf:                                           # the two members of a tensor this script uses
+            def __init__(self, nbytes):
+                self.ptr, self.nbytes = C.c_void_p(), nbytes
+                assert alib.ibu_device_alloc(actx, nbytes, C.byref(self.ptr)) == 0
+
+            def data_ptr(self):
+                return self.ptr.value
+
+            def numel(self):
+                return self.nbytes
+
+        buf = LibBuf
     recs, back = buf(n * 24), buf(n * 24)
     bc, umi, idx = buf(n * bc_max), buf(n * umi_max), buf(n * 8)   # ONE set of arrays for every pair of lengths: same placement
     c0, c1 = buf(n * 8), buf(n * 8)

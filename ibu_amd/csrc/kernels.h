@@ -85,12 +85,12 @@ hipError_t launch_records_census(const LaunchCfg&, const void* recs, size_t n, u
 hipError_t launch_compact(const LaunchCfg&, const CompactPlan& pl, const void* recs, size_t n, void* elems, hipStream_t st);
 hipError_t launch_expand(const LaunchCfg&, const CompactPlan& pl, const void* elems, size_t n, void* recs, hipStream_t st);
 // The multi-GPU sort on 12-byte elements (sort.hip, used by multi_sort.cpp): how many prefix passes a sort of n_scale records like
-// these n wants (synchronises st); elements -> owner order by the splitters (d_starts: u64[256] in `scratch`, the first element of
-// every owner's piece); received elements -> sorted records.
+// these n wants (synchronises st); records -> 12-byte elements at `elems`, stamped with their key range among the splitters, -> range order at `out`
+// (d_starts: u64[256] in `scratch`, the first element of every range); received elements -> sorted records.
 hipError_t launch_estimate_prefix(const LaunchCfg&, const void* recs, size_t n, size_t n_scale, void* tmp, const CompactPlan& pl,
                                   uint32_t* prefix_passes, hipStream_t st);
-hipError_t launch_partition_elems(const LaunchCfg&, void* elems, size_t n, const void* d_split, uint32_t nsplit, void* out, void* scratch,
-                                  size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st);
+hipError_t launch_partition_elems(const LaunchCfg&, const CompactPlan& pl, const void* recs, void* elems, size_t n, const void* d_split,
+                                  uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st);
 bool sort_elems_supported(const LaunchCfg&, const void* recs, const void* tmp, size_t capacity);
 hipError_t launch_sort_elems(const LaunchCfg&, const CompactPlan& pl, void* recs, void* tmp, size_t n, uint32_t prefix_passes, void* scratch,
                              size_t scratch_bytes, hipStream_t st);

@@ -130,7 +130,8 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   if (rc) return rc;
   std::vector<Rec> split;
   pick_splitters(samp, F, split);
-  // 2. every shard: elements in range order in the upper half of its scratch; fine[i][f] = first element of range f.
+  // 2. every shard: records -> elements stamped with their range (one kernel) -> range order in the upper half of its scratch;
+  //    fine[i][f] = first element of range f.
   //    The largest shard also says how many prefix passes a sort of `total` records like its own wants (it is a sample of them).
   size_t big = 0;
   for (size_t i = 1; i < W; ++i)
@@ -153,9 +154,9 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     if (i == big) IBU_HIP(launch_estimate_prefix(c->cfg, shards[i].d_records, n, total, t, plan, &prefix_passes, st));   // (scratch: the head of d_tmp)
     IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
     IBU_HIP(launch_compact(c->cfg, plan, d_split_recs, F - 1, d_split_elems, st));
-    IBU_HIP(launch_compact(c->cfg, plan, shards[i].d_records, n, t, st));
     const uint64_t* d_starts = nullptr;
-    IBU_HIP(launch_partition_elems(c->cfg, t, n, d_split_elems, (uint32_t)(F - 1), t + 12 * shards[i].capacity, c->d_sort_scratch, need, &d_starts, st));
+    IBU_HIP(launch_partition_elems(c->cfg, plan, shards[i].d_records, t, n, d_split_elems, (uint32_t)(F - 1), t + 12 * shards[i].capacity, c->d_sort_scratch, need,
+                                   &d_starts, st));
     IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
     IBU_HIP(hipStreamSynchronize(st));
     fine[i][F] = n;

@@ -535,7 +535,7 @@ static hipError_t estimate_compact_prefix(const LaunchCfg& cfg, const void* recs
 // ---- the multi-GPU sort on 12-byte elements: partition first, sort once (multi_sort.cpp, round 4) -----------------------------------
 // Round 3 sorted every shard, exchanged the pieces between the splitters and sorted every owner's pieces AGAIN.  Now a shard is only
 // PARTITIONED before the exchange: its records become 12-byte elements (one plan for all shards, at most 11 varying bytes), every
-// element gets the number of its key range — how many of the (up to 255) splitters are not above it — in its free top byte, and one
+// element gets — in the same kernel — the number of its key range — how many of the (up to 255) splitters are not above it — in its free top byte, and one
 // ordinary element pass on that byte (count from the side stream, scan, scatter: the kernels of the sort) moves the elements into
 // range order; the scan's bin starts are the range boundaries, from which the caller cuts the owners' pieces.  The owner sorts the elements it received straight into records (launch_sort_elems: the
 // passes of the sort without its census and compress steps — the sender made the elements).
@@ -548,16 +548,33 @@ ibu_k_sort_stamp_bucket(ElemT<3>* __restrict__ elems, u64 n, const ElemT<3>* __r
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     EV<3> e = ld_elem<3>(elems + i);
     e.w[2] &= 0x00FFFFFFu;                                    // (zero already: at most 11 bytes vary)
-    u32 lo = 0, hi = nsplit;                                  // owner = splitters <= e (the element as a 96-bit integer orders like the record)
-    while (lo < hi) {
-      const u32 mid = (lo + hi) >> 1;
-      const u32 s2 = sp[3 * mid + 2], s1 = sp[3 * mid + 1], s0 = sp[3 * mid];
-      const bool le = s2 != e.w[2] ? s2 < e.w[2] : (s1 != e.w[1] ? s1 < e.w[1] : s0 <= e.w[0]);
-      if (le) lo = mid + 1; else hi = mid;
-    }
-    e.w[2] |= lo << 24;
+    const u32 g = range_of(sp, nsplit, e);
+    e.w[2] |= g << 24;
     st_elem<3>(elems + i, e);
-    digits[i] = (uint8_t)lo;
+    digits[i] = (uint8_t)g;
+  }
+}
+// records -> stamped elements + the digit stream of the ranges: the tiled rows in ONE kernel (ibu_k_sort_compress<.., STAMP>), the
+// peeled head row and the rest rows (fewer than 129 in all) through the tail compress kernel and the stamp kernel above.
+static void launch_compress_stamped(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, ElemT<3>* out, uint8_t* digits,
+                                    const ElemT<3>* split, u32 nsplit, hipStream_t st) {
+  const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? (n ? 1 : 0) : 0;
+  const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
+  if (head) {
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail<3>, dim3(1), dim3(256), 0, st, (const u64*)recs, (u64)0, (u64)head, pl, 0u, out, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(ibu_k_sort_stamp_bucket, dim3(1), dim3(256), 0, st, out, (u64)head, split, nsplit, digits);
+  }
+  if (main_rows) {
+    static std::atomic<int> occ;
+    const u32 nt = (u32)(main_rows / kTileRecs);
+    hipLaunchKernelGGL((ibu_k_sort_compress<false, 3, true>), dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<false, 3, true>, 0, &occ))),
+                       dim3(kBlock), 0, st, static_cast<const uint8_t*>(recs) + 24 * head, nt, pl, 0u, out + head, digits + head, (u64*)nullptr, split, nsplit);
+  }
+  const size_t done = head + main_rows;
+  if (done < n) {
+    hipLaunchKernelGGL(ibu_k_sort_compress_tail<3>, dim3(tail_grid(n - done)), dim3(256), 0, st, (const u64*)recs, (u64)done, (u64)n, pl, 0u, out,
+                       (uint8_t*)nullptr);
+    hipLaunchKernelGGL(ibu_k_sort_stamp_bucket, dim3(1), dim3(256), 0, st, out + done, (u64)(n - done), split, nsplit, digits + done);
   }
 }
 static const CompactVariant* elems_variant(const LaunchCfg& cfg, size_t n, size_t scratch_bytes) {
@@ -578,10 +595,10 @@ hipError_t launch_estimate_prefix(const LaunchCfg& cfg, const void* recs, size_t
   if (e == hipSuccess) *prefix_passes = P;
   return e;
 }
-hipError_t launch_partition_elems(const LaunchCfg& cfg, void* elems, size_t n, const void* d_split, uint32_t nsplit, void* out, void* scratch,
-                                  size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st) {
+hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, void* elems, size_t n, const void* d_split,
+                                  uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st) {
   (void)hipGetLastError();
-  if (n == 0 || nsplit > 255) return hipErrorInvalidValue;
+  if (n == 0 || nsplit > 255 || pl.k > 11) return hipErrorInvalidValue;
   const CompactVariant* cv = elems_variant(cfg, n, scratch_bytes);
   if (!cv) return hipErrorInvalidValue;
   uint8_t* sc = static_cast<uint8_t*>(scratch);
@@ -599,9 +616,7 @@ hipError_t launch_partition_elems(const LaunchCfg& cfg, void* elems, size_t n, c
     if (e != hipSuccess) return e;
   }
   const u32 cap = (u32)cfg.cus * 8;
-  const u64 want = (n + 255) / 256;
-  hipLaunchKernelGGL(ibu_k_sort_stamp_bucket, dim3((u32)(want < cap ? want : cap)), dim3(256), 0, st, static_cast<ElemT<3>*>(elems), (u64)n,
-                     static_cast<const ElemT<3>*>(d_split), nsplit, digits);
+  launch_compress_stamped(cfg, pl, recs, n, static_cast<ElemT<3>*>(elems), digits, static_cast<const ElemT<3>*>(d_split), nsplit, st);
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   hipLaunchKernelGGL(cv->counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n, L.ntiles,
                      counts);

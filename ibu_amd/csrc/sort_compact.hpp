@@ -73,13 +73,34 @@ __device__ __forceinline__ u32 elem_byte(EV<W> e, u32 byte) {  // byte: uniform
 // L + 64 of the tile: stride-24 ds_read_b64 is conflict-free and each of its two element stores is 768 contiguous bytes.
 // CENSUS: the exact census (OR / AND words, order flags: CensusAcc) of the same records is accumulated on the way — the
 // speculative path of the sort, whose plan comes from a SAMPLE and is checked against this census afterwards.
-template <bool CENSUS, int W>
-__global__ void __launch_bounds__(kBlock, CENSUS ? (W == 4 ? 5 : 7) : 8)   // the launcher keeps at most 7 workgroups per CU resident (LaunchCfg); 16-byte elements with the census need 84 VGPRs
+// The key range of a 12-byte element among up to 255 splitter elements staged in LDS (the multi-GPU sort: sort.hip, "partition
+// first"): how many splitters are not above it — the element as a 96-bit integer orders like the record.
+__device__ __forceinline__ u32 range_of(const u32* sp, u32 nsplit, const EV<3>& e) {
+  u32 lo = 0, hi = nsplit;
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    const u32 s2 = sp[3 * mid + 2], s1 = sp[3 * mid + 1], s0 = sp[3 * mid];
+    const bool le = s2 != e.w[2] ? s2 < e.w[2] : (s1 != e.w[1] ? s1 < e.w[1] : s0 <= e.w[0]);
+    if (le) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// STAMP (W = 3, at most 11 varying bytes): every element also gets its key range among the `nsplit` splitter elements at `split`
+// in its free top byte, and the digit stream holds the ranges — the compress and the stamp step of the multi-GPU sort in one read
+// of the records.
+template <bool CENSUS, int W, bool STAMP = false>
+__global__ void __launch_bounds__(kBlock, CENSUS ? (W == 4 ? 5 : 7) : (STAMP ? 7 : 8))   // the launcher keeps at most 7 workgroups per CU resident (LaunchCfg); 16-byte elements with the census need 84 VGPRs
 ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, ElemT<W>* __restrict__ out,
-                    uint8_t* __restrict__ digits, u64* __restrict__ census) {
+                    uint8_t* __restrict__ digits, u64* __restrict__ census, const ElemT<3>* __restrict__ split = nullptr, u32 nsplit = 0) {
+  static_assert(!STAMP || (W == 3 && !CENSUS), "ranges are stamped into 12-byte elements");
   constexpr int kSlice = CENSUS ? kSliceBytes : kTileBytes;  // with the census: the record in front of the tile is staged too (ibu_k_sort_census)
   constexpr int kLead = CENSUS ? kPrevBytes : 0;
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kSlice];
+  __shared__ u32 sp[STAMP ? 3 * 256 : 1];
+  if constexpr (STAMP) {
+    for (u32 i = threadIdx.x; i < 3 * nsplit; i += kBlock) sp[i] = reinterpret_cast<const u32*>(split)[i];
+    __syncthreads();                                         // (before any wave leaves)
+  }
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
   uint8_t* tile = lds + wib * kSlice + kLead;
   const TileRange tr = tile_range(ntiles, wib);             // which tiles this wave sweeps (kcommon.hpp)
@@ -110,8 +131,18 @@ ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl
           if (lane > 0 || t > 0) acc.pair(r[-3], r[-2], r[-1], r[0], r[1], r[2]);   // lane 0: the record in front of the tile
           acc.pair(q[-3], q[-2], q[-1], q[0], q[1], q[2]);
         }
-        const EV<W> e0 = compress_rec<W>(r[0], r[1], r[2], pl), e1 = compress_rec<W>(q[0], q[1], q[2], pl);
+        EV<W> e0 = compress_rec<W>(r[0], r[1], r[2], pl), e1 = compress_rec<W>(q[0], q[1], q[2], pl);
         const size_t row = (size_t)t * kTileRecs + lane;
+        if constexpr (STAMP) {
+          const u32 g0 = range_of(sp, nsplit, e0), g1 = range_of(sp, nsplit, e1);
+          e0.w[2] |= g0 << 24;
+          e1.w[2] |= g1 << 24;
+          st_elem<W>(out + row, e0);
+          st_elem<W>(out + row + kWave, e1);
+          digits[row] = (uint8_t)g0;
+          digits[row + kWave] = (uint8_t)g1;
+          return;
+        }
         st_elem<W>(out + row, e0);
         st_elem<W>(out + row + kWave, e1);
         if (digits) {                                        // uniform (NULL: ibu_records_compact, no pass follows)

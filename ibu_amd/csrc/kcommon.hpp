@@ -51,7 +51,9 @@ __host__ __device__ constexpr int len_of_mode(int m) { return m == 1 ? 8 : m == 
 static inline int mode_of_len(uint32_t len) {
   switch (len) {
     case 8: return 1;
+#ifndef IBU_NO_LEN10   // (A/B builds: length 10 through the runtime-length kernels)
     case 10: return 2;
+#endif
     case 12: return 3;
     case 16: return 4;
     case 32: return 5;

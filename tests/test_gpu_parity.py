@@ -355,6 +355,68 @@ def test_invalid_bases_reported(ia, ctx, oracle, n, lens):
     assert d_codes.download(np.uint64).tobytes() == wc.tobytes()
 
 
+@pytest.mark.parametrize("lens", [(5, 5), (13, 16), (16, 13), (31, 3), (17, 19), (9, 32)])
+@pytest.mark.parametrize("n", [131, 40_003])
+def test_invalid_bases_in_runtime_length_fields(ia, ctx_order, oracle, n, lens):
+    """The runtime-length kernels pack a field chunk by chunk (its code stream) and attribute an offending byte to its ROW on a
+    slow path taken only by the tiles that hold one: bad rows in the first, a middle and the last tile, at the first and last
+    base of a row, in a row that straddles two 16-byte chunks, in both fields of one row, in neighbouring rows — first bad row,
+    count and the zeroed fields equal the oracle's, under both bit orders, for lengths on either side of a specialised one."""
+    ctx, order = ctx_order
+    bc_len, umi_len = lens
+    recs = oracle.generate(SEED + 9, 0, n, bc_len, umi_len)
+    bc, umi, idx = oracle.decode_records(recs, bc_len, umi_len, order)
+    bc, umi = bc.copy(), umi.copy()
+    rows = sorted({1, 2, 127, 128, n // 2, n - 2, n - 1})
+    bc[rows[0] * bc_len] = ord("N")                            # first base
+    bc[rows[1] * bc_len + bc_len - 1] = ord("n")               # last base, the row after
+    umi[rows[2] * umi_len + umi_len // 2] = 0x00               # last row of the first tile
+    umi[rows[3] * umi_len] = 0xFF                              # first row of the second tile
+    bc[rows[4] * bc_len + bc_len // 2] = ord("U")
+    umi[rows[4] * umi_len + umi_len - 1] = ord("-")            # the same row bad in both fields: counted once
+    bc[rows[5] * bc_len] = ord("g") + 1                        # 'h'
+    umi[rows[6] * umi_len + umi_len - 1] = ord("T") ^ 0x80     # the very last byte of the column
+    d_back = ctx.alloc(n * 24)
+    ctx.encode_ascii(_up(ctx, bc), _up(ctx, umi), _up(ctx, idx), n, bc_len, umi_len, d_back)
+    want, fb, nb = oracle.encode_records(bc, umi, idx, n, bc_len, umi_len, order=order)
+    with pytest.raises(ia.IbuError) as ei:
+        ctx.codec_status()
+    assert ei.value.kind == "InvalidBase"
+    assert (ei.value.first_bad, ei.value.n_bad) == (fb, nb) == (rows[0], len(rows))
+    assert d_back.download().tobytes() == want.tobytes()
+    for col, length in ((bc, bc_len), (umi, umi_len)):          # the single-column kernel on the same columns
+        d_codes = ctx.alloc(n * 8)
+        ctx.pack_2bit(_up(ctx, col), n, length, d_codes)
+        wc, fb, nb = oracle.pack_column(col, n, length, order)
+        with pytest.raises(ia.IbuError) as ei:
+            ctx.codec_status()
+        assert (ei.value.first_bad, ei.value.n_bad) == (fb, nb)
+        assert d_codes.download(np.uint64).tobytes() == wc.tobytes()
+
+
+def test_every_byte_value_in_a_runtime_length_row(ctx, oracle):
+    """All 256 byte values in every position of a 7-base row (a length without a specialisation: rows straddle chunks)."""
+    base = b"ACGTACG"
+    rows = []
+    for pos in range(7):
+        for b in range(256):
+            r = bytearray(base)
+            r[pos] = b
+            rows.append(bytes(r))
+    a = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    n = len(rows)
+    d_codes = ctx.alloc(n * 8)
+    ctx.pack_2bit(_up(ctx, a), n, 7, d_codes)
+    want, fb, nb = oracle.pack_column(a, n, 7)
+    fbd, nbd = None, 0
+    try:
+        ctx.codec_status()
+    except Exception as e:
+        fbd, nbd = e.first_bad, e.n_bad
+    assert (fbd, nbd) == (fb, nb) and nb == 7 * (256 - 8)
+    assert d_codes.download(np.uint64).tobytes() == want.tobytes()
+
+
 def test_every_byte_value_classified(ctx, oracle):
     """All 256 byte values in every position of a 4-base row."""
     rows = []

@@ -54,7 +54,7 @@ def test_kernel_resources_reads_every_code_object():
     # 512 // vgprs (allocated in eights), and a 256-thread workgroup takes one wave on each of the CU's four SIMDs.
     budget = {"ibu_k_sort_finish_elems<3, 1792, 256>": 128, "ibu_k_sort_finish_elems<4, 1792, 256>": 168, "ibu_k_sort_finish<1024, 256, true>": 128,
               "ibu_k_sort_scatter_elems<256, 20, false, 3, unsigned int>": 256, "ibu_k_sort_scatter_elems<256, 20, false, 3, unsigned long long>": 256,
-              "ibu_k_sort_compress<true, 3>": 72, "ibu_k_sort_compress<false, 3>": 64, "ibu_k_deserialize": 64, "ibu_k_serialize": 64,
+              "ibu_k_sort_compress<true, 3, false>": 72, "ibu_k_sort_compress<false, 3, false>": 64, "ibu_k_sort_compress<false, 3, true>": 72, "ibu_k_deserialize": 64, "ibu_k_serialize": 64,
               "ibu_k_encode<16, 12, false>": 80, "ibu_k_reduce": 64}
     for name, cap in budget.items():
         k = next((v for kk, v in ks.items() if kk.endswith(name)), None)

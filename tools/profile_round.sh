@@ -8,7 +8,7 @@
 #      tools/kbench.py and tools/sortbench.py -> pmc CSVs + pmc_traffic.json (round-tagged)
 # Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 N=${2:-1e9}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -55,6 +55,23 @@ for C in FETCH_SIZE WRITE_SIZE; do
     > "$OUT/pmc_sort_$C.log" 2>&1 || exit 1
   cp "$(largest "$OUT/pmc_sort/$C" '*counter_collection.csv')" "$OUT/${TAG}_pmc_${C}_sort_1e9.csv"
 done
-python3 tools/pmc_traffic.py "$OUT/pmc" "$N" 16,12 "$TAG" > "$OUT/pmc_traffic.json" || exit 1
-rm -rf "$OUT/prof_bench" "$OUT/prof_sort"   # the raw traces are large; the summaries above are what is kept
+python3 tools/pmc_traffic.py "$OUT/pmc" "$N" 16,12 "$TAG" > "$OUT/pmc_traffic_16_12.json" || exit 1
+# the runtime-length kernels (round 4: through the code stream): the same two passes at (31,31), 5e8 records
+for C in FETCH_SIZE WRITE_SIZE; do
+  step "pmc $C over kbench, lens 31,31"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_gen/$C" -- python3 tools/kbench.py --records 5e8 --lens 31,31 --rounds 2 \
+    --kernels decode,encode,unpack,pack > "$OUT/pmc_kbench_gen_$C.log" 2>&1 < /dev/null || exit 1
+done
+python3 tools/pmc_traffic.py "$OUT/pmc_gen" 5e8 31,31 "$TAG" > "$OUT/pmc_traffic_31_31.json" || exit 1
+python3 - "$OUT/pmc_traffic_16_12.json" "$OUT/pmc_traffic_31_31.json" > "$OUT/pmc_traffic.json" <<'PY' || exit 1
+import json, sys
+a, g = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+a["runtime_length_31_31"] = {k: v for k, v in g.items() if not k.startswith("_")}
+a["runtime_length_31_31"]["_records"] = g["_records"]
+print(json.dumps(a, indent=1))
+PY
+step "the multi-GPU sort rehearsed on this GPU (8 and 2 contexts)"
+python3 tools/sortbench.py --records "$N" --shards 8 --rounds 3 > "$OUT/${TAG}_sort_contexts_rehearsal.jsonl" 2>> "$OUT/sort.err" < /dev/null || exit 1
+python3 tools/sortbench.py --records "$N" --shards 2 --rounds 3 >> "$OUT/${TAG}_sort_contexts_rehearsal.jsonl" 2>> "$OUT/sort.err" < /dev/null || exit 1
+rm -rf "$OUT/prof_bench" "$OUT/prof_sort" "$OUT/pmc" "$OUT/pmc_sort" "$OUT/pmc_gen"   # the raw traces are large; the summaries above are what is kept
 step done

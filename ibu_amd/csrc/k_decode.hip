@@ -10,7 +10,7 @@ namespace ibu {
 // Records per wave iteration = 128 * NT.  With NT = 2 every ASCII column whose length is a multiple of 4 is a whole
 // number of 64-lane store rounds (16*len chunks), so no round is partial, and a wave keeps twice the bytes in flight:
 // 1.0-1.7 % faster for the dword-path specialisations with at least 20 bases per record ((16,12) in every one of ten
-// placements, (32,32), (12,8), (32,12)); slower for (8,8) by 1 %, and the byte-path length 10 spills (2.7x slower), so
+// placements, (32,32), (12,8), (32,12)); slower for (8,8) by 1 %, so
 // NT is a property of the instantiation: dec_nt<BC, UM>().  -DIBU_DECODE_NT=1|2 forces one value everywhere (A/B builds).
 constexpr bool dword_len(int len) { return len > 0 && (len & 3) == 0; }
 #ifndef IBU_DECODE_GEN_NT
@@ -82,7 +82,6 @@ __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs<dec_nt<
 #endif
 template <int BC, int UM, bool MSB>
 constexpr int dec_waves() {
-  if (BC == 10 || UM == 10) return (BC == 10 && UM == 10) ? 2 : 3;                       // the byte path
   if (BC == 0 || UM == 0) return (BC == 12 || UM == 12) ? 5 : IBU_DECODE_GEN_WAVES;     // a runtime-length field: the code stream
   if (dec_nt<BC, UM>() > 1) return (BC == 12 || UM == 12) ? 4 : (MSB ? 4 : 5);
   return MSB ? 6 : 7;
@@ -184,15 +183,15 @@ extern "C" __global__ void ibu_k_unpack_tail(const u64* codes, u64 row0, u64 n, 
 typedef void (*DecFn)(const uint8_t*, u32, u32, u32, uint8_t*, uint8_t*, u64*);
 template <int B, int U, bool M>
 static constexpr DecFn dec_entry() { return ibu_k_decode<len_of_mode(B), len_of_mode(U), M>; }
-#define IBU_DEC_ROW(B, M) {dec_entry<B, 0, M>(), dec_entry<B, 1, M>(), dec_entry<B, 2, M>(), dec_entry<B, 3, M>(), dec_entry<B, 4, M>(), dec_entry<B, 5, M>()}
-#define IBU_DEC_TABLE(M) {IBU_DEC_ROW(0, M), IBU_DEC_ROW(1, M), IBU_DEC_ROW(2, M), IBU_DEC_ROW(3, M), IBU_DEC_ROW(4, M), IBU_DEC_ROW(5, M)}
+#define IBU_DEC_ROW(B, M) {dec_entry<B, 0, M>(), dec_entry<B, 1, M>(), dec_entry<B, 2, M>(), dec_entry<B, 3, M>(), dec_entry<B, 4, M>()}
+#define IBU_DEC_TABLE(M) {IBU_DEC_ROW(0, M), IBU_DEC_ROW(1, M), IBU_DEC_ROW(2, M), IBU_DEC_ROW(3, M), IBU_DEC_ROW(4, M)}
 static const DecFn kDecTable[2][kNumLenModes][kNumLenModes] = {IBU_DEC_TABLE(false), IBU_DEC_TABLE(true)};  // [base_order][bc][umi]
 // records per wave iteration of each instantiation (the same for both base orders)
 template <int B, int U>
 static constexpr int dec_recs() { return kTileRecs * dec_nt<len_of_mode(B), len_of_mode(U)>(); }
-#define IBU_DEC_RECS_ROW(B) {dec_recs<B, 0>(), dec_recs<B, 1>(), dec_recs<B, 2>(), dec_recs<B, 3>(), dec_recs<B, 4>(), dec_recs<B, 5>()}
+#define IBU_DEC_RECS_ROW(B) {dec_recs<B, 0>(), dec_recs<B, 1>(), dec_recs<B, 2>(), dec_recs<B, 3>(), dec_recs<B, 4>()}
 static const int kDecRecsTable[kNumLenModes][kNumLenModes] = {IBU_DEC_RECS_ROW(0), IBU_DEC_RECS_ROW(1), IBU_DEC_RECS_ROW(2),
-                                                              IBU_DEC_RECS_ROW(3), IBU_DEC_RECS_ROW(4), IBU_DEC_RECS_ROW(5)};
+                                                              IBU_DEC_RECS_ROW(3), IBU_DEC_RECS_ROW(4)};
 
 hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint32_t bc_len, uint32_t umi_len,
                          uint8_t* bc, uint8_t* umi, uint64_t* idx, hipStream_t st) {
@@ -222,7 +221,7 @@ hipError_t launch_decode(const LaunchCfg& cfg, const void* recs, size_t n, uint3
 
 typedef void (*UnpFn)(const u64*, u32, u32, uint8_t*);
 #define IBU_UNP_ROW(M) {ibu_k_unpack<len_of_mode(0), M>, ibu_k_unpack<len_of_mode(1), M>, ibu_k_unpack<len_of_mode(2), M>, \
-                        ibu_k_unpack<len_of_mode(3), M>, ibu_k_unpack<len_of_mode(4), M>, ibu_k_unpack<len_of_mode(5), M>}
+                        ibu_k_unpack<len_of_mode(3), M>, ibu_k_unpack<len_of_mode(4), M>}
 static const UnpFn kUnpTable[2][kNumLenModes] = {IBU_UNP_ROW(false), IBU_UNP_ROW(true)};
 
 hipError_t launch_unpack(const LaunchCfg& cfg, const uint64_t* codes, size_t n, uint32_t len, uint8_t* out,

@@ -28,8 +28,6 @@ namespace ibu {
 #define IBU_ENCODE_GEN_MINWAVES 4
 #endif
 constexpr int encode_minwaves(int bc, int um) {
-  const bool bytes = (bc & 3) != 0 || (um & 3) != 0;          // a specialised length off the dword path: 10
-  if (bytes) return 3;
   if (bc == 0 || um == 0) return IBU_ENCODE_GEN_MINWAVES;
   return (bc <= 16 && um <= 16) ? IBU_ENCODE_MINWAVES : 4;
 }
@@ -238,15 +236,15 @@ extern "C" __global__ void ibu_k_pack_tail(const uint8_t* in, u64 row0, u64 n, u
 typedef void (*EncFn)(const uint8_t*, const uint8_t*, const u64*, u64, u64, u32, u32, u32, u32, uint8_t*, u64*);
 template <int B, int U, bool M>
 static constexpr EncFn enc_entry() { return ibu_k_encode<len_of_mode(B), len_of_mode(U), M>; }
-#define IBU_ENC_ROW(B, M) {enc_entry<B, 0, M>(), enc_entry<B, 1, M>(), enc_entry<B, 2, M>(), enc_entry<B, 3, M>(), enc_entry<B, 4, M>(), enc_entry<B, 5, M>()}
-#define IBU_ENC_TABLE(M) {IBU_ENC_ROW(0, M), IBU_ENC_ROW(1, M), IBU_ENC_ROW(2, M), IBU_ENC_ROW(3, M), IBU_ENC_ROW(4, M), IBU_ENC_ROW(5, M)}
+#define IBU_ENC_ROW(B, M) {enc_entry<B, 0, M>(), enc_entry<B, 1, M>(), enc_entry<B, 2, M>(), enc_entry<B, 3, M>(), enc_entry<B, 4, M>()}
+#define IBU_ENC_TABLE(M) {IBU_ENC_ROW(0, M), IBU_ENC_ROW(1, M), IBU_ENC_ROW(2, M), IBU_ENC_ROW(3, M), IBU_ENC_ROW(4, M)}
 static const EncFn kEncTable[2][kNumLenModes][kNumLenModes] = {IBU_ENC_TABLE(false), IBU_ENC_TABLE(true)};  // [base_order][bc][umi]
 // 128-row tiles per wave iteration of each instantiation (the same for both base orders)
 template <int B, int U>
 static constexpr int enc_nt_of() { return enc_nt<len_of_mode(B), len_of_mode(U)>(); }
-#define IBU_ENC_NT_ROW(B) {enc_nt_of<B, 0>(), enc_nt_of<B, 1>(), enc_nt_of<B, 2>(), enc_nt_of<B, 3>(), enc_nt_of<B, 4>(), enc_nt_of<B, 5>()}
+#define IBU_ENC_NT_ROW(B) {enc_nt_of<B, 0>(), enc_nt_of<B, 1>(), enc_nt_of<B, 2>(), enc_nt_of<B, 3>(), enc_nt_of<B, 4>()}
 static const int kEncNtTable[kNumLenModes][kNumLenModes] = {IBU_ENC_NT_ROW(0), IBU_ENC_NT_ROW(1), IBU_ENC_NT_ROW(2),
-                                                            IBU_ENC_NT_ROW(3), IBU_ENC_NT_ROW(4), IBU_ENC_NT_ROW(5)};
+                                                            IBU_ENC_NT_ROW(3), IBU_ENC_NT_ROW(4)};
 
 hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t* umi, const uint64_t* idx,
                          uint64_t first_index, size_t n, uint32_t bc_len, uint32_t umi_len, void* recs,
@@ -282,7 +280,7 @@ hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t*
 
 typedef void (*PackFn)(const uint8_t*, u64, u32, u32, u64*, u64*);
 #define IBU_PACK_ROW(M) {ibu_k_pack<len_of_mode(0), M>, ibu_k_pack<len_of_mode(1), M>, ibu_k_pack<len_of_mode(2), M>, \
-                         ibu_k_pack<len_of_mode(3), M>, ibu_k_pack<len_of_mode(4), M>, ibu_k_pack<len_of_mode(5), M>}
+                         ibu_k_pack<len_of_mode(3), M>, ibu_k_pack<len_of_mode(4), M>}
 static const PackFn kPackTable[2][kNumLenModes] = {IBU_PACK_ROW(false), IBU_PACK_ROW(true)};
 
 hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32_t len, uint64_t* codes,

@@ -44,19 +44,18 @@ static constexpr int kTileRecs = 128;              // records per wave tile
 static constexpr int kTileBytes = kTileRecs * 24;  // 3072
 static constexpr u32 kPool = 0x54474341u;          // "ACGT" little-endian: byte k = base code k
 
-// Lengths with a fully specialised (constant-folded, straight-line) kernel; every other length
-// 1..32 runs the generic kernel (runtime loops).  Mode 0 = generic.
-static constexpr int kNumLenModes = 6;
-__host__ __device__ constexpr int len_of_mode(int m) { return m == 1 ? 8 : m == 2 ? 10 : m == 3 ? 12 : m == 4 ? 16 : m == 5 ? 32 : 0; }
+// Lengths with a fully specialised (constant-folded, straight-line) kernel; every other length 1..32 runs the runtime-length
+// kernels (mode 0: the field goes through its code stream, below).  Length 10 had a specialisation until round 4 — a byte path
+// (10 % 4 != 0) under a two- or three-wave register budget; through the code stream the same arrays run (10,10) encode 2.5 %,
+// pack 10 % faster and decode level (profiles/r04_i_kbench_len10.jsonl), so it went.
+static constexpr int kNumLenModes = 5;
+__host__ __device__ constexpr int len_of_mode(int m) { return m == 1 ? 8 : m == 2 ? 12 : m == 3 ? 16 : m == 4 ? 32 : 0; }
 static inline int mode_of_len(uint32_t len) {
   switch (len) {
     case 8: return 1;
-#ifndef IBU_NO_LEN10   // (A/B builds: length 10 through the runtime-length kernels)
-    case 10: return 2;
-#endif
-    case 12: return 3;
-    case 16: return 4;
-    case 32: return 5;
+    case 12: return 2;
+    case 16: return 3;
+    case 32: return 4;
     default: return 0;
   }
 }
@@ -263,37 +262,18 @@ __device__ __forceinline__ u32x4 expand_chunk(const uint8_t* tile, u32 rstride, 
 #elif IBU_PROBE == 2
   { u32x4 o; o.x = o.y = o.z = o.w = c + len + rstride + foff; return o; }
 #endif
-  if ((len & 3) == 0) {
-    const u32 l4 = len >> 2;                       // code bytes per row (1..8)
-    if (l4 == 4) return expand16(*reinterpret_cast<const u32*>(tile + c * rstride + foff));
-    if (l4 == 8) return expand16(*reinterpret_cast<const u32*>(tile + (c >> 1) * rstride + foff + (c & 1) * 4));
-    const u32 d = 4 * c;                           // 4,8,12,20,24,28 bases: gather 4 code bytes
-    u32 r = (d * (65536u / l4 + 1)) >> 16;         // d / l4 for d < 1024
-    u32 q = d - r * l4;
-    u32 v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = expand4(tile[r * rstride + foff + q]);
-      if (++q == l4) { q = 0; ++r; }
-    }
-    u32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-    return o;
-  }
-  // len not a multiple of 4: rows straddle dwords; resolve every output byte on its own.
-  const u32 o0 = 16 * c;
-  u32 r = (o0 * ((1u << 20) / len + 1)) >> 20;     // o0 / len for o0 < 128*len
-  u32 p = o0 - r * len;
+  // len is a multiple of 4 (expand_field: every specialised length is; any other length goes through its code stream, below)
+  const u32 l4 = len >> 2;                         // code bytes per row (1..8)
+  if (l4 == 4) return expand16(*reinterpret_cast<const u32*>(tile + c * rstride + foff));
+  if (l4 == 8) return expand16(*reinterpret_cast<const u32*>(tile + (c >> 1) * rstride + foff + (c & 1) * 4));
+  const u32 d = 4 * c;                             // 4,8,12,20,24,28 bases: gather 4 code bytes
+  u32 r = (d * (65536u / l4 + 1)) >> 16;           // d / l4 for d < 1024
+  u32 q = d - r * l4;
   u32 v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    u32 w = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const u32 code = __builtin_amdgcn_ubfe((u32)tile[r * rstride + foff + (p >> 2)], 2 * (p & 3), 2);  // v_bfe_u32: base p of the row
-      w |= ((kPool >> (8 * code)) & 0xFFu) << (8 * b);
-      if (++p == len) { p = 0; ++r; }
-    }
-    v[j] = w;
+    v[j] = expand4(tile[r * rstride + foff + q]);
+    if (++q == l4) { q = 0; ++r; }
   }
   u32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
   return o;
@@ -380,9 +360,10 @@ __device__ __forceinline__ u64 stream_row(const u32* stream, u32 r, u32 len) {
 //             recompute and re-store the LAST chunk (same bytes, same address: benign) so no
 //             store is exec-branched and the store count per tile is exact.
 //   LEN == 0: runtime length: rows -> code stream -> chunks (above).
-template <int LEN, int NT = 1>  // NT: 128-record tiles staged back to back in `tile`
+template <int LEN, int NT = 1>  // NT: 128-record tiles staged back to back in `tile`; LEN: 0 or a multiple of 4
 __device__ __forceinline__ void expand_field(const uint8_t* tile, u32 rstride, u32 foff, u32 rt_len,
                                              uint8_t* out_tile, u32 lane, u32* stream = nullptr) {
+  static_assert((LEN & 3) == 0, "specialised lengths are multiples of 4");
   if constexpr (LEN > 0) {
     constexpr u32 last = 8 * LEN * NT - 1;
     constexpr int rounds = (8 * LEN * NT + kWave - 1) / kWave;
@@ -417,13 +398,8 @@ template <int LEN>
 __device__ __forceinline__ u64 pack_row(const uint8_t* field, u32 r, u32 rt_len, bool& ok) {
   if constexpr (LEN > 0 && (LEN & 3) == 0) {
     return pack_row_dwords<LEN / 4>(field + r * LEN, ok);
-  } else if constexpr (LEN > 0) {
-    const uint8_t* row = field + r * LEN;
-    u64 v = 0;
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) v |= (u64)pack1(row[i], ok) << (2 * i);
-    return v;
   } else {
+    static_assert(LEN == 0, "specialised lengths are multiples of 4; every other length is a runtime length");
     return stream_row(reinterpret_cast<const u32*>(field), r, rt_len);
   }
 }

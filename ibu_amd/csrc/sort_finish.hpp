@@ -283,9 +283,6 @@ ibu_k_sort_finish(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u64
 // dwordx3, fully coalesced).  Elements compare as W-word little-endian integers, which is the record order (COMPACT-KEY
 // passes); index bytes that the passes do not sort on (input in index order) take part in the comparison here — the same
 // result, because the passes are stable and the input's index order is the element order on those bytes.
-#ifndef IBU_FINISH_V2
-#define IBU_FINISH_V2 1
-#endif
 template <int W, int T, int M>
 struct FinishElemShape {
   static constexpr int L = T + M;
@@ -403,82 +400,6 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
       m = stop - s0;
       return found && s0 >= begin && m <= (u32)M && (nx < end || end_is_head);
     };
-#if IBU_FINISH_V2
-    // Round 4: every element settles its place in ONE step — runs of three and more count inside their run on the spot (2 % of the
-    // elements at 1e9 well-spread records: a wave pays for its longest such run, three or four candidates, instead of a worklist with
-    // its atomics, a barrier and a second look at the bitmap) — and writes WHERE IT COMES FROM at its place (`tgt[place] = i`), so
-    // step 5 reads the window through that index instead of a permuted copy: no second staging pass, no barrier in front of it, and
-    // the tile's registers are dead once the window is staged.  Four barriers per tile instead of six.
-    bool inversion = false;
-#pragma unroll 1
-    for (u32 i = begin + tid; i < end; i += kSortThreads) {
-      u32 me[W];
-#pragma unroll
-      for (int w = 0; w < W; ++w) me[w] = stage[W * i + w];
-      u32 s0, nx, m;
-      bool found;
-      run_around(hw, i, nwords, s0, found, nx);
-      if (short_run(s0, found, nx, m)) {
-        u32 place;
-        if (m <= 2u) {
-          const u32 p = m == 2u ? s0 + (u32)(i == s0) : i;   // the other element of a pair (a run of one: itself, which counts nothing)
-          u32 a[W];
-#pragma unroll
-          for (int w = 0; w < W; ++w) a[w] = stage[W * p + w];
-          place = s0 + elem_before<W>(a, me, (u32)(p < i));
-        } else {
-          u32 cnt = 0;
-          for (u32 j = s0; j < s0 + m; j += 2) {
-            const u32 j1 = j + 1 < s0 + m ? j + 1 : j;         // clamped: in the window, not counted
-            u32 a[W], b[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) { a[w] = stage[W * j + w]; b[w] = stage[W * j1 + w]; }
-            cnt += elem_before<W>(a, me, (u32)(j < i));
-            cnt += elem_before<W>(b, me, (u32)(j1 < i)) & (u32)(j + 1 < s0 + m);
-          }
-          place = s0 + cnt;
-        }
-        tgt[place] = (uint16_t)i;
-      } else {                                                // part of a long run
-        tgt[i] = (uint16_t)i;
-        if (!((hw[i >> 6] >> (i & 63u)) & 1ull)) {            // same run as the element in front (i = 0: the one in front of the window)
-          u32 prev[W];
-#pragma unroll
-          for (int w = 0; w < W; ++w) prev[w] = stage[W * i + w - W];
-          inversion = inversion || elem_before<W>(me, prev, 0u);
-        }
-      }
-    }
-    if (inversion) misc[2] = 1u;
-    __syncthreads();
-    if (misc[2]) {                                            // a long run that is not in order: not this kernel's to sort
-      if (tid == 0) *overflow = 1u;
-      return;
-    }
-    // 5. the chunk [begin, end) leaves as records: one lane per half record (ibu_k_sort_scatter_elems' last-pass write-out), the
-    //    element of place p read through tgt[p].  The lane's half (its parity; kSortThreads is even) is selected HERE, per tile.
-    const u32 hj = tid & 1u;
-    u32 hsel[3][2], hbase[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      hsel[k][0] = hj ? pl.xsel[3 + k][0] : pl.xsel[k][0];
-      hsel[k][1] = hj ? pl.xsel[3 + k][1] : pl.xsel[k][1];
-      const u64 bf = hj ? pl.base[(3 + k) >> 1] : pl.base[k >> 1];
-      hbase[k] = ((3 * (hj ? 1 : 0) + k) & 1) ? (u32)(bf >> 32) : (u32)bf;
-    }
-    uint8_t* out = static_cast<uint8_t*>(dst_v) + 24 * (size_t)base;
-#pragma unroll 1
-    for (u32 h = 2 * begin + tid; h < 2 * end; h += kSortThreads) {   // kSortThreads is even: a lane keeps its half
-      const u32 p = h >> 1, q = tgt[p];
-      u32 e[4] = {stage[W * q], stage[W * q + 1], stage[W * q + 2], 0};
-      if constexpr (W == 4) e[3] = stage[W * q + 3];
-      u32x3 o;
-      o.x = hbase[0] | __builtin_amdgcn_perm(e[1], e[0], hsel[0][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[0][1]);
-      o.y = hbase[1] | __builtin_amdgcn_perm(e[1], e[0], hsel[1][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[1][1]);
-      o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
-      __builtin_nontemporal_store(o, reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * hj));   // the chunk is contiguous: nothing for the L2 to merge
-    }
-#else
     bool inversion = false;
 #pragma unroll 1
     for (u32 i = begin + tid; i < end; i += kSortThreads) {
@@ -573,7 +494,6 @@ ibu_k_sort_finish_elems(const ElemT<W>* __restrict__ src, void* __restrict__ dst
       o.z = hbase[2] | __builtin_amdgcn_perm(e[1], e[0], hsel[2][0]) | __builtin_amdgcn_perm(e[3], e[2], hsel[2][1]);
       __builtin_nontemporal_store(o, reinterpret_cast<u32x3_a4*>(out + 24 * (size_t)p + 12 * hj));   // the chunk is contiguous: nothing for the L2 to merge
     }
-#endif
   };
   EV<W> va[PER], vb[PER], fa, fb;
   load(tile, va, fa);

@@ -524,14 +524,21 @@ class MmapReader:
             return as_dict(total), [as_dict(parts[i]) for i in range(n)], list(stats)[:n]
         return total.count, None, list(stats)[:n]
 
-    def decode_to_host(self, ctx, shard=0, n_shards=1, ring=None, want=("bc", "umi", "index")):
+    def decode_to_host(self, ctx, shard=0, n_shards=1, ring=None, want=("bc", "umi", "index"), out=None):
         """One shard -> (barcode ASCII [n, bc_len], UMI ASCII [n, umi_len], index [n]) as numpy arrays in host
-        memory, unpacked on the GPU.  Columns not in `want` come back as None."""
+        memory, unpacked on the GPU.  Columns not in `want` come back as None.  out = (bc, umi, index) arrays of those
+        shapes to fill instead of fresh ones (memory that has been written before takes no page faults: 1.7x the rate)."""
         a, b = shard_range(self.len(), n_shards, shard)
         n, h = b - a, self.header()
-        bc = np.empty((n, h.bc_len), dtype=np.uint8) if "bc" in want else None
-        umi = np.empty((n, h.umi_len), dtype=np.uint8) if "umi" in want else None
-        idx = np.empty(n, dtype=np.uint64) if "index" in want else None
+        if out is not None:
+            bc, umi, idx = out
+            for arr, shape, dt in ((bc, (n, h.bc_len), np.uint8), (umi, (n, h.umi_len), np.uint8), (idx, (n,), np.uint64)):
+                if arr is not None and (arr.shape != shape or arr.dtype != dt or not arr.flags.c_contiguous):
+                    raise ValueError("out: C-contiguous arrays of shapes (n, bc_len) u8, (n, umi_len) u8, (n,) u64")
+        else:
+            bc = np.empty((n, h.bc_len), dtype=np.uint8) if "bc" in want else None
+            umi = np.empty((n, h.umi_len), dtype=np.uint8) if "umi" in want else None
+            idx = np.empty(n, dtype=np.uint64) if "index" in want else None
         st = CStreamStats()
         _check(lib.ibu_mmap_decode_to_host(self._m, ctx._c, _ring(ring), shard, n_shards,
                                            _hptr(bc) if bc is not None else None, _hptr(umi) if umi is not None else None,

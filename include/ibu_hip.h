@@ -547,10 +547,13 @@ int32_t ibu_reader_process_device(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_rin
  * h_bc_ascii + i*bc_len ...); any of them may be NULL to skip that column.
  * WHEN NOT TO CALL THIS: whenever the columns are wanted in HOST memory and nothing else runs on the device.  Every record
  * crosses PCIe twice (24 B in, bc_len + umi_len + 8 B out) between two host copies (map -> pinned, pinned -> caller, the
- * second one faulting in the caller's fresh pages), and the kernel is 2 % of the wall time: 0.28-0.40 G records/s at 16/12 on
- * a one-GPU box of this pool at every size from 1e6 to 1e9 records (tools/e2e.py rows "mmap decode_to_host": the rate does
- * not grow with the size, so there is no crossover), where a plain loop over MmapReader::slice with a scalar 2-bit unpack on
- * the same box's 16 CPUs decodes AND re-encodes 0.73-0.84 G records/s (bench.py: cpu_baseline).  The call exists so that the
+ * second one faulting in the caller's fresh pages), and the kernel is 2 % of the wall time: 0.3-0.7 G records/s at 16/12 on
+ * a one-GPU box of this pool into FRESH output arrays at every size from 1e6 to 1e9 records (tools/e2e.py rows "mmap
+ * decode_to_host": the rate does not grow with the size, so there is no crossover) — 58 of 145 ms at 1e8 records are the
+ * kernel's page faults on 3.6 GB of new pages, which neither more threads nor MADV_POPULATE_WRITE ahead of the copies make
+ * cheaper (profiles/r04_k_*) — and 1.15-1.2 G records/s into arrays that have been written before (a reused buffer); a
+ * plain loop over MmapReader::slice with a scalar 2-bit unpack on the same box's 16 CPUs decodes AND re-encodes 0.55-0.84 G
+ * records/s (bench.py: cpu_baseline) and pays the same page faults.  The call exists so that the
  * API is complete for consumers that hold their sequences in host memory; the device pays off when the columns STAY
  * resident — ibu_mmap_process_device(s) with IBU_PROC_DECODE (2.2 G records/s, PCIe-bound one way) and everything behind
  * it (sort, per-barcode aggregation, re-encoding) at HBM rates. */

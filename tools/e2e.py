@@ -121,6 +121,10 @@ def main():
                 h_bc, h_umi, h_idx, st = m.decode_to_host(ctx, ring=cring)
                 emit(f"mmap decode_to_host, {rep}", time.perf_counter() - t0, st)
             assert [h_bc.tobytes(), h_umi.tobytes(), h_idx.tobytes()] == plain
+            t0 = time.perf_counter()                         # into the arrays of the last call: pages that exist (a reused buffer)
+            _, _, _, st = m.decode_to_host(ctx, ring=cring, out=(h_bc, h_umi, h_idx))
+            emit("mmap decode_to_host, into arrays written before (no page faults)", time.perf_counter() - t0, st)
+            assert [h_bc.tobytes(), h_umi.tobytes(), h_idx.tobytes()] == plain
             # the same call on a hundredth and a tenth of the file (one shard of the static split): the rate at the sizes where a
             # caller might hope the GPU pays for host -> host decoding.  It does not at any size: see include/ibu_hip.h
             for parts in (100, 10):

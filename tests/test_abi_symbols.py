@@ -55,7 +55,7 @@ def test_no_product_kernel_uses_scratch():
     import kernel_resources
     from ibu_amd import _lib
     ks = kernel_resources.all_kernels(_lib.SO_PATH)
-    assert len(ks) > 200 and any("ibu_k_sort_compress<true, 3>" in k for k in ks), sorted(ks)[:5]
+    assert len(ks) > 150 and any("ibu_k_sort_compress<true, 3, false>" in k for k in ks), sorted(ks)[:5]
     spilling = {k: v["private_segment_fixed_size"] for k, v in ks.items() if v.get("private_segment_fixed_size", 0)}
     assert not spilling, spilling
     dynamic = [k for k, v in ks.items() if v.get("uses_dynamic_stack", 0)]

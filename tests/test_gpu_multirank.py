@@ -52,6 +52,37 @@ def test_bench_two_ranks_on_one_gpu_weak():
     assert out["config"]["records_per_rank"] == [50_000_000, 50_000_000]
 
 
+def test_bench_bare_with_gpus_2_starts_its_own_ranks_or_fails_loudly():
+    """`python bench.py --gpus 2` run bare: bench.py starts the two ranks itself as a child
+    torch.distributed.run — on this one-GPU box the ranks share cuda:0 over gloo — and the line says n_gpus: 2.  Never a
+    silent one-GPU run."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--records", "20000001", "--backend", "gloo",
+                        "--share-gpu", "--no-cpu-baseline", "--placement-tries", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["global_count"] == 20_000_001 and out["config"]["records_per_rank"] == [10_000_000, 10_000_001]
+
+
+def test_bench_one_gpu_line_carries_the_e2e_leg(tmp_path):
+    """The driver's N = 1 line: headline + an `e2e` object with the three file -> result rates, each checked against K4 of the
+    resident copy inside bench.py (small sizes here: the rates are not asserted)."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--records", "3000001", "--no-cpu-baseline", "--no-wide-leg",
+                        "--no-sort-leg", "--placement-tries", "1", "--e2e-records", "700003", "--e2e-dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    e = out["e2e"]
+    assert "error" not in e, e
+    for leg in ("load_to_device", "mmap_process_devices_decode", "gzip_reader_process_device_decode"):
+        assert e[leg]["records_per_s"] > 0 and e[leg]["GBps_of_file"] > 0 and e[leg]["totals_equal_resident_copy"] is True, (leg, e[leg])
+    assert e["mmap_process_devices_decode"]["devices"] >= 1 and 0 < e["gzip_reader_process_device_decode"]["gz_ratio"] < 1
+    assert not list(tmp_path.iterdir())                       # the leg removes its files
+
+
 @pytest.mark.parametrize("proc", ["reduce", "decode"])
 def test_sharded_file_two_ranks(tmp_path, proc, oracle):
     n = 3_000_001

@@ -550,7 +550,36 @@ def test_all_rows_invalid_is_counted_exactly(ia, ctx):
     ctx.codec_status()  # re-armed
 
 
-@pytest.mark.parametrize("lens", [(16, 12), (32, 32)])
+def test_runtime_length_decode_is_a_prefix_of_the_32_base_decode_1e9(ia, ctx):
+    """A size-independent property that ties the runtime-length kernels to a specialised one at BASELINE's full size: with
+    the first base in the least significant bits, the L-base decode of a code word is the first L bases of its 32-base
+    decode, whatever the bits above 2 L hold (F7).  1e9 full-range records through ibu_k_decode<32,32> and through the
+    runtime-length kernel at (31,17), (5,29): pieces at the start, in the middle and at the end compared on the host."""
+    n = 1_000_000_000
+    recs = ctx.alloc(n * 24)
+    ctx.generate(0x1B00002, 0, n, 32, 32, recs)                # full-range u64 fields
+    bc32, umi32 = ctx.alloc(n * 32), ctx.alloc(n * 32)
+    ctx.decode_ascii(recs, n, 32, 32, bc32, umi32, None)
+    piece = 200_000
+    spots = [0, n // 2 - 77, n - piece]
+
+    def rows(buf, length, lo):
+        return ia.DeviceBuffer.wrap(ctx, buf.ptr + lo * length, piece * length).download().reshape(piece, length)
+
+    ref = [(rows(bc32, 32, lo), rows(umi32, 32, lo)) for lo in spots]
+    for bc_len, umi_len in ((31, 17), (5, 29)):
+        bc, umi = ctx.alloc(n * bc_len), ctx.alloc(n * umi_len)
+        ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, None)
+        for lo, (rb, ru) in zip(spots, ref):
+            assert np.array_equal(rows(bc, bc_len, lo), rb[:, :bc_len]), (bc_len, lo)
+            assert np.array_equal(rows(umi, umi_len, lo), ru[:, :umi_len]), (umi_len, lo)
+        bc.free()
+        umi.free()
+    for b_ in (recs, bc32, umi32):
+        b_.free()
+
+
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32), (31, 31), (17, 19)])
 def test_full_size_roundtrip_properties_1e9(ia, ctx, lens):
     """BASELINE.json's full size (1e9 records; configs[2] and configs[3] shapes) through size-independent properties:
     encode(decode(x)) == x, count and closed-form sums, decoded alphabet, index column, and sort -> sorted with the

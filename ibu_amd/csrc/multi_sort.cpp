@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -119,7 +120,12 @@ int32_t plan_landing(const ibu_sort_shard_t* shards, size_t W, const std::vector
 }
 
 // ---- PARTITION FIRST -------------------------------------------------------------------------------------------------------
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, const CompactPlan& plan, size_t total) {
+  const bool trace = getenv("IBU_TRACE_SORT") != nullptr;
+  double t_mark = now_ms(), t_phase[5] = {0, 0, 0, 0, 0};
+  auto lap = [&](int k) { const double t = now_ms(); t_phase[k] = t - t_mark; t_mark = t; };
   // 1. 255 splitters from samples of the (unsorted) shards cut the key space into 256 FINE ranges — more than there are owners:
   //    the samples only have to make the ranges small, the exact counts of the partition pass then say which consecutive ranges
   //    an owner gets (a range is ~1/256 of the records: the owners' loads differ by about that much, not by the sampling noise
@@ -130,6 +136,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   if (rc) return rc;
   std::vector<Rec> split;
   pick_splitters(samp, F, split);
+  lap(0);
   // 2. every shard: records -> elements stamped with their range (one kernel) -> range order in the upper half of its scratch;
   //    fine[i][f] = first element of range f.
   //    The largest shard also says how many prefix passes a sort of `total` records like its own wants (it is a sample of them).
@@ -163,6 +170,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     return IBU_OK;
   });
   if (rc) return rc;
+  lap(1);
   // which ranges an owner gets: consecutive ones, up to the point nearest to its share of the records (and not past its capacity
   // while an earlier cut avoids that; the last owner takes what is left)
   std::vector<uint64_t> g(F, 0);
@@ -203,6 +211,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     return IBU_OK;
   });
   if (rc) return rc;                                          // (joined: the upper halves are not read any more)
+  lap(2);
   // 4. every owner sorts what it received, elements -> records
   rc = on_every_context(W, [&](size_t j) -> int32_t {
     ibu_ctx_t* c = ctxs[j];
@@ -216,7 +225,10 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     return IBU_OK;
   });
   if (rc) return rc;
-  if (getenv("IBU_TRACE_SORT")) fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u)\n", W, prefix_passes);
+  lap(3);
+  if (trace)
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u; ms: samples %.2f, partition %.2f, exchange %.2f, sort %.2f)\n", W,
+            prefix_passes, t_phase[0], t_phase[1], t_phase[2], t_phase[3]);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
 }

@@ -70,13 +70,11 @@ __device__ __forceinline__ void decode_tile(uint8_t* tile, const DecRegs<dec_nt<
 // Two register sets take turns (phase A expands `a` while `b` is in flight, phase B the
 // reverse): the next tile's loads are issued FIRST in each phase, never copied, never
 // behind a wait.
-// Register budget: the dword-path specialisations fit 72 VGPRs (7 waves/SIMD); the byte-path
-// (len % 4 != 0) and generic kernels would spill there, so they get 168 (3 waves/SIMD).  72 VGPRs
-// (7 waves/SIMD) measured as fast as 64 (8) for the streaming kernels (profiles/r01_b sweep).
-// (NT = 2 holds twice the tile registers: 5 waves/SIMD.)
-// (Round 3: the code objects' metadata showed five instantiations with scratch under those budgets — (12,12), (12,32), (32,12)
-// at NT = 2, whose length-12 gathers hold more addresses than the dword reads of 16 / 32, and (10,10) both orders;
-// tools/kernel_resources.py, now a CPU test.  They get one wave per SIMD less.)
+// Register budget: the specialisations (all on the dword path since round 4) fit 72 VGPRs (7 waves/SIMD), measured as fast as 64
+// (8) for the streaming kernels (profiles/r01_b sweep); NT = 2 holds twice the tile registers: 5 waves/SIMD, and 4 where a
+// length-12 field is in it (its gathers hold more addresses than the dword reads of 16 / 32: round 3 found those three with
+// scratch in the code objects' metadata — tools/kernel_resources.py, a CPU test).  A runtime-length field goes through its code
+// stream and needs no more registers than a specialised one (68 VGPRs at (0,0)): six waves/SIMD (168 VGPRs and three until round 4).
 #ifndef IBU_DECODE_GEN_WAVES
 #define IBU_DECODE_GEN_WAVES 6
 #endif

@@ -20,10 +20,9 @@ namespace ibu {
 #ifndef IBU_ENCODE_MINWAVES
 #define IBU_ENCODE_MINWAVES 6
 #endif
-// Register budget (waves/SIMD): short dword-path rows fit 80 VGPRs; 32-base rows need 128;
-// byte-path (len % 4 != 0) and generic kernels get 168 — none of the instantiations spills.
-// A runtime-length field (0) lands as its code stream and costs no more registers than a dword-path field (round 4; it was
-// packed byte by byte under a 168-VGPR budget before).
+// Register budget (waves/SIMD): short rows fit 80 VGPRs; 32-base rows need 128 — none of the instantiations spills.
+// A runtime-length field (0) lands as its code stream and costs no more registers than a specialised one (round 4; it was
+// packed byte by byte under a 168-VGPR budget before, like the length-10 specialisation that round 4 retired).
 #ifndef IBU_ENCODE_GEN_MINWAVES
 #define IBU_ENCODE_GEN_MINWAVES 4
 #endif

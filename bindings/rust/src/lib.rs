@@ -466,6 +466,14 @@ pub mod device {
             check(unsafe { ffi::ibu_ctx_create(device, &mut raw) })?;
             Ok(Self { raw })
         }
+        /// `ibu_ctx_set_option`: `"base_order"` (bit order of the 2-bit codec), `"alloc_probe_tries"` (placement probing for the
+        /// arrays of 256 MiB and more that the library allocates: `alloc`, the destination of `load_to_device`), `"blocks_per_cu"`,
+        /// the sort's A/B switches; unknown keys and out-of-range values are `InvalidArg`.
+        pub fn set_option(&self, key: &str, value: i64) -> Result<()> {
+            let k = CString::new(key).unwrap();
+            check(unsafe { ffi::ibu_ctx_set_option(self.raw, k.as_ptr(), value) })
+        }
+        /// Device memory from the library (placement-probed under option `"alloc_probe_tries"` from 256 MiB on).
         pub fn alloc(&self, bytes: usize) -> Result<DeviceBuf<'_>> {
             let mut p = std::ptr::null_mut();
             check(unsafe { ffi::ibu_device_alloc(self.raw, bytes, &mut p) })?;
@@ -511,7 +519,9 @@ pub mod device {
         }
         /// The same order over several shards, one per context (= per GPU), in one call (`ibu_sort_records_contexts`): shard i
         /// ends up with the i-th range of the global order; returns the new record counts.  `shards[i]` = (records, tmp, n,
-        /// capacity in records) on `ctxs[i]`'s device.
+        /// capacity in records) on `ctxs[i]`'s device.  Leave headroom in `capacity` (the owners' shares differ by a percent or
+        /// two); a shard that would overflow fails the call with every shard still holding its own records.  Experimental: never
+        /// run on two distinct GPUs.
         pub fn sort_records_contexts(ctxs: &[&Context], shards: &[(&DeviceBuf, &DeviceBuf, usize, usize)]) -> Result<Vec<usize>> {
             assert_eq!(ctxs.len(), shards.len());
             let raw: Vec<*mut ffi::ibu_ctx_t> = ctxs.iter().map(|c| c.raw).collect();

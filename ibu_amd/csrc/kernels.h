@@ -90,7 +90,9 @@ hipError_t launch_expand(const LaunchCfg&, const CompactPlan& pl, const void* el
 hipError_t launch_estimate_prefix(const LaunchCfg&, const void* recs, size_t n, size_t n_scale, void* tmp, const CompactPlan& pl,
                                   uint32_t* prefix_passes, hipStream_t st);
 hipError_t launch_partition_elems(const LaunchCfg&, const CompactPlan& pl, const void* recs, void* elems, size_t n, const void* d_split,
-                                  uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st);
+                                  uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
+                                  const uint64_t** d_census /*nullable: the exact census words of these records, accumulated on the way*/, hipStream_t st);
+hipError_t launch_records_census_sample(const LaunchCfg&, const void* recs, size_t n, uint64_t* d_census /*u64[8 x 64]*/, bool* exact, hipStream_t st);
 bool sort_elems_supported(const LaunchCfg&, const void* recs, const void* tmp, size_t capacity);
 hipError_t launch_sort_elems(const LaunchCfg&, const CompactPlan& pl, void* recs, void* tmp, size_t n, uint32_t prefix_passes, void* scratch,
                              size_t scratch_bytes, hipStream_t st);

@@ -122,7 +122,11 @@ int32_t plan_landing(const ibu_sort_shard_t* shards, size_t W, const std::vector
 // ---- PARTITION FIRST -------------------------------------------------------------------------------------------------------
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, const CompactPlan& plan, size_t total) {
+// `guessed`: the plan comes from SAMPLE censuses (three ranges of every shard); the partition pass then accumulates the exact census of
+// every record on the way, and *covered says afterwards whether the guess was the truth — the same bytes vary.  If it was not
+// (false), nothing has been exchanged and no record touched: the caller runs the call again with the exact plan it now has.
+int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, const CompactPlan& plan, size_t total, bool guessed,
+                             std::vector<std::array<uint64_t, 8>>* exact_words, bool* covered) {
   const bool trace = getenv("IBU_TRACE_SORT") != nullptr;
   double t_mark = now_ms(), t_phase[5] = {0, 0, 0, 0, 0};
   auto lap = [&](int k) { const double t = now_ms(); t_phase[k] = t - t_mark; t_mark = t; };
@@ -161,16 +165,30 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     if (i == big) IBU_HIP(launch_estimate_prefix(c->cfg, shards[i].d_records, n, total, t, plan, &prefix_passes, st));   // (scratch: the head of d_tmp)
     IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
     IBU_HIP(launch_compact(c->cfg, plan, d_split_recs, F - 1, d_split_elems, st));
-    const uint64_t* d_starts = nullptr;
+    const uint64_t *d_starts = nullptr, *d_words = nullptr;
     IBU_HIP(launch_partition_elems(c->cfg, plan, shards[i].d_records, t, n, d_split_elems, (uint32_t)(F - 1), t + 12 * shards[i].capacity, c->d_sort_scratch, need,
-                                   &d_starts, st));
+                                   &d_starts, guessed ? &d_words : nullptr, st));
     IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
+    if (guessed) IBU_HIP(hipMemcpyAsync((*exact_words)[i].data(), d_words, 64, hipMemcpyDeviceToHost, st));
     IBU_HIP(hipStreamSynchronize(st));
     fine[i][F] = n;
     return IBU_OK;
   });
   if (rc) return rc;
   lap(1);
+  if (guessed) {                                              // was the guess the truth?  (a byte that varies in a sample varies; the other way round is the question)
+    uint64_t o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
+    for (size_t i = 0; i < W; ++i)
+      if (shards[i].n)
+        for (int f = 0; f < 3; ++f) { o[f] |= (*exact_words)[i][f]; a[f] &= (*exact_words)[i][3 + f]; }
+    CompactPlan exact;
+    compact_plan_init(o, a, &exact);
+    *covered = exact.k == plan.k && memcmp(exact.csel, plan.csel, sizeof exact.csel) == 0 && memcmp(exact.base, plan.base, sizeof exact.base) == 0;
+    if (!*covered) {
+      if (trace) fprintf(stderr, "ibu sort: contexts=%zu the sampled plan missed a varying byte: again with the exact census\n", W);
+      return IBU_OK;
+    }
+  }
   // which ranges an owner gets: consecutive ones, up to the point nearest to its share of the records (and not past its capacity
   // while an earlier cut avoids that; the last owner takes what is left)
   std::vector<uint64_t> g(F, 0);
@@ -336,21 +354,63 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
     return r ? r : ibu_ctx_synchronize(ctxs[0], nullptr);
   }
   try {
-    // one plan for everybody: the census words of every shard combined
+    // one plan for everybody: the census words of every shard combined.  First from SAMPLES (three ranges of every shard: microseconds):
+    // if that plan qualifies for the partition-first form, the partition pass takes the exact census on its way (24 B/record less to
+    // read than a census pass of its own) and the guess is checked afterwards; a miss costs the partition pass it wasted.
     CompactPlan plan;
     memset(&plan, 0, sizeof plan);
     bool have_plan = false;
-    if (ctxs[0]->cfg.sort_compact != 0) {
-      std::vector<std::array<uint64_t, 8>> words(W);
-      int32_t rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
-      if (rc) return rc;
+    std::vector<std::array<uint64_t, 8>> words(W);
+    auto combine = [&](CompactPlan* out) {
       uint64_t o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
-      for (auto& w : words)
-        for (int f = 0; f < 3; ++f) { o[f] |= w[f]; a[f] &= w[3 + f]; }
-      compact_plan_init(o, a, &plan);
-      have_plan = true;
+      for (size_t i = 0; i < W; ++i)
+        if (shards[i].n)
+          for (int f = 0; f < 3; ++f) { o[f] |= words[i][f]; a[f] &= words[i][3 + f]; }
+      compact_plan_init(o, a, out);
+    };
+    if (ctxs[0]->cfg.sort_compact != 0 && total > 0) {
+      bool all_exact = true;
+      std::vector<char> was_exact(W, 1);
+      int32_t rc = IBU_OK;
+      if (aligned && W <= 256) {
+        rc = on_every_context(W, [&](size_t i) -> int32_t {
+          ibu_ctx_t* c = ctxs[i];
+          if (!shards[i].n) return IBU_OK;
+          IBU_HIP(hipSetDevice(c->device));
+          int32_t r = ensure_sort_scratch(c, 4096);
+          if (r) return r;
+          bool ex = true;
+          uint64_t* d_c = static_cast<uint64_t*>(c->d_sort_scratch);
+          IBU_HIP(launch_records_census_sample(c->cfg, shards[i].d_records, shards[i].n, d_c, &ex, c->stream));
+          IBU_HIP(hipMemcpyAsync(words[i].data(), d_c, 64, hipMemcpyDeviceToHost, c->stream));
+          IBU_HIP(hipStreamSynchronize(c->stream));
+          was_exact[i] = ex ? 1 : 0;
+          return IBU_OK;
+        });
+        if (rc) return rc;
+        for (size_t i = 0; i < W; ++i) all_exact = all_exact && was_exact[i];
+        combine(&plan);
+        if (plan.k <= 11) {
+          bool covered = true;
+          rc = sort_partition_first(ctxs, W, shards, plan, total, !all_exact, &words, &covered);
+          if (rc || covered) return rc;
+          combine(&plan);                                       // `words` now holds every shard's exact census
+          have_plan = true;
+        }
+      }
+      if (!have_plan) {
+        rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
+        if (rc) return rc;
+        for (size_t i = 0; i < W; ++i)
+          if (!shards[i].n) words[i] = {0, 0, 0, ~0ull, ~0ull, ~0ull, 0, 0};
+        combine(&plan);
+        have_plan = true;
+      }
     }
-    if (have_plan && plan.k <= 11 && W <= 256 && aligned && total > 0) return sort_partition_first(ctxs, W, shards, plan, total);
+    if (have_plan && plan.k <= 11 && W <= 256 && aligned && total > 0) {
+      bool covered = true;
+      return sort_partition_first(ctxs, W, shards, plan, total, false, &words, &covered);
+    }
     return sort_sort_first(ctxs, W, shards, plan, have_plan);
   } catch (...) {
     return caught_io("ibu_sort_records_contexts");

@@ -274,6 +274,19 @@ hipError_t launch_records_census(const LaunchCfg& cfg, const void* recs, size_t 
   hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, (u64*)d_census);
   return hipGetLastError();
 }
+// The census of three SAMPLE ranges (first / middle / last 32 Ki records) — what the sort's speculation guesses its plan from; inputs
+// too small for three ranges get the exact census.  `exact` says which it was.
+static constexpr size_t kCensusSample = 32768;
+hipError_t launch_records_census_sample(const LaunchCfg& cfg, const void* recs, size_t n, uint64_t* d_census, bool* exact, hipStream_t st) {
+  (void)hipGetLastError();
+  *exact = n < 4 * kCensusSample || (reinterpret_cast<uintptr_t>(recs) & 15u) != 0;
+  if (*exact) return launch_records_census(cfg, recs, n, d_census, st);
+  hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, (u64*)d_census);
+  const size_t starts[3] = {0, (n / 2) & ~(size_t)1, (n - kCensusSample) & ~(size_t)1};   // even rows: 16-byte aligned
+  for (size_t s0 : starts) launch_census(cfg, static_cast<const u64*>(recs) + 3 * s0, kCensusSample, (u64*)d_census, nullptr, st);
+  hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, (u64*)d_census);
+  return hipGetLastError();
+}
 // records -> elements of W words (pl.k <= 4 W).  Records that start at an odd record of a larger array (8- but not 16-byte
 // aligned) are PEELED like everywhere else (kcommon.hpp): one record through the per-record kernel brings the rest to a
 // 16-byte boundary for the tiled kernel (the elements need no more than their 4-byte alignment).
@@ -556,8 +569,9 @@ ibu_k_sort_stamp_bucket(ElemT<3>* __restrict__ elems, u64 n, const ElemT<3>* __r
 }
 // records -> stamped elements + the digit stream of the ranges: the tiled rows in ONE kernel (ibu_k_sort_compress<.., STAMP>), the
 // peeled head row and the rest rows (fewer than 129 in all) through the tail compress kernel and the stamp kernel above.
+// census (nullable; 16-byte aligned records only): the exact census words are accumulated on the way, as in the sort's speculative path.
 static void launch_compress_stamped(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, size_t n, ElemT<3>* out, uint8_t* digits,
-                                    const ElemT<3>* split, u32 nsplit, hipStream_t st) {
+                                    const ElemT<3>* split, u32 nsplit, hipStream_t st, u64* census = nullptr) {
   const size_t head = (reinterpret_cast<uintptr_t>(recs) & 15u) ? (n ? 1 : 0) : 0;
   const size_t main_rows = ((n - head) / kTileRecs) * kTileRecs;
   if (head) {
@@ -565,16 +579,22 @@ static void launch_compress_stamped(const LaunchCfg& cfg, const CompactPlan& pl,
     hipLaunchKernelGGL(ibu_k_sort_stamp_bucket, dim3(1), dim3(256), 0, st, out, (u64)head, split, nsplit, digits);
   }
   if (main_rows) {
-    static std::atomic<int> occ;
+    static std::atomic<int> occ[2];
     const u32 nt = (u32)(main_rows / kTileRecs);
-    hipLaunchKernelGGL((ibu_k_sort_compress<false, 3, true>), dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<false, 3, true>, 0, &occ))),
-                       dim3(kBlock), 0, st, static_cast<const uint8_t*>(recs) + 24 * head, nt, pl, 0u, out + head, digits + head, (u64*)nullptr, split, nsplit);
+    if (census)
+      hipLaunchKernelGGL((ibu_k_sort_compress<true, 3, true>), dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<true, 3, true>, 0, &occ[1]))),
+                         dim3(kBlock), 0, st, static_cast<const uint8_t*>(recs) + 24 * head, nt, pl, 0u, out + head, digits + head, census, split, nsplit);
+    else
+      hipLaunchKernelGGL((ibu_k_sort_compress<false, 3, true>), dim3(grid_for(nt, cfg.cus, resident_blocks<kBlock>(cfg, ibu_k_sort_compress<false, 3, true>, 0, &occ[0]))),
+                         dim3(kBlock), 0, st, static_cast<const uint8_t*>(recs) + 24 * head, nt, pl, 0u, out + head, digits + head, (u64*)nullptr, split, nsplit);
   }
   const size_t done = head + main_rows;
   if (done < n) {
     hipLaunchKernelGGL(ibu_k_sort_compress_tail<3>, dim3(tail_grid(n - done)), dim3(256), 0, st, (const u64*)recs, (u64)done, (u64)n, pl, 0u, out,
                        (uint8_t*)nullptr);
     hipLaunchKernelGGL(ibu_k_sort_stamp_bucket, dim3(1), dim3(256), 0, st, out + done, (u64)(n - done), split, nsplit, digits + done);
+    if (census)   // the rest rows of the census (each row also against its predecessor)
+      hipLaunchKernelGGL(ibu_k_sort_census_tail, dim3(tail_grid(n - done)), dim3(256), 0, st, (const u64*)recs, (u64)done, (u64)n, census, (u32*)nullptr);
   }
 }
 static const CompactVariant* elems_variant(const LaunchCfg& cfg, size_t n, size_t scratch_bytes) {
@@ -596,9 +616,11 @@ hipError_t launch_estimate_prefix(const LaunchCfg& cfg, const void* recs, size_t
   return e;
 }
 hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, void* elems, size_t n, const void* d_split,
-                                  uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st) {
+                                  uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
+                                  const uint64_t** d_census, hipStream_t st) {
   (void)hipGetLastError();
   if (n == 0 || nsplit > 255 || pl.k > 11) return hipErrorInvalidValue;
+  if (d_census && (reinterpret_cast<uintptr_t>(recs) & 15u)) return hipErrorInvalidValue;
   const CompactVariant* cv = elems_variant(cfg, n, scratch_bytes);
   if (!cv) return hipErrorInvalidValue;
   uint8_t* sc = static_cast<uint8_t*>(scratch);
@@ -616,7 +638,13 @@ hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, c
     if (e != hipSuccess) return e;
   }
   const u32 cap = (u32)cfg.cus * 8;
-  launch_compress_stamped(cfg, pl, recs, n, static_cast<ElemT<3>*>(elems), digits, static_cast<const ElemT<3>*>(d_split), nsplit, st);
+  u64* census = d_census ? reinterpret_cast<u64*>(sc) : nullptr;   // the census slots sit at the head of the scratch (SortLayout)
+  if (census) hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
+  launch_compress_stamped(cfg, pl, recs, n, static_cast<ElemT<3>*>(elems), digits, static_cast<const ElemT<3>*>(d_split), nsplit, st, census);
+  if (census) {
+    hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, census);
+    *d_census = reinterpret_cast<const uint64_t*>(census);    // u64[8]: OR x 3, AND x 3, index drops, order drops — of exactly these n records
+  }
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   hipLaunchKernelGGL(cv->counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n, L.ntiles,
                      counts);

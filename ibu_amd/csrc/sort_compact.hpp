@@ -87,12 +87,12 @@ __device__ __forceinline__ u32 range_of(const u32* sp, u32 nsplit, const EV<3>& 
 }
 // STAMP (W = 3, at most 11 varying bytes): every element also gets its key range among the `nsplit` splitter elements at `split`
 // in its free top byte, and the digit stream holds the ranges — the compress and the stamp step of the multi-GPU sort in one read
-// of the records.
+// of the records (with CENSUS: and the exact census of a plan that was guessed from samples).
 template <bool CENSUS, int W, bool STAMP = false>
 __global__ void __launch_bounds__(kBlock, CENSUS ? (W == 4 ? 5 : 7) : (STAMP ? 7 : 8))   // the launcher keeps at most 7 workgroups per CU resident (LaunchCfg); 16-byte elements with the census need 84 VGPRs
 ibu_k_sort_compress(const uint8_t* __restrict__ recs, u32 ntiles, CompactPlan pl, u32 first_byte, ElemT<W>* __restrict__ out,
                     uint8_t* __restrict__ digits, u64* __restrict__ census, const ElemT<3>* __restrict__ split = nullptr, u32 nsplit = 0) {
-  static_assert(!STAMP || (W == 3 && !CENSUS), "ranges are stamped into 12-byte elements");
+  static_assert(!STAMP || W == 3, "ranges are stamped into 12-byte elements");
   constexpr int kSlice = CENSUS ? kSliceBytes : kTileBytes;  // with the census: the record in front of the tile is staged too (ibu_k_sort_census)
   constexpr int kLead = CENSUS ? kPrevBytes : 0;
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kSlice];

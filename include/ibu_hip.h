@@ -382,8 +382,8 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * its size (about 512 per shard in all), pick n_ctxs - 1 splitters; every record travels once to the owner of its range
  * (hipMemcpyPeerAsync: over xGMI between GPUs).  Two forms (multi_sort.cpp):
  *   partition first — at most 11 key bytes vary over ALL shards (16/12 records with indices below 2^32), at most 256 shards,
- *     16-byte aligned buffers: a shard is compacted to 12-byte elements (ibu_records_compact with one plan from the combined
- *     census words), the elements are put in owner order by one pass of the sort's own kernels, the owners pull their pieces
+ *     16-byte aligned buffers: a shard is compacted to 12-byte elements (one plan for all shards from the combined census words —
+ *     of sample ranges when the shards are large, checked against the exact census the partition pass takes on its way), the elements are put in owner order by one pass of the sort's own kernels, the owners pull their pieces
  *     (12 bytes per record on the links) and sort them straight into records.  Nothing is sorted twice;
  *   sort first — everything else (option "sort_compact" = 0 on ctxs[0] forces it): every shard sorted where it lives, cut at
  *     the splitters by binary search, 24-byte records exchanged (12-byte elements when exactly 12 bytes vary), owners sort again.

@@ -1032,6 +1032,42 @@ def test_sort_records_contexts_with_sixteen_shards_and_with_equal_records(ia, or
             c.close()
 
 
+@pytest.mark.parametrize("miss", [False, True])
+def test_sort_records_contexts_on_a_sampled_plan(ia, oracle, capfd, miss):
+    """Shards of 2^17 records and more: the plan (which key bytes vary) is guessed from three sample ranges of every shard and the
+    partition pass takes the exact census on its way.  miss: a UMI byte that is constant in every sample range and varies in between —
+    the call notices, says so, and runs again on the exact plan; either way the result is the oracle's order."""
+    counts = [200_003, 150_001, 262_144]
+    total = sum(counts)
+    recs = oracle.generate(SEED + 31, 0, total, 16, 10)         # 10-base UMIs: their fourth key byte is constant (zero)
+    rng = np.random.default_rng(77)
+    rng.shuffle(recs)
+    recs["index"] = rng.integers(0, 2**24, total, dtype=np.uint64)
+    if miss:                                                   # rows 40 000 .. 60 000 of shard 0 lie in none of its sample ranges
+        recs["umi"][40_000:60_000] |= rng.integers(1, 256, 20_000, dtype=np.uint64) << np.uint64(24)
+    want = oracle.sort_records(recs).tobytes()
+    cap = total
+    ctxs = [ia.Context(0) for _ in counts]
+    try:
+        shards, at = [], 0
+        for c, n in zip(ctxs, counts):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            d.upload(recs[at:at + n])
+            shards.append((d, t, n, cap))
+            at += n
+        capfd.readouterr()
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        trace = capfd.readouterr().err
+        assert sum(out) == total
+        assert b"".join(shards[k][0].download(count=24 * out[k]).tobytes() for k in range(3)) == want
+        if trace:
+            assert ("the sampled plan missed a varying byte" in trace) == miss, trace
+            assert "partition first" in trace
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("IBU_FUZZ_SEEDS_MC", "12"))))
 def test_sort_records_contexts_fuzz(ia, oracle, seed):
     """Seeded fuzz of the multi-context sort: 2 .. 6 shards of uneven sizes (empty ones included), keys that compact or do not,

@@ -25,7 +25,9 @@ step "bench under rocprofv3 --kernel-trace --stats"
 # so the decode launches of the profiled process are the first-placement probe (2), the kept arrays' probe (2), warm-up and the timed
 # steps — their rocprofv3 average agrees with the HIP-event time of the timed steps to 0.1 %.  With --placement-tries 1 the profiled
 # process would time whatever first placement it drew: 10.17 ms twice in round 3 against 9.36 for the probed headline.)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline \
+# (--no-e2e-leg: that leg launches the same decode / encode instantiations on ring slots and on a 1e8-record copy; in the stats file their
+# short launches would be averaged with the headline's — 89 decode launches of 1.9 ms on average instead of 17 of 9.45, r04_fin's first run)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline --no-e2e-leg \
   > "$OUT/${TAG}_bench_1e9_under_rocprof.json" 2> "$OUT/prof_bench.err" || exit 1
 cp "$(largest "$OUT/prof_bench" '*kernel_stats.csv')" "$OUT/${TAG}_bench_1e9_kernel_stats.csv"
 

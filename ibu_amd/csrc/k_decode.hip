@@ -126,9 +126,12 @@ ibu_k_decode(const uint8_t* __restrict__ recs, u32 ntiles, u32 bc_len, u32 umi_l
 #ifndef IBU_UNPACK_GEN_NT
 #define IBU_UNPACK_GEN_NT 2
 #endif
-constexpr int unpack_nt(int len) { return len == 0 ? IBU_UNPACK_GEN_NT : 2; }   // (four tiles spill under the 64-VGPR budget of eight waves per SIMD)
+// Round 4: four tiles at six waves per SIMD for rows of at most 16 bases (+1 % on 1e9 codes, profiles/r04_t; 32-base rows would spill
+// there and keep two tiles at eight waves).
+constexpr int unpack_nt(int len) { return len == 0 ? IBU_UNPACK_GEN_NT : len <= 16 ? 4 : 2; }
+constexpr int unpack_waves(int len) { return len == 0 ? 6 : len <= 16 ? 6 : 8; }
 template <int LEN, bool MSB>
-__global__ void __launch_bounds__(kBlock, LEN == 0 ? 6 : dword_len(LEN) ? 8 : 3)
+__global__ void __launch_bounds__(kBlock, unpack_waves(LEN))
 ibu_k_unpack(const u64* __restrict__ codes, u32 ntiles /*of NT x 128 codes*/, u32 len, uint8_t* __restrict__ out) {
   constexpr int NT = unpack_nt(LEN);
   constexpr int kWaveLds = 1024 * NT + (LEN == 0 ? (int)stream_bytes(NT) : 0);   // a runtime length goes through the code stream

@@ -157,49 +157,56 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   bad.flush(status);
 }
 
-// Single ASCII column -> u64 codes.
+// Single ASCII column -> u64 codes.  NT 128-row tiles per wave iteration: two for the specialised rows of at most 16 bases, at six
+// waves per SIMD instead of eight (round 3 measured two tiles at eight waves: they spilled) — same arrays, one process, 1e9 rows
+// (profiles/r04_t_kbench_pack_unpack.jsonl): pack<16> 5.17 -> 5.37 TB/s, pack<12> 5.15 -> 5.29, pack<8> 5.24 -> 5.32.
+constexpr int pack_nt(int len) { return (len > 0 && len <= 16) ? 2 : 1; }
 template <int LEN, bool MSB>
-__global__ void __launch_bounds__(kBlock, (LEN <= 16 && (LEN & 3) == 0) ? 8 : 4)
-ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles, u32 len, u64* __restrict__ codes,
+__global__ void __launch_bounds__(kBlock, LEN == 0 ? 8 : LEN <= 16 ? 6 : 4)
+ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles /*of NT x 128 rows*/, u32 len, u64* __restrict__ codes,
            u64* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kTileRecs * 32];
+  constexpr int NT = pack_nt(LEN), kRows = kTileRecs * NT;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kRows * 32];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* asc = lds + wib * kTileRecs * 32;
+  uint8_t* asc = lds + wib * kRows * 32;
   const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
   const u32 nwaves = tr.stride;
   u32 t = tr.t;
   ntiles = tr.end;
   if (LEN > 0) len = LEN;
   if (t >= ntiles) return;
-  AsciiStage<LEN> sv;
-  sv.issue(in + (size_t)t * kTileRecs * len, len, lane);
+  AsciiStage<LEN, NT> sv;
+  sv.issue(in + (size_t)t * kRows * len, len, lane);
   BadRows bad;
   for (;;) {
-    const size_t row0 = (size_t)t * kTileRecs;
+    const size_t row0 = (size_t)t * kRows;
     wave_lds_fence();
     const bool chunks_ok = sv.land(asc, len, lane);
     const u32 tn = t + nwaves;
     const bool more = tn < ntiles;
-    sv.issue(in + (size_t)(more ? tn : t) * kTileRecs * len, len, lane);  // unconditional, see kcommon.hpp
+    sv.issue(in + (size_t)(more ? tn : t) * kRows * len, len, lane);  // unconditional, see kcommon.hpp
     wave_lds_fence();
-    bool ok0 = true, ok1 = true;
-    u64 v0 = pack_row<LEN>(asc, 2 * lane, len, ok0);
-    u64 v1 = pack_row<LEN>(asc, 2 * lane + 1, len, ok1);
-    if constexpr (LEN == 0) {                      // a tile with an offending byte: its rows again, byte by byte (see ibu_k_encode)
-      if (__ballot(!chunks_ok) != 0) {
-        const size_t r0 = row0 + 2 * lane;
-        v0 = pack_row_bytes(in + r0 * len, len, ok0);
-        v1 = pack_row_bytes(in + (r0 + 1) * len, len, ok1);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const u32 r = 128 * j + 2 * lane;
+      bool ok0 = true, ok1 = true;
+      u64 v0 = pack_row<LEN>(asc, r, len, ok0);
+      u64 v1 = pack_row<LEN>(asc, r + 1, len, ok1);
+      if constexpr (LEN == 0) {                    // a tile with an offending byte: its rows again, byte by byte (see ibu_k_encode)
+        if (__ballot(!chunks_ok) != 0) {
+          v0 = pack_row_bytes(in + (row0 + r) * len, len, ok0);
+          v1 = pack_row_bytes(in + (row0 + r + 1) * len, len, ok1);
+        }
       }
+      if constexpr (MSB) { v0 = rev_pairs(v0, len); v1 = rev_pairs(v1, len); }
+      if (!ok0) v0 = 0;
+      if (!ok1) v1 = 0;
+      bad.note(!ok0, row_base + row0 + r);
+      bad.note(!ok1, row_base + row0 + r + 1);
+      u32x4 o; o.x = (u32)v0; o.y = (u32)(v0 >> 32); o.z = (u32)v1; o.w = (u32)(v1 >> 32);
+      st16(reinterpret_cast<uint8_t*>(codes) + (row0 + 128 * j) * 8 + 16 * lane, o);
     }
-    if constexpr (MSB) { v0 = rev_pairs(v0, len); v1 = rev_pairs(v1, len); }
-    if (!ok0) v0 = 0;
-    if (!ok1) v1 = 0;
-    bad.note(!ok0, row_base + row0 + 2 * lane);
-    bad.note(!ok1, row_base + row0 + 2 * lane + 1);
-    u32x4 o; o.x = (u32)v0; o.y = (u32)(v0 >> 32); o.z = (u32)v1; o.w = (u32)(v1 >> 32);
-    st16(reinterpret_cast<uint8_t*>(codes) + row0 * 8 + 16 * lane, o);
     if (!more) break;
     t = tn;
   }
@@ -287,12 +294,13 @@ hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[2] = {{in, len}, {codes, 8}};
-  const RowSplit rs = split_rows(cfg, sp, 2, n, kTileRecs);
+  const size_t tile_rows = (size_t)kTileRecs * pack_nt(len_of_mode(mode_of_len(len)));
+  const RowSplit rs = split_rows(cfg, sp, 2, n, tile_rows);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_pack_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, in, (u64)0, (u64)rs.head, len, cfg.base_order,
                        (u64*)codes, (u64*)status);
   if (rs.main) {
-    const u32 ntiles = (u32)(rs.main / kTileRecs);
+    const u32 ntiles = (u32)(rs.main / tile_rows);
     const int m = mode_of_len(len), mo = cfg.base_order ? 1 : 0;
     static std::atomic<int> occ[2][kNumLenModes];
     hipLaunchKernelGGL(kPackTable[mo][m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kPackTable[mo][m], 0, &occ[mo][m]))),

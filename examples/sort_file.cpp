@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
   try {
     if (nctx > 1) return sort_over_contexts(argv[1], argv[2], nctx);
     ibu::device::Context ctx(0);
+    ctx.set_option("alloc_probe_tries", 4);                     // resident arrays of 256 MiB and more choose their placement (ibu_hip.h)
     const double t0 = now();
     auto [h, d_recs, n] = ctx.load_to_device(argv[1]);          // load_to_vec, device form
     const double t1 = now();

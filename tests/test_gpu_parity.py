@@ -1,6 +1,8 @@
 """GPU parity tests: every HIP kernel, called through the C ABI (ibu_amd -> libibu_hip.so),
 bit-exact against the CPU oracle on the same seeded inputs.  Integer / byte work: the bar is
 equality of every byte, no tolerance.  Run on the MI355X box with `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -233,6 +235,70 @@ def test_shard_starting_at_record_k_is_peeled(ia, ctx, oracle, k, lens):
     ctx.codec_status()
     mask = np.uint64((1 << (2 * bc_len)) - 1) if bc_len < 32 else np.uint64(2**64 - 1)
     assert (c1.download(np.uint64, count=n, offset=8 * k) == (cols[:, 0] & mask)).all()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IBU_FUZZ_SEEDS_CODEC", "40"))))
+def test_codec_fuzz(ia, ctx, ctx_msb, oracle, seed):
+    """Seeded fuzz of the fused codec and the single-column codec: any (bc_len, umi_len) in {1..32}^2, any n up to ~70 000, a shard
+    that starts at record k of a larger buffer (peeled rows), either bit order, full-range field values (bits above 2 len
+    ignored), a NULL output column now and then, and in a third of the cases a few offending bytes anywhere — every output
+    byte, the first bad row and the count equal the oracle's."""
+    rng = np.random.default_rng(9000 + seed)
+    order = int(rng.integers(0, 2))
+    c = ctx_msb if order else ctx
+    bc_len, umi_len = int(rng.integers(1, 33)), int(rng.integers(1, 33))
+    n = int(rng.choice([1, 63, 128, 129, 300, 5000, 33_333, 70_001]))
+    k = int(rng.choice([0, 0, 1, 2, 3, 7]))
+    recs = oracle.generate(SEED + seed, 0, n + k, 32, 32)      # full-range u64 fields
+    shard = recs[k:]
+    d_all = _up(c, recs)
+    want_bc, want_umi, want_idx = oracle.decode_records(shard, bc_len, umi_len, order)
+    d_bc, d_umi, d_idx = c.alloc((n + k) * bc_len), c.alloc((n + k) * umi_len), c.alloc((n + k) * 8)
+    pb, pu, pi = d_bc.ptr + k * bc_len, d_umi.ptr + k * umi_len, d_idx.ptr + 8 * k
+    skip = int(rng.integers(0, 6))                             # 1: no barcode column, 2: no UMI column
+    c.decode_ascii(d_all.ptr + 24 * k, n, bc_len, umi_len, None if skip == 1 else pb, None if skip == 2 else pu, pi)
+    if skip != 1:
+        assert d_bc.download(count=n * bc_len, offset=k * bc_len).tobytes() == want_bc.tobytes(), (seed, bc_len, umi_len, n, k, order)
+    if skip != 2:
+        assert d_umi.download(count=n * umi_len, offset=k * umi_len).tobytes() == want_umi.tobytes(), (seed, bc_len, umi_len, n, k, order)
+    assert d_idx.download(np.uint64, count=n, offset=8 * k).tobytes() == want_idx.tobytes()
+    bc, umi = want_bc.copy().reshape(-1), want_umi.copy().reshape(-1)
+    if seed % 3 == 0:                                          # offending bytes, anywhere
+        for _ in range(int(rng.integers(1, 6))):
+            col = bc if rng.integers(0, 2) else umi
+            col[int(rng.integers(0, col.size))] = int(rng.choice([0, ord("N"), ord("n"), 0xC1, ord("U"), 255, ord("@")]))
+    if rng.integers(0, 2):
+        low = rng.integers(0, 2, bc.size).astype(bool)         # lower case packs like upper case
+        bc = np.where(low & (bc >= 65) & (bc <= 90), bc | 0x20, bc).astype(np.uint8)
+    d_bc.upload(np.concatenate([np.zeros(k * bc_len, np.uint8), bc]))
+    d_umi.upload(np.concatenate([np.zeros(k * umi_len, np.uint8), umi]))
+    d_back = c.alloc((n + k) * 24)
+    c.encode_ascii(pb, pu, pi, n, bc_len, umi_len, d_back.ptr + 24 * k)
+    want, fb, nb = oracle.encode_records(bc, umi, want_idx, n, bc_len, umi_len, order=order)
+    try:
+        c.codec_status()
+        got_bad = (None, 0)
+    except ia.IbuError as e:
+        assert e.kind == "InvalidBase"
+        got_bad = (e.first_bad, e.n_bad)
+    assert got_bad == ((fb, nb) if nb else (None, 0)), (seed, bc_len, umi_len, n, k, order)
+    assert d_back.download(count=n * 24, offset=24 * k).tobytes() == want.tobytes(), (seed, bc_len, umi_len, n, k, order)
+    # the single-column kernels on the barcode column
+    d_codes = c.alloc((n + k) * 8)
+    c.pack_2bit(pb, n, bc_len, d_codes.ptr + 8 * k)
+    wc, fb, nb = oracle.pack_column(bc, n, bc_len, order)
+    try:
+        c.codec_status()
+        got_bad = (None, 0)
+    except ia.IbuError as e:
+        got_bad = (e.first_bad, e.n_bad)
+    assert got_bad == ((fb, nb) if nb else (None, 0))
+    assert d_codes.download(np.uint64, count=n, offset=8 * k).tobytes() == wc.tobytes()
+    c.unpack_2bit(d_codes.ptr + 8 * k, n, bc_len, pb)
+    c.synchronize()
+    assert d_bc.download(count=n * bc_len, offset=k * bc_len).tobytes() == oracle.unpack_column(wc, bc_len, order).tobytes()
+    for b_ in (d_all, d_bc, d_umi, d_idx, d_back, d_codes):
+        b_.free()
 
 
 @pytest.mark.parametrize("k", [1, 3])

@@ -435,6 +435,53 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
     return out
 
 
+def sort_contexts_rehearsal(ia, n, bc_len, umi_len, seed, k=8, rounds=3):
+    """ibu_sort_records_contexts — the sort over several GPUs behind ONE call of the C ABI — REHEARSED with k contexts that all
+    sit on this one GPU (the call allows it): the k shards' kernels share the device and the exchange is a device-local copy, so
+    the time says what the call's control flow and its 3-passes-before-the-exchange cost, NOT how it scales; distinct GPUs have
+    never run (no such box in any round).  Checked: every shard sorted, the shards' boundaries in order, count / wrapping sums /
+    XORs of all shards together unchanged."""
+    import statistics
+
+    import numpy as np
+
+    ctxs = [ia.Context(0) for _ in range(k)]
+    try:
+        per, cap = n // k, int(n // k * 1.25) + k + 1
+        bufs = [(c.alloc(24 * cap), c.alloc(24 * cap)) for c in ctxs]
+        ts, outs, before = [], None, None
+        for _ in range(rounds + 1):
+            tot = {"count": 0, "sum": [0, 0, 0], "xor": [0, 0, 0]}
+            for i, (c, (d, _)) in enumerate(zip(ctxs, bufs)):  # shard i = rows [i per, (i + 1) per) of the generator's stream
+                c.generate(seed, i * per, per, bc_len, umi_len, d)
+                r = c.reduce(d, per)
+                tot = {"count": tot["count"] + r["count"], "sum": [(a + b) & (2**64 - 1) for a, b in zip(tot["sum"], r["sum"])],
+                       "xor": [a ^ b for a, b in zip(tot["xor"], r["xor"])]}
+            before = tot
+            t0 = time.perf_counter()
+            outs = ia.Context.sort_records_contexts(ctxs, [(d, t, per, cap) for d, t in bufs])
+            ts.append(time.perf_counter() - t0)
+        after = {"count": 0, "sum": [0, 0, 0], "xor": [0, 0, 0]}
+        edges = []
+        ok = sum(outs) == per * k
+        for c, (d, _), m in zip(ctxs, bufs, outs):
+            ok = ok and (m == 0 or bool(c.is_sorted(d, m)))
+            r = c.reduce(d, m)
+            after = {"count": after["count"] + r["count"], "sum": [(a + b) & (2**64 - 1) for a, b in zip(after["sum"], r["sum"])],
+                     "xor": [a ^ b for a, b in zip(after["xor"], r["xor"])]}
+            if m:
+                edges.append((tuple(int(x) for x in d.download(np.uint64, count=3)),
+                              tuple(int(x) for x in d.download(np.uint64, count=3, offset=24 * (m - 1)))))
+        ok = ok and after == before and all(edges[i][1] <= edges[i + 1][0] for i in range(len(edges) - 1))
+        sec = statistics.median(ts[1:])
+        return {"contexts_on_this_gpu": k, "records": per * k, "seconds": sec, "records_per_s": per * k / sec, "records_per_shard_after": outs,
+                "globally_sorted_and_multiset_preserved": bool(ok),
+                "note": "a rehearsal on ONE GPU (shared by the contexts; the exchange is a device-local copy): not a scaling measurement"}
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 class Leg:
     """One resident workload: this rank's shard [first, first + n) of the synthetic stream, its output columns and the
     re-encoded records.  step() = K2 decode followed by K3 encode."""
@@ -669,6 +716,13 @@ def main():
             sort_leg = sort_and_aggregate(ctx, n, bc_len, umi_len, args.seed, torch=torch, dev=dev)
         except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
             sort_leg = {"error": f"{type(e).__name__}: {e}"}
+        try:                 # the multi-GPU form of the sort (one call of the C ABI), rehearsed with 8 contexts on this GPU
+            torch.cuda.empty_cache()
+            sort_leg["contexts_rehearsal"] = sort_contexts_rehearsal(ibu_amd, n, bc_len, umi_len, args.seed)
+            if not sort_leg["contexts_rehearsal"]["globally_sorted_and_multiset_preserved"]:
+                raise SystemExit("ibu_sort_records_contexts: the shards do not form one sorted sequence of the input's records")
+        except Exception as e:
+            sort_leg["contexts_rehearsal"] = {"error": f"{type(e).__name__}: {e}"}
 
     e2e = None
     if world == 1 and not args.no_e2e_leg:

@@ -83,6 +83,21 @@ def test_bench_one_gpu_line_carries_the_e2e_leg(tmp_path):
     assert not list(tmp_path.iterdir())                       # the leg removes its files
 
 
+def test_bench_sort_leg_carries_the_multi_context_rehearsal():
+    """The sort leg of the driver's N = 1 line: the three single-GPU sorts, the per-barcode aggregation and the multi-GPU form of
+    the sort rehearsed with 8 contexts on this GPU, each checked inside bench.py."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--records", "3000001", "--no-cpu-baseline", "--no-wide-leg",
+                        "--no-e2e-leg", "--placement-tries", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    sl = out["sort_leg"]
+    assert "error" not in sl and sl["read_order"]["sorted_and_multiset_preserved"] and sl["barcode_counts"]["counts_add_up"], sl
+    cr = sl["contexts_rehearsal"]
+    assert "error" not in cr and cr["contexts_on_this_gpu"] == 8 and cr["globally_sorted_and_multiset_preserved"] is True, cr
+    assert sum(cr["records_per_shard_after"]) == cr["records"] == 3_000_000
+
+
 @pytest.mark.parametrize("proc", ["reduce", "decode"])
 def test_sharded_file_two_ranks(tmp_path, proc, oracle):
     n = 3_000_001

@@ -157,12 +157,12 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
   bad.flush(status);
 }
 
-// Single ASCII column -> u64 codes.  NT 128-row tiles per wave iteration: two for the specialised rows of at most 16 bases, at six
-// waves per SIMD instead of eight (round 3 measured two tiles at eight waves: they spilled) — same arrays, one process, 1e9 rows
+// Single ASCII column -> u64 codes.  NT 128-row tiles per wave iteration: two for the specialised rows of at most 16 bases, at five
+// or four waves per SIMD instead of eight (round 3 measured two tiles at eight waves: they spilled) — same arrays, one process, 1e9 rows
 // (profiles/r04_t_kbench_pack_unpack.jsonl): pack<16> 5.17 -> 5.37 TB/s, pack<12> 5.15 -> 5.29, pack<8> 5.24 -> 5.32.
 constexpr int pack_nt(int len) { return (len > 0 && len <= 16) ? 2 : 1; }
 template <int LEN, bool MSB>
-__global__ void __launch_bounds__(kBlock, LEN == 0 ? 8 : LEN <= 16 ? 6 : 4)
+__global__ void __launch_bounds__(kBlock, LEN == 0 ? 8 : LEN <= 12 ? 5 : 4)   // (what two tiles of rows leave: 69-80 / 108 VGPRs)
 ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles /*of NT x 128 rows*/, u32 len, u64* __restrict__ codes,
            u64* __restrict__ status) {
   constexpr int NT = pack_nt(LEN), kRows = kTileRecs * NT;

@@ -93,6 +93,8 @@ hipError_t launch_partition_elems(const LaunchCfg&, const CompactPlan& pl, const
                                   uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
                                   const uint64_t** d_census /*nullable: the exact census words of these records, accumulated on the way*/, hipStream_t st);
 hipError_t launch_records_census_sample(const LaunchCfg&, const void* recs, size_t n, uint64_t* d_census /*u64[8 x 64]*/, bool* exact, hipStream_t st);
+hipError_t launch_partition_records(const LaunchCfg&, const void* recs, size_t n, const void* d_split /*24-byte records*/, uint32_t nsplit, void* out,
+                                    void* scratch, size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st);   // the same on 24-byte records (any key)
 bool sort_elems_supported(const LaunchCfg&, const void* recs, const void* tmp, size_t capacity);
 hipError_t launch_sort_elems(const LaunchCfg&, const CompactPlan& pl, void* recs, void* tmp, size_t n, uint32_t prefix_passes, void* scratch,
                              size_t scratch_bytes, hipStream_t st);

@@ -6,16 +6,20 @@
 // one), and shard i ends up with the i-th contiguous range of the global order.  A host thread per context, like
 // process_contexts (stream.cpp); the phases are separated by joins, which is all the cross-device ordering there is.
 //
-// Two forms.  PARTITION FIRST (round 4; keys of which at most 11 bytes vary over ALL shards — 16/12 records with indices below
-// 2^32 —, up to 256 shards): nothing is sorted before the exchange.  A shard is compacted to 12-byte elements (one plan for all
-// shards from the combined census words), every element gets the number of its key RANGE (256 of them, cut by sampled splitters)
-// in its free top byte, one ordinary element pass on that byte puts the elements in range order (sort.hip:
+// Three forms.  PARTITION FIRST ON ELEMENTS (round 4; keys of which at most 11 bytes vary over ALL shards — 16/12 records with
+// indices below 2^32 —, up to 256 shards, 16-byte aligned buffers): nothing is sorted before the exchange.  A shard is compacted to
+// 12-byte elements (one plan for all shards from the combined census words — of SAMPLE ranges when the shards are large, checked
+// against the exact census the partition pass takes on its way), every element gets the number of its key RANGE (256 of them, cut by
+// sampled splitters) in its free top byte, one ordinary element pass on that byte puts the elements in range order (sort.hip:
 // launch_partition_elems), the exact counts of that pass say which consecutive ranges an owner gets, the owners pull their
-// pieces — 12 bytes per record on the links — and sort them straight into records (launch_sort_elems: the sort's passes without its census and
-// compress steps).  Every record is sorted ONCE; round 3 sorted every shard, exchanged, and sorted every owner's pieces again
-// (one-GPU rehearsal at 1e9 records: 0.097 s; DESIGN.md §5 has this round's).  SORT FIRST (the round-3 form, kept for every
-// other input: wide keys, unaligned buffers, sort_compact = 0): shards sorted where they live, cut at the splitters by binary
-// search, 24-byte records (or 12-byte elements when exactly 12 bytes vary) exchanged, owners sort again.
+// pieces — 12 bytes per record on the links — and sort them straight into records (launch_sort_elems: the sort's passes without
+// its census and compress steps).  Every record is sorted ONCE; round 3 sorted every shard, exchanged, and sorted every owner's
+// pieces again (one-GPU rehearsal at 1e9 records: 0.097 s then, 0.048 now).  PARTITION FIRST ON RECORDS (any other key, any 8-byte
+// aligned buffer, up to 256 shards): the same scheme on 24-byte records — the range goes into the digit side stream, one 24-byte
+// pass whose digit comes from that stream orders the records by range in the shard's scratch, the owners pull their pieces over
+// their own (dead) records and sort once; no census (full-range (32,32) records: 0.091 s; (32,12): 0.073).  SORT FIRST (the
+// round-3 form: more than 256 shards, or sort_compact = 0 on ctxs[0]): shards sorted where they live, cut at the splitters by
+// binary search, 24-byte records (or 12-byte elements when at most 12 bytes vary) exchanged, owners sort again.
 //
 // The one-process-per-GPU form of the same algorithm is ibu_amd/sharding.py (torch.distributed: all-gather of the samples,
 // all-to-all of 12-byte compacted keys).  Neither has run on more than one distinct GPU yet (no multi-GPU box in any round's
@@ -104,6 +108,8 @@ size_t sample_budget(size_t W) {
   return want < 16384 ? 16384 : (want > (1u << 19) ? (1u << 19) : want);
 }
 
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // who receives how much, and where each piece lands at its owner (pieces in shard order); a shard without the room fails the call
 int32_t plan_landing(const ibu_sort_shard_t* shards, size_t W, const std::vector<std::vector<uint64_t>>& bound, std::vector<size_t>& n_out,
                      std::vector<std::vector<size_t>>& land, const char* state) {
@@ -119,9 +125,33 @@ int32_t plan_landing(const ibu_sort_shard_t* shards, size_t W, const std::vector
   return IBU_OK;
 }
 
-// ---- PARTITION FIRST -------------------------------------------------------------------------------------------------------
-double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// Which of the 256 key ranges an owner gets: consecutive ones, up to the point nearest to its share of the records (and not past its
+// capacity while an earlier cut avoids that; the last owner takes what is left).  fine[i][f]: first element of range f in shard i
+// (fine[i][256] = its count); bound[i][j]: first element of owner j's piece in shard i.
+void cut_owners(const ibu_sort_shard_t* shards, size_t W, const std::vector<std::vector<uint64_t>>& fine, size_t total,
+                std::vector<std::vector<uint64_t>>& bound) {
+  constexpr size_t F = 256;
+  std::vector<uint64_t> g(F, 0);
+  for (size_t i = 0; i < W; ++i)
+    for (size_t f = 0; f < F; ++f) g[f] += fine[i][f + 1] - fine[i][f];
+  std::vector<size_t> cut(W + 1, F);
+  cut[0] = 0;
+  uint64_t cum = 0;
+  for (size_t j = 0, f = 0; j + 1 < W; ++j) {
+    const long double target = (long double)total * (j + 1) / W;
+    uint64_t load = 0;
+    while (f < F && load + g[f] <= shards[j].capacity && (long double)cum + (long double)g[f] / 2 <= target) {
+      load += g[f];
+      cum += g[f];
+      ++f;
+    }
+    cut[j + 1] = f;
+  }
+  for (size_t i = 0; i < W; ++i)
+    for (size_t j = 0; j <= W; ++j) bound[i][j] = fine[i][cut[j]];
+}
 
+// ---- PARTITION FIRST -------------------------------------------------------------------------------------------------------
 // `guessed`: the plan comes from SAMPLE censuses (three ranges of every shard); the partition pass then accumulates the exact census of
 // every record on the way, and *covered says afterwards whether the guess was the truth — the same bytes vary.  If it was not
 // (false), nothing has been exchanged and no record touched: the caller runs the call again with the exact plan it now has.
@@ -189,27 +219,8 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
       return IBU_OK;
     }
   }
-  // which ranges an owner gets: consecutive ones, up to the point nearest to its share of the records (and not past its capacity
-  // while an earlier cut avoids that; the last owner takes what is left)
-  std::vector<uint64_t> g(F, 0);
-  for (size_t i = 0; i < W; ++i)
-    for (size_t f = 0; f < F; ++f) g[f] += fine[i][f + 1] - fine[i][f];
-  std::vector<size_t> cut(W + 1, F);
-  cut[0] = 0;
-  uint64_t cum = 0;
-  for (size_t j = 0, f = 0; j + 1 < W; ++j) {
-    const long double target = (long double)total * (j + 1) / W;
-    uint64_t load = 0;
-    while (f < F && load + g[f] <= shards[j].capacity && (long double)cum + (long double)g[f] / 2 <= target) {
-      load += g[f];
-      cum += g[f];
-      ++f;
-    }
-    cut[j + 1] = f;
-  }
   std::vector<std::vector<uint64_t>> bound(W, std::vector<uint64_t>(W + 1, 0));
-  for (size_t i = 0; i < W; ++i)
-    for (size_t j = 0; j <= W; ++j) bound[i][j] = fine[i][cut[j]];
+  cut_owners(shards, W, fine, total, bound);
   std::vector<size_t> n_out(W, 0);
   std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));   // land[j][i]: element offset of shard i's piece at owner j
   rc = plan_landing(shards, W, bound, n_out, land, "no shard's records were touched");
@@ -247,6 +258,78 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   if (trace)
     fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u; ms: samples %.2f, partition %.2f, exchange %.2f, sort %.2f)\n", W,
             prefix_passes, t_phase[0], t_phase[1], t_phase[2], t_phase[3]);
+  for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
+  return IBU_OK;
+}
+
+// ---- PARTITION FIRST on 24-byte records (any key) -------------------------------------------------------------------------------
+// The same scheme without the elements: keys of more than 11 varying bytes (full-range (32,32) records: 20), or buffers the element
+// kernels cannot take.  A record's key range goes into the digit side stream, one 24-byte pass of the sort puts the records in range
+// order in the shard's scratch, the owners pull their pieces over their own (dead) records and sort them once.  No census at all.
+int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, size_t total) {
+  const bool trace = getenv("IBU_TRACE_SORT") != nullptr;
+  double t_mark = now_ms(), t_phase[4] = {0, 0, 0, 0};
+  auto lap = [&](int k) { const double t = now_ms(); t_phase[k] = t - t_mark; t_mark = t; };
+  constexpr size_t F = 256;
+  std::vector<std::vector<Rec>> samp(W);
+  int32_t rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
+  if (rc) return rc;
+  std::vector<Rec> split;
+  pick_splitters(samp, F, split);
+  lap(0);
+  std::vector<std::vector<uint64_t>> fine(W, std::vector<uint64_t>(F + 1, 0));
+  const size_t split_bytes = kRec * (F - 1) + 512;
+  rc = on_every_context(W, [&](size_t i) -> int32_t {
+    ibu_ctx_t* c = ctxs[i];
+    const size_t n = shards[i].n;
+    if (!n) return IBU_OK;
+    IBU_HIP(hipSetDevice(c->device));
+    const size_t need = sort_scratch_bytes(c->cfg, n);
+    int32_t r = ensure_sort_scratch(c, need + split_bytes);   // the splitters ride behind the sort's own scratch
+    if (r) return r;
+    hipStream_t st = c->stream;
+    uint8_t* d_split_recs = static_cast<uint8_t*>(c->d_sort_scratch) + ((need + 255) & ~(size_t)255);
+    IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
+    const uint64_t* d_starts = nullptr;
+    IBU_HIP(launch_partition_records(c->cfg, shards[i].d_records, n, d_split_recs, (uint32_t)(F - 1), shards[i].d_tmp, c->d_sort_scratch, need, &d_starts, st));
+    IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
+    IBU_HIP(hipStreamSynchronize(st));
+    fine[i][F] = n;
+    return IBU_OK;
+  });
+  if (rc) return rc;
+  lap(1);
+  std::vector<std::vector<uint64_t>> bound(W, std::vector<uint64_t>(W + 1, 0));
+  cut_owners(shards, W, fine, total, bound);
+  std::vector<size_t> n_out(W, 0);
+  std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));
+  rc = plan_landing(shards, W, bound, n_out, land, "no shard's records were touched");
+  if (rc) return rc;
+  // the exchange: every owner pulls its pieces from the shards' scratch over its own records (partitioned into its scratch: dead)
+  rc = on_every_context(W, [&](size_t j) -> int32_t {
+    IBU_HIP(hipSetDevice(ctxs[j]->device));
+    uint8_t* d = static_cast<uint8_t*>(shards[j].d_records);
+    for (size_t i = 0; i < W; ++i) {
+      const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
+      if (!cnt) continue;
+      enable_peer(ctxs[j]->device, ctxs[i]->device);
+      const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + kRec * bound[i][j];
+      IBU_HIP(hipMemcpyPeerAsync(d + kRec * land[j][i], ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ctxs[j]->stream));
+    }
+    IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
+    return IBU_OK;
+  });
+  if (rc) return rc;                                          // (joined: the scratch arrays are not read any more)
+  lap(2);
+  rc = on_every_context(W, [&](size_t j) -> int32_t {
+    int32_t r = ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr);
+    return r ? r : ibu_ctx_synchronize(ctxs[j], nullptr);
+  });
+  if (rc) return rc;
+  lap(3);
+  if (trace)
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first; ms: samples %.2f, partition %.2f, exchange %.2f, sort %.2f)\n", W, t_phase[0],
+            t_phase[1], t_phase[2], t_phase[3]);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
 }
@@ -368,12 +451,11 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
           for (int f = 0; f < 3; ++f) { o[f] |= words[i][f]; a[f] &= words[i][3 + f]; }
       compact_plan_init(o, a, out);
     };
-    if (ctxs[0]->cfg.sort_compact != 0 && total > 0) {
-      bool all_exact = true;
-      std::vector<char> was_exact(W, 1);
-      int32_t rc = IBU_OK;
-      if (aligned && W <= 256) {
-        rc = on_every_context(W, [&](size_t i) -> int32_t {
+    if (ctxs[0]->cfg.sort_compact != 0 && total > 0 && W <= 256) {      // PARTITION FIRST: elements if the keys allow it, else records
+      if (aligned) {
+        bool all_exact = true;
+        std::vector<char> was_exact(W, 1);
+        int32_t rc = on_every_context(W, [&](size_t i) -> int32_t {
           ibu_ctx_t* c = ctxs[i];
           if (!shards[i].n) return IBU_OK;
           IBU_HIP(hipSetDevice(c->device));
@@ -395,21 +477,17 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
           rc = sort_partition_first(ctxs, W, shards, plan, total, !all_exact, &words, &covered);
           if (rc || covered) return rc;
           combine(&plan);                                       // `words` now holds every shard's exact census
-          have_plan = true;
+          if (plan.k <= 11) return sort_partition_first(ctxs, W, shards, plan, total, false, &words, &covered);
         }
       }
-      if (!have_plan) {
-        rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
-        if (rc) return rc;
-        for (size_t i = 0; i < W; ++i)
-          if (!shards[i].n) words[i] = {0, 0, 0, ~0ull, ~0ull, ~0ull, 0, 0};
-        combine(&plan);
-        have_plan = true;
-      }
+      return sort_partition_first_records(ctxs, W, shards, total);   // more than 11 varying key bytes, or buffers the element kernels cannot take
     }
-    if (have_plan && plan.k <= 11 && W <= 256 && aligned && total > 0) {
-      bool covered = true;
-      return sort_partition_first(ctxs, W, shards, plan, total, false, &words, &covered);
+    // SORT FIRST: told to (sort_compact = 0 on ctxs[0]), more than 256 shards, or nothing to sort
+    if (ctxs[0]->cfg.sort_compact != 0 && total > 0) {
+      int32_t rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
+      if (rc) return rc;
+      combine(&plan);
+      have_plan = true;
     }
     return sort_sort_first(ctxs, W, shards, plan, have_plan);
   } catch (...) {

@@ -136,6 +136,8 @@ struct SweepVariant {
   void (*counts_recs)(const uint8_t*, u32, u32, u32, uint16_t*, uint8_t*);
   void (*counts_tail)(const u64*, u64, u32, u32, u32, uint16_t*, u64*);
   void (*counts_bytes)(const uint8_t*, u64, u32, uint16_t*);
+  const void* scatter32_stream;   // the digit from the side stream (launch_partition_records)
+  const void* scatter64_stream;
 };
 #ifdef IBU_SORT_PROBE
 #define IBU_WM 2
@@ -147,7 +149,8 @@ static SweepVariant sweep_variant() {
   typedef SweepShape<TH, R> S;
   return {TH, S::T, S::lds, reinterpret_cast<const void*>(ibu_k_sort_scatter<TH, R, u32, WM>),
           reinterpret_cast<const void*>(ibu_k_sort_scatter<TH, R, u64, WM>), ibu_k_sort_tilecounts_recs<S::T>,
-          ibu_k_sort_tilecounts_recs_tail<S::T>, ibu_k_sort_tilecounts_bytes<S::T>};
+          ibu_k_sort_tilecounts_recs_tail<S::T>, ibu_k_sort_tilecounts_bytes<S::T>,
+          reinterpret_cast<const void*>(ibu_k_sort_scatter<TH, R, u32, WM, true>), reinterpret_cast<const void*>(ibu_k_sort_scatter<TH, R, u64, WM, true>)};
 }
 // cfg.sort_variant: tile shape (A/B through ibu_ctx_set_option(ctx, "sort_variant", k))
 static const SweepVariant kSweep[] = {
@@ -666,6 +669,70 @@ hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, c
   e = hipLaunchKernel(k_scatter, dim3((L.ntiles + 7u) & ~7u), dim3(cv->threads), args, cv->lds, st);
   if (e != hipSuccess) return e;
   *d_starts = reinterpret_cast<const uint64_t*>(binbase);                                  // u64[256]: first element of every owner's piece
+  return hipGetLastError();
+}
+// The same partition pass on 24-byte RECORDS (keys of more than 11 varying bytes, or buffers the element kernels cannot take): a
+// record's key range — how many of the up to 255 splitter records are not above it — goes into the digit side stream, and one
+// ordinary 24-byte pass whose digit comes from that stream (ibu_k_sort_scatter, field > 2) moves the records into range order.
+extern "C" __global__ void __launch_bounds__(256)
+ibu_k_sort_stamp_records(const u64* __restrict__ recs, u64 n, const u64* __restrict__ split, u32 nsplit, uint8_t* __restrict__ digits) {
+  __shared__ u64 sp[3 * 256];
+  for (u32 i = threadIdx.x; i < 3 * nsplit; i += blockDim.x) sp[i] = split[i];
+  __syncthreads();
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const u64 b = recs[3 * i], u = recs[3 * i + 1], x = recs[3 * i + 2];
+    u32 lo = 0, hi = nsplit;                                  // range = splitters <= record
+    while (lo < hi) {
+      const u32 mid = (lo + hi) >> 1;
+      if (!rec_less(b, u, x, sp[3 * mid], sp[3 * mid + 1], sp[3 * mid + 2])) lo = mid + 1; else hi = mid;
+    }
+    digits[i] = (uint8_t)lo;
+  }
+}
+hipError_t launch_partition_records(const LaunchCfg& cfg, const void* recs, size_t n, const void* d_split, uint32_t nsplit, void* out, void* scratch,
+                                    size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st) {
+  (void)hipGetLastError();
+  if (n == 0 || nsplit > 255) return hipErrorInvalidValue;
+  const SweepVariant& sv = pick_variant(cfg);
+  if ((n + sv.tile - 1) / sv.tile >= (1ull << 31)) return hipErrorInvalidValue;
+  const SortLayout L = sort_layout(cfg, n, sv.tile);
+  if (scratch_bytes < L.total) return hipErrorInvalidValue;
+  uint8_t* sc = static_cast<uint8_t*>(scratch);
+  u64* binbase = reinterpret_cast<u64*>(sc + L.binbase);
+  u32* blocksum = reinterpret_cast<u32*>(sc + L.blocksum);
+  u64* blockoff = reinterpret_cast<u64*>(sc + L.blockoff);
+  uint16_t* counts = reinterpret_cast<uint16_t*>(sc + L.counts);
+  void* pos = sc + L.pos;
+  uint8_t* digits = sc + L.digits;
+  const void* scatter = L.idx64 ? sv.scatter64_stream : sv.scatter32_stream;
+  hipError_t e;
+  if (sv.lds > 48 * 1024) {
+    e = hipFuncSetAttribute(scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv.lds);
+    if (e != hipSuccess) return e;
+  }
+  const u32 cap = (u32)cfg.cus * 8;
+  const u64 want = (n + 255) / 256;
+  hipLaunchKernelGGL(ibu_k_sort_stamp_records, dim3((u32)(want < cap ? want : cap)), dim3(256), 0, st, static_cast<const u64*>(recs), (u64)n,
+                     static_cast<const u64*>(d_split), nsplit, digits);
+  const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
+  hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n, L.ntiles, counts);
+  hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
+  hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
+  if (L.idx64)
+    hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
+                       (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
+  else
+    hipLaunchKernelGGL(ibu_k_sort_tilepos<u32>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
+                       (const u64*)blockoff, (const u64*)binbase, static_cast<u32*>(pos));
+  u64 n_arg = n;
+  u32 f_arg = 3, s_arg = 0, nf_arg = 3, ns_arg = 0;           // this pass's digit: from the side stream; no pass follows
+  const u64* src_arg = static_cast<const u64*>(recs);
+  u64* dst_arg = static_cast<u64*>(out);
+  void* args[] = {&src_arg, &dst_arg, &n_arg, &f_arg, &s_arg, &nf_arg, &ns_arg, &pos, &digits};
+  e = hipLaunchKernel(scatter, dim3((L.ntiles + 7u) & ~7u), dim3(sv.threads), args, sv.lds, st);
+  if (e != hipSuccess) return e;
+  *d_starts = reinterpret_cast<const uint64_t*>(binbase);     // u64[256]: first record of every range
   return hipGetLastError();
 }
 bool sort_elems_supported(const LaunchCfg& cfg, const void* recs, const void* tmp, size_t capacity) {

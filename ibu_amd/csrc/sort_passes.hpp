@@ -240,8 +240,13 @@ struct SweepShape {
 };
 
 // field / shift: this pass's digit; nfield / nshift: the next pass's (nfield > 2: there is none, no side stream).
+// DSTREAM: this pass's digit is not a key byte but comes FROM the side stream (digits[i] of record i of `src`: the key range a
+// record belongs to — the multi-GPU sort's partition pass, sort.hip launch_partition_records; there is no next pass then: nfield > 2).
 // WMODE 0: the real thing.  WMODE 2 (probe builds, -DIBU_SORT_PROBE, WRONG output): the permuted tile goes out linearly.
-template <int THREADS, int ROUNDS, class IDX, int WMODE>
+// DSTREAM: a separate instantiation — as a run-time case of the ordinary kernel the extra load made the register allocator aim for
+// twice the occupancy the LDS allows and spill 256 bytes per lane (full-range (32,32) sort 0.063 -> 0.100 s until the code objects'
+// metadata was looked at again).
+template <int THREADS, int ROUNDS, class IDX, int WMODE, bool DSTREAM = false>
 __global__ void __launch_bounds__(THREADS)
 ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u32 field, u32 shift, u32 nfield, u32 nshift,
                    const IDX* __restrict__ pos, uint8_t* __restrict__ digits) {
@@ -300,7 +305,9 @@ ibu_k_sort_scatter(const u64* __restrict__ src, u64* __restrict__ dst, u64 n, u3
     r0[r] = r1[r] = r2[r] = 0;
     if (valid) { r0[r] = stage[3 * slot]; r1[r] = stage[3 * slot + 1]; r2[r] = stage[3 * slot + 2]; }
     const u64 key = field == 0 ? r0[r] : (field == 1 ? r1[r] : r2[r]);
-    const u32 d = (u32)(key >> shift) & 255u;
+    u32 d;
+    if constexpr (DSTREAM) d = valid ? (u32)digits[tbase + slot] : 0u;
+    else d = (u32)(key >> shift) & 255u;
     const DigitPeers pe = match_digit(d, __ballot(valid));
     const u32 before = pe.before;
     const u32 prev = valid ? whist[wib * kBins + d] : 0;

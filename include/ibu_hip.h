@@ -380,13 +380,17 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * bytes of scratch on the same device.  On return shard i holds the i-th contiguous range of the global order and
  * shards[i].n says how many records that is (their sum is unchanged).  Evenly spaced samples of every shard, in proportion to
  * its size (about 512 per shard in all), pick n_ctxs - 1 splitters; every record travels once to the owner of its range
- * (hipMemcpyPeerAsync: over xGMI between GPUs).  Two forms (multi_sort.cpp):
- *   partition first — at most 11 key bytes vary over ALL shards (16/12 records with indices below 2^32), at most 256 shards,
- *     16-byte aligned buffers: a shard is compacted to 12-byte elements (one plan for all shards from the combined census words —
- *     of sample ranges when the shards are large, checked against the exact census the partition pass takes on its way), the elements are put in owner order by one pass of the sort's own kernels, the owners pull their pieces
- *     (12 bytes per record on the links) and sort them straight into records.  Nothing is sorted twice;
- *   sort first — everything else (option "sort_compact" = 0 on ctxs[0] forces it): every shard sorted where it lives, cut at
- *     the splitters by binary search, 24-byte records exchanged (12-byte elements when exactly 12 bytes vary), owners sort again.
+ * (hipMemcpyPeerAsync: over xGMI between GPUs).  Three forms (multi_sort.cpp):
+ *   partition first on elements — at most 11 key bytes vary over ALL shards (16/12 records with indices below 2^32), at most 256
+ *     shards, 16-byte aligned buffers: a shard is compacted to 12-byte elements (one plan for all shards from the combined census
+ *     words — of sample ranges when the shards are large, checked against the exact census the partition pass takes on its way),
+ *     the elements are put in the order of 256 sampled key ranges by one pass of the sort's own kernels, the owners are cut on the
+ *     exact counts, pull their pieces (12 bytes per record on the links) and sort them straight into records;
+ *   partition first on records — any other key or alignment, at most 256 shards: the same on 24-byte records (their key range in
+ *     the digit side stream, one 24-byte pass into the shard's scratch, the owners pull over their own records and sort once);
+ *   sort first — more than 256 shards, or option "sort_compact" = 0 on ctxs[0]: every shard sorted where it lives, cut at the
+ *     splitters by binary search, 24-byte records exchanged (12-byte elements when at most 12 bytes vary), owners sort again.
+ * Nothing is sorted twice in the first two.
  * One host thread per context; the first error in context order is the call's.  A shard that would receive more than its
  * capacity: IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) before anything has moved between
  * shards: every shard still holds its own records (untouched, or sorted locally on the sort-first path) — leave headroom for

@@ -206,14 +206,15 @@ def test_compact_expand_copy_generate_stay_inside_their_buffers(ia, ctx, oracle,
 
 
 @pytest.mark.parametrize("w", [2, 8, 16])
-@pytest.mark.parametrize("form", ["partition_first", "sort_first", "sort_first_wide_keys"])
+@pytest.mark.parametrize("form", ["partition_first", "partition_first_records", "sort_first", "sort_first_wide_keys"])
 @pytest.mark.parametrize("fill", ["minimal", "roomy"])
 def test_sort_records_contexts_stays_inside_records_and_tmp(ia, ctx, oracle, w, form, fill):
     """The multi-context sort with every shard's d_records / d_tmp carved at exactly capacity x 24 bytes (ADVICE r03 / VERDICT r03
     weak 6: with 8 and more contexts the splitters and their positions, 32 (W - 1) bytes, overran a d_tmp of the minimal
     capacity W + 1).  minimal: the smallest capacity the call accepts, one below it refused; roomy: shards of a few thousand
-    records.  All contexts on the box's one GPU; both forms of the call and both exchange formats."""
-    lens = (32, 32) if form == "sort_first_wide_keys" else (16, 12)
+    records.  All contexts on the box's one GPU; the three forms of the call (partition first on 12-byte elements, on 24-byte records;
+    sort first) and both exchange formats."""
+    lens = (32, 32) if form in ("sort_first_wide_keys", "partition_first_records") else (16, 12)
     cap_min = max(w + 1, -(-32 * (w - 1) // 24))
     cap = cap_min if fill == "minimal" else 4000
     rng = np.random.default_rng(w * 7 + len(form))
@@ -224,7 +225,7 @@ def test_sort_records_contexts_stays_inside_records_and_tmp(ia, ctx, oracle, w, 
     ctxs = [ia.Context(0) for _ in range(w)]
     ar = _arena(ia, ctx, *([24 * cap] * (2 * w)))
     try:
-        if form == "sort_first":
+        if form.startswith("sort_first"):                      # (the option that forces the round-3 form)
             ctxs[0].set_option("sort_compact", 0)
         shards, at = [], 0
         for n in counts:

@@ -23,6 +23,8 @@ def _rand_bits(torch, g, nbits, count):
 def shards_main(a, ia, bc_len, umi_len):
     k = a.shards
     ctxs = [ia.Context(0) for _ in range(k)]
+    if a.sort_first:                                           # the round-3 form of the call (every shard sorted, exchanged, sorted again)
+        ctxs[0].set_option("sort_compact", 0)
     for n in (int(float(x)) for x in a.records.split(",")):
         per, cap = n // k, int(n // k * 1.25) + k + 1
         bufs = [(c.alloc(24 * cap), c.alloc(24 * cap)) for c in ctxs]
@@ -36,7 +38,8 @@ def shards_main(a, ia, bc_len, umi_len):
             ts.append(time.perf_counter() - t0)
         assert sum(outs) == per * k and all(c.is_sorted(d, m) for c, (d, _), m in zip(ctxs, bufs, outs))
         sec = statistics.median(ts[1:])
-        print(json.dumps({"n": per * k, "lens": [bc_len, umi_len], "contexts_on_device_0": k, "seconds": round(sec, 4),
+        print(json.dumps({"n": per * k, "lens": [bc_len, umi_len], "contexts_on_device_0": k, "form": "sort first (forced)" if a.sort_first else "default",
+                          "seconds": round(sec, 4),
                           "M_records_per_s": round(per * k / sec / 1e6, 1), "records_per_shard_after": outs,
                           "note": "one GPU: the K local sorts share it and the exchange is a device-local copy"}), flush=True)
         for d, t in bufs:
@@ -60,6 +63,7 @@ def main():
     ap.add_argument("--whitelist", type=int, default=0,
                     help="K > 0: barcodes drawn from K distinct ones with a skewed distribution (rank ~ K u^3: a single-cell run, where a few "
                          "thousand cells hold most reads), random UMIs, records in read order; built on the device with torch")
+    ap.add_argument("--sort-first", action="store_true", help="with --shards: force the round-3 form of ibu_sort_records_contexts (sort_compact = 0 on the first context)")
     ap.add_argument("--shards", type=int, default=0,
                     help="K > 0: time ibu_sort_records_contexts over K contexts instead — all on device 0 (the one-GPU rehearsal of the "
                          "multi-GPU sort: K local sorts, the device-to-device exchange, K sorts of what arrived), n / K records each")

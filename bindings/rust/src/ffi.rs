@@ -1,4 +1,4 @@
-//! Raw `extern "C"` declarations — one-to-one with include/ibu_hip.h (ABI revision 3).
+//! Raw `extern "C"` declarations — one-to-one with include/ibu_hip.h (ABI revision 4).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -51,6 +51,21 @@ pub struct ibu_stream_stats_t {
     pub batches: u64,
     pub seconds_total: f64,
     pub seconds_kernel: f64,
+    pub numa_node: i32,
+    pub ring_node: i32,
+}
+/// `ibu_ctx_numa`: where the context's device hangs off the host and where its pinned ring landed.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ibu_numa_info_t {
+    pub mode: i32,
+    pub node: i32,
+    pub usable_cpus: i32,
+    pub ring_node: i32,
+    pub ring_placed: i32,
+    pub reserved: i32,
+    pub pci_bus_id: [c_char; 32],
+    pub cpulist: [c_char; 256],
 }
 #[repr(C)]
 #[derive(Debug, Clone, Copy, Default)]
@@ -75,7 +90,7 @@ pub struct ibu_decode_sink_t {
     pub d_bc_ascii: *mut u8,
     pub d_umi_ascii: *mut u8,
     pub d_index: *mut u64,
-    /// rows every non-NULL column can hold (ABI revision 3): a longer stream is IBU_ERR_INVALID_ARG, never an overrun
+    /// rows every non-NULL column can hold (ABI revision 4): a longer stream is IBU_ERR_INVALID_ARG, never an overrun
     pub cap_records: usize,
 }
 /// Plan of the compacted keys (the varying bytes of a set of records as 12-byte elements): ibu_key_plan_init.
@@ -100,6 +115,7 @@ pub enum ibu_writer_t {}
 pub enum ibu_reader_t {}
 pub enum ibu_mmap_t {}
 pub enum ibu_ctx_t {}
+pub enum ibu_stream_t {}
 pub type ibu_write_fn = unsafe extern "C" fn(*mut c_void, *const u8, usize) -> i32;
 pub type ibu_flush_fn = unsafe extern "C" fn(*mut c_void) -> i32;
 pub type ibu_read_fn = unsafe extern "C" fn(*mut c_void, *mut u8, usize, *mut usize) -> i32;
@@ -236,4 +252,17 @@ extern "C" {
                                      total: *mut ibu_reduce_result_t, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_reader_process_device(r: *mut ibu_reader_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
                                      proc_: i32, sink: *mut c_void, stats: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_ctx_numa(ctx: *const ibu_ctx_t, out: *mut ibu_numa_info_t) -> i32;
+    pub fn ibu_numa_of_pci(sysfs_root: *const c_char, pci_bus_id: *const c_char, node: *mut i32, cpulist: *mut c_char,
+                           cap: usize, usable_cpus: *mut i32) -> i32;
+    pub fn ibu_stream_open_reader(r: *mut ibu_reader_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
+                                  out: *mut *mut ibu_stream_t) -> i32;
+    pub fn ibu_stream_open_mmap(m: *const ibu_mmap_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t, shard: usize,
+                                n_shards: usize, out: *mut *mut ibu_stream_t) -> i32;
+    pub fn ibu_stream_header(s: *const ibu_stream_t, out: *mut ibu_header_t) -> i32;
+    pub fn ibu_stream_next(s: *mut ibu_stream_t, stream: *mut c_void, d_records: *mut *const c_void, n: *mut usize,
+                           first_index: *mut u64) -> i32;
+    pub fn ibu_stream_release(s: *mut ibu_stream_t, d_records: *const c_void, stream: *mut c_void) -> i32;
+    pub fn ibu_stream_stats(s: *const ibu_stream_t, out: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_stream_close(s: *mut ibu_stream_t);
 }

@@ -291,6 +291,15 @@ impl PathReader {
         Ok(Self(raw))
     }
 }
+impl PathReader {
+    /// Pull-style device stream over the rest of this reader (`ibu_stream_open_reader`): `Reader::read_batch` + `Iterator`
+    /// (reader.rs:218-242, :279-306) with the batch in HBM.  The reader is borrowed mutably for as long as the stream lives.
+    pub fn device_stream<'a>(&'a mut self, ctx: &'a device::Context) -> Result<device::DeviceStream<'a>> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ffi::ibu_stream_open_reader(self.0, ctx.raw, std::ptr::null(), &mut raw) })?;
+        Ok(device::DeviceStream { raw, _p: PhantomData })
+    }
+}
 impl Iterator for PathReader {
     type Item = Result<Record>;
     fn next(&mut self) -> Option<Self::Item> {
@@ -389,6 +398,15 @@ impl MmapReader {
         })?;
         parts.truncate(n);
         Ok((total, parts))
+    }
+}
+impl MmapReader {
+    /// Pull-style device stream over one shard of the static split (`ibu_stream_open_mmap`): the per-batch loop of
+    /// `process_parallel` (mmap.rs:312-320) with every batch resident in HBM.
+    pub fn device_stream<'a>(&'a self, ctx: &'a device::Context, shard: usize, n_shards: usize) -> Result<device::DeviceStream<'a>> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ffi::ibu_stream_open_mmap(self.raw, ctx.raw, std::ptr::null(), shard, n_shards, &mut raw) })?;
+        Ok(device::DeviceStream { raw, _p: PhantomData })
     }
 }
 impl Drop for MmapReader {
@@ -519,8 +537,9 @@ pub mod device {
         }
         /// The same order over several shards, one per context (= per GPU), in one call (`ibu_sort_records_contexts`): shard i
         /// ends up with the i-th range of the global order; returns the new record counts.  `shards[i]` = (records, tmp, n,
-        /// capacity in records) on `ctxs[i]`'s device.  Leave headroom in `capacity` (the owners' shares differ by a percent or
-        /// two); a shard that would overflow fails the call with every shard still holding its own records.  Experimental: never
+        /// capacity in records) on `ctxs[i]`'s device.  Leave headroom in `capacity` (up to 32 shards the owners are cut at the
+        /// boundaries of 256 sampled key ranges: shares differ by up to total / 256 — 3 % of a share with 8 shards, 12 % with 32;
+        /// beyond that, and when such a cut does not fit, at sampled quantiles: a few percent); a shard that would overflow fails the call with every shard still holding its own records.  Experimental: never
         /// run on two distinct GPUs.
         pub fn sort_records_contexts(ctxs: &[&Context], shards: &[(&DeviceBuf, &DeviceBuf, usize, usize)]) -> Result<Vec<usize>> {
             assert_eq!(ctxs.len(), shards.len());
@@ -594,6 +613,68 @@ pub mod device {
             let (mut h, mut p, mut n) = (bytemuck::Zeroable::zeroed(), std::ptr::null_mut(), 0usize);
             check(unsafe { ffi::ibu_load_to_device(self.raw, c.as_ptr(), std::ptr::null(), &mut h, &mut p, 0, &mut n, std::ptr::null_mut()) })?;
             Ok((h, p, n))
+        }
+    }
+    /// `ibu_stream_t`: iterate to pull one device-resident batch at a time.  An `Err` item is the source's error
+    /// (`TruncatedRecord`, `Io`, `Niffler` ...), delivered after the batches in front of it; iteration ends after it.
+    pub struct DeviceStream<'a> {
+        pub(crate) raw: *mut ffi::ibu_stream_t,
+        pub(crate) _p: PhantomData<&'a ()>,
+    }
+    /// One batch: `n` records of 24 bytes at `d_records` (a device ring slot), the first of them record number `first_index`.
+    /// Dropping it gives the slot back: it is refilled once the work queued so far on the context's stream has run.
+    pub struct DeviceBatch<'s> {
+        pub d_records: *const c_void,
+        pub n: usize,
+        pub first_index: u64,
+        stream: *mut ffi::ibu_stream_t,
+        _p: PhantomData<&'s ()>,
+    }
+    impl<'a> DeviceStream<'a> {
+        pub fn header(&self) -> Result<Header> {
+            let mut h: Header = bytemuck::Zeroable::zeroed();
+            check(unsafe { ffi::ibu_stream_header(self.raw, &mut h) })?;
+            Ok(h)
+        }
+        pub fn stats(&self) -> Result<ffi::ibu_stream_stats_t> {
+            let mut st = ffi::ibu_stream_stats_t::default();
+            check(unsafe { ffi::ibu_stream_stats(self.raw, &mut st) })?;
+            Ok(st)
+        }
+        /// The next batch, to be read on `hip_stream` (null: the context's stream); `Ok(None)` at the end.
+        pub fn next_on(&mut self, hip_stream: *mut c_void) -> Result<Option<DeviceBatch<'_>>> {
+            let (mut d, mut n, mut first) = (std::ptr::null(), 0usize, 0u64);
+            check(unsafe { ffi::ibu_stream_next(self.raw, hip_stream, &mut d, &mut n, &mut first) })?;
+            Ok(if n == 0 { None } else { Some(DeviceBatch { d_records: d, n, first_index: first, stream: self.raw, _p: PhantomData }) })
+        }
+    }
+    impl<'a> Iterator for DeviceStream<'a> {
+        type Item = Result<DeviceBatch<'a>>;
+        fn next(&mut self) -> Option<Self::Item> {
+            let (mut d, mut n, mut first) = (std::ptr::null(), 0usize, 0u64);
+            match check(unsafe { ffi::ibu_stream_next(self.raw, std::ptr::null_mut(), &mut d, &mut n, &mut first) }) {
+                Err(e) => Some(Err(e)),
+                Ok(()) if n != 0 => Some(Ok(DeviceBatch { d_records: d, n, first_index: first, stream: self.raw, _p: PhantomData })),
+                Ok(()) => None,
+            }
+        }
+    }
+    impl Drop for DeviceBatch<'_> {
+        fn drop(&mut self) {
+            unsafe { ffi::ibu_stream_release(self.stream, self.d_records, std::ptr::null_mut()) };
+        }
+    }
+    impl Drop for DeviceStream<'_> {
+        fn drop(&mut self) {
+            unsafe { ffi::ibu_stream_close(self.raw) }
+        }
+    }
+    impl Context {
+        /// Where the device hangs off the host and where the pinned ring landed (`ibu_ctx_numa`, option `"numa"`).
+        pub fn numa(&self) -> Result<ffi::ibu_numa_info_t> {
+            let mut i: ffi::ibu_numa_info_t = unsafe { std::mem::zeroed() };
+            check(unsafe { ffi::ibu_ctx_numa(self.raw, &mut i) })?;
+            Ok(i)
         }
     }
     impl Drop for Context {

@@ -14,7 +14,7 @@ from collections import namedtuple
 import numpy as np
 
 from . import _lib
-from ._lib import CAllocProbe, CDecodeSink, CErrorDetail, CKeyPlan, CHeader, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
+from ._lib import CAllocProbe, CDecodeSink, CErrorDetail, CKeyPlan, CHeader, CNumaInfo, CProcessorVTable, CRecord, CReduceResult, CRingConfig, CStreamStats
 
 lib = _lib.load()
 
@@ -368,6 +368,10 @@ class Reader:
         return ctx._run_proc(lambda c, rg, s, st: lib.ibu_reader_process_device(self._r, c, rg, proc, s, st),
                              proc, sink, ring, (h.bc_len, h.umi_len))
 
+    def device_stream(self, ctx, ring=None):
+        """Pull-style device stream over the rest of this reader (ibu_stream_open_reader): iterate DeviceBatches."""
+        return DeviceStream._open(lambda out: lib.ibu_stream_open_reader(self._r, ctx._c, _ring(ring), out), ctx, self)
+
     def close(self):
         if getattr(self, "_r", None):
             lib.ibu_reader_close(self._r)
@@ -524,6 +528,10 @@ class MmapReader:
             return as_dict(total), [as_dict(parts[i]) for i in range(n)], list(stats)[:n]
         return total.count, None, list(stats)[:n]
 
+    def device_stream(self, ctx, shard=0, n_shards=1, ring=None):
+        """Pull-style device stream over one shard of the static split (ibu_stream_open_mmap): iterate DeviceBatches."""
+        return DeviceStream._open(lambda out: lib.ibu_stream_open_mmap(self._m, ctx._c, _ring(ring), shard, n_shards, out), ctx, self)
+
     def decode_to_host(self, ctx, shard=0, n_shards=1, ring=None, want=("bc", "umi", "index"), out=None):
         """One shard -> (barcode ASCII [n, bc_len], UMI ASCII [n, umi_len], index [n]) as numpy arrays in host
         memory, unpacked on the GPU.  Columns not in `want` come back as None.  out = (bc, umi, index) arrays of those
@@ -636,6 +644,92 @@ class DeviceBuffer:
     __del__ = free
 
 
+class DeviceBatch:
+    """One device-resident batch of a DeviceStream: `n` AoS records at device pointer `ptr` (a ring slot), the first of them
+    record number `first_index` of the stream.  release() (or leaving the `with` block) gives the slot back: it is refilled once
+    the work queued so far on `stream` (default: the context's) has run."""
+
+    def __init__(self, stream, ptr, n, first_index):
+        self._s, self.ptr, self.n, self.first_index, self.nbytes = stream, ptr, n, first_index, n * RECORD_SIZE
+
+    def download(self):
+        """The batch as a host REC_DTYPE array (synchronises the context's stream)."""
+        return DeviceBuffer.wrap(self._s.ctx, self.ptr, self.nbytes).download().view(REC_DTYPE)
+
+    def release(self, stream=None):
+        if self.ptr:
+            p, self.ptr = self.ptr, 0
+            _check(lib.ibu_stream_release(self._s._s, p, stream))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.release()
+
+
+class DeviceStream:
+    """ibu_stream_t — the device form of `Reader::read_batch` + `Iterator` (reader.rs:218-242, :279-306) and of the per-batch loop
+    of process_parallel (mmap.rs:312-320): iterate to pull one DeviceBatch at a time, run any kernels on it, release it.
+    A source error (TruncatedRecord, Io, Niffler ...) is raised by the iteration after the batches in front of it."""
+
+    @classmethod
+    def _open(cls, call, ctx, source):
+        out = C.c_void_p()
+        _check(call(C.byref(out)))
+        s = cls.__new__(cls)
+        s._s, s.ctx, s._source = out, ctx, source   # the source (Reader / MmapReader) must outlive the stream
+        return s
+
+    def header(self):
+        h = CHeader()
+        _check(lib.ibu_stream_header(self._s, C.byref(h)))
+        return Header._wrap(h)
+
+    def next_batch(self, stream=None):
+        """-> DeviceBatch, or None at the end of the stream.  `stream`: the stream the batch will be read on (None: the context's)."""
+        p, n, first = C.c_void_p(), C.c_size_t(), C.c_uint64()
+        _check(lib.ibu_stream_next(self._s, stream, C.byref(p), C.byref(n), C.byref(first)))
+        if n.value == 0:
+            return None
+        return DeviceBatch(self, p.value, n.value, first.value)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.next_batch()
+        if b is None:
+            raise StopIteration
+        return b
+
+    def stats(self):
+        st = CStreamStats()
+        _check(lib.ibu_stream_stats(self._s, C.byref(st)))
+        return st
+
+    def close(self):
+        if getattr(self, "_s", None):
+            lib.ibu_stream_close(self._s)
+            self._s = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def numa_of_pci(pci_bus_id, sysfs_root=None):
+    """(node, cpulist, usable_cpus) of a PCI function from a sysfs tree (ibu_numa_of_pci); node -1 = the platform does not say."""
+    node, usable, buf = C.c_int32(), C.c_int32(), C.create_string_buffer(256)
+    _check(lib.ibu_numa_of_pci(None if sysfs_root is None else str(sysfs_root).encode(), str(pci_bus_id).encode(), C.byref(node),
+                               buf, 256, C.byref(usable)))
+    return node.value, buf.value.decode(), usable.value
+
+
 class Context:
     """ibu_ctx_t: one per host thread and GPU.  Every method launches asynchronously on
     `stream` (default: the context's own stream) unless it says it synchronises."""
@@ -655,6 +749,13 @@ class Context:
 
     def set_option(self, key, value):
         _check(lib.ibu_ctx_set_option(self._c, key.encode(), int(value)))
+
+    def numa(self):
+        """Where the device hangs off the host and where the pinned ring landed (ibu_ctx_numa)."""
+        i = CNumaInfo()
+        _check(lib.ibu_ctx_numa(self._c, C.byref(i)))
+        return {"mode": i.mode, "node": i.node, "usable_cpus": i.usable_cpus, "ring_node": i.ring_node,
+                "ring_placed": bool(i.ring_placed), "pci_bus_id": i.pci_bus_id.decode(), "cpulist": i.cpulist.decode()}
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
@@ -830,5 +931,5 @@ class Context:
 
 __all__ = ["Header", "Record", "HEADER_SIZE", "MAGIC", "RECORD_SIZE", "VERSION", "IbuError", "load_to_vec",
            "MmapReader", "Reader", "Writer", "ParallelProcessor", "ProcessError", "shard_range", "Context",
-           "DeviceBuffer", "records_array", "key_plan", "REC_DTYPE", "device_count", "PROC_REDUCE", "PROC_DECODE",
+           "DeviceBuffer", "DeviceStream", "DeviceBatch", "numa_of_pci", "records_array", "key_plan", "REC_DTYPE", "device_count", "PROC_REDUCE", "PROC_DECODE",
            "DEFAULT_BUFFER_SIZE", "BATCH_SIZE"]

@@ -36,7 +36,12 @@ class CRingConfig(C.Structure):  # ibu_ring_config_t
 
 class CStreamStats(C.Structure):  # ibu_stream_stats_t
     _fields_ = [("records", u64), ("bytes_h2d", u64), ("bytes_d2h", u64), ("batches", u64),
-                ("seconds_total", C.c_double), ("seconds_kernel", C.c_double)]
+                ("seconds_total", C.c_double), ("seconds_kernel", C.c_double), ("numa_node", i32), ("ring_node", i32)]
+
+
+class CNumaInfo(C.Structure):  # ibu_numa_info_t
+    _fields_ = [("mode", i32), ("node", i32), ("usable_cpus", i32), ("ring_node", i32), ("ring_placed", i32), ("reserved", i32),
+                ("pci_bus_id", C.c_char * 32), ("cpulist", C.c_char * 256)]
 
 
 class CKeyPlan(C.Structure):  # ibu_key_plan_t
@@ -164,6 +169,15 @@ SIGNATURES = {
     "ibu_sort_records_contexts": (i32, [P(vp), sz, P(CSortShard)]),
     "ibu_mmap_process_contexts": (i32, [vp, P(vp), sz, P(CRingConfig), i32, vp, P(CReduceResult), P(CStreamStats)]),
     "ibu_reader_process_device": (i32, [vp, vp, P(CRingConfig), i32, vp, P(CStreamStats)]),
+    "ibu_ctx_numa": (i32, [vp, P(CNumaInfo)]),
+    "ibu_numa_of_pci": (i32, [C.c_char_p, C.c_char_p, P(i32), C.c_char_p, sz, P(i32)]),
+    "ibu_stream_open_reader": (i32, [vp, vp, P(CRingConfig), P(vp)]),
+    "ibu_stream_open_mmap": (i32, [vp, vp, P(CRingConfig), sz, sz, P(vp)]),
+    "ibu_stream_header": (i32, [vp, P(CHeader)]),
+    "ibu_stream_next": (i32, [vp, vp, P(vp), P(sz), P(u64)]),
+    "ibu_stream_release": (i32, [vp, vp, vp]),
+    "ibu_stream_stats": (i32, [vp, P(CStreamStats)]),
+    "ibu_stream_close": (None, [vp]),
 }
 
 

@@ -70,9 +70,11 @@ int32_t codec_ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg) {
     IBU_HIP(hipEventCreateWithFlags(&r.down[i], hipEventDisableTiming));
     r.events = i + 1;
   }
+  PreferNode prefer(feed_place(ctx).node);   // option "numa": the pinned halves on the device's node (stream.cpp: ring_ensure)
+  const unsigned hflags = prefer.active() ? hipHostMallocNumaUser : hipHostMallocDefault;
   for (uint32_t i = 0; i < slots; ++i) {
-    IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_aos[i]), slot_records * IBU_RECORD_SIZE, hipHostMallocDefault));
-    IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_col[i]), slot_records * kMaxCols, hipHostMallocDefault));
+    IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_aos[i]), slot_records * IBU_RECORD_SIZE, hflags));
+    IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_col[i]), slot_records * kMaxCols, hflags));
     IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_status[i]), 2 * sizeof(uint64_t), hipHostMallocDefault));
     IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.d_aos[i]), slot_records * IBU_RECORD_SIZE));
     IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.d_col[i]), slot_records * kMaxCols));
@@ -148,6 +150,7 @@ extern "C" int32_t ibu_mmap_decode_to_host(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
                                            ibu_stream_stats_t* stats) {
   if (!m || !ctx) return err_arg("NULL argument");
   IBU_HIP(hipSetDevice(ctx->device));
+  RunOnNode on_node(feed_place(ctx));   // this thread, the collector and the copy threads on the device's node for the length of the call (option "numa")
   const double t0 = now_s();
   if (stats) memset(stats, 0, sizeof *stats);
   size_t start = 0, end = 0;
@@ -245,6 +248,7 @@ extern "C" int32_t ibu_writer_write_ascii_batch(ibu_writer_t* w, ibu_ctx_t* ctx,
   if (bc_len == 0 || bc_len > IBU_MAX_SEQ_LEN) return err_bc_len(bc_len);
   if (umi_len == 0 || umi_len > IBU_MAX_SEQ_LEN) return err_umi_len(umi_len);
   IBU_HIP(hipSetDevice(ctx->device));
+  RunOnNode on_node(feed_place(ctx));
   const double t0 = now_s();
   if (stats) memset(stats, 0, sizeof *stats);
   if (n == 0) return IBU_OK;

@@ -6,6 +6,7 @@
 
 #include "common.hpp"
 #include "kernels.h"
+#include "numa.hpp"
 
 namespace ibu {
 
@@ -28,6 +29,8 @@ struct Ring {
   std::vector<uint8_t*> dev;     // hipMalloc, same size (H2D landing zone / D2H source)
   std::vector<hipEvent_t> copied;    // H2D (or D2H) of the slot finished
   std::vector<hipEvent_t> consumed;  // kernel that read the slot finished
+  int node = -1;                     // NUMA node the pinned slots' pages are on, as the kernel reports it (-1: it would not say)
+  bool placed = false;               // the slots were allocated under a preferred-node policy (option "numa" on and accepted)
 };
 
 // Staging ring of the host <-> host codec pipelines (codec_stream.cpp): per slot one AoS side (24 B/record) and
@@ -59,24 +62,35 @@ struct ibu_ctx {
   size_t runs_scratch_bytes = 0;
   ibu::Ring ring;
   ibu::CodecRing cring;
+  void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
+  int peer_access = 1;             // option "peer_access": 0 = never enable direct peer access for this context's pulls (the runtime stages the copies)
+  int numa_mode = 1;               // option "numa": 1 = auto (feed threads and the pinned ring on the device's node), 0 = off
+  char pci_bus_id[32] = {0};       // "0000:c1:00.0"
+  ibu::NumaPlace place;            // the device's node and its CPUs (node -1 / ncpus 0: unknown -> nothing is pinned)
 };
 
 namespace ibu {
 int32_t ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_dev);
 void ring_release(ibu_ctx* ctx);
 void codec_ring_release(ibu_ctx* ctx);
+int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hipMalloc, or the probed form under option "alloc_probe_tries"
 // The context's sort scratch (census slots, histograms, digit side stream): grows only; the one allocation a launch path may make.
 inline int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   if (need > ctx->sort_scratch_bytes) {
     if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));
     ctx->d_sort_scratch = nullptr;
     ctx->sort_scratch_bytes = 0;
-    IBU_HIP(hipMalloc(&ctx->d_sort_scratch, need));
+    const int32_t rc = ctx_alloc(ctx, need, &ctx->d_sort_scratch);   // (placement-probed under option "alloc_probe_tries": 1e9 records' side stream is 1.75 GB the passes stream through)
+    if (rc) { ctx->d_sort_scratch = nullptr; return rc; }
     ctx->sort_scratch_bytes = need;
   }
   return IBU_OK;
 }
-int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hipMalloc, or the probed form under option "alloc_probe_tries"
+// Where the host side of this context's feed belongs (option "numa"): the device's node, or nowhere in particular.
+inline const NumaPlace& feed_place(const ibu_ctx* ctx) {
+  static const NumaPlace nowhere;
+  return ctx->numa_mode ? ctx->place : nowhere;
+}
 inline hipStream_t pick_stream(const ibu_ctx* ctx, void* stream) {
   return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 }

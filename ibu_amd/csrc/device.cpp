@@ -59,6 +59,12 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
   // blocks_per_cu keeps LaunchCfg's measured default; ibu_ctx_set_option overrides it
   static const int trace_rows_env = [] { const char* v = getenv("IBU_TRACE_ROWS"); return (v && *v && *v != '0') ? 1 : 0; }();   // read once
   ctx->cfg.trace_rows = trace_rows_env;
+  // Where the device hangs off the host (numa.hpp): feeds the ring's placement and the feeder threads' affinity (option "numa").
+  // IBU_SYSFS_ROOT: a test tree instead of /sys.  Failure of any step leaves node -1: nothing is pinned, as before round 5.
+  if (hipDeviceGetPCIBusId(ctx->pci_bus_id, (int)sizeof ctx->pci_bus_id, device) == hipSuccess)
+    numa_lookup(getenv("IBU_SYSFS_ROOT"), ctx->pci_bus_id, nullptr, &ctx->place);
+  else
+    (void)hipGetLastError();
   hipError_t rc = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
@@ -129,8 +135,18 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     return IBU_OK;
   }
   if (strcmp(key, "alloc_probe_tries") == 0) {
-    if (value < 1 || value > IBU_ALLOC_PROBE_MAX) return err_arg("alloc_probe_tries must be 1..16");
+    if (value < 0 || value > IBU_ALLOC_PROBE_MAX) return err_arg("alloc_probe_tries must be 0 (auto) .. 16");
     ctx->cfg.alloc_probe_tries = (int)value;
+    return IBU_OK;
+  }
+  if (strcmp(key, "peer_access") == 0) {
+    if (value != 0 && value != 1) return err_arg("peer_access must be 0 or 1");
+    ctx->peer_access = (int)value;
+    return IBU_OK;
+  }
+  if (strcmp(key, "numa") == 0) {
+    if (value != 0 && value != 1) return err_arg("numa must be 0 (off) or 1 (auto)");
+    ctx->numa_mode = (int)value;
     return IBU_OK;
   }
   if (strcmp(key, "trace_rows") == 0) {
@@ -145,6 +161,18 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
   return err_arg("unknown option key");
 }
 extern "C" int32_t ibu_ctx_device(const ibu_ctx_t* ctx) { return ctx ? ctx->device : -1; }
+extern "C" int32_t ibu_ctx_numa(const ibu_ctx_t* ctx, ibu_numa_info_t* out) {
+  if (!ctx || !out) return err_arg("ctx or out is NULL");
+  memset(out, 0, sizeof *out);
+  out->mode = ctx->numa_mode;
+  out->node = ctx->place.node;
+  out->usable_cpus = ctx->place.ncpus;
+  out->ring_node = ctx->ring.slots ? ctx->ring.node : -1;
+  out->ring_placed = ctx->ring.slots && ctx->ring.placed ? 1 : 0;
+  snprintf(out->pci_bus_id, sizeof out->pci_bus_id, "%s", ctx->pci_bus_id);
+  snprintf(out->cpulist, sizeof out->cpulist, "%s", ctx->place.cpulist);
+  return IBU_OK;
+}
 extern "C" void* ibu_ctx_stream(const ibu_ctx_t* ctx) { return ctx ? ctx->stream : nullptr; }
 extern "C" int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream) {
   int32_t rc = check_ctx(ctx);
@@ -160,8 +188,31 @@ extern "C" int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr) 
 }
 // Long-lived device memory the library allocates for a caller: with the context option "alloc_probe_tries" > 1, arrays of at least
 // 256 MiB go through the placement probing below (smaller ones are not worth the candidates' time: the ring's slots, scratch).
+// Option "alloc_probe_tries": how many candidates an allocation of `bytes` draws.  Auto (0) probes only what is worth it and
+// cannot hurt: at least 1 GiB (the arrays whose placement the streaming kernels feel; smaller ones are ring slots and scratch
+// tables) and at least three candidates fitting the free memory at once (so that the candidates never push a caller out of memory).
+static uint32_t probe_tries_for(const ibu_ctx* ctx, size_t bytes) {
+  const int t = ctx->cfg.alloc_probe_tries;
+  if (t == 1) return 1;
+  if (t > 1) return bytes >= ((size_t)256 << 20) ? (uint32_t)t : 1u;
+  if (bytes < ((size_t)1 << 30)) return 1;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  const size_t fit = free_b / bytes;
+  return fit < 3 ? 1u : (fit < 4 ? (uint32_t)fit : 4u);
+}
 int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
-  if (ctx->cfg.alloc_probe_tries > 1 && bytes >= ((size_t)256 << 20)) return ibu_device_alloc_probed(ctx, bytes, (uint32_t)ctx->cfg.alloc_probe_tries, d_ptr, nullptr);
+  const uint32_t tries = probe_tries_for(ctx, bytes);
+  if (tries > 1) {
+    ibu_alloc_probe_t rep;
+    const int32_t rc = ibu_device_alloc_probed(ctx, bytes, tries, d_ptr, &rep);
+    if (rc == IBU_OK && trace_sort()) {
+      fprintf(stderr, "ibu alloc: %zu bytes probed: %u candidates, kept #%u (ms:", bytes, rep.tries, rep.chosen);
+      for (uint32_t k = 0; k < rep.tries; ++k) fprintf(stderr, " %.3f", rep.ms[k]);
+      fprintf(stderr, ")\n");
+    }
+    return rc;
+  }
   IBU_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
   return IBU_OK;
 }
@@ -195,23 +246,27 @@ extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_
   }
   uint32_t best = 0;
   if (got > 1) {
+    // The read half of the probe is the reduce kernel; it accumulates into a PRIVATE scratch accumulator, never into ctx->d_acc:
+    // reset; {load_to_device; reduce} x N; fetch must add up over all N files whether or not the loads were probed.
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint64_t* d_probe_acc = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_probe_acc), kReduceAccBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_probe_acc, 0, kReduceAccBytes, ctx->stream);
     for (uint32_t k = 0; k < got && e == hipSuccess; ++k)
       for (int run = 0; run < 2 && e == hipSuccess; ++run) {   // the first run touches the pages' translations
         e = hipEventRecord(e0, ctx->stream);
         if (e == hipSuccess) e = launch_generate(ctx->cfg, 0x1B0, 0, nrec, 32, 32, cand[k], ctx->stream);
-        if (e == hipSuccess) e = launch_reduce(ctx->cfg, cand[k], nrec, ctx->d_acc, ctx->stream);
+        if (e == hipSuccess) e = launch_reduce(ctx->cfg, cand[k], nrec, d_probe_acc, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms[k], e0, e1);
       }
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream);   // the accumulator is the caller's again
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (d_probe_acc) (void)hipFree(d_probe_acc);
     if (e != hipSuccess) {
       for (uint32_t k = 0; k < got; ++k) (void)hipFree(cand[k]);
       return hip_fail(e, "ibu_device_alloc_probed");

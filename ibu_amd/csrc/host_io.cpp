@@ -65,7 +65,7 @@ extern "C" const char* ibu_status_name(int32_t s) {
 extern "C" const char* ibu_version(void) { return "ibu_hip 0.1.0 (format v2, reference ibu 0.2.1, gfx950)"; }
 // 2: + device_copy, barcode_counts, decode_to_host, write_ascii_batch, ctx_set_option
 // 3: ibu_decode_sink_t.cap_records (layout change), + lower_bound_records, "base_order" / "sort_variant" options
-extern "C" uint32_t ibu_abi_revision(void) { return 3; }
+extern "C" uint32_t ibu_abi_revision(void) { return 4; }
 extern "C" void ibu_free(void* p) { free(p); }
 
 // ------------------------------------------------------------------------------------------
@@ -1149,8 +1149,10 @@ int32_t ibu::reader_read_direct(ibu_reader_t* r, uint8_t* dst, size_t cap_bytes,
     if (got == 0) { *eof = true; break; }
     read += got;
   }
-  if (read % IBU_RECORD_SIZE != 0)                     // only at the end of the stream: it ends inside a record
-    return err_truncated(r->bytes_read + (read - read % IBU_RECORD_SIZE));
+  if (read % IBU_RECORD_SIZE != 0) {                   // only at the end of the stream: it ends inside a record
+    *got_bytes = read - read % IBU_RECORD_SIZE;        // the complete records in front of the cut (the pull stream hands out their whole refills)
+    return err_truncated(r->bytes_read + *got_bytes);
+  }
   r->bytes_read += read;
   *got_bytes = read;
   return IBU_OK;

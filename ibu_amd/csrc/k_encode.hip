@@ -160,23 +160,32 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
 // Single ASCII column -> u64 codes.  NT 128-row tiles per wave iteration: two for the specialised rows of at most 16 bases, at five
 // or four waves per SIMD instead of eight (round 3 measured two tiles at eight waves: they spilled) — same arrays, one process, 1e9 rows
 // (profiles/r04_t_kbench_pack_unpack.jsonl): pack<16> 5.17 -> 5.37 TB/s, pack<12> 5.15 -> 5.29, pack<8> 5.24 -> 5.32.
+// Runtime lengths (LEN == 0) are staged as their code stream, whose dword c is chunk c of the column whatever the length: GNT
+// tiles and RND load rounds per iteration chosen by the launcher so that every round carries chunks — 4 tiles for rows of at most
+// 8 bases, 2 up to 24, 1 beyond, and ceil(len * GNT / 8) rounds.  Round 4 staged one tile four rounds deep at any length: at 5
+// bases three of the four loads of a lane re-read the column's last chunk (2.0 vector loads per row where 0.31 carry data; SQ
+// pass profiles/r05_b_sq5) and the kernel ran 0.86 of its own 5R:8W yardstick.
 constexpr int pack_nt(int len) { return (len > 0 && len <= 16) ? 2 : 1; }
-template <int LEN, bool MSB>
-__global__ void __launch_bounds__(kBlock, LEN == 0 ? 8 : LEN <= 12 ? 5 : 4)   // (what two tiles of rows leave: 69-80 / 108 VGPRs)
+template <int LEN, bool MSB, int GNT = 1, int RND = 0>
+__global__ void __launch_bounds__(kBlock, LEN == 0 ? ((GNT >= 4 || RND >= 5) ? 6 : 8) : LEN <= 12 ? 5 : 4)   // (what two tiles of rows leave: 69-80 / 108 VGPRs; four
+                                                                                              // tiles of runtime-length rows spill under 64)
 ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles /*of NT x 128 rows*/, u32 len, u64* __restrict__ codes,
            u64* __restrict__ status) {
-  constexpr int NT = pack_nt(LEN), kRows = kTileRecs * NT;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kRows * 32];
+  constexpr int NT = LEN > 0 ? pack_nt(LEN) : GNT, kRows = kTileRecs * NT;
+  // a wave's slice: the ASCII rows of its tiles, or (LEN == 0) their code stream — 4 bytes per chunk, 64 chunks per round, padded
+  // for stream_row's third dword
+  constexpr u32 kWaveLds = LEN > 0 ? (u32)(kRows * LEN) : (u32)(256 * (RND > 0 ? RND : 4)) + kStreamPad;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * kWaveLds];
   const u32 lane = threadIdx.x & (kWave - 1);
   const u32 wib = threadIdx.x >> 6;
-  uint8_t* asc = lds + wib * kRows * 32;
+  uint8_t* asc = lds + wib * kWaveLds;
   const TileRange tr = tile_range(ntiles, wib);   // which tiles this wave sweeps (kcommon.hpp)
   const u32 nwaves = tr.stride;
   u32 t = tr.t;
   ntiles = tr.end;
   if (LEN > 0) len = LEN;
   if (t >= ntiles) return;
-  AsciiStage<LEN, NT> sv;
+  AsciiStage<LEN, NT, RND> sv;
   sv.issue(in + (size_t)t * kRows * len, len, lane);
   BadRows bad;
   for (;;) {
@@ -285,25 +294,48 @@ hipError_t launch_encode(const LaunchCfg& cfg, const uint8_t* bc, const uint8_t*
 }
 
 typedef void (*PackFn)(const uint8_t*, u64, u32, u32, u64*, u64*);
-#define IBU_PACK_ROW(M) {ibu_k_pack<len_of_mode(0), M>, ibu_k_pack<len_of_mode(1), M>, ibu_k_pack<len_of_mode(2), M>, \
+#define IBU_PACK_ROW(M) {nullptr /* runtime lengths: pack_gen_entry */, ibu_k_pack<len_of_mode(1), M>, ibu_k_pack<len_of_mode(2), M>, \
                          ibu_k_pack<len_of_mode(3), M>, ibu_k_pack<len_of_mode(4), M>}
 static const PackFn kPackTable[2][kNumLenModes] = {IBU_PACK_ROW(false), IBU_PACK_ROW(true)};
+// Runtime lengths: tiles per iteration (4 / 2 / 1 for rows of at most 8 / 24 / 32 bases) and load rounds = ceil(len * tiles / 8).
+struct PackShape { int nt, rounds; };
+static inline PackShape pack_shape(uint32_t len) {
+  const int nt = len <= 8 ? 4 : len <= 24 ? 2 : 1;
+  return {nt, (int)(len * nt + 7) / 8};
+}
+template <bool M>
+static PackFn pack_gen_entry(int nt, int rounds) {
+  switch (nt * 10 + rounds) {
+    case 41: return ibu_k_pack<0, M, 4, 1>;   // 1-2 bases
+    case 42: return ibu_k_pack<0, M, 4, 2>;   // 3-4
+    case 43: return ibu_k_pack<0, M, 4, 3>;   // 5-6
+    case 44: return ibu_k_pack<0, M, 4, 4>;   // 7 (8 has its specialisation)
+    case 23: return ibu_k_pack<0, M, 2, 3>;   // 9-11 (12 specialised)
+    case 24: return ibu_k_pack<0, M, 2, 4>;   // 13-15
+    case 25: return ibu_k_pack<0, M, 2, 5>;   // 17-20 (round 5 measured one tile, three rounds at 20 bases: 0.93 of its 5R:2W yardstick)
+    case 26: return ibu_k_pack<0, M, 2, 6>;   // 21-24
+    default: return ibu_k_pack<0, M, 1, 4>;   // 25-31
+  }
+}
 
 hipError_t launch_pack(const LaunchCfg& cfg, const uint8_t* in, size_t n, uint32_t len, uint64_t* codes,
                        uint64_t* status, hipStream_t st) {
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   if (n == 0) return hipSuccess;
   const Span sp[2] = {{in, len}, {codes, 8}};
-  const size_t tile_rows = (size_t)kTileRecs * pack_nt(len_of_mode(mode_of_len(len)));
+  const int m = mode_of_len(len), mo = cfg.base_order ? 1 : 0;
+  const PackShape shape = m ? PackShape{pack_nt(len_of_mode(m)), 0} : pack_shape(len);
+  const size_t tile_rows = (size_t)kTileRecs * shape.nt;
   const RowSplit rs = split_rows(cfg, sp, 2, n, tile_rows);
   if (rs.head)
     hipLaunchKernelGGL(ibu_k_pack_tail, dim3(tail_grid(rs.head)), dim3(256), 0, st, in, (u64)0, (u64)rs.head, len, cfg.base_order,
                        (u64*)codes, (u64*)status);
   if (rs.main) {
     const u32 ntiles = (u32)(rs.main / tile_rows);
-    const int m = mode_of_len(len), mo = cfg.base_order ? 1 : 0;
-    static std::atomic<int> occ[2][kNumLenModes];
-    hipLaunchKernelGGL(kPackTable[mo][m], dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, kPackTable[mo][m], 0, &occ[mo][m]))),
+    const PackFn fn = m ? kPackTable[mo][m] : (mo ? pack_gen_entry<true>(shape.nt, shape.rounds) : pack_gen_entry<false>(shape.nt, shape.rounds));
+    static std::atomic<int> occ[2][kNumLenModes], occ_gen[2][33];
+    std::atomic<int>* oc = m ? &occ[mo][m] : &occ_gen[mo][len];
+    hipLaunchKernelGGL(fn, dim3(grid_for(ntiles, cfg.cus, resident_blocks<kBlock>(cfg, fn, 0, oc))),
                        dim3(kBlock), 0, st, adv(in, rs.head * len), (u64)rs.head, ntiles, len, adv((u64*)codes, 8 * rs.head),
                        (u64*)status);
   }

@@ -408,14 +408,15 @@ __device__ __forceinline__ u64 pack_row(const uint8_t* field, u32 r, u32 rt_len,
 //   LEN > 0 : ceil(LEN/8) wave-wide dwordx4 loads in straight-line code; lanes past the last
 //             chunk re-read the last chunk (same cache line as their neighbours: no extra HBM
 //             traffic) and skip the LDS write.
-//   LEN == 0: runtime length; 4 rounds, the unused ones predicated off; lands as the field's code stream.
-template <int LEN, int NT = 1>  // NT: 128-row tiles back to back (specialised lengths only)
+//   LEN == 0: runtime length; RND rounds (0: four, the most a 128-row tile of 32-base rows needs), the unused ones predicated
+//             off; lands as the field's code stream.  A caller that knows the row length class picks NT and RND so that every
+//             round carries chunks (ibu_k_pack: short rows staged four rounds deep used a quarter of their loads).
+template <int LEN, int NT = 1, int RND = 0>  // NT: 128-row tiles back to back
 struct AsciiStage {
-  static_assert(LEN > 0 || NT == 1, "a runtime-length field is staged one tile at a time");
-  static constexpr int rounds = LEN > 0 ? (LEN * NT + 7) / 8 : 4;
+  static constexpr int rounds = LEN > 0 ? (LEN * NT + 7) / 8 : (RND > 0 ? RND : 4);
   u32x4 v[rounds];
   __device__ __forceinline__ void issue(const uint8_t* g, u32 rt_len, u32 lane) {
-    const u32 last = 8 * (LEN > 0 ? (u32)(LEN * NT) : rt_len) - 1;
+    const u32 last = 8 * (LEN > 0 ? (u32)(LEN * NT) : rt_len * NT) - 1;
 #pragma unroll
     for (int i = 0; i < rounds; ++i) {
       u32 c = lane + 64 * i;
@@ -424,10 +425,10 @@ struct AsciiStage {
     }
   }
   // Registers -> LDS.  LEN > 0: the ASCII bytes, linear.  LEN == 0: every 16-byte chunk packed to the 32 code bits of its 16
-  // bases = dword c of the field's code stream (needs 32*len + kStreamPad <= 128*len bytes: the same area).  Returns false in
+  // bases = dword c of the field's code stream (the rows of the NT tiles are contiguous, so is their stream).  Returns false in
   // a lane one of whose chunks holds a byte outside ACGTacgt (LEN == 0 only; rows are attributed by the caller's slow path).
   __device__ __forceinline__ bool land(uint8_t* lds, u32 rt_len, u32 lane) const {
-    const u32 nchunks = 8 * (LEN > 0 ? (u32)(LEN * NT) : rt_len);
+    const u32 nchunks = 8 * (LEN > 0 ? (u32)(LEN * NT) : rt_len * NT);
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < rounds; ++i) {

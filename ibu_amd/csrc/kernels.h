@@ -16,7 +16,7 @@ struct LaunchCfg {
   int sort_compact = 1;    // compact-key passes (12-byte elements when at most 12 key bytes vary): 0 = never, k = tile shape kCompact[k-1]
   int sort_hybrid = 1;     // wide keys (more than 16 varying bytes): LSD over the top P varying bytes only, then ONE finishing pass that completes every run of equal prefix in LDS (sort.hip, ibu_k_sort_finish): 0 = never, 1 = when at least three passes are saved, 2 = whenever one is (tests)
   int sort_idx64 = 0;      // test knob: 1 = the sort indexes with 64 bits at any size (the kernels inputs of 2^32 records and more take)
-  int alloc_probe_tries = 1; // placement probing inside the library: allocations of at least 256 MiB the library makes for the caller (ibu_device_alloc, ibu_load_to_device's destination) draw this many candidates and keep the fastest (device.cpp: ibu_device_alloc_probed); 1 = plain hipMalloc
+  int alloc_probe_tries = 0; // placement probing inside the library, for resident arrays the library allocates (ibu_device_alloc, ibu_load_to_device's destination, the sort scratch): 0 = auto (>= 1 GiB and at least three candidates fit: up to four), 1 = plain hipMalloc, k = allocations of at least 256 MiB draw k candidates and keep the fastest (device.cpp: ibu_device_alloc_probed)
   int trace_rows = 0;      // tests: one stderr line per launch saying how many rows took the tiled / the tail kernel (kcommon.hpp: split_rows)
   uint32_t base_order = 0; // bit order of the 2-bit codec: 0 = base i at bits [2i,2i+1] (default), 1 = first base most significant
 };
@@ -66,6 +66,7 @@ hipError_t launch_mismatch(const LaunchCfg&, const void* a, const void* b, size_
 hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
 
 // sort.hip
+bool trace_sort();   // IBU_TRACE_SORT set to anything but "" / "0" (read once): one stderr line per sort / probed allocation saying what was chosen
 hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n, void* scratch,
                                size_t scratch_bytes, hipStream_t st);
 size_t sort_scratch_bytes(const LaunchCfg&, size_t n);

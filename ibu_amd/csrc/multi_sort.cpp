@@ -4,7 +4,12 @@
 // process_parallel.  Sample sort: samples of all shards pick n - 1 splitters, every record travels to the
 // owner of the range between two splitters device to device (hipMemcpyPeerAsync: over xGMI between GPUs, a plain copy inside
 // one), and shard i ends up with the i-th contiguous range of the global order.  A host thread per context, like
-// process_contexts (stream.cpp); the phases are separated by joins, which is all the cross-device ordering there is.
+// process_contexts (stream.cpp).  Ordering across devices (partition-first forms): the two points at which the HOST needs every
+// shard's answer — the samples (to pick the splitters) and the range counts of the partition pass (to cut the owners' pieces; the
+// sizes of the peer copies are host arguments) — are joins; from there on the devices order themselves: an owner's sort is
+// queued behind its own pulls on its stream and behind the "pulled" events of the owners that read its scratch
+// (hipStreamWaitEvent across devices), and the call joins once more at the end.  Round 4 joined after the exchange as well: no
+// owner sorted until the slowest pull of ANY owner had finished.
 //
 // Three forms.  PARTITION FIRST ON ELEMENTS (round 4; keys of which at most 11 bytes vary over ALL shards — 16/12 records with
 // indices below 2^32 —, up to 256 shards, 16-byte aligned buffers): nothing is sorted before the exchange.  A shard is compacted to
@@ -69,9 +74,10 @@ int32_t on_every_context(size_t n, F&& fn) {
 
 // Direct xGMI access where the topology has it (current device = the puller's); already enabled, or not possible (the runtime
 // stages the copy then): neither is an error.  Peer access stays enabled for the rest of the process.
-void enable_peer(int self, int peer) {
+void enable_peer(const ibu_ctx* puller, int peer) {
+  const int self = puller->device;
   int can = 0;
-  if (self != peer && hipDeviceCanAccessPeer(&can, self, peer) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(peer, 0);
+  if (puller->peer_access && self != peer && hipDeviceCanAccessPeer(&can, self, peer) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(peer, 0);
   (void)hipGetLastError();
 }
 
@@ -107,6 +113,9 @@ size_t sample_budget(size_t W) {
   const size_t want = 512 * W;                                // ~512 samples per owner: its share is known to a few percent
   return want < 16384 ? 16384 : (want > (1u << 19) ? (1u << 19) : want);
 }
+
+constexpr size_t kPartitionFirstMaxShards = 32;
+constexpr int32_t kLandingFailed = -77;   // internal: a shard would receive more than its capacity (detail set); the partition-first forms fall back on it
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -151,13 +160,59 @@ void cut_owners(const ibu_sort_shard_t* shards, size_t W, const std::vector<std:
     for (size_t j = 0; j <= W; ++j) bound[i][j] = fine[i][cut[j]];
 }
 
+// The exchange and the owners' sorts without a join between them.  pull(j, i, cnt, first, land): queue owner j's copy of `cnt`
+// units of shard i, from unit `first` of its partitioned scratch to unit `land` at the owner, on ctxs[j]->stream.
+// sort(j): queue owner j's sort on ctxs[j]->stream (may synchronise that stream itself).  What orders them:
+//   - owner j's sort follows its own pulls in its stream;
+//   - the sort overwrites shard j's scratch, which the OTHER owners read: it waits (hipStreamWaitEvent, across devices) for the
+//     `pulled` event of every owner that takes a piece of shard j.  The events are recorded by an enqueue-only round of the
+//     host threads (no device is waited for) before any sort is queued — an event that has not been recorded yet would not be
+//     waited for.
+// One join at the end.  *t_enqueue_ms / *t_total_ms: for the trace.
+template <class Pull, class Sort>
+int32_t exchange_then_sort(ibu_ctx_t* const* ctxs, size_t W, const std::vector<std::vector<uint64_t>>& bound, const std::vector<std::vector<size_t>>& land,
+                           Pull pull, Sort sort, double* t_enqueue_ms) {
+  std::vector<hipEvent_t> pulled(W, nullptr);
+  const double t0 = now_ms();
+  int32_t rc = on_every_context(W, [&](size_t j) -> int32_t {
+    IBU_HIP(hipSetDevice(ctxs[j]->device));
+    IBU_HIP(hipEventCreateWithFlags(&pulled[j], hipEventDisableTiming));
+    for (size_t i = 0; i < W; ++i) {
+      const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
+      if (!cnt) continue;
+      enable_peer(ctxs[j], ctxs[i]->device);
+      const int32_t r = pull(j, i, cnt, (size_t)bound[i][j], land[j][i]);
+      if (r) return r;
+    }
+    IBU_HIP(hipEventRecord(pulled[j], ctxs[j]->stream));
+    return IBU_OK;
+  });
+  *t_enqueue_ms = now_ms() - t0;
+  if (rc == IBU_OK)
+    rc = on_every_context(W, [&](size_t j) -> int32_t {
+      IBU_HIP(hipSetDevice(ctxs[j]->device));
+      for (size_t k = 0; k < W; ++k)
+        if (k != j && bound[j][k + 1] > bound[j][k]) IBU_HIP(hipStreamWaitEvent(ctxs[j]->stream, pulled[k], 0));   // owner k reads shard j's scratch
+      const int32_t r = sort(j);
+      if (r) return r;
+      IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
+      return IBU_OK;
+    });
+  if (rc != IBU_OK)                                            // leave nothing in flight over the shards (their contents are unspecified now)
+    for (size_t j = 0; j < W; ++j) { (void)hipSetDevice(ctxs[j]->device); (void)hipStreamSynchronize(ctxs[j]->stream); }
+  for (size_t j = 0; j < W; ++j)
+    if (pulled[j]) { (void)hipSetDevice(ctxs[j]->device); (void)hipEventDestroy(pulled[j]); }
+  return rc;
+}
+
 // ---- PARTITION FIRST -------------------------------------------------------------------------------------------------------
 // `guessed`: the plan comes from SAMPLE censuses (three ranges of every shard); the partition pass then accumulates the exact census of
 // every record on the way, and *covered says afterwards whether the guess was the truth — the same bytes vary.  If it was not
 // (false), nothing has been exchanged and no record touched: the caller runs the call again with the exact plan it now has.
+// `split`: the 255 splitters; empty = sample the shards and pick them, kept for a second run (a plan miss re-runs only the partition pass).
 int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, const CompactPlan& plan, size_t total, bool guessed,
-                             std::vector<std::array<uint64_t, 8>>* exact_words, bool* covered) {
-  const bool trace = getenv("IBU_TRACE_SORT") != nullptr;
+                             std::vector<std::array<uint64_t, 8>>* exact_words, bool* covered, std::vector<Rec>& split) {
+  const bool trace = trace_sort();
   double t_mark = now_ms(), t_phase[5] = {0, 0, 0, 0, 0};
   auto lap = [&](int k) { const double t = now_ms(); t_phase[k] = t - t_mark; t_mark = t; };
   // 1. 255 splitters from samples of the (unsorted) shards cut the key space into 256 FINE ranges — more than there are owners:
@@ -165,11 +220,13 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   //    an owner gets (a range is ~1/256 of the records: the owners' loads differ by about that much, not by the sampling noise
   //    of W - 1 splitters drawn from unsorted data)
   constexpr size_t F = 256;
-  std::vector<std::vector<Rec>> samp(W);
-  int32_t rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
-  if (rc) return rc;
-  std::vector<Rec> split;
-  pick_splitters(samp, F, split);
+  int32_t rc = IBU_OK;
+  if (split.empty()) {
+    std::vector<std::vector<Rec>> samp(W);
+    rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
+    if (rc) return rc;
+    pick_splitters(samp, F, split);
+  }
   lap(0);
   // 2. every shard: records -> elements stamped with their range (one kernel) -> range order in the upper half of its scratch;
   //    fine[i][f] = first element of range f.
@@ -224,40 +281,33 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   std::vector<size_t> n_out(W, 0);
   std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));   // land[j][i]: element offset of shard i's piece at owner j
   rc = plan_landing(shards, W, bound, n_out, land, "no shard's records were touched");
-  if (rc) return rc;
-  // 3. the exchange: every owner pulls its pieces into the LOWER half of its scratch (its own unpartitioned elements: dead)
-  rc = on_every_context(W, [&](size_t j) -> int32_t {
-    IBU_HIP(hipSetDevice(ctxs[j]->device));
-    uint8_t* t = static_cast<uint8_t*>(shards[j].d_tmp);
-    for (size_t i = 0; i < W; ++i) {
-      const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
-      if (!cnt) continue;
-      enable_peer(ctxs[j]->device, ctxs[i]->device);
-      const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + 12 * (shards[i].capacity + bound[i][j]);
-      IBU_HIP(hipMemcpyPeerAsync(t + 12 * land[j][i], ctxs[j]->device, src, ctxs[i]->device, 12 * cnt, ctxs[j]->stream));
-    }
-    IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
-    return IBU_OK;
-  });
-  if (rc) return rc;                                          // (joined: the upper halves are not read any more)
+  if (rc) return kLandingFailed;
   lap(2);
-  // 4. every owner sorts what it received, elements -> records
-  rc = on_every_context(W, [&](size_t j) -> int32_t {
-    ibu_ctx_t* c = ctxs[j];
-    if (!n_out[j]) return IBU_OK;
-    IBU_HIP(hipSetDevice(c->device));
-    const size_t need = sort_scratch_bytes(c->cfg, n_out[j]);
-    int32_t r = ensure_sort_scratch(c, need);
-    if (r) return r;
-    IBU_HIP(launch_sort_elems(c->cfg, plan, shards[j].d_records, shards[j].d_tmp, n_out[j], prefix_passes, c->d_sort_scratch, c->sort_scratch_bytes, c->stream));
-    IBU_HIP(hipStreamSynchronize(c->stream));
-    return IBU_OK;
-  });
+  // 3. the exchange — every owner pulls its pieces into the LOWER half of its scratch (its own unpartitioned elements: dead) — and
+  // 4. every owner sorts what it received, elements -> records, queued behind its pulls and behind the pulls that read ITS upper half
+  double t_enq = 0;
+  rc = exchange_then_sort(
+      ctxs, W, bound, land,
+      [&](size_t j, size_t i, size_t cnt, size_t first, size_t at) -> int32_t {
+        const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + 12 * (shards[i].capacity + first);
+        IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_tmp) + 12 * at, ctxs[j]->device, src, ctxs[i]->device, 12 * cnt, ctxs[j]->stream));
+        return IBU_OK;
+      },
+      [&](size_t j) -> int32_t {
+        ibu_ctx_t* c = ctxs[j];
+        if (!n_out[j]) return IBU_OK;
+        const size_t need = sort_scratch_bytes(c->cfg, n_out[j]);
+        int32_t r = ensure_sort_scratch(c, need);
+        if (r) return r;
+        IBU_HIP(launch_sort_elems(c->cfg, plan, shards[j].d_records, shards[j].d_tmp, n_out[j], prefix_passes, c->d_sort_scratch, c->sort_scratch_bytes, c->stream));
+        return IBU_OK;
+      },
+      &t_enq);
   if (rc) return rc;
   lap(3);
   if (trace)
-    fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u; ms: samples %.2f, partition %.2f, exchange %.2f, sort %.2f)\n", W,
-            prefix_passes, t_phase[0], t_phase[1], t_phase[2], t_phase[3]);
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u; host joins: samples, range counts, end; ms: samples %.2f, "
+            "partition %.2f, plan %.2f, exchange+sort %.2f of which enqueueing the pulls %.2f)\n", W, prefix_passes, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_enq);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
 }
@@ -267,7 +317,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
 // kernels cannot take.  A record's key range goes into the digit side stream, one 24-byte pass of the sort puts the records in range
 // order in the shard's scratch, the owners pull their pieces over their own (dead) records and sort them once.  No census at all.
 int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, size_t total) {
-  const bool trace = getenv("IBU_TRACE_SORT") != nullptr;
+  const bool trace = trace_sort();
   double t_mark = now_ms(), t_phase[4] = {0, 0, 0, 0};
   auto lap = [&](int k) { const double t = now_ms(); t_phase[k] = t - t_mark; t_mark = t; };
   constexpr size_t F = 256;
@@ -304,32 +354,25 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   std::vector<size_t> n_out(W, 0);
   std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));
   rc = plan_landing(shards, W, bound, n_out, land, "no shard's records were touched");
-  if (rc) return rc;
-  // the exchange: every owner pulls its pieces from the shards' scratch over its own records (partitioned into its scratch: dead)
-  rc = on_every_context(W, [&](size_t j) -> int32_t {
-    IBU_HIP(hipSetDevice(ctxs[j]->device));
-    uint8_t* d = static_cast<uint8_t*>(shards[j].d_records);
-    for (size_t i = 0; i < W; ++i) {
-      const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
-      if (!cnt) continue;
-      enable_peer(ctxs[j]->device, ctxs[i]->device);
-      const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + kRec * bound[i][j];
-      IBU_HIP(hipMemcpyPeerAsync(d + kRec * land[j][i], ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ctxs[j]->stream));
-    }
-    IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
-    return IBU_OK;
-  });
-  if (rc) return rc;                                          // (joined: the scratch arrays are not read any more)
+  if (rc) return kLandingFailed;
   lap(2);
-  rc = on_every_context(W, [&](size_t j) -> int32_t {
-    int32_t r = ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr);
-    return r ? r : ibu_ctx_synchronize(ctxs[j], nullptr);
-  });
+  // the exchange — every owner pulls its pieces from the shards' scratch over its own records (partitioned into its scratch: dead) —
+  // and the owners' sorts, each behind its own pulls and behind the pulls that read ITS scratch
+  double t_enq = 0;
+  rc = exchange_then_sort(
+      ctxs, W, bound, land,
+      [&](size_t j, size_t i, size_t cnt, size_t first, size_t at) -> int32_t {
+        const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + kRec * first;
+        IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_records) + kRec * at, ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ctxs[j]->stream));
+        return IBU_OK;
+      },
+      [&](size_t j) -> int32_t { return ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr); },
+      &t_enq);
   if (rc) return rc;
   lap(3);
   if (trace)
-    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first; ms: samples %.2f, partition %.2f, exchange %.2f, sort %.2f)\n", W, t_phase[0],
-            t_phase[1], t_phase[2], t_phase[3]);
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first; host joins: samples, range counts, end; ms: samples %.2f, partition %.2f, "
+            "plan %.2f, exchange+sort %.2f of which enqueueing the pulls %.2f)\n", W, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_enq);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
 }
@@ -386,7 +429,7 @@ int32_t sort_sort_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shar
     for (size_t i = 0; i < W; ++i) {
       const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
       if (!cnt) continue;
-      enable_peer(ctxs[j]->device, ctxs[i]->device);
+      enable_peer(ctxs[j], ctxs[i]->device);
       const uint8_t* src = static_cast<const uint8_t*>(compact ? shards[i].d_tmp : shards[i].d_records) + wire * bound[i][j];
       IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ctxs[j]->stream));
     }
@@ -406,7 +449,7 @@ int32_t sort_sort_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shar
     return r;
   });
   if (rc) return rc;
-  if (getenv("IBU_TRACE_SORT")) fprintf(stderr, "ibu sort: contexts=%zu exchange=%zu bytes per record (sort first)\n", W, wire);
+  if (trace_sort()) fprintf(stderr, "ibu sort: contexts=%zu exchange=%zu bytes per record (sort first)\n", W, wire);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
 }
@@ -451,11 +494,17 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
           for (int f = 0; f < 3; ++f) { o[f] |= words[i][f]; a[f] &= words[i][3 + f]; }
       compact_plan_init(o, a, out);
     };
-    if (ctxs[0]->cfg.sort_compact != 0 && total > 0 && W <= 256) {      // PARTITION FIRST: elements if the keys allow it, else records
+    // PARTITION FIRST while an owner's share is many of the 256 fine ranges (the owners are cut at range boundaries: loads are
+    // quantised to total / 256 — 3 % of a share with 8 shards, 12 % with 32; beyond that the sort-first form cuts finer), elements
+    // if the keys allow it, else records.  A cut that does not fit a shard's capacity falls back to the sort-first form as
+    // well: nothing has moved at that point (the partitioned copies sit in the scratch arrays).
+    if (ctxs[0]->cfg.sort_compact != 0 && total > 0 && W <= kPartitionFirstMaxShards) {
+      int32_t rc = IBU_OK;
+      bool tried_elements = false;
       if (aligned) {
         bool all_exact = true;
         std::vector<char> was_exact(W, 1);
-        int32_t rc = on_every_context(W, [&](size_t i) -> int32_t {
+        rc = on_every_context(W, [&](size_t i) -> int32_t {
           ibu_ctx_t* c = ctxs[i];
           if (!shards[i].n) return IBU_OK;
           IBU_HIP(hipSetDevice(c->device));
@@ -474,15 +523,22 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
         combine(&plan);
         if (plan.k <= 11) {
           bool covered = true;
-          rc = sort_partition_first(ctxs, W, shards, plan, total, !all_exact, &words, &covered);
-          if (rc || covered) return rc;
-          combine(&plan);                                       // `words` now holds every shard's exact census
-          if (plan.k <= 11) return sort_partition_first(ctxs, W, shards, plan, total, false, &words, &covered);
+          std::vector<Rec> split;                               // sampled once: a plan miss re-runs the partition pass only
+          tried_elements = true;
+          rc = sort_partition_first(ctxs, W, shards, plan, total, !all_exact, &words, &covered, split);
+          if (rc == IBU_OK && !covered) {
+            combine(&plan);                                     // `words` now holds every shard's exact census
+            tried_elements = plan.k <= 11;
+            if (tried_elements) rc = sort_partition_first(ctxs, W, shards, plan, total, false, &words, &covered, split);
+          }
         }
       }
-      return sort_partition_first_records(ctxs, W, shards, total);   // more than 11 varying key bytes, or buffers the element kernels cannot take
+      if (!tried_elements) rc = sort_partition_first_records(ctxs, W, shards, total);   // more than 11 varying key bytes, or buffers the element kernels cannot take
+      if (rc != kLandingFailed) return rc;
+      if (trace_sort()) fprintf(stderr, "ibu sort: contexts=%zu the range cut does not fit a shard's capacity: falling back to the sort-first form\n", W);
+      return sort_sort_first(ctxs, W, shards, plan, false);
     }
-    // SORT FIRST: told to (sort_compact = 0 on ctxs[0]), more than 256 shards, or nothing to sort
+    // SORT FIRST: told to (sort_compact = 0 on ctxs[0]), more than 32 shards, or nothing to sort
     if (ctxs[0]->cfg.sort_compact != 0 && total > 0) {
       int32_t rc = on_every_context(W, [&](size_t i) -> int32_t { return ibu_records_census(ctxs[i], shards[i].d_records, shards[i].n, words[i].data(), nullptr); });
       if (rc) return rc;

@@ -361,7 +361,6 @@ hipError_t launch_expand(const LaunchCfg& cfg, const CompactPlan& pl, const void
 // ibu_k_sort_finish_elems completes the runs of equal prefix and writes the records; if it overflows (long runs), all passes run
 // after all, starting from the prefix-sorted elements wherever they ended (elems_at).  W = 4 needs an even P (the elements must
 // end in tmp: the records are written over the other buffer).
-static bool trace_sort();
 template <int W>
 static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVariant& cv, void* recs, void* tmp, size_t n, uint8_t* sc,
                                         const CompactPlan& pl, const u32* passes, u32 npass, hipStream_t st, bool compressed = false,
@@ -482,7 +481,7 @@ static hipError_t launch_compact_passes(const LaunchCfg& cfg, const CompactVaria
 }
 
 // IBU_TRACE_SORT=1: one line per sort on stderr saying which path it took (tests assert on it; never set in production)
-static bool trace_sort() {
+bool trace_sort() {
   static const bool on = [] { const char* v = getenv("IBU_TRACE_SORT"); return v && *v && *v != '0'; }();
   return on;
 }

@@ -5,14 +5,22 @@
 //
 //   file/mmap/gz --host threads--> pinned[slot] --copy_stream H2D--> dev[slot] --stream--> kernel
 //
+// ONE pipeline feeds the device: the pull stream (ibu_stream_*, below) — a producer thread that fills pinned slots and queues
+// their H2D copies, and a consumer that takes device-resident batches in order.  ibu_mmap_process_device and
+// ibu_reader_process_device are that consumer with one of the two built-in processors as the loop body.
+//
 // These are the device-backed forms of load_to_vec (reader.rs:510-535), Writer::write_batch
 // (writer.rs:315-351), MmapReader::process_parallel (mmap.rs:286-332, ONE shard of its static
 // split per call = per GPU) and the streaming Reader (reader.rs:279-306, incl. the gzip path
 // of reader.rs:345-352).
 #include <errno.h>
+#include <pthread.h>
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -133,28 +141,6 @@ int32_t make_proc(ibu_ctx* ctx, int32_t proc, const ibu_header_t& h, void* sink,
   return IBU_OK;
 }
 
-// Push one filled pinned slot to the device and run the processor on it.
-int32_t submit_slot(ibu_ctx* ctx, KernelClock& kc, DeviceProc& dp, uint32_t s, size_t n, size_t row0,
-                    ibu_stream_stats_t* stats) {
-  Ring& r = ctx->ring;
-  const size_t bytes = n * IBU_RECORD_SIZE;
-  IBU_HIP(hipMemcpyAsync(r.dev[s], r.pinned[s], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-  IBU_HIP(hipEventRecord(r.copied[s], ctx->copy_stream));
-  IBU_HIP(hipStreamWaitEvent(ctx->stream, r.copied[s], 0));
-  IBU_HIP(hipEventRecord(kc.a[s], ctx->stream));
-  int32_t rc = dp.launch(r.dev[s], n, row0);
-  if (rc) return rc;
-  IBU_HIP(hipEventRecord(kc.b[s], ctx->stream));
-  IBU_HIP(hipEventRecord(r.consumed[s], ctx->stream));
-  kc.live[s] = 1;
-  if (stats) {
-    stats->bytes_h2d += bytes;
-    stats->records += n;
-    stats->batches += 1;
-  }
-  return IBU_OK;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -178,6 +164,7 @@ int32_t ibu::ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_d
   slot_records = (slot_records + 127) & ~(size_t)127;  // whole kernel tiles, 16-B aligned column offsets
   const size_t slot_bytes = slot_records * IBU_RECORD_SIZE;
   Ring& r = ctx->ring;
+  if (ctx->ring_lent) return err_arg("the context's ring is lent to an open ibu_stream_t: close the stream first (or use a second context)");
   if (r.slots == slots && r.slot_bytes == slot_bytes && (!need_dev || !r.dev.empty())) return IBU_OK;
   (void)hipStreamSynchronize(ctx->copy_stream);
   (void)hipStreamSynchronize(ctx->stream);
@@ -189,8 +176,17 @@ int32_t ibu::ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_d
     IBU_HIP(hipEventCreateWithFlags(&r.copied[i], hipEventDisableTiming));
     IBU_HIP(hipEventCreateWithFlags(&r.consumed[i], hipEventDisableTiming));
   }
-  for (uint32_t i = 0; i < slots; ++i)
-    IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.pinned[i]), slot_bytes, hipHostMallocDefault));
+  {
+    // Option "numa": the pinned slots on the node the device hangs off.  Under a preferred-node policy of this thread the
+    // allocation follows it (hipHostMallocNumaUser); a kernel that refuses the policy (a container's seccomp profile) leaves
+    // the runtime's own choice, as before.  Either way ring.node says where the pages are, if the kernel will tell.
+    PreferNode prefer(ctx->numa_mode ? ctx->place.node : -1);
+    const unsigned flags = prefer.active() ? hipHostMallocNumaUser : hipHostMallocDefault;
+    for (uint32_t i = 0; i < slots; ++i)
+      IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.pinned[i]), slot_bytes, flags));
+    r.placed = prefer.active();
+  }
+  r.node = node_of_range(r.pinned[0], slot_bytes);
   if (need_dev) {
     r.dev.assign(slots, nullptr);
     for (uint32_t i = 0; i < slots; ++i) IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.dev[i]), slot_bytes));
@@ -208,6 +204,7 @@ extern "C" int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ib
                                       ibu_stream_stats_t* stats) {
   if (!ctx || !path || !header || !d_records || !n) return err_arg("NULL argument");
   IBU_HIP(hipSetDevice(ctx->device));
+  RunOnNode on_node(feed_place(ctx));   // for the length of the call this thread and the pread threads it starts run on the device's node (option "numa")
   const double t0 = now_s();
   int fd = -1;
   size_t num = 0;
@@ -272,6 +269,7 @@ extern "C" int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* 
                                                     ibu_stream_stats_t* stats) {
   if (!w || !ctx || (!d_records && n)) return err_arg("NULL argument");
   IBU_HIP(hipSetDevice(ctx->device));
+  RunOnNode on_node(feed_place(ctx));   // the copies pinned ring -> writer buffer / file on the device's node (option "numa")
   const double t0 = now_s();
   if (stats) memset(stats, 0, sizeof *stats);
   int32_t rc = ring_ensure(ctx, cfg, false);
@@ -310,13 +308,404 @@ extern "C" int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* 
 }
 
 // ------------------------------------------------------------------------------------------
-// MmapReader::process_parallel, device form (one shard of the static split)
+// The pull stream: Reader::read_batch + Iterator (reader.rs:218-242, :279-306) and the per-batch loop of process_parallel
+// (mmap.rs:312-320) with the batch in HBM
 // ------------------------------------------------------------------------------------------
+// A producer thread owns the source, the pinned slots and the copy stream; the consumer (the caller's thread) owns the order in
+// which batches are taken and the streams that read them.  Slot s goes FREE -> (filled, H2D queued) READY -> (next) HELD ->
+// (release: `consumed[s]` recorded on the caller's stream) RELEASED -> (producer waits for that event) refilled.  The producer
+// fills slots in ring order, so a batch held for long stalls the ring when its turn comes again — never correctness.
+struct ibu_stream {
+  ibu_ctx* ctx = nullptr;
+  ibu_header_t header{};
+  ibu_reader_t* rd = nullptr;        // source: a borrowed Reader ...
+  const ibu_mmap_t* m = nullptr;     // ... or records [start, end) of a map
+  size_t start = 0, end = 0;
+  uint32_t feeders = 4;
+  size_t slot_records = 0;
+  uint64_t first0 = 0;               // number of the stream's first record (mmap: start; reader: 0)
+  double t0 = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  enum : uint8_t { FREE, READY, HELD, RELEASED };
+  struct Slot { uint8_t state = FREE; size_t n = 0; uint64_t first = 0; };
+  std::vector<Slot> slot;
+  std::deque<uint32_t> ready;        // READY slots in stream order
+  uint32_t held = 0;
+  bool stop = false, done = false;
+  int32_t rc = IBU_OK;               // the source's error, delivered after the batches in front of it
+  ibu_error_detail_t detail{};
+  ibu_stream_stats_t stats{};
+  std::vector<uint8_t> stage;        // Reader sources with slots smaller than one refill: the refill being handed out piecewise
+  size_t stage_pos = 0, stage_len = 0;   // records
+  bool src_eof = false;              // the Reader source reported its end
+  std::thread producer;
+};
+
+namespace {
+
+// One slot's worth of a Reader source into `dst`: *filled records to deliver (possibly > 0 together with an error: the batch in
+// front of a truncation), *eof = the source has ended.
+// The stream delivers EXACTLY the records the reference's iterator yields, also in front of an error.  The reference refills
+// IBU_DEFAULT_BUFFER_SIZE (= 49 152 records) at a time and a source that ends inside a record loses its whole final refill
+// (reader.rs:232-237, quirk Q8); a record may therefore only be handed out once the refill it belongs to has arrived whole.
+// So the stream reads in whole refills, counted from where it took over (the reader's own buffer empty = a refill boundary):
+//   a slot of at least one refill asks the source for floor(room / refill) refills in one call, straight into the pinned slot
+//     (parallel preads of a plain file, the inflate threads' own copies; no detour through the reader's buffer) — every batch
+//     ends on a refill boundary;
+//   a smaller slot (test rings) goes through a one-refill staging buffer.
+int32_t fill_from_reader(ibu_stream* s, uint8_t* dst, size_t* filled, bool* eof) {
+  ibu_reader_t* rd = s->rd;
+  const size_t cap = s->slot_records;
+  constexpr size_t kRefill = IBU_DEFAULT_BUFFER_SIZE, kRefillRecords = kRefill / IBU_RECORD_SIZE;
+  size_t n = 0;
+  *filled = 0;
+  for (;;) {
+    const ibu_record_t* recs;
+    size_t have = 0;
+    ibu_reader_buffered(rd, &recs, &have);
+    if (have == 0) break;            // records the caller had pulled into the reader's buffer before the stream took over go first
+    const size_t take = have < cap - n ? have : cap - n;
+    memcpy(dst + n * IBU_RECORD_SIZE, recs, take * IBU_RECORD_SIZE);
+    ibu_reader_consume(rd, take);
+    n += take;
+    if (n == cap) { *filled = n; return IBU_OK; }
+  }
+  if (s->stage_pos < s->stage_len) {                   // small slots: the rest of the staged refill
+    const size_t take = s->stage_len - s->stage_pos < cap - n ? s->stage_len - s->stage_pos : cap - n;
+    memcpy(dst + n * IBU_RECORD_SIZE, s->stage.data() + s->stage_pos * IBU_RECORD_SIZE, take * IBU_RECORD_SIZE);
+    s->stage_pos += take;
+    *filled = n + take;
+    *eof = s->src_eof && s->stage_pos == s->stage_len;
+    return IBU_OK;
+  }
+  if (s->src_eof) { *filled = n; *eof = true; return IBU_OK; }
+  const size_t room = cap - n;
+  if (room >= kRefillRecords) {
+    const size_t ask = room / kRefillRecords * kRefill;
+    size_t got = 0;
+    const int32_t rc = reader_read_direct(rd, dst + n * IBU_RECORD_SIZE, ask, &got, &s->src_eof);
+    if (rc == IBU_ERR_TRUNCATED_RECORD) {              // `got` = the complete record bytes in front of the cut: its whole refills go out
+      *filled = n + got / kRefill * kRefillRecords;
+      *eof = true;
+      return rc;
+    }
+    if (rc) { *eof = true; return rc; }
+    *filled = n + got / IBU_RECORD_SIZE;
+    *eof = s->src_eof;               // a short read is the end of the source: this batch is the last
+    return IBU_OK;
+  }
+  if (n) { *filled = n; return IBU_OK; }               // buffered records left less than a refill of room: a short batch
+  try {
+    if (s->stage.size() < kRefill) s->stage.resize(kRefill);
+  } catch (...) {
+    *eof = true;
+    return caught_io("ibu_stream: staging buffer");
+  }
+  size_t got = 0;
+  const int32_t rc = reader_read_direct(rd, s->stage.data(), kRefill, &got, &s->src_eof);
+  if (rc) { *eof = true; return rc; }                  // truncated: the final refill is dropped whole
+  s->stage_len = got / IBU_RECORD_SIZE;
+  s->stage_pos = s->stage_len < cap ? s->stage_len : cap;
+  memcpy(dst, s->stage.data(), s->stage_pos * IBU_RECORD_SIZE);
+  *filled = s->stage_pos;
+  *eof = s->src_eof && s->stage_pos == s->stage_len;
+  return IBU_OK;
+}
+
+void stream_produce(ibu_stream* s) {
+  ibu_ctx* ctx = s->ctx;
+  Ring& r = ctx->ring;
+  (void)pthread_setname_np(pthread_self(), "ibu-feed");
+  RunOnNode on_node(feed_place(ctx));   // this thread and every thread it starts (feeders, inflate workers) on the device's node
+  int32_t rc = IBU_OK;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
+  const uint8_t* map = s->m ? static_cast<const uint8_t*>(ibu_mmap_base(s->m)) + IBU_HEADER_SIZE : nullptr;
+  uint64_t delivered = 0;
+  size_t row = s->start;
+  bool eof = s->m ? s->start >= s->end : false;
+  for (size_t k = 0; rc == IBU_OK && !eof; ++k) {
+    const uint32_t si = (uint32_t)(k % r.slots);
+    bool released = false;
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [&] { return s->stop || s->slot[si].state == ibu_stream::FREE || s->slot[si].state == ibu_stream::RELEASED; });
+      if (s->stop) break;
+      released = s->slot[si].state == ibu_stream::RELEASED;
+    }
+    if (released) {                  // the consumer's work on the slot's previous batch (and so its H2D) is done
+      e = hipEventSynchronize(r.consumed[si]);
+      if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
+    }
+    size_t n = 0;
+    int32_t src_rc = IBU_OK;
+    if (s->m) {
+      n = s->end - row < s->slot_records ? s->end - row : s->slot_records;
+      const uint8_t* srcp = map + row * IBU_RECORD_SIZE;
+      uint8_t* dst = r.pinned[si];
+      parallel_bytes(n * IBU_RECORD_SIZE, s->feeders, [&](size_t off, size_t len) {
+        memcpy(dst + off, srcp + off, len);  // page-cache / page-fault side of the reference's hot loop
+        return 0;
+      });
+      row += n;
+      eof = row >= s->end;
+    } else {
+      src_rc = fill_from_reader(s, r.pinned[si], &n, &eof);
+    }
+    if (n) {
+      const size_t bytes = n * IBU_RECORD_SIZE;
+      e = hipMemcpyAsync(r.dev[si], r.pinned[si], bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(r.copied[si], ctx->copy_stream);
+      if (e != hipSuccess) { rc = hip_fail(e, "H2D"); break; }
+      std::lock_guard<std::mutex> g(s->mu);
+      s->slot[si].state = ibu_stream::READY;
+      s->slot[si].n = n;
+      s->slot[si].first = s->first0 + delivered;
+      s->ready.push_back(si);
+      s->stats.records += n;
+      s->stats.bytes_h2d += bytes;
+      s->stats.batches += 1;
+      delivered += n;
+      s->cv.notify_all();
+    }
+    if (src_rc) rc = src_rc;
+  }
+  std::lock_guard<std::mutex> g(s->mu);
+  s->rc = rc;
+  if (rc) s->detail = tls_error();   // the detail lives in THIS thread's slot: next() copies it into its caller's
+  s->done = true;
+  s->cv.notify_all();
+}
+
+int32_t stream_open(ibu_ctx* ctx, const ibu_ring_config_t* cfg, ibu_stream* s) {
+  IBU_HIP(hipSetDevice(ctx->device));
+  int32_t rc = ring_ensure(ctx, cfg, true);
+  if (rc) return rc;
+  Ring& r = ctx->ring;
+  s->ctx = ctx;
+  s->feeders = feeder_threads(cfg);
+  s->slot_records = r.slot_bytes / IBU_RECORD_SIZE;
+  s->t0 = now_s();
+  s->stats.numa_node = feed_place(ctx).node;
+  s->stats.ring_node = r.node;
+  try {
+    s->slot.assign(r.slots, ibu_stream::Slot());
+    ctx->ring_lent = s;
+    s->producer = std::thread(stream_produce, s);
+  } catch (...) {
+    ctx->ring_lent = nullptr;
+    return caught_io("ibu_stream_open");
+  }
+  return IBU_OK;
+}
+
+// The consumer side of next(): the oldest READY slot, the caller's stream ordered behind its copy.  *n == 0: end of stream.
+int32_t stream_take(ibu_stream* s, hipStream_t st, uint32_t* slot_out, size_t* n, uint64_t* first) {
+  Ring& r = s->ctx->ring;
+  uint32_t si = 0;
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    for (;;) {
+      if (!s->ready.empty()) break;
+      if (s->done) {
+        *n = 0;
+        if (s->rc) { tls_error() = s->detail; return s->rc; }
+        return IBU_OK;
+      }
+      if (s->held >= r.slots) return err_arg("every ring slot is held: release a batch before asking for the next");
+      s->cv.wait(lk);
+    }
+    si = s->ready.front();
+    s->ready.pop_front();
+    s->slot[si].state = ibu_stream::HELD;
+    ++s->held;
+    *n = s->slot[si].n;
+    *first = s->slot[si].first;
+  }
+  IBU_HIP(hipStreamWaitEvent(st, r.copied[si], 0));
+  *slot_out = si;
+  return IBU_OK;
+}
+
+int32_t stream_give_back(ibu_stream* s, uint32_t si, hipStream_t st) {
+  Ring& r = s->ctx->ring;
+  hipError_t e = hipEventRecord(r.consumed[si], st);
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    s->slot[si].state = ibu_stream::RELEASED;   // (even when the record failed: the stream must be able to end)
+    --s->held;
+    s->cv.notify_all();
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+  return IBU_OK;
+}
+
+void stream_shutdown(ibu_stream* s) {
+  ibu_ctx* ctx = s->ctx;
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    s->stop = true;
+    s->cv.notify_all();
+  }
+  if (s->producer.joinable()) s->producer.join();
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->copy_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (uint32_t i = 0; i < s->slot.size(); ++i)   // work the caller queued on its own streams before releasing
+    if (s->slot[i].state == ibu_stream::RELEASED) (void)hipEventSynchronize(ctx->ring.consumed[i]);
+  ctx->ring_lent = nullptr;
+}
+
+}  // namespace
+
+extern "C" int32_t ibu_stream_open_reader(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, ibu_stream_t** out) {
+  if (!r || !ctx || !out) return err_arg("NULL argument");
+  *out = nullptr;
+  ibu_stream* s = new (std::nothrow) ibu_stream;
+  if (!s) return err_io(ENOMEM, "ibu_stream_open_reader");
+  s->rd = r;
+  ibu_reader_header(r, &s->header);
+  const int32_t rc = stream_open(ctx, cfg, s);
+  if (rc) { delete s; return rc; }
+  *out = s;
+  return IBU_OK;
+}
+
+extern "C" int32_t ibu_stream_open_mmap(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, size_t shard,
+                                        size_t n_shards, ibu_stream_t** out) {
+  if (!m || !ctx || !out) return err_arg("NULL argument");
+  *out = nullptr;
+  size_t start = 0, end = 0;
+  int32_t rc = ibu_shard_range(ibu_mmap_len(m), n_shards, shard, &start, &end);  // mmap.rs:297-307
+  if (rc) return rc;
+  ibu_stream* s = new (std::nothrow) ibu_stream;
+  if (!s) return err_io(ENOMEM, "ibu_stream_open_mmap");
+  s->m = m;
+  s->start = start;
+  s->end = end;
+  s->first0 = start;
+  ibu_mmap_header(m, &s->header);
+  rc = stream_open(ctx, cfg, s);
+  if (rc) { delete s; return rc; }
+  *out = s;
+  return IBU_OK;
+}
+
+extern "C" int32_t ibu_stream_header(const ibu_stream_t* s, ibu_header_t* out) {
+  if (!s || !out) return err_arg("NULL argument");
+  *out = s->header;
+  return IBU_OK;
+}
+
+extern "C" int32_t ibu_stream_next(ibu_stream_t* s, void* stream, const void** d_records, size_t* n, uint64_t* first_index) {
+  if (!s || !d_records || !n) return err_arg("NULL argument");
+  *d_records = nullptr;
+  *n = 0;
+  IBU_HIP(hipSetDevice(s->ctx->device));
+  uint32_t si = 0;
+  uint64_t first = 0;
+  const int32_t rc = stream_take(s, pick_stream(s->ctx, stream), &si, n, &first);
+  if (rc || *n == 0) return rc;
+  *d_records = s->ctx->ring.dev[si];
+  if (first_index) *first_index = first;
+  return IBU_OK;
+}
+
+extern "C" int32_t ibu_stream_release(ibu_stream_t* s, const void* d_records, void* stream) {
+  if (!s || !d_records) return err_arg("NULL argument");
+  IBU_HIP(hipSetDevice(s->ctx->device));
+  Ring& r = s->ctx->ring;
+  uint32_t si = r.slots;
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    for (uint32_t i = 0; i < r.slots; ++i)
+      if (r.dev[i] == d_records && s->slot[i].state == ibu_stream::HELD) si = i;
+  }
+  if (si == r.slots) return err_arg("not a batch this stream handed out and still holds");
+  return stream_give_back(s, si, pick_stream(s->ctx, stream));
+}
+
+extern "C" int32_t ibu_stream_stats(const ibu_stream_t* s, ibu_stream_stats_t* out) {
+  if (!s || !out) return err_arg("NULL argument");
+  ibu_stream* m = const_cast<ibu_stream*>(s);
+  std::lock_guard<std::mutex> g(m->mu);
+  *out = m->stats;
+  out->seconds_total = now_s() - m->t0;
+  return IBU_OK;
+}
+
+extern "C" void ibu_stream_close(ibu_stream_t* s) {
+  if (!s) return;
+  stream_shutdown(s);
+  delete s;
+}
+
+// ------------------------------------------------------------------------------------------
+// The two built-in device processors over the pull stream: process_parallel (mmap.rs:286-332, one shard of the static split)
+// and the streaming Reader (reader.rs:279-306, :345-352), device forms
+// ------------------------------------------------------------------------------------------
+namespace {
+int32_t run_processor(ibu_stream* s, int32_t proc, void* sink, ibu_stream_stats_t* stats) {
+  ibu_ctx* ctx = s->ctx;
+  Ring& r = ctx->ring;
+  DeviceProc dp;
+  int32_t rc = make_proc(ctx, proc, s->header, sink, &dp);
+  if (rc) return rc;
+  KernelClock kc;
+  rc = kc.init(r.slots);
+  if (rc) return rc;
+  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream));
+  for (;;) {
+    uint32_t si = 0;
+    size_t n = 0;
+    uint64_t first = 0;
+    rc = stream_take(s, ctx->stream, &si, &n, &first);
+    if (rc || n == 0) break;
+    const size_t row0 = (size_t)(first - s->first0);
+    rc = dp.fits(n, row0);           // a gzip / BGZF / xz / zstd stream does not announce its length: every batch is checked
+    if (rc == IBU_OK) {
+      kc.harvest(si);                // the slot's previous kernel finished before the producer refilled it: no wait
+      hipError_t e = hipEventRecord(kc.a[si], ctx->stream);
+      if (e == hipSuccess) {
+        rc = dp.launch(r.dev[si], n, row0);
+        if (rc == IBU_OK) e = hipEventRecord(kc.b[si], ctx->stream);
+      }
+      if (rc == IBU_OK && e != hipSuccess) rc = hip_fail(e, "hipEventRecord");
+      if (rc == IBU_OK) kc.live[si] = 1;
+    }
+    const int32_t rel = stream_give_back(s, si, ctx->stream);
+    if (rc == IBU_OK) rc = rel;
+    if (rc) break;
+  }
+  if (rc) return rc;
+  if (proc == IBU_PROC_REDUCE) rc = ibu_reduce_fetch(ctx, ctx->stream, static_cast<ibu_reduce_result_t*>(sink));
+  else if (hipError_t e = hipStreamSynchronize(ctx->stream); e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
+  if (rc) return rc;
+  for (uint32_t i = 0; i < r.slots; ++i) kc.harvest(i);
+  if (stats) {
+    std::lock_guard<std::mutex> g(s->mu);
+    *stats = s->stats;
+    stats->seconds_kernel = kc.ms * 1e-3;
+  }
+  return IBU_OK;
+}
+// open -> run -> close, with the error (and its detail) of the first failing step
+int32_t process_stream(ibu_stream* s, int32_t open_rc, int32_t proc, void* sink, ibu_stream_stats_t* stats, double t0) {
+  if (open_rc) return open_rc;
+  const int32_t rc = run_processor(s, proc, sink, stats);
+  const ibu_error_detail_t keep = tls_error();
+  ibu_stream_close(s);               // drains the copy stream and the context's stream: nothing is in flight over ring memory
+  if (rc) { tls_error() = keep; return rc; }
+  if (stats) stats->seconds_total = now_s() - t0;
+  return IBU_OK;
+}
+}  // namespace
+
 extern "C" int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                            int32_t proc, size_t shard, size_t n_shards, void* sink,
                                            ibu_stream_stats_t* stats) {
   if (!m || !ctx) return err_arg("NULL argument");
-  IBU_HIP(hipSetDevice(ctx->device));
   const double t0 = now_s();
   if (stats) memset(stats, 0, sizeof *stats);
   size_t start = 0, end = 0;
@@ -327,39 +716,11 @@ extern "C" int32_t ibu_mmap_process_device(const ibu_mmap_t* m, ibu_ctx_t* ctx, 
   DeviceProc dp;
   rc = make_proc(ctx, proc, h, sink, &dp);
   if (rc) return rc;
-  rc = dp.fits(end - start, 0);   // the shard's size is known up front
+  rc = dp.fits(end - start, 0);   // the shard's size is known up front: refused before any work starts
   if (rc) return rc;
-  rc = ring_ensure(ctx, cfg, true);
-  if (rc) return rc;
-  Ring& r = ctx->ring;
-  KernelClock kc;
-  rc = kc.init(r.slots);
-  if (rc) return rc;
-  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream));
-  const size_t slot_records = r.slot_bytes / IBU_RECORD_SIZE;
-  const uint8_t* base = static_cast<const uint8_t*>(ibu_mmap_base(m)) + IBU_HEADER_SIZE;
-  size_t k = 0;
-  for (size_t row = start; row < end && rc == IBU_OK; row += slot_records, ++k) {
-    const uint32_t s = (uint32_t)(k % r.slots);
-    const size_t nb = end - row < slot_records ? end - row : slot_records;
-    hipError_t e = hipEventSynchronize(r.consumed[s]);  // the kernel that read dev[s] (and so its H2D) is done
-    if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
-    kc.harvest(s);
-    const uint8_t* srcp = base + row * IBU_RECORD_SIZE;
-    uint8_t* dst = r.pinned[s];
-    parallel_bytes(nb * IBU_RECORD_SIZE, feeder_threads(cfg), [&](size_t off, size_t len) {
-      memcpy(dst + off, srcp + off, len);  // page-cache / page-fault side of the reference's hot loop
-      return 0;
-    });
-    rc = submit_slot(ctx, kc, dp, s, nb, row - start, stats);
-  }
-  if (rc) return drain(ctx, rc);
-  if (proc == IBU_PROC_REDUCE) rc = ibu_reduce_fetch(ctx, ctx->stream, static_cast<ibu_reduce_result_t*>(sink));
-  else if (hipError_t e = hipStreamSynchronize(ctx->stream); e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
-  if (rc) return drain(ctx, rc);
-  for (uint32_t s = 0; s < r.slots; ++s) kc.harvest(s);
-  if (stats) { stats->seconds_kernel = kc.ms * 1e-3; stats->seconds_total = now_s() - t0; }
-  return IBU_OK;
+  ibu_stream_t* s = nullptr;
+  rc = ibu_stream_open_mmap(m, ctx, cfg, shard, n_shards, &s);
+  return process_stream(s, rc, proc, sink, stats, t0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -471,64 +832,14 @@ extern "C" int32_t ibu_mmap_process_devices(const ibu_mmap_t* m, const int32_t* 
 extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                              int32_t proc, void* sink, ibu_stream_stats_t* stats) {
   if (!rd || !ctx) return err_arg("NULL argument");
-  IBU_HIP(hipSetDevice(ctx->device));
   const double t0 = now_s();
   if (stats) memset(stats, 0, sizeof *stats);
   ibu_header_t h;
   ibu_reader_header(rd, &h);
   DeviceProc dp;
-  int32_t rc = make_proc(ctx, proc, h, sink, &dp);
+  int32_t rc = make_proc(ctx, proc, h, sink, &dp);   // argument errors before the producer thread exists
   if (rc) return rc;
-  rc = ring_ensure(ctx, cfg, true);
-  if (rc) return rc;
-  Ring& r = ctx->ring;
-  KernelClock kc;
-  rc = kc.init(r.slots);
-  if (rc) return rc;
-  if (proc == IBU_PROC_REDUCE) IBU_HIP(hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream));
-  const size_t slot_records = r.slot_bytes / IBU_RECORD_SIZE;
-  size_t total = 0, k = 0;
-  bool eof = false;
-  while (!eof && rc == IBU_OK) {
-    const uint32_t s = (uint32_t)(k % r.slots);
-    hipError_t e = hipEventSynchronize(r.consumed[s]);
-    if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
-    kc.harvest(s);
-    size_t filled = 0;
-    while (filled < slot_records) {
-      const ibu_record_t* recs;
-      size_t have = 0;
-      ibu_reader_buffered(rd, &recs, &have);
-      if (have == 0) {
-        // the source fills the pinned slot directly (parallel preads of a plain file, the inflate threads' own copies):
-        // no detour through the reader's 1.18 MB buffer; the truncation rule of reader.rs:232-237 applies to the slot
-        size_t got = 0;
-        rc = reader_read_direct(rd, r.pinned[s] + filled * IBU_RECORD_SIZE, (slot_records - filled) * IBU_RECORD_SIZE, &got, &eof);
-        if (rc) { eof = true; break; }
-        filled += got / IBU_RECORD_SIZE;
-        if (eof) break;
-        continue;
-      }
-      // records the caller had already pulled into the reader's buffer (read_batch / next before this call) go first
-      const size_t take = have < slot_records - filled ? have : slot_records - filled;
-      memcpy(r.pinned[s] + filled * IBU_RECORD_SIZE, recs, take * IBU_RECORD_SIZE);
-      ibu_reader_consume(rd, take);
-      filled += take;
-    }
-    if (rc) break;
-    if (filled) {
-      rc = dp.fits(filled, total);  // a gzip / BGZF / xz / zstd stream does not announce its length: check every batch
-      if (rc) break;
-      rc = submit_slot(ctx, kc, dp, s, filled, total, stats);
-      total += filled;
-      ++k;
-    }
-  }
-  if (rc) return drain(ctx, rc);
-  if (proc == IBU_PROC_REDUCE) rc = ibu_reduce_fetch(ctx, ctx->stream, static_cast<ibu_reduce_result_t*>(sink));
-  else if (hipError_t e = hipStreamSynchronize(ctx->stream); e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
-  if (rc) return drain(ctx, rc);
-  for (uint32_t s = 0; s < r.slots; ++s) kc.harvest(s);
-  if (stats) { stats->seconds_kernel = kc.ms * 1e-3; stats->seconds_total = now_s() - t0; }
-  return IBU_OK;
+  ibu_stream_t* s = nullptr;
+  rc = ibu_stream_open_reader(rd, ctx, cfg, &s);
+  return process_stream(s, rc, proc, sink, stats, t0);
 }

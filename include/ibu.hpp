@@ -133,6 +133,8 @@ using RingConfig = ibu_ring_config_t;
 using ReduceResult = ibu_reduce_result_t;
 using DecodeSink = ibu_decode_sink_t;   // {d_bc_ascii, d_umi_ascii, d_index, cap_records}: device columns and the rows they hold
 using AllocProbe = ibu_alloc_probe_t;
+using NumaInfo = ibu_numa_info_t;
+class DeviceStream;
 
 // ---- io/writer.rs ----------------------------------------------------------------------------------------------
 class Writer {
@@ -248,6 +250,8 @@ class Reader {
   // (The sink is ONE argument on purpose: revision 3 had squeezed `size_t cap_records` in front of other defaulted size_t
   // parameters, and a revision-2 positional call still compiled with shifted meanings.  Old calls no longer compile.)
   inline StreamStats process_device_decode(device::Context& ctx, const DecodeSink& sink, const RingConfig* ring = nullptr);
+  // pull-style device stream over the rest of this reader: the caller takes one device-resident batch at a time (DeviceStream below)
+  inline DeviceStream device_stream(device::Context& ctx, const RingConfig* ring = nullptr);
   ibu_reader_t* raw() const { return r_; }
 
  private:
@@ -345,6 +349,8 @@ class MmapReader {
   // one shard -> ASCII barcodes / UMIs + index column in HOST memory, unpacked on the GPU
   struct Decoded { std::vector<uint8_t> bc, umi; std::vector<uint64_t> index; StreamStats stats; };
   inline Decoded decode_to_host(device::Context& ctx, size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
+  // pull-style device stream over one shard of the static split (DeviceStream below)
+  inline DeviceStream device_stream(device::Context& ctx, size_t shard = 0, size_t n_shards = 1, const RingConfig* ring = nullptr) const;
   ibu_mmap_t* raw() const { return m_; }
 
  private:
@@ -430,6 +436,8 @@ class Context {
     void* p = nullptr; check(ibu_device_alloc_probed(c_, bytes, tries, &p, report)); return p;
   }
   void free(void* p) { check(ibu_device_free(c_, p)); }
+  // where the device hangs off the host and where the pinned ring landed (option "numa")
+  NumaInfo numa() const { NumaInfo i; check(ibu_ctx_numa(c_, &i)); return i; }
   void upload(void* d_dst, const void* h_src, size_t bytes) { check(ibu_memcpy_h2d(c_, d_dst, h_src, bytes, nullptr)); synchronize(); }
   void download(void* h_dst, const void* d_src, size_t bytes) { check(ibu_memcpy_d2h(c_, h_dst, d_src, bytes, nullptr)); synchronize(); }
 
@@ -489,6 +497,56 @@ inline MmapReader::Decoded MmapReader::decode_to_host(device::Context& ctx, size
   d.stats = StreamStats{};
   check(ibu_mmap_decode_to_host(m_, ctx.raw(), ring, shard, n_shards, d.bc.data(), d.umi.data(), d.index.data(), &d.stats));
   return d;
+}
+// ---- pull-style device record stream (ibu_stream_*) -------------------------------------------------------------------
+// The device form of Reader::read_batch + Iterator (reader.rs:218-242, :279-306) and of process_parallel's per-batch loop
+// (mmap.rs:312-320): `while (auto b = stream.next()) { ...kernels on b->d_records...; }` — a batch gives its ring slot back
+// when it goes out of scope (work queued on its stream so far is waited for before the slot is refilled).
+class DeviceBatch {
+ public:
+  const void* d_records = nullptr;   // n AoS records in a device ring slot
+  size_t n = 0;
+  uint64_t first_index = 0;          // number of the batch's first record (mmap: position in the map; reader: records delivered before)
+  DeviceBatch(ibu_stream_t* s, const void* d, size_t n_, uint64_t first, void* stream) : d_records(d), n(n_), first_index(first), s_(s), stream_(stream) {}
+  DeviceBatch(DeviceBatch&& o) noexcept : d_records(o.d_records), n(o.n), first_index(o.first_index), s_(o.s_), stream_(o.stream_) { o.s_ = nullptr; }
+  DeviceBatch(const DeviceBatch&) = delete;
+  DeviceBatch& operator=(const DeviceBatch&) = delete;
+  ~DeviceBatch() { if (s_) (void)ibu_stream_release(s_, d_records, stream_); }
+  void release() { if (s_) { ibu_stream_t* s = s_; s_ = nullptr; check(ibu_stream_release(s, d_records, stream_)); } }
+ private:
+  ibu_stream_t* s_;
+  void* stream_;
+};
+class DeviceStream {
+ public:
+  explicit DeviceStream(ibu_stream_t* s) : s_(s) {}
+  DeviceStream(DeviceStream&& o) noexcept : s_(o.s_) { o.s_ = nullptr; }
+  DeviceStream(const DeviceStream&) = delete;
+  DeviceStream& operator=(const DeviceStream&) = delete;
+  ~DeviceStream() { if (s_) ibu_stream_close(s_); }
+  Header header() const { Header h; check(ibu_stream_header(s_, &h)); return h; }
+  // `stream`: the hipStream_t the batch will be read on (nullptr: the context's).  nullopt at the end; a source error
+  // (TruncatedRecord, Io, Niffler ...) throws after the batches in front of it have been handed out.
+  std::optional<DeviceBatch> next(void* stream = nullptr) {
+    const void* d = nullptr; size_t n = 0; uint64_t first = 0;
+    check(ibu_stream_next(s_, stream, &d, &n, &first));
+    if (n == 0) return std::nullopt;
+    return std::optional<DeviceBatch>(std::in_place, s_, d, n, first, stream);
+  }
+  StreamStats stats() const { StreamStats st{}; check(ibu_stream_stats(s_, &st)); return st; }
+  ibu_stream_t* raw() const { return s_; }
+ private:
+  ibu_stream_t* s_;
+};
+inline DeviceStream Reader::device_stream(device::Context& ctx, const RingConfig* ring) {
+  ibu_stream_t* s = nullptr;
+  check(ibu_stream_open_reader(r_, ctx.raw(), ring, &s));
+  return DeviceStream(s);
+}
+inline DeviceStream MmapReader::device_stream(device::Context& ctx, size_t shard, size_t n_shards, const RingConfig* ring) const {
+  ibu_stream_t* s = nullptr;
+  check(ibu_stream_open_mmap(m_, ctx.raw(), ring, shard, n_shards, &s));
+  return DeviceStream(s);
 }
 inline std::pair<ReduceResult, StreamStats> Reader::process_device_reduce(device::Context& ctx, const RingConfig* ring) {
   ReduceResult r{}; StreamStats st{};

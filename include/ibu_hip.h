@@ -229,6 +229,24 @@ typedef struct ibu_ctx ibu_ctx_t;
 int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out);
 void ibu_ctx_destroy(ibu_ctx_t* ctx);
 int32_t ibu_ctx_device(const ibu_ctx_t* ctx);
+/* Where the context's device hangs off the host and where its pinned ring landed (option "numa").  The reference's workers are
+ * OS threads over one shared map (mmap.rs:308-322) and leave placement to the kernel; with a GPU per worker the copy
+ * page cache -> pinned ring -> PCIe is local only if ring and feeder threads sit on the GPU's socket. */
+typedef struct ibu_numa_info {
+  int32_t mode;          /* option "numa": 1 auto, 0 off */
+  int32_t node;          /* NUMA node of the device's PCI function; -1: the platform does not say */
+  int32_t usable_cpus;   /* CPUs of that node the process may run on (what the feeder threads are pinned to when mode = 1) */
+  int32_t ring_node;     /* node the pinned ring's pages are on, as the kernel reports it (move_pages); -1: no ring yet / it will not say */
+  int32_t ring_placed;   /* 1: the ring was allocated under a preferred-node policy the kernel accepted */
+  int32_t reserved;
+  char pci_bus_id[32];   /* "0000:c1:00.0" */
+  char cpulist[256];     /* the node's CPUs as sysfs spells them, "" when unknown */
+} ibu_numa_info_t;
+int32_t ibu_ctx_numa(const ibu_ctx_t* ctx, ibu_numa_info_t* out);
+/* The lookup on its own, against any sysfs tree (sysfs_root NULL = "/sys"): *node = NUMA node of PCI function `pci_bus_id`
+ * (-1 unknown), cpulist = the node's CPUs ("" unknown), *usable_cpus (nullable) = how many of them the calling thread may use. */
+int32_t ibu_numa_of_pci(const char* sysfs_root, const char* pci_bus_id, int32_t* node, char* cpulist, size_t cap,
+                        int32_t* usable_cpus);
 void* ibu_ctx_stream(const ibu_ctx_t* ctx);        /* hipStream_t */
 int32_t ibu_ctx_synchronize(ibu_ctx_t* ctx, void* stream);
 int32_t ibu_device_count(int32_t* n);
@@ -261,11 +279,26 @@ int32_t ibu_device_count(int32_t* n);
  *                           The reference holds no codec code and no vector, so the order is UNPINNED; the second
  *                           value is the hedge: if an external bitnuc vector shows the other order, callers flip this
  *                           option and no kernel changes.
- *   "alloc_probe_tries" 1..16  placement probing as a property of the library (default 1 = plain allocations): arrays of at
- *                           least 256 MiB that the library allocates for the caller — ibu_device_alloc, the destination of
- *                           ibu_load_to_device — draw this many candidates and keep the fastest, as
- *                           ibu_device_alloc_probed does on request (see there for why).  Costs a write + read of every
- *                           candidate (~0.3 ms per GB each) once per allocation.
+ *   "alloc_probe_tries" 0..16  placement probing as a property of the library, for the arrays the library allocates and that stay
+ *                           resident — ibu_device_alloc, the destination of ibu_load_to_device, the context's sort scratch.
+ *                           0 = auto (default): an allocation of at least 1 GiB of which at least three candidates fit in the
+ *                           device's free memory draws up to four and keeps the fastest, anything else is a plain
+ *                           allocation; 1 = never probe; k > 1 = allocations of at least 256 MiB draw k candidates.  What
+ *                           probing is and why: ibu_device_alloc_probed.  What it costs: a write + read of every candidate
+ *                           (~0.3 ms per GB each, twice), the candidates' memory for that long (k x bytes at the peak), and
+ *                           one synchronisation of the context's stream per probed allocation.  It never touches the reduce
+ *                           accumulator (reset / reduce ... / fetch may span allocations).  IBU_TRACE_SORT=1 prints what was
+ *                           drawn and chosen.
+ *   "numa"           0 | 1  1 = auto (default): the context looks up the NUMA node its device hangs off (PCI bus id ->
+ *                           /sys/bus/pci/devices/<bdf>/numa_node -> that node's cpulist) and keeps its host side there: the pinned
+ *                           ring is allocated under a preferred-node policy, the threads that fill it (the stream producer and its
+ *                           feeders, the preads of ibu_load_to_device, the inflate workers a stream starts) run on the node's
+ *                           CPUs (those of them the process may use).  A platform that does not say (node -1, no sysfs, a
+ *                           kernel that refuses set_mempolicy) changes nothing: threads and pages go where they went before.
+ *                           0 = off.  ibu_ctx_numa says what was found and where the ring landed.
+ *   "peer_access"    0 | 1  the multi-GPU sort's pulls (ibu_sort_records_contexts): 1 (default) = the pulling context enables direct
+ *                           peer access to the shard's device where the topology has it (copies go over xGMI without staging; it
+ *                           stays enabled for the process), 0 = never: the runtime stages the copies through the host.
  *   "trace_rows"     0 | 1  tests: one stderr line per kernel launch of the streaming entry points saying how many rows took
  *                           the tiled and how many the one-thread-per-row kernel.  A context starts with the value the
  *                           environment variable IBU_TRACE_ROWS had when the library first created a context (read once).
@@ -273,8 +306,8 @@ int32_t ibu_device_count(int32_t* n);
 #define IBU_BASE_ORDER_LSB_FIRST 0
 #define IBU_BASE_ORDER_MSB_FIRST 1
 int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t value);
-/* Device memory helpers for callers without their own allocator (tests in C, Rust shim).  With option "alloc_probe_tries" > 1
- * allocations of at least 256 MiB are placement-probed (ibu_device_alloc_probed below). */
+/* Device memory helpers for callers without their own allocator (tests in C, Rust shim).  Large allocations are placement-probed
+ * as option "alloc_probe_tries" says (default auto: >= 1 GiB with room for three candidates; ibu_device_alloc_probed below). */
 int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr);
 int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr);
 /* ibu_device_alloc with PLACEMENT PROBING, for arrays that stay resident (no reference counterpart: the crate holds its records in
@@ -284,8 +317,9 @@ int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr);
  * `bytes` bytes (all held at once, so that they are different pages; stops quietly at the first that does not fit), streams
  * one write and one read over each, keeps the fastest in *d_ptr and frees the others.  tries <= 1, or fewer than 4096
  * records' worth of bytes: a plain allocation.  `report` (nullable) says what was measured; candidate 0 is what
- * ibu_device_alloc would have returned.  Contents unspecified.  Uses the context's stream and reduce accumulator
- * (which it leaves reset), synchronises; release with ibu_device_free. */
+ * ibu_device_alloc would have returned.  Contents unspecified.  Runs on the context's stream and synchronises it; the reduce
+ * accumulator is not touched (the probe reduces into scratch of its own), so reset / reduce ... / fetch may span allocations.
+ * Holds tries x bytes of device memory while it measures.  Release with ibu_device_free. */
 #define IBU_ALLOC_PROBE_MAX 16
 typedef struct ibu_alloc_probe {
   uint32_t tries;                  /* candidates that were allocated and timed (<= the request) */
@@ -379,22 +413,28 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * shards[i] lives on ctxs[i]'s device: n records in d_records, which has room for `capacity` records; d_tmp: capacity * 24
  * bytes of scratch on the same device.  On return shard i holds the i-th contiguous range of the global order and
  * shards[i].n says how many records that is (their sum is unchanged).  Evenly spaced samples of every shard, in proportion to
- * its size (about 512 per shard in all), pick n_ctxs - 1 splitters; every record travels once to the owner of its range
- * (hipMemcpyPeerAsync: over xGMI between GPUs).  Three forms (multi_sort.cpp):
- *   partition first on elements — at most 11 key bytes vary over ALL shards (16/12 records with indices below 2^32), at most 256
+ * its size (max(16 384, 512 x n_ctxs) records in all, at most 2^19), pick the splitters; every record travels once to the owner of
+ * its range (hipMemcpyPeerAsync: over xGMI between GPUs).  Three forms (multi_sort.cpp):
+ *   partition first on elements — at most 11 key bytes vary over ALL shards (16/12 records with indices below 2^32), at most 32
  *     shards, 16-byte aligned buffers: a shard is compacted to 12-byte elements (one plan for all shards from the combined census
- *     words — of sample ranges when the shards are large, checked against the exact census the partition pass takes on its way),
- *     the elements are put in the order of 256 sampled key ranges by one pass of the sort's own kernels, the owners are cut on the
- *     exact counts, pull their pieces (12 bytes per record on the links) and sort them straight into records;
- *   partition first on records — any other key or alignment, at most 256 shards: the same on 24-byte records (their key range in
+ *     words — of sample ranges when the shards are large, checked against the exact census the partition pass takes on its way;
+ *     a miss re-runs that pass only), the elements are put in the order of 256 sampled key ranges by one pass of the sort's own
+ *     kernels, the owners are cut on the exact counts at range boundaries, pull their pieces (12 bytes per record on the links)
+ *     and sort them straight into records;
+ *   partition first on records — any other key or alignment, at most 32 shards: the same on 24-byte records (their key range in
  *     the digit side stream, one 24-byte pass into the shard's scratch, the owners pull over their own records and sort once);
- *   sort first — more than 256 shards, or option "sort_compact" = 0 on ctxs[0]: every shard sorted where it lives, cut at the
- *     splitters by binary search, 24-byte records exchanged (12-byte elements when at most 12 bytes vary), owners sort again.
- * Nothing is sorted twice in the first two.
+ *   sort first — more than 32 shards, option "sort_compact" = 0 on ctxs[0], or a range cut of the first two forms that does not
+ *     fit a shard's capacity: every shard sorted where it lives, cut at n_ctxs - 1 splitters by binary search, 24-byte records
+ *     exchanged (12-byte elements when at most 12 bytes vary), owners sort again.
+ * Nothing is sorted twice in the first two.  How even the shares come out: the partition-first forms cut at the boundaries of 256
+ * sampled ranges, so an owner's load is quantised to about total / 256 — 3 % of a share with 8 shards, 12 % with 32 —; the
+ * sort-first form cuts at sampled quantiles of sorted shards, a few percent at any shard count.  In the partition-first forms the
+ * host joins its worker threads where it needs every shard's answer (samples, range counts) and once at the end; the exchange and
+ * the owners' sorts are ordered on the devices (stream order and cross-device events).
  * One host thread per context; the first error in context order is the call's.  A shard that would receive more than its
  * capacity: IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) before anything has moved between
  * shards: every shard still holds its own records (untouched, or sorted locally on the sort-first path) — leave headroom for
- * uneven splits (the samples balance well-spread keys to a few percent; many equal records all go to one owner).  After ANY
+ * uneven splits (see above for how even the shares come out; many equal records all go to one owner).  After ANY
  * OTHER error (a failed copy or kernel once the exchange has begun) the contents of the shards are unspecified.  Capacity: at
  * least n_ctxs + 1 records and 24 x capacity >= 32 x (n_ctxs - 1) bytes (the sort-first form stages the splitters and their
  * positions in d_tmp).  n_ctxs == 1 is ibu_sort_records.  Two contexts may share a device (a rehearsal on one GPU); the same
@@ -476,6 +516,8 @@ typedef struct ibu_stream_stats {
   uint64_t batches;
   double seconds_total;
   double seconds_kernel; /* sum of hipEvent kernel spans */
+  int32_t numa_node;     /* ABI revision 4: node of the device the stream fed (-1: unknown or option "numa" = 0) */
+  int32_t ring_node;     /* node the pinned ring's pages are on (-1: the kernel would not say) */
 } ibu_stream_stats_t;
 
 /* Device analogue of load_to_vec (reader.rs:510-535): whole uncompressed file -> device AoS
@@ -497,6 +539,47 @@ int32_t ibu_writer_write_batch_device(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu
  * call above. */
 int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                          const void* d_records, size_t n, void* producer_stream, ibu_stream_stats_t* stats);
+
+/* ---- pull-style device record stream ------------------------------------------------------------------------------------
+ * The device form of Reader::read_batch + Iterator (reader.rs:218-242, :279-306) and of the per-batch loop of process_parallel
+ * (mmap.rs:312-320): the CALLER pulls one device-resident batch at a time and runs whatever it likes on it — its own kernels,
+ * or this library's (decode, sort, reduce, aggregation) — the user half of ParallelProcessor (parallel.rs:100-190) with the
+ * records already in HBM.  ibu_mmap_process_device / ibu_reader_process_device (below) are this loop with one of the two
+ * built-in processors as the body; there is one pipeline.
+ *
+ *   source --producer thread (+ feeders)--> pinned slot --copy stream H2D--> device slot --ibu_stream_next--> caller
+ *
+ * open: the stream borrows the context's ring (cfg as for the other stream calls) and starts a producer thread that fills
+ *   pinned slots from the source and queues their H2D copies; the first batch is on its way before the first next().  Until
+ *   close, the context's other ring users (load_to_device, write_batch_device, process_device, another stream) return
+ *   IBU_ERR_INVALID_ARG; kernel entry points, the sort and the host<->host codec pipelines are unaffected.  A reader source is
+ *   borrowed, read from where it stands (records already buffered by read_batch / next come first) and must not be touched
+ *   until close; an mmap source is one shard of the static split (ibu_shard_range).
+ * next: *d_records = the batch (a device ring slot: *n records of 24 bytes, 16-byte aligned), *first_index = the number of the
+ *   batch's first record (mmap: its position in the map; reader: records this stream delivered before it).  `stream`
+ *   (NULL = ibu_ctx_stream(ctx)) is the stream the caller will read the batch on: it is made to wait for the batch's copy, so
+ *   work queued on it afterwards sees the records.  *n == 0 with IBU_OK: the end of the stream (again on every later call).
+ *   Batches are whole slots except the last; their concatenation is the source's record sequence.  Blocks while no batch is ready.
+ * release: the caller is done queueing work on the batch; the slot is refilled once everything queued on `stream` so far has
+ *   run.  Batches may be held and released in any order, at most slots - 1 at a time: next() with every slot held returns
+ *   IBU_ERR_INVALID_ARG instead of waiting for ever.
+ * Errors of the source surface in order: next() first hands out every batch in front of the error, then returns it, and
+ *   keeps returning it.  A stream that ends inside a record is TruncatedRecord{pos} with the reference's position, after
+ *   exactly the records the reference's iterator yields before its Err: whole refills of IBU_DEFAULT_BUFFER_SIZE counted from
+ *   where the stream took over; the complete records of the final partial refill are dropped with it (quirk Q8,
+ *   reader.rs:232-237).
+ * close: stops the producer, waits for the copies in flight and for the context's stream, returns the ring.  Batches still
+ *   held are invalid afterwards.  The reader / map stays open and is the caller's to close. */
+typedef struct ibu_stream ibu_stream_t;
+int32_t ibu_stream_open_reader(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, ibu_stream_t** out);
+int32_t ibu_stream_open_mmap(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, size_t shard, size_t n_shards,
+                             ibu_stream_t** out);
+int32_t ibu_stream_header(const ibu_stream_t* s, ibu_header_t* out);
+int32_t ibu_stream_next(ibu_stream_t* s, void* stream, const void** d_records, size_t* n, uint64_t* first_index);
+int32_t ibu_stream_release(ibu_stream_t* s, const void* d_records, void* stream);
+/* records / batches / bytes_h2d delivered so far, seconds since open, the NUMA fields; seconds_kernel is 0 (the kernels are the caller's) */
+int32_t ibu_stream_stats(const ibu_stream_t* s, ibu_stream_stats_t* out);
+void ibu_stream_close(ibu_stream_t* s);
 
 /* Device processors for process_parallel. */
 enum {

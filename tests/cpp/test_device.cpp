@@ -206,6 +206,66 @@ TEST(file_streams_to_and_from_the_device) {
   CHECK(bc.download<uint8_t>(wbc.size()) == wbc); CHECK(umi.download<uint8_t>(wumi.size()) == wumi); CHECK(idx.download<uint64_t>(n) == widx);
   unlink(path.c_str());
 }
+TEST(pull_stream_hands_out_device_batches_in_order) {
+  // Reader::read_batch + Iterator on the device (reader.rs:218-242, :279-306): batches concatenate to the file's records; a
+  // truncated file throws TruncatedRecord after exactly the whole refills in front of the cut (quirk Q8)
+  const Header h(16, 12);
+  const size_t n = 3 * 49152 + 777;
+  auto recs = oracle_records(0x1B00007, 0, n, 16, 12);
+  const std::string path = tmp_path("pull");
+  {
+    Writer w = Writer::from_path(path, h);
+    w.write_batch(recs.data(), recs.size());
+    w.finish();
+  }
+  RingConfig ring{3, 49152, 2, 0};
+  {
+    Reader r = Reader::from_path(path);
+    DeviceStream s = r.device_stream(ctx(), &ring);
+    CHECK(s.header() == h);
+    std::vector<Record> got;
+    uint64_t expect_first = 0;
+    while (auto b = s.next()) {
+      CHECK_EQ(b->first_index, expect_first);
+      std::vector<Record> part(b->n);
+      ctx().download(static_cast<void*>(part.data()), b->d_records, b->n * 24);
+      got.insert(got.end(), part.begin(), part.end());
+      expect_first += b->n;
+    }                                                               // (each batch released by its destructor)
+    CHECK(got == recs);
+    CHECK_EQ(s.stats().records, (uint64_t)n);
+  }
+  {
+    MmapReader m(path);
+    uint64_t count = 0;
+    ctx().reduce(nullptr, 0);                                       // reset
+    for (size_t sh = 0; sh < 2; ++sh) {
+      DeviceStream s = m.device_stream(ctx(), sh, 2, &ring);
+      while (auto b = s.next()) { check(ibu_reduce(ctx().raw(), b->d_records, b->n, nullptr)); count += b->n; }
+    }
+    ReduceResult r{};
+    check(ibu_reduce_fetch(ctx().raw(), nullptr, &r));
+    orc_reduce want;
+    orc_reduce_records(reinterpret_cast<const orc_record*>(recs.data()), n, &want);
+    CHECK_EQ(count, (uint64_t)n); CHECK_EQ(r.count, want.count);
+    for (int f = 0; f < 3; ++f) { CHECK_EQ(r.sum[f], want.sum[f]); CHECK_EQ(r.xor_[f], want.xor_[f]); }
+  }
+  CHECK_EQ(truncate(path.c_str(), 32 + 24 * n - 5), 0);
+  {
+    Reader r = Reader::from_path(path);
+    DeviceStream s = r.device_stream(ctx(), &ring);
+    size_t seen = 0;
+    bool threw = false;
+    try {
+      while (auto b = s.next()) seen += b->n;
+    } catch (const IbuError& e) {
+      threw = e.kind() == IbuError::TruncatedRecord;
+    }
+    CHECK(threw);
+    CHECK_EQ(seen, (size_t)(3 * 49152));
+  }
+  unlink(path.c_str());
+}
 TEST(argument_errors_surface_as_ibu_errors) {
   const Header h(16, 12);
   DeviceBuffer d(ctx(), 24 * 16);

@@ -188,3 +188,29 @@ def test_sort_file_example(built, tmp_path, oracle):
     r = _run([os.path.join(built, "sort_file"), str(src), str(multi), "--contexts", "3"])
     assert r.returncode == 0, r.stderr
     assert "300000 records over 3 contexts" in r.stdout and multi.read_bytes() == dst.read_bytes()
+
+
+@pytest.mark.gpu
+def test_stream_pull_example(built, tmp_path, oracle):
+    """random -> gzip -> stream_pull: the per-barcode record counts gathered batch by batch from the pull stream are the
+    oracle's counts over the whole file (BarcodeAnalyzer, parallel.rs:72-98)."""
+    import gzip
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import ibu_amd as ia
+
+    src = tmp_path / "in.ibu"
+    r = _run([os.path.join(built, "random"), str(src), "--records", "0.4", "--barcodes", "300", "--max-index", "100000", "--seed", "11"])
+    assert r.returncode == 0, r.stderr
+    gz = tmp_path / "in.ibu.gz"
+    gz.write_bytes(gzip.compress(src.read_bytes(), 1))
+    _, recs = ia.load_to_vec(src)
+    bcs, counts, _ = oracle.barcode_counts(oracle.sort_records(recs))
+    want = sorted(zip((int(c) for c in counts), (int(b) for b in bcs)), key=lambda t: (-t[0], t[1]))[:4]
+    for path in (src, gz):
+        r = _run([os.path.join(built, "stream_pull"), str(path), "--top", "4", "--slot-records", "98304", "--json"])
+        assert r.returncode == 0, r.stderr
+        out = json.loads(r.stdout)
+        assert out["records"] == 400_000 and out["barcodes"] == 300 and out["batches"] == 5   # 4 x 98 304 + 6 784
+        assert [(c, b) for b, c in out["top"]] == want

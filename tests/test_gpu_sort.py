@@ -1102,3 +1102,92 @@ def test_sort_records_contexts_fuzz(ia, oracle, seed):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("k", [33, 64, 128])
+def test_sort_records_contexts_with_many_shards_at_a_quarter_of_headroom(ia, oracle, k, capfd):
+    """More than 32 shards take the sort-first form (W - 1 splitters from sorted shards: shares within a few percent), so that
+    1.25 x the even share is room enough — with the 256 fixed ranges of the partition-first forms an owner of 128 would get one or
+    two ranges, 50-100 % off its share."""
+    n_each = 3001
+    total = n_each * k
+    recs = oracle.generate(SEED + k, 0, total, 16, 12)
+    np.random.default_rng(k).shuffle(recs)
+    cap = n_each * 5 // 4
+    ctxs = [ia.Context(0) for _ in range(k)]
+    try:
+        shards = []
+        for i, c in enumerate(ctxs):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            d.upload(recs[i * n_each:(i + 1) * n_each])
+            shards.append((d, t, n_each, cap))
+        capfd.readouterr()
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        trace = capfd.readouterr().err
+        assert sum(out) == total and max(out) <= cap
+        assert b"".join(shards[i][0].download(count=24 * out[i]).tobytes() for i in range(k)) == oracle.sort_records(recs).tobytes()
+        if trace:
+            assert "(sort first)" in trace and "partition first" not in trace
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("lens", [(16, 12), (32, 32)])
+def test_sort_records_contexts_falls_back_when_the_range_cut_does_not_fit(ia, oracle, lens, capfd):
+    """Capacity = the even share + 300 records: the partition-first cut (whole ranges of ~1/256 of the records, the last owner
+    taking what the others left) does not fit, the sort-first cut (sampled quantiles of sorted shards) does — the call falls back
+    instead of failing, and says so."""
+    k, n_each = 4, 100_000
+    total = k * n_each
+    recs = oracle.generate(SEED + 404, 0, total, *lens)
+    np.random.default_rng(404).shuffle(recs)
+    cap = n_each + 300
+    ctxs = [ia.Context(0) for _ in range(k)]
+    try:
+        shards = []
+        for i, c in enumerate(ctxs):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            d.upload(recs[i * n_each:(i + 1) * n_each])
+            shards.append((d, t, n_each, cap))
+        capfd.readouterr()
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        trace = capfd.readouterr().err
+        assert sum(out) == total and max(out) <= cap
+        assert b"".join(shards[i][0].download(count=24 * out[i]).tobytes() for i in range(k)) == oracle.sort_records(recs).tobytes()
+        if trace:
+            assert "falling back to the sort-first form" in trace and "(sort first)" in trace, trace
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_sort_records_contexts_orders_exchange_and_sorts_on_the_devices(ia, oracle, capfd):
+    """The partition-first forms join their host threads where the host needs every shard's answer and once at the end; the
+    exchange and the owners' sorts are chained by stream order and events (no join in between).  Also with direct peer access
+    switched off on every context (option "peer_access" = 0: the branch a topology without it takes)."""
+    k, n_each = 8, 150_000
+    total = k * n_each
+    for lens in ((16, 12), (32, 32)):
+        recs = oracle.generate(SEED + 808, 0, total, *lens)
+        np.random.default_rng(808).shuffle(recs)
+        want = oracle.sort_records(recs).tobytes()
+        for peer in (1, 0):
+            cap = n_each * 5 // 4
+            ctxs = [ia.Context(0) for _ in range(k)]
+            try:
+                shards = []
+                for i, c in enumerate(ctxs):
+                    c.set_option("peer_access", peer)
+                    d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+                    d.upload(recs[i * n_each:(i + 1) * n_each])
+                    shards.append((d, t, n_each, cap))
+                capfd.readouterr()
+                out = ia.Context.sort_records_contexts(ctxs, shards)
+                trace = capfd.readouterr().err
+                assert b"".join(shards[i][0].download(count=24 * out[i]).tobytes() for i in range(k)) == want
+                if trace:
+                    assert "partition first" in trace and "host joins: samples, range counts, end" in trace, trace
+            finally:
+                for c in ctxs:
+                    c.close()

@@ -535,16 +535,17 @@ def test_alloc_probed_keeps_one_usable_candidate(ia, ctx, oracle):
 
 
 def test_alloc_probe_tries_option_makes_placement_the_librarys(ia, oracle, tmp_path):
-    """Option "alloc_probe_tries" (VERDICT r03 next-6): the arrays the library allocates for a caller — ibu_device_alloc, the
-    destination of ibu_load_to_device — are placement-probed from 256 MiB on; below that, and with the default of 1, they are
-    plain allocations.  What comes back is ordinary memory with the right contents; the option is validated."""
+    """Option "alloc_probe_tries": the arrays the library allocates for a caller — ibu_device_alloc, the destination of
+    ibu_load_to_device — are placement-probed from 256 MiB on with an explicit count (from 1 GiB on in the default auto mode);
+    below that they are plain allocations.  What comes back is ordinary memory with the right contents; the option is validated."""
     c = ia.Context(0)
     ring = {"slots": 3, "slot_records": 1 << 20, "feeder_threads": 4}
     try:
         with pytest.raises(ia.IbuError):
-            c.set_option("alloc_probe_tries", 0)
+            c.set_option("alloc_probe_tries", -1)
         with pytest.raises(ia.IbuError):
             c.set_option("alloc_probe_tries", 17)
+        c.set_option("alloc_probe_tries", 0)                      # auto (the default): probes from 1 GiB on when three candidates fit
         c.set_option("alloc_probe_tries", 3)
         n = (256 << 20) // 24 + 1001                              # just past the threshold
         d = c.alloc(24 * n)
@@ -562,5 +563,38 @@ def test_alloc_probe_tries_option_makes_placement_the_librarys(ia, oracle, tmp_p
         c.free(dptr)
         small = c.alloc(4096)                                     # below the threshold: plain
         small.free()
+    finally:
+        c.close()
+
+
+def test_probed_allocations_leave_the_reduce_accumulator_alone(ia, oracle, capfd):
+    """reset; reduce(A); <a probed allocation>; reduce(B); fetch adds up A and B (the probe used to run its read half
+    into the context's accumulator and leave it reset).  Also the default auto mode: 1.2 GiB draws candidates and says so."""
+    c = ia.Context(0)
+    try:
+        n = 1_000_003
+        a, b = c.alloc(24 * n), c.alloc(24 * n)
+        c.generate(SEED, 0, n, 16, 12, a)
+        c.generate(SEED, n, n, 16, 12, b)
+        want = oracle.reduce_records(oracle.generate(SEED, 0, 2 * n, 16, 12))
+        c.reduce(a, n, reset=True, fetch=False)
+        big, rep = c.alloc_probed(300 << 20, 3)                   # explicit probing in the middle of an accumulation
+        assert rep["tries"] == 3
+        c.reduce(b, n, reset=False, fetch=False)
+        assert c.reduce_fetch() == want
+        big.free()
+        capfd.readouterr()
+        c.reduce(a, n, reset=True, fetch=False)
+        auto = c.alloc(1288490189)                                # 1.2 GiB under the default option: auto-probed (IBU_TRACE_SORT says so)
+        c.reduce(b, n, reset=False, fetch=False)
+        assert c.reduce_fetch() == want
+        err = capfd.readouterr().err
+        if os.environ.get("IBU_TRACE_SORT", "") not in ("", "0"):
+            assert "ibu alloc: 1288490189 bytes probed" in err and "candidates" in err
+        auto.free()
+        c.set_option("alloc_probe_tries", 1)                      # never probe
+        plain = c.alloc(1288490189)
+        assert "probed" not in capfd.readouterr().err
+        plain.free()
     finally:
         c.close()

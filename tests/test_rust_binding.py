@@ -106,7 +106,7 @@ def _twins():
     return {"ibu_header_t": _lib.CHeader, "ibu_record_t": _lib.CRecord, "ibu_error_detail_t": _lib.CErrorDetail,
             "ibu_reduce_result_t": _lib.CReduceResult, "ibu_ring_config_t": _lib.CRingConfig, "ibu_stream_stats_t": _lib.CStreamStats,
             "ibu_alloc_probe_t": _lib.CAllocProbe, "ibu_sort_shard_t": _lib.CSortShard, "ibu_decode_sink_t": _lib.CDecodeSink,
-            "ibu_key_plan_t": _lib.CKeyPlan, "ibu_processor_vtable_t": _lib.CProcessorVTable}
+            "ibu_key_plan_t": _lib.CKeyPlan, "ibu_processor_vtable_t": _lib.CProcessorVTable, "ibu_numa_info_t": _lib.CNumaInfo}
 
 
 def test_ctypes_structs_have_the_sizes_the_header_compiles_to(tmp_path):

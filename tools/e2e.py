@@ -93,6 +93,18 @@ def main():
         _, st = m.process_device(ctx, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
         emit("mmap process_device DECODE", time.perf_counter() - t0, st)
         plain = [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()]
+        # 3p. the same through the PULL stream (ibu_stream_*): the caller takes device batches and launches the decode itself
+        for rep in ("first", "second"):
+            t0 = time.perf_counter()
+            with m.device_stream(ctx, ring=ring) as s_:
+                for b in s_:
+                    ctx.decode_ascii(b.ptr, b.n, bc_len, umi_len, d_bc.ptr + b.first_index * bc_len, d_umi.ptr + b.first_index * umi_len,
+                                     d_idx.ptr + b.first_index * 8)
+                    b.release()
+                ctx.synchronize()
+                st = s_.stats()
+            emit(f"mmap device_stream pull -> caller-launched DECODE ({rep})", time.perf_counter() - t0, st, numa=ctx.numa())
+        assert [d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()] == plain
         # 3a. the one-call multi-device form (ibu_mmap_process_devices / _contexts): a host thread + context per listed device.
         # The box has ONE GPU, so the lists repeat ordinal 0 — this measures the call's own overhead (contexts, rings) and
         # whether two workers overlap better on one PCIe link, not multi-GPU scaling (unmeasured).

@@ -109,6 +109,20 @@ def main():
                 steps = span // 16 // max(r_ % 10, w_) // 4 * 4
                 mix_ops[tag_] = (lambda r_=r_, w_=w_, steps=steps: mix.hbm_mix(r_, w_, recs.data_ptr(), back.data_ptr(), steps, 256 * 7, st),
                                  (r_ % 10 + w_) * 16 * steps / n)
+            # the yardstick of the single-column pack ON PACK'S OWN ARRAYS (bc -> c1, same placement): bc_len bytes read, 8 written
+            # per row as R : W plain 16-byte streams.  31 bases has no small ratio: 4 : 1 (32 bytes read) is the nearest, its
+            # rate is computed on the bytes it really moves.
+            ratio = {8: (1, 1), 12: (3, 2), 16: (2, 1), 32: (4, 1), 31: (4, 1), 5: (5, 8), 7: (7, 8), 20: (5, 2)}.get(bc_len)
+            if ratio:
+                r_, w_ = ratio
+                steps = min(n * bc_len // 16 // r_, n * 8 // 16 // w_) // 4 * 4   # both streams inside their arrays (31 bases: 4 : 1 over 31/32 of the rows)
+                assert r_ * 16 * steps <= n * bc_len and w_ * 16 * steps <= n * 8, "yardstick would leave its arrays"
+                for nb in (7, 8, 4):
+                    mix_ops[f"ypack{nb}"] = (lambda r_=r_, w_=w_, steps=steps, nb=nb: mix.hbm_mix(r_, w_, bc.data_ptr(), c1.data_ptr(), steps, 256 * nb, st),
+                                             (r_ + w_) * 16 * steps / n)
+                    if (w_, r_) in ((1, 1), (2, 3), (1, 2), (1, 4)) and umi_max >= bc_len:   # unpack's mix: codes -> the UMI column's array (bc keeps valid ASCII for pack)
+                        mix_ops[f"yunpack{nb}"] = (lambda r_=r_, w_=w_, steps=steps, nb=nb: mix.hbm_mix(w_, r_, c0.data_ptr(), umi.data_ptr(), steps, 256 * nb, st),
+                                                   (r_ + w_) * 16 * steps / n)
 
         names = [k for k in a.kernels.split(",") if k in ops_for(lib0, ctx0, bc_len, umi_len)]
         runs = []  # (tag, blocks, kernel, fn, bytes_per_record, lib, ctx)

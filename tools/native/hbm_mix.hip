@@ -92,5 +92,6 @@ extern "C" int hbm_mix(int r, int w, const void* src, void* dst, uint64_t steps,
 #define PCASE(R, W) if (r == 10 + R && w == W) { hipLaunchKernelGGL((k_mix_pipe<R, W>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, steps); return (int)hipGetLastError(); }
   PCASE(1, 1) PCASE(2, 3) PCASE(3, 2)
   CASE(1, 1) CASE(2, 3) CASE(3, 2) CASE(1, 2) CASE(2, 1) CASE(3, 1) CASE(1, 3) CASE(4, 1)
+  CASE(5, 8) CASE(7, 8) CASE(5, 2) CASE(1, 4)   // pack's mixes at 5 / 7 / 20 bases per row, unpack's at 32
   return -1;
 }

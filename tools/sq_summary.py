@@ -5,6 +5,7 @@
 
 Cycle counters (SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_*) are printed as fractions of the waves'
 cycles; SQ_INSTS_* as thread-instructions per record when --records is given (wave instructions x 64 / N), else per launch.
+Any other counter (TCC_*, TCP_*: tools/mem_pmc.sh) is printed under its own name, per record with --records, else per launch.
 Counters are averaged over the launches of a kernel."""
 import argparse
 import collections
@@ -38,10 +39,10 @@ def main():
         for n, v in sorted(c.items()):
             if n.startswith("SQ_INSTS_"):
                 out[n[9:].lower() + ("_per_record" if a.records else "")] = round(v * 64 / a.records, 2) if a.records else v
-            elif wc and n != "SQ_WAVE_CYCLES":
+            elif n.startswith("SQ_") and wc and n != "SQ_WAVE_CYCLES":
                 out[n[3:].lower() + "_frac"] = round(v / wc, 3)
-            elif n != "SQ_WAVE_CYCLES":
-                out[n] = v
+            elif n != "SQ_WAVE_CYCLES":        # TCC_* / TCP_* (tools/mem_pmc.sh) and SQ cycle counters without SQ_WAVE_CYCLES: own name
+                out[n + ("_per_record" if a.records else "")] = round(v / a.records, 4) if a.records else v
         print(json.dumps(out))
 
 

@@ -123,10 +123,47 @@ def usable_cores():
     return n
 
 
+class LegCheckFailed(Exception):
+    """A correctness check of a side leg (sort, e2e, rehearsal) failed.  Recorded in the line as that leg's `error` — the
+    headline stands on its own and is still printed — and turned into a non-zero exit status after the line is out."""
+
+
 def cpu_baseline(args):
     """The oracle (a C restatement of the reference's CPU path: static range split over OS threads,
     1Mi-record batches, scalar 2-bit codec) timed on this box's host cores on a bounded sample."""
     from oracle import oracle as orc  # the checker, used here only as the reported baseline
+
+    def cpu_phases(args, quota):
+        """BASELINE.md §2's CPU phases — the reference's two example programs — from the oracle's restatement, each timed on its own on a
+        bounded sample (about 1-3 s in all): the write_record loop (examples/roundtrip.rs:33-49), the streaming Reader with its XOR
+        checksum (:80-100), load_to_vec (:122-131), MmapReader::process_parallel summing the fields (examples/parallel.rs:93-105) on 1
+        thread and on the quota's worth, and the scalar 2-bit decode+encode on 1 thread (the headline baseline is the same on `threads`)."""
+        import tempfile
+
+        from oracle import oracle as orc  # the checker, used here only as the reported baseline
+
+        n = 20_000_000
+        path = os.path.join(args.e2e_dir or tempfile.gettempdir(), f"ibu_bench_cpu_{os.getpid()}.ibu")
+        try:
+            sec, xor, sums = orc.bench_phases(path, n, quota)
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+        want = [499_999_500_000 * (n // 1_000_000), None, n * (n - 1) // 2]   # barcode = i % 1e6, index = i
+        ok = sums[0] == want[0] and sums[2] == want[2] % 2**64
+        n1 = 4_000_000
+        t1, chk = orc.bench_decode_encode(n1, args.bc_len, args.umi_len, args.seed, 1)
+        rate = lambda s_: {"seconds": s_, "records_per_s": n / s_, "GBps_of_file": 24 * n / s_ / 1e9}
+        return {
+            "sample": f"{n} records (16,12), the file in {os.path.dirname(path)} (page cache); codec leg {n1} records",
+            "write_record_loop": dict(rate(sec["write_record"]), threads=1, ref="examples/roundtrip.rs:33-49"),
+            "streaming_reader_xor": dict(rate(sec["reader_xor"]), threads=1, xor_checksum=xor, ref="examples/roundtrip.rs:80-100"),
+            "load_to_vec": dict(rate(sec["load_to_vec"]), threads=1, ref="examples/roundtrip.rs:122-131"),
+            "process_parallel_sum_T1": dict(rate(sec["process_parallel_1"]), threads=1, ref="examples/parallel.rs:93-105"),
+            "process_parallel_sum_Tquota": dict(rate(sec["process_parallel_T"]), threads=quota, field_sums_as_expected=bool(ok)),
+            "decode_encode_T1": {"seconds": t1, "records_per_s": n1 / t1, "threads": 1, "roundtrip_exact": chk != 2**64 - 1,
+                                 "what": "scalar 2-bit unpack + pack of every record (the headline baseline on one thread)"},
+        }
 
     quota = usable_cores()
     n = int(args.cpu_sample) or 100_000_000
@@ -144,12 +181,21 @@ def cpu_baseline(args):
     t, chk = orc.bench_decode_encode(n, args.bc_len, args.umi_len, args.seed, threads, reps)
     assert chk != 2**64 - 1, "oracle round trip failed"
     n_total = n * reps
+    try:
+        phases = cpu_phases(args, quota)
+    except Exception as e:  # the baseline number stands on its own
+        phases = {"error": f"{type(e).__name__}: {e}"}
     return {
-        "value": n_total / t, "unit": "records/s", "cores": threads, "kind": "port",
+        "value": n_total / t, "unit": "records/s",
+        # `cores` is the contract's name for the THREADS the baseline ran on (it may exceed the CPUs the cgroup grants: under a
+        # quota the second thread per CPU still pays); what the box really gives is beside it
+        "cores": threads, "threads": threads, "cpu_quota": quota, "cores_visible": len(os.sched_getaffinity(0)),
+        "kind": "port",
         "sample": f"{reps} pass(es) over {n} records bc_len={args.bc_len} umi_len={args.umi_len}, decode+encode, static split over "
-                  f"{threads} OS threads (C restatement of the reference's std::thread path; the reference is Rust "
+                  f"{threads} OS threads on a {quota}-CPU quota (C restatement of the reference's std::thread path; the reference is Rust "
                   f"and cannot be built here)",
-        "seconds": t, "cpu_seconds": t * min(threads, quota), "cpu_quota": quota,
+        "seconds": t, "cpu_seconds": t * min(threads, quota),
+        "phases": phases,
     }
 
 
@@ -185,7 +231,7 @@ def traffic_from_profile(bc_len, umi_len, n):
         return None, None
 
 
-def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
+def place_leg(make, tries, set_bytes, torch, dev, sharers=1, ctx=None, library_default=False):
     """Placement probing — since round 3 a LIBRARY call, not bench-side logic.  On this part the rate of a read+write
     streaming kernel depends on WHERE the driver put the arrays' physical pages: the same kernel on the same GPU runs
     9.4 ... 11.3 ms from one allocation to the next (profiles/README.md: pool survey, r02_placement_pmc, r02_ag — physical
@@ -199,12 +245,29 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1):
     `value_first_placement`; (2) unless --placement-tries 1, that set is freed and every array is allocated again through
     the probing call.  All of it happens before the timed region; every candidate's time is in the line (`placement`)."""
     free_b, _ = torch.cuda.mem_get_info(dev)
+    if ctx is not None:
+        ctx.set_option("alloc_probe_tries", 1)           # plain hipMalloc: what the library did by default until round 4
     first = make(1)
+    if ctx is not None:
+        ctx.set_option("alloc_probe_tries", 0)           # back to the library's default (auto)
     first_probe = first.probe()
     bytes_per_launch = first.n * (24 + first.bc_len + first.umi_len + 8)
     info = {"tries": 1, "first_placement_probe_ms_decode_encode": [round(v, 3) for v in first_probe],
             "first_placement_decode_frac": round(bytes_per_launch / (first_probe[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "first_placement_records_per_s": first.n / ((first_probe[0] + first_probe[1]) * 1e-3)}
+    if library_default:
+        # (1b) what a caller of ibu_device_alloc gets under the library's DEFAULT option (round 5: "alloc_probe_tries" = 0 = auto —
+        # arrays of 1 GiB and more draw up to four candidates when three fit): the same five arrays from plain ctx.alloc calls
+        first.free()
+        t0 = time.perf_counter()
+        first = make(1)
+        alloc_s = time.perf_counter() - t0
+        dprobe = first.probe()
+        info.update(library_default_probe_ms_decode_encode=[round(v, 3) for v in dprobe],
+                    library_default_decode_frac=round(bytes_per_launch / (dprobe[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    library_default_records_per_s=first.n / ((dprobe[0] + dprobe[1]) * 1e-3),
+                    library_default_alloc_seconds=round(alloc_s, 3),
+                    library_default_option='alloc_probe_tries = 0 (auto): ibu_device_alloc of >= 1 GiB draws up to 4 candidates when 3 fit')
     # 0 = auto: as many candidates as fit beside the arrays already chosen, at most 16.  The largest array (24 B/record)
     # sets the bound: the other arrays of the set stay allocated while it is probed.
     biggest = max(24 * first.n, 1)
@@ -278,7 +341,7 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3, torch=None, dev=
             if name == "whitelist_read_order":
                 out[name]["input"] = "barcodes from 100000 distinct, rank ~ K u^3; random UMIs; index increasing"
             if not ok:
-                raise SystemExit("device sort: result not sorted or records changed")
+                raise LegCheckFailed("device sort: result not sorted or records changed")
         # aggregation of the sorted records: size query (count pass + scan), then the whole call into device arrays
         nb, npairs = C.c_size_t(), C.c_size_t()
         _check(lib.ibu_barcode_counts(ctx._c, _dptr(d), n, None, None, None, 0, C.byref(nb), C.byref(npairs), None))
@@ -301,7 +364,7 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3, torch=None, dev=
         out["barcode_counts"] = {"seconds": statistics.median(ts[1:]), "distinct_barcodes": nb.value, "barcode_umi_pairs": npairs.value,
                                  "counts_add_up": bool(adds_up), "checked": "device-side K4 reduce of the (barcode, count, unique) columns"}
         if not adds_up:
-            raise SystemExit("ibu_barcode_counts: the counts column does not add up to the record count")
+            raise LegCheckFailed("ibu_barcode_counts: the counts column does not add up to the record count")
         for b in outs:
             b.free()
     finally:
@@ -310,7 +373,7 @@ def sort_and_aggregate(ctx, n, bc_len, umi_len, seed, rounds=3, torch=None, dev=
     return out
 
 
-def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
+def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
     """File -> result rates on this box, PCIe included — reported beside the headline, NEVER part of `value` (BASELINE.md §3
     asks for the kernel-resident and the file -> result rates separately; configs[4] is the gzip form).  A file of `n`
     synthetic records is written from device memory (`Writer::write_batch` of a device slice), then read back three ways:
@@ -361,15 +424,35 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
         assert os.path.getsize(path) == file_bytes
 
         best = None
-        for _ in range(2):                               # the first call allocates the pinned ring and warms the page cache
+        for rep in range(2):                             # the first call allocates the pinned ring and warms the page cache
             t0 = time.perf_counter()
             _, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
             dt = time.perf_counter() - t0
             ok = got_n == n and ctx.reduce(dptr, n) == want
+            dec = None
+            if ok and rep == 1 and torch is not None:
+                # decode of the records where the LIBRARY put them (the destination is the library's allocation: placement-probed
+                # under the default option from 1 GiB on) into columns from ibu_device_alloc: the kernel's rate a file-based caller sees
+                cols = [ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)]
+                ms = []
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(torch.cuda.ExternalStream(ctx.stream))
+                    ctx.decode_ascii(dptr, n, bc_len, umi_len, *cols)
+                    e1.record(torch.cuda.ExternalStream(ctx.stream))
+                    e1.synchronize()
+                    ms.append(e0.elapsed_time(e1))
+                for b in cols:
+                    b.free()
+                gbps = n * (24 + bc_len + umi_len + 8) / (min(ms[1:]) * 1e-3) / 1e9
+                dec = {"decode_ms_on_the_loaded_records": min(ms[1:]), "decode_GBps": gbps, "decode_frac_of_peak": gbps / HBM_PEAK_GBPS,
+                       "arrays": "destination allocated by ibu_load_to_device, columns by ibu_device_alloc (library default placement)"}
             ctx.free(dptr)
             if not ok:
-                raise SystemExit("e2e: load_to_device returned other records than were written")
+                raise LegCheckFailed("e2e: load_to_device returned other records than were written")
             best = rate(dt, st, first_call_seconds=best["seconds"] if best else None, totals_equal_resident_copy=True)
+            if dec:
+                best["then_decode"] = dec
         out["load_to_device"] = best
 
         m = ia.MmapReader.new(path)
@@ -396,7 +479,7 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
                 got = wadd(got, c.reduce(back, a1 - a0))
                 back.free()
         if count != n or got != want:
-            raise SystemExit("e2e: mmap -> DECODE over the devices does not reproduce the records written")
+            raise LegCheckFailed("e2e: mmap -> DECODE over the devices does not reproduce the records written")
         best["totals_equal_resident_copy"] = True
         out["mmap_process_devices_decode"] = best
         m.close()
@@ -421,7 +504,7 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
         ok = ctxs[0].reduce(back, n) == want
         back.free()
         if not ok:
-            raise SystemExit("e2e: gzip -> DECODE does not reproduce the records written")
+            raise LegCheckFailed("e2e: gzip -> DECODE does not reproduce the records written")
         out["gzip_reader_process_device_decode"] = rate(dt, st, gz_bytes=gz_bytes, gz_ratio=gz_bytes / file_bytes, compress_seconds=tc,
                                                         input="ONE gzip member, level 1 (what `gzip -1` writes), inflated on the host cores",
                                                         totals_equal_resident_copy=True)
@@ -431,6 +514,7 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
         for f in (path, gz):
             if os.path.exists(f):
                 os.unlink(f)
+    out["numa"] = ctx.numa()   # where the device hangs off the host, and where the pinned ring of the runs above landed (option "numa")
     out["leg_seconds"] = time.perf_counter() - t_leg
     return out
 
@@ -620,6 +704,7 @@ def main():
     import ibu_amd
     from ibu_amd import sharding
 
+    exit_code = 0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
@@ -657,7 +742,8 @@ def main():
             dist.barrier()
 
     leg, placement = place_leg(lambda tries: Leg(ctx, torch, dev, st, args.seed, first, n, bc_len, umi_len, tries), args.placement_tries,
-                               n * (48 + bc_len + umi_len + 8), torch, dev, sharers=world if args.share_gpu else 1)
+                               n * (48 + bc_len + umi_len + 8), torch, dev, sharers=world if args.share_gpu else 1, ctx=ctx,
+                               library_default=(world == 1))
     elapsed, dec_ms, enc_ms = leg.timed(args.steps, args.warmup, barrier)
     per_rank = [[float(n), dec_ms, enc_ms, elapsed]]
     if use_dist:
@@ -690,7 +776,7 @@ def main():
         leg.free()
         nw = int(args.wide_records) or n
         wl, w_placement = place_leg(lambda tries: Leg(ctx, torch, dev, st, 0x1B00002, 0, nw, 32, 32, tries), min(args.placement_tries or 2, 2),
-                                    nw * (48 + 72), torch, dev)
+                                    nw * (48 + 72), torch, dev, ctx=ctx)
         w_steps = max(1, min(args.steps, 5))
         w_el, w_dec, w_enc = wl.timed(w_steps, 1, barrier)
         _, w_ok = wl.verify(not args.no_verify)
@@ -720,7 +806,7 @@ def main():
             torch.cuda.empty_cache()
             sort_leg["contexts_rehearsal"] = sort_contexts_rehearsal(ibu_amd, n, bc_len, umi_len, args.seed)
             if not sort_leg["contexts_rehearsal"]["globally_sorted_and_multiset_preserved"]:
-                raise SystemExit("ibu_sort_records_contexts: the shards do not form one sorted sequence of the input's records")
+                raise LegCheckFailed("ibu_sort_records_contexts: the shards do not form one sorted sequence of the input's records")
         except Exception as e:
             sort_leg["contexts_rehearsal"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -730,7 +816,7 @@ def main():
         leg.free()
         torch.cuda.empty_cache()
         try:
-            e2e = e2e_leg(ctx, ibu_amd, args.e2e_records, bc_len, umi_len, args.seed, args.e2e_dir)
+            e2e = e2e_leg(ctx, ibu_amd, args.e2e_records, bc_len, umi_len, args.seed, args.e2e_dir, torch=torch)
         except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
             e2e = {"error": f"{type(e).__name__}: {e}"}
 
@@ -749,6 +835,10 @@ def main():
             # any probing: placement.first_placement_*), scaled to the job like `value`; `value` itself is measured on arrays from
             # ibu_device_alloc_probed unless --placement-tries 1.  Compare THIS number with round 1 / BENCH_r01.
             "value_first_placement": placement["first_placement_records_per_s"] * (n_global / max(n, 1)),
+            # the same on arrays from plain ibu_device_alloc calls under the library's default option (auto probing): what a caller
+            # that does nothing about placement gets since round 5
+            "value_library_default_placement": (placement["library_default_records_per_s"] * (n_global / max(n, 1))
+                                                if "library_default_records_per_s" in placement else None),
             "unit": "records/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -793,9 +883,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
+        failed = [k for k, leg_ in (("sort_leg", sort_leg), ("e2e", e2e)) if isinstance(leg_, dict) and
+                  (str(leg_.get("error", "")).startswith("LegCheckFailed") or str(leg_.get("contexts_rehearsal", {}).get("error", "")).startswith("LegCheckFailed"))]
+        if failed:                                   # the line is out; a WRONG result in a side leg still fails the run
+            exit_code = 3
+            print(f"bench.py: correctness check failed in {failed}", file=sys.stderr)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

@@ -162,12 +162,12 @@ ibu_k_encode(const uint8_t* __restrict__ bc_in, const uint8_t* __restrict__ umi_
 // (profiles/r04_t_kbench_pack_unpack.jsonl): pack<16> 5.17 -> 5.37 TB/s, pack<12> 5.15 -> 5.29, pack<8> 5.24 -> 5.32.
 // Runtime lengths (LEN == 0) are staged as their code stream, whose dword c is chunk c of the column whatever the length: GNT
 // tiles and RND load rounds per iteration chosen by the launcher so that every round carries chunks — 4 tiles for rows of at most
-// 8 bases, 2 up to 24, 1 beyond, and ceil(len * GNT / 8) rounds.  Round 4 staged one tile four rounds deep at any length: at 5
+// 8 bases, 2 beyond, and ceil(len * GNT / 8) rounds.  Round 4 staged one tile four rounds deep at any length: at 5
 // bases three of the four loads of a lane re-read the column's last chunk (2.0 vector loads per row where 0.31 carry data; SQ
 // pass profiles/r05_b_sq5) and the kernel ran 0.86 of its own 5R:8W yardstick.
 constexpr int pack_nt(int len) { return (len > 0 && len <= 16) ? 2 : 1; }
 template <int LEN, bool MSB, int GNT = 1, int RND = 0>
-__global__ void __launch_bounds__(kBlock, LEN == 0 ? ((GNT >= 4 || RND >= 5) ? 6 : 8) : LEN <= 12 ? 5 : 4)   // (what two tiles of rows leave: 69-80 / 108 VGPRs; four
+__global__ void __launch_bounds__(kBlock, LEN == 0 ? (RND >= 7 ? 5 : (GNT >= 4 || RND >= 5) ? 6 : 8) : LEN <= 12 ? 5 : 4)   // (what two tiles of rows leave: 69-80 / 108 VGPRs; four
                                                                                               // tiles of runtime-length rows spill under 64)
 ibu_k_pack(const uint8_t* __restrict__ in, u64 row_base, u32 ntiles /*of NT x 128 rows*/, u32 len, u64* __restrict__ codes,
            u64* __restrict__ status) {
@@ -297,10 +297,10 @@ typedef void (*PackFn)(const uint8_t*, u64, u32, u32, u64*, u64*);
 #define IBU_PACK_ROW(M) {nullptr /* runtime lengths: pack_gen_entry */, ibu_k_pack<len_of_mode(1), M>, ibu_k_pack<len_of_mode(2), M>, \
                          ibu_k_pack<len_of_mode(3), M>, ibu_k_pack<len_of_mode(4), M>}
 static const PackFn kPackTable[2][kNumLenModes] = {IBU_PACK_ROW(false), IBU_PACK_ROW(true)};
-// Runtime lengths: tiles per iteration (4 / 2 / 1 for rows of at most 8 / 24 / 32 bases) and load rounds = ceil(len * tiles / 8).
+// Runtime lengths: tiles per iteration (4 for rows of at most 8 bases, 2 beyond) and load rounds = ceil(len * tiles / 8).
 struct PackShape { int nt, rounds; };
 static inline PackShape pack_shape(uint32_t len) {
-  const int nt = len <= 8 ? 4 : len <= 24 ? 2 : 1;
+  const int nt = len <= 8 ? 4 : 2;
   return {nt, (int)(len * nt + 7) / 8};
 }
 template <bool M>
@@ -314,7 +314,8 @@ static PackFn pack_gen_entry(int nt, int rounds) {
     case 24: return ibu_k_pack<0, M, 2, 4>;   // 13-15
     case 25: return ibu_k_pack<0, M, 2, 5>;   // 17-20 (round 5 measured one tile, three rounds at 20 bases: 0.93 of its 5R:2W yardstick)
     case 26: return ibu_k_pack<0, M, 2, 6>;   // 21-24
-    default: return ibu_k_pack<0, M, 1, 4>;   // 25-31
+    case 27: return ibu_k_pack<0, M, 2, 7>;   // 25-28 (one tile, four rounds at 25 bases: 0.66 of peak where 24 ran 0.73)
+    default: return ibu_k_pack<0, M, 2, 8>;   // 29-31
   }
 }
 

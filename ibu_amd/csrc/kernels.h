@@ -68,7 +68,7 @@ hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
 // sort.hip
 bool trace_sort();   // IBU_TRACE_SORT set to anything but "" / "0" (read once): one stderr line per sort / probed allocation saying what was chosen
 hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n, void* scratch,
-                               size_t scratch_bytes, hipStream_t st);
+                               size_t scratch_bytes, hipStream_t st, const uint64_t* known_words = nullptr /*u64[6]: OR x 3, AND x 3 of a superset: no census pass*/);
 size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
 int sort_num_variants();
 int sort_num_compact_variants();
@@ -95,7 +95,8 @@ hipError_t launch_partition_elems(const LaunchCfg&, const CompactPlan& pl, const
                                   const uint64_t** d_census /*nullable: the exact census words of these records, accumulated on the way*/, hipStream_t st);
 hipError_t launch_records_census_sample(const LaunchCfg&, const void* recs, size_t n, uint64_t* d_census /*u64[8 x 64]*/, bool* exact, hipStream_t st);
 hipError_t launch_partition_records(const LaunchCfg&, const void* recs, size_t n, const void* d_split /*24-byte records*/, uint32_t nsplit, void* out,
-                                    void* scratch, size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st);   // the same on 24-byte records (any key)
+                                    void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
+                                    const uint64_t** d_census /*nullable: the exact OR / AND words of these records, accumulated on the way*/, hipStream_t st);   // the same on 24-byte records (any key)
 bool sort_elems_supported(const LaunchCfg&, const void* recs, const void* tmp, size_t capacity);
 hipError_t launch_sort_elems(const LaunchCfg&, const CompactPlan& pl, void* recs, void* tmp, size_t n, uint32_t prefix_passes, void* scratch,
                              size_t scratch_bytes, hipStream_t st);

@@ -88,13 +88,18 @@ int32_t sample_shards(ibu_ctx_t* const* ctxs, const ibu_sort_shard_t* shards, si
   for (size_t i = 0; i < W; ++i) total += shards[i].n;
   return on_every_context(W, [&](size_t i) -> int32_t {
     const size_t n = shards[i].n;
-    size_t take = total ? (size_t)(((long double)budget * n) / total) + 1 : 0;
-    if (take > n) take = n;
+    size_t want = total ? (size_t)(((long double)budget * n) / total) + 1 : 0;
+    if (want > n) want = n;
+    if (!want) { samp[i].clear(); return IBU_OK; }
+    // one strided copy: the stride is an integer, so the COUNT is what gives way — take = n / stride samples, centred, reach
+    // within half a stride of both ends.  (Round 4 fixed the count and floored the stride: 513 samples at stride 5 of 3001
+    // records never saw the top 15 % of a sorted shard, and the last owner of 33 received 5.6 shares.)
+    const size_t stride = (n + want - 1) / want;             // >= 1
+    const size_t take = n / stride;                          // 1 .. want
+    const size_t first = (n - take * stride) / 2 + stride / 2;
     try { samp[i].resize(take); } catch (...) { return caught_io("ibu_sort_records_contexts"); }
-    if (!take) return IBU_OK;
     IBU_HIP(hipSetDevice(ctxs[i]->device));
-    const size_t stride = n / take;                          // >= 1
-    IBU_HIP(hipMemcpy2DAsync(samp[i].data(), kRec, static_cast<const uint8_t*>(shards[i].d_records) + kRec * (stride / 2), stride * kRec, kRec, take,
+    IBU_HIP(hipMemcpy2DAsync(samp[i].data(), kRec, static_cast<const uint8_t*>(shards[i].d_records) + kRec * first, stride * kRec, kRec, take,
                              hipMemcpyDeviceToHost, ctxs[i]->stream));
     IBU_HIP(hipStreamSynchronize(ctxs[i]->stream));
     return IBU_OK;
@@ -315,7 +320,8 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
 // ---- PARTITION FIRST on 24-byte records (any key) -------------------------------------------------------------------------------
 // The same scheme without the elements: keys of more than 11 varying bytes (full-range (32,32) records: 20), or buffers the element
 // kernels cannot take.  A record's key range goes into the digit side stream, one 24-byte pass of the sort puts the records in range
-// order in the shard's scratch, the owners pull their pieces over their own (dead) records and sort them once.  No census at all.
+// order in the shard's scratch, the owners pull their pieces over their own (dead) records and sort them once.  The census is taken by the
+// partition pass on its way (the stamp kernel reads every record anyway) and shared: no owner runs one of its own.
 int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, size_t total) {
   const bool trace = trace_sort();
   double t_mark = now_ms(), t_phase[4] = {0, 0, 0, 0};
@@ -328,6 +334,7 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   pick_splitters(samp, F, split);
   lap(0);
   std::vector<std::vector<uint64_t>> fine(W, std::vector<uint64_t>(F + 1, 0));
+  std::vector<std::array<uint64_t, 8>> words(W);
   const size_t split_bytes = kRec * (F - 1) + 512;
   rc = on_every_context(W, [&](size_t i) -> int32_t {
     ibu_ctx_t* c = ctxs[i];
@@ -340,15 +347,22 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
     hipStream_t st = c->stream;
     uint8_t* d_split_recs = static_cast<uint8_t*>(c->d_sort_scratch) + ((need + 255) & ~(size_t)255);
     IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
-    const uint64_t* d_starts = nullptr;
-    IBU_HIP(launch_partition_records(c->cfg, shards[i].d_records, n, d_split_recs, (uint32_t)(F - 1), shards[i].d_tmp, c->d_sort_scratch, need, &d_starts, st));
+    const uint64_t *d_starts = nullptr, *d_words = nullptr;
+    IBU_HIP(launch_partition_records(c->cfg, shards[i].d_records, n, d_split_recs, (uint32_t)(F - 1), shards[i].d_tmp, c->d_sort_scratch, need, &d_starts, &d_words, st));
     IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
+    IBU_HIP(hipMemcpyAsync(words[i].data(), d_words, 64, hipMemcpyDeviceToHost, st));   // the exact OR / AND words of this shard's records, taken on the way
     IBU_HIP(hipStreamSynchronize(st));
     fine[i][F] = n;
     return IBU_OK;
   });
   if (rc) return rc;
   lap(1);
+  // ONE census for everybody: the words of all shards combined say which key bytes vary anywhere; every owner's sort takes them as
+  // given and runs no census pass of its own (round 4: eight private ones, 24 B/record read again)
+  uint64_t all_words[6] = {0, 0, 0, ~0ull, ~0ull, ~0ull};
+  for (size_t i = 0; i < W; ++i)
+    if (shards[i].n)
+      for (int f = 0; f < 3; ++f) { all_words[f] |= words[i][f]; all_words[3 + f] &= words[i][3 + f]; }
   std::vector<std::vector<uint64_t>> bound(W, std::vector<uint64_t>(W + 1, 0));
   cut_owners(shards, W, fine, total, bound);
   std::vector<size_t> n_out(W, 0);
@@ -366,7 +380,14 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
         IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_records) + kRec * at, ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ctxs[j]->stream));
         return IBU_OK;
       },
-      [&](size_t j) -> int32_t { return ibu_sort_records(ctxs[j], shards[j].d_records, shards[j].d_tmp, n_out[j], nullptr); },
+      [&](size_t j) -> int32_t {
+        ibu_ctx_t* c = ctxs[j];
+        if (n_out[j] < 2) return IBU_OK;
+        int32_t r = ensure_sort_scratch(c, sort_scratch_bytes(c->cfg, n_out[j]));
+        if (r) return r;
+        IBU_HIP(launch_sort_records(c->cfg, shards[j].d_records, shards[j].d_tmp, n_out[j], c->d_sort_scratch, c->sort_scratch_bytes, c->stream, all_words));
+        return IBU_OK;
+      },
       &t_enq);
   if (rc) return rc;
   lap(3);

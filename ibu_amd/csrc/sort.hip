@@ -673,14 +673,22 @@ hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, c
 // The same partition pass on 24-byte RECORDS (keys of more than 11 varying bytes, or buffers the element kernels cannot take): a
 // record's key range — how many of the up to 255 splitter records are not above it — goes into the digit side stream, and one
 // ordinary 24-byte pass whose digit comes from that stream (ibu_k_sort_scatter, field > 2) moves the records into range order.
-extern "C" __global__ void __launch_bounds__(256)
-ibu_k_sort_stamp_records(const u64* __restrict__ recs, u64 n, const u64* __restrict__ split, u32 nsplit, uint8_t* __restrict__ digits) {
+// CENSUS: the exact census words of the records (OR / AND of every field) are accumulated on the way — the owners' sorts of the
+// multi-GPU form then need no census pass of their own (the order flags are not taken: pieces of several shards interleave).
+template <bool CENSUS>
+__global__ void __launch_bounds__(256)
+ibu_k_sort_stamp_records(const u64* __restrict__ recs, u64 n, const u64* __restrict__ split, u32 nsplit, uint8_t* __restrict__ digits,
+                         u64* __restrict__ census) {
   __shared__ u64 sp[3 * 256];
   for (u32 i = threadIdx.x; i < 3 * nsplit; i += blockDim.x) sp[i] = split[i];
   __syncthreads();
   const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u64 ref[3] = {recs[0], recs[1], recs[2]};            // n >= 1; uniform address: scalar loads
+  CensusAcc acc;
+  const bool any_rows = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~(u32)(kWave - 1)) < n;   // wave-uniform: the wave's first row exists
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const u64 b = recs[3 * i], u = recs[3 * i + 1], x = recs[3 * i + 2];
+    if constexpr (CENSUS) acc.rec(b, u, x, ref);
     u32 lo = 0, hi = nsplit;                                  // range = splitters <= record
     while (lo < hi) {
       const u32 mid = (lo + hi) >> 1;
@@ -688,9 +696,10 @@ ibu_k_sort_stamp_records(const u64* __restrict__ recs, u64 n, const u64* __restr
     }
     digits[i] = (uint8_t)lo;
   }
+  if constexpr (CENSUS) acc.flush(census, nullptr, ref, any_rows);
 }
 hipError_t launch_partition_records(const LaunchCfg& cfg, const void* recs, size_t n, const void* d_split, uint32_t nsplit, void* out, void* scratch,
-                                    size_t scratch_bytes, const uint64_t** d_starts, hipStream_t st) {
+                                    size_t scratch_bytes, const uint64_t** d_starts, const uint64_t** d_census, hipStream_t st) {
   (void)hipGetLastError();
   if (n == 0 || nsplit > 255) return hipErrorInvalidValue;
   const SweepVariant& sv = pick_variant(cfg);
@@ -712,8 +721,17 @@ hipError_t launch_partition_records(const LaunchCfg& cfg, const void* recs, size
   }
   const u32 cap = (u32)cfg.cus * 8;
   const u64 want = (n + 255) / 256;
-  hipLaunchKernelGGL(ibu_k_sort_stamp_records, dim3((u32)(want < cap ? want : cap)), dim3(256), 0, st, static_cast<const u64*>(recs), (u64)n,
-                     static_cast<const u64*>(d_split), nsplit, digits);
+  u64* census = d_census ? reinterpret_cast<u64*>(sc) : nullptr;   // the census slots sit at the head of the scratch (SortLayout)
+  if (census) {
+    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
+    hipLaunchKernelGGL(ibu_k_sort_stamp_records<true>, dim3((u32)(want < cap ? want : cap)), dim3(256), 0, st, static_cast<const u64*>(recs), (u64)n,
+                       static_cast<const u64*>(d_split), nsplit, digits, census);
+    hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, census);
+    *d_census = reinterpret_cast<const uint64_t*>(census);    // u64[8]: OR x 3, AND x 3 of exactly these n records ([6], [7]: not taken)
+  } else {
+    hipLaunchKernelGGL(ibu_k_sort_stamp_records<false>, dim3((u32)(want < cap ? want : cap)), dim3(256), 0, st, static_cast<const u64*>(recs), (u64)n,
+                       static_cast<const u64*>(d_split), nsplit, digits, (u64*)nullptr);
+  }
   const u32 wave_grid = (L.ntiles + kSortWaves - 1) / kSortWaves;
   hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n, L.ntiles, counts);
   hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
@@ -756,8 +774,11 @@ hipError_t launch_sort_elems(const LaunchCfg& cfg, const CompactPlan& pl, void* 
 
 // Not purely asynchronous: the census result comes back to the host (one 64-byte read) to pick the passes; everything
 // after that is queued on `st`.
+// known_words (nullable): census words the caller already has for a SUPERSET of these records (the multi-GPU sort: the partition pass
+// took them over all shards) — OR x 3, AND x 3; no census pass runs, no record is assumed in index order or sorted, and the bytes
+// that vary in the superset get their passes (a byte that happens to be constant here costs one identity pass).
 hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size_t n, void* scratch,
-                               size_t scratch_bytes, hipStream_t st) {
+                               size_t scratch_bytes, hipStream_t st, const uint64_t* known_words) {
   (void)hipGetLastError();
   if (n < 2) return hipSuccess;
   const SweepVariant& sv = pick_variant(cfg);
@@ -798,7 +819,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   // (Rounds 1-2 started at 2^23: one read of the records saved against one more host round trip.  With prefix + finish behind the
   // guess the sizes in between gain 2x — 3e5 / 1e6 / 4e6 records: 0.42 / 0.75 / 1.07 ms -> 0.27 / 0.42 / 0.58 ms.)
   const size_t guess_min = cfg.sort_guess == 1 ? 4 * kSample : ((size_t)cfg.sort_guess > 4 * kSample ? (size_t)cfg.sort_guess : 4 * kSample);
-  if (compact_ok && cfg.sort_guess && n >= guess_min) {
+  if (!known_words && compact_ok && cfg.sort_guess && n >= guess_min) {
     hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
     const size_t starts[3] = {0, (n / 2) & ~(size_t)1, (n - kSample) & ~(size_t)1};   // even rows: 16-byte aligned
     for (size_t s0 : starts) launch_census(cfg, static_cast<const u64*>(recs) + 3 * s0, kSample, census, nullptr, st);
@@ -826,16 +847,22 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
       fprintf(stderr, "ibu sort: n=%zu samples in order: read-only census first\n", n);
     }
   }
-  if (!speculated) {
-    hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
-    launch_census(cfg, recs, n, census, nullptr, st);
-  }
-  hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, census);
   u64 c[8];
-  e = hipMemcpyAsync(c, census, sizeof c, hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return e;
-  e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return e;
+  if (known_words) {
+    for (int w = 0; w < 6; ++w) c[w] = known_words[w];
+    c[6] = c[7] = 1;                 // nothing is known about the order
+    if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu census words given by the caller: no census pass\n", n);
+  } else {
+    if (!speculated) {
+      hipLaunchKernelGGL(ibu_k_sort_census_init, dim3(1), dim3(kCensusSlots * 8), 0, st, census);
+      launch_census(cfg, recs, n, census, nullptr, st);
+    }
+    hipLaunchKernelGGL(ibu_k_sort_census_fold, dim3(1), dim3(kCensusSlots), 0, st, census);
+    e = hipMemcpyAsync(c, census, sizeof c, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+  }
   if (c[7] == 0) {                   // no record is smaller than its predecessor: already sorted
     if (trace_sort()) fprintf(stderr, "ibu sort: n=%zu already sorted%s\n", n, speculated ? " (a speculative compress pass was spent)" : "");   // spent only when the samples saw a drop and the whole did not: impossible, the samples are rows of the whole
     return hipSuccess;

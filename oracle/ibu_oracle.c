@@ -811,3 +811,68 @@ double orc_bench_reduce(size_t n, uint64_t seed, int threads, orc_reduce* out) {
   free(in);
   return t1 - t0;
 }
+
+/* ---- the example programs' phases (bench.py: cpu_baseline.phases) ------------------------------------------------ */
+int orc_bench_phases(const char* path, size_t n, int threads, double seconds[5], uint64_t* xor_checksum, uint64_t sums[3], orc_err* e) {
+  orc_header h;
+  orc_header_new(&h, 16, 12);
+  orc_header_set_sorted(&h);
+  /* examples/roundtrip.rs:33-49 — one write_record per record */
+  double t0 = now_s();
+  orc_writer* w = orc_writer_new_file(path, &h);
+  if (!w) return ORC_E_IO;
+  for (size_t i = 0; i < n; i++) {
+    orc_record r = {(uint64_t)i % 1000000u, ((uint64_t)i * 31u) % 1000000u, (uint64_t)i};
+    int rc = orc_writer_write_record(w, &r);
+    if (rc) { orc_writer_drop(w); return rc; }
+  }
+  int rc = orc_writer_finish(w);
+  orc_writer_drop(w);
+  if (rc) return rc;
+  seconds[0] = now_s() - t0;
+  /* examples/roundtrip.rs:80-100 — the iterator, XOR of every field */
+  t0 = now_s();
+  orc_reader* rd = NULL;
+  rc = orc_reader_new_file(path, &rd, e);
+  if (rc) return rc;
+  uint64_t x = 0, seen = 0;
+  for (;;) {
+    orc_record r;
+    int got = 0;
+    rc = orc_reader_next(rd, &r, &got, e);
+    if (rc) { orc_reader_free(rd); return rc; }
+    if (!got) break;
+    x ^= r.barcode ^ r.umi ^ r.index;
+    seen++;
+  }
+  orc_reader_free(rd);
+  seconds[1] = now_s() - t0;
+  if (seen != n) return ORC_E_IO;
+  if (xor_checksum) *xor_checksum = x;
+  /* examples/roundtrip.rs:122-131 */
+  t0 = now_s();
+  orc_record* recs = NULL;
+  size_t got_n = 0;
+  orc_header hh;
+  rc = orc_load_to_vec(path, &hh, &recs, &got_n, e);
+  if (rc) return rc;
+  seconds[2] = now_s() - t0;
+  orc_free(recs);
+  if (got_n != n) return ORC_E_IO;
+  /* examples/parallel.rs:93-105 — process_parallel with the summing processor, T = 1 and T = threads */
+  orc_mmap* m = NULL;
+  rc = orc_mmap_new(path, &m, e);
+  if (rc) return rc;
+  orc_reduce red;
+  for (int pass = 0; pass < 2; pass++) {
+    const size_t T = pass == 0 ? 1 : (size_t)(threads > 0 ? threads : 1);
+    t0 = now_s();
+    rc = orc_mmap_process_parallel(m, T, T, &red, e);
+    seconds[3 + pass] = now_s() - t0;
+    if (rc) { orc_mmap_free(m); return rc; }
+  }
+  orc_mmap_free(m);
+  if (red.count != n) return ORC_E_IO;
+  if (sums) { sums[0] = red.sum[0]; sums[1] = red.sum[1]; sums[2] = red.sum[2]; }
+  return 0;
+}

@@ -171,5 +171,14 @@ size_t orc_lower_bound(const orc_record* sorted, size_t n, const orc_record* key
 double orc_bench_decode_encode(size_t n, uint32_t bc_len, uint32_t umi_len, uint64_t seed, int threads, int reps,
                                uint64_t* checksum); /* seconds for `reps` passes over n records */
 double orc_bench_reduce(size_t n, uint64_t seed, int threads, orc_reduce* out);
+/* The phases of the reference's two example programs on a file of n records (16,12; sorted flag set), each timed on its own:
+ *   seconds[0]  the write_record loop: Record(i % 1e6, 31 i % 1e6, i) for i in 0..n, then finish   examples/roundtrip.rs:33-49
+ *   seconds[1]  the streaming Reader, XOR of the three fields of every record                      examples/roundtrip.rs:80-100
+ *   seconds[2]  load_to_vec                                                                        examples/roundtrip.rs:122-131
+ *   seconds[3]  MmapReader::process_parallel, sum of the three fields, 1 thread                    examples/parallel.rs:93-105
+ *   seconds[4]  the same on `threads` threads
+ * *xor_checksum = the streaming read's checksum, sums[3] = process_parallel's field sums (threads run).  0 or an ORC_E_* code.
+ * The file is left in place (the caller removes it). */
+int orc_bench_phases(const char* path, size_t n, int threads, double seconds[5], uint64_t* xor_checksum, uint64_t sums[3], orc_err* e);
 
 #endif

@@ -442,3 +442,15 @@ def bench_reduce(n, seed, threads):
     r = Reduce()
     t = lib.orc_bench_reduce(n, seed, threads, C.byref(r))
     return t, {"count": r.count, "sum": list(r.sum), "xor": list(r.xor_)}
+
+
+def bench_phases(path, n, threads):
+    """The phases of the reference's example programs on a file of n records (ibu_oracle.h: orc_bench_phases) ->
+    ({"write_record": s, "reader_xor": s, "load_to_vec": s, "process_parallel_1": s, "process_parallel_T": s}, xor, sums)."""
+    lib.orc_bench_phases.restype = C.c_int
+    lib.orc_bench_phases.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint64), C.POINTER(Err)]
+    sec, x, sums, e = (C.c_double * 5)(), C.c_uint64(), (C.c_uint64 * 3)(), Err()
+    _check(lib.orc_bench_phases(str(path).encode(), n, threads, sec, C.byref(x), sums, C.byref(e)), e)
+    names = ["write_record", "reader_xor", "load_to_vec", "process_parallel_1", "process_parallel_T"]
+    return dict(zip(names, (float(v) for v in sec))), x.value, [int(v) for v in sums]

@@ -685,6 +685,58 @@ def test_full_size_roundtrip_properties_1e9(ia, ctx, lens):
     assert ctx.reduce(recs, n) == red
 
 
+def test_full_size_sort_and_decode_against_the_oracle_on_key_ranges_1e9(ia, ctx, oracle):
+    """ONE oracle comparison at BASELINE.json's full size (the 1e9 results had only been compared with
+    themselves).  The device generates and sorts 1e9 16/12 records; the oracle generates the same stream on the host in chunks of
+    1e7 and keeps the records whose barcode falls into 16 narrow ranges (about 1e5 records each), sorts each kept set with its
+    qsort — and the device's sorted output between lower_bound((lo, 0, 0)) and lower_bound((hi, 0, 0)) must be those bytes
+    (order: record.rs:58).  The decode kernel then runs over all 1e9 sorted records and its columns over the same 16 slices
+    must be the oracle's decode of the kept records (record.rs:19-27)."""
+    n, bc_len, umi_len, seed = 1_000_000_000, 16, 12, 0x1B00003
+    k_ranges, width = 16, 429_497                                # 2^32 barcodes x 1e-4: ~1e5 of the 1e9 records per range
+    rng = np.random.default_rng(20251005)
+    los = np.sort(rng.integers(0, 2**32 - width, k_ranges, dtype=np.uint64))
+    assert np.all(np.diff(los) > width)
+    edges = np.stack([los, los + np.uint64(width)], axis=1).reshape(-1)   # lo0, hi0, lo1, hi1, ...
+    recs, tmp = ctx.alloc(n * 24), ctx.alloc(n * 24)
+    ctx.generate(seed, 0, n, bc_len, umi_len, recs)
+    ctx.sort_records(recs, tmp, n)                               # (queued; the host filters meanwhile)
+    kept = [[] for _ in range(k_ranges)]
+    chunk = 10_000_000
+    for lo in range(0, n, chunk):
+        part = oracle.generate(seed, lo, min(chunk, n - lo), bc_len, umi_len)
+        where = np.searchsorted(edges, part["barcode"], side="right")   # odd: inside a range
+        inside = np.flatnonzero(where & 1)
+        for r in np.unique(where[inside] >> 1):
+            kept[int(r)].append(part[inside[(where[inside] >> 1) == r]])
+        del part
+    ctx.synchronize()
+    keys = np.zeros(2 * k_ranges, dtype=ia.REC_DTYPE)
+    keys["barcode"] = edges
+    d_keys, d_pos = ctx.upload(keys), ctx.alloc(8 * 2 * k_ranges)
+    ctx.lower_bound(recs, n, d_keys, 2 * k_ranges, d_pos)
+    ctx.synchronize()
+    pos = d_pos.download(np.uint64).reshape(-1, 2)
+    bc, umi, idx = ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)
+    ctx.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx)     # K2 over all 1e9 sorted records
+    ctx.synchronize()
+    total = 0
+    for r in range(k_ranges):
+        want = oracle.sort_records(np.concatenate(kept[r]))
+        p0, p1 = int(pos[r][0]), int(pos[r][1])
+        assert p1 - p0 == len(want) and len(want) > 50_000, (r, p0, p1, len(want))
+        got = ia.DeviceBuffer.wrap(ctx, recs.ptr + 24 * p0, 24 * (p1 - p0)).download()
+        assert got.tobytes() == want.tobytes(), f"sorted output differs from the oracle in key range {r}"
+        wbc, wumi, widx = oracle.decode_records(want, bc_len, umi_len)
+        assert ia.DeviceBuffer.wrap(ctx, bc.ptr + bc_len * p0, bc_len * (p1 - p0)).download().tobytes() == wbc.tobytes(), r
+        assert ia.DeviceBuffer.wrap(ctx, umi.ptr + umi_len * p0, umi_len * (p1 - p0)).download().tobytes() == wumi.tobytes(), r
+        assert ia.DeviceBuffer.wrap(ctx, idx.ptr + 8 * p0, 8 * (p1 - p0)).download().tobytes() == widx.tobytes(), r
+        total += len(want)
+    assert total > 1_000_000
+    for b_ in (recs, tmp, bc, umi, idx, d_keys, d_pos):
+        b_.free()
+
+
 def test_generate_into_an_8_byte_aligned_buffer(ia, ctx, oracle):
     """Not 16-B aligned: every record takes the one-thread-per-record kernel; same bytes."""
     n = 10_007

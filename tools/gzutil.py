@@ -3,7 +3,8 @@
 compressed in parallel the way pigz does it, as many members, and as BGZF blocks.  Not part of the product."""
 import os
 import zlib
-from concurrent.futures import ProcessPoolExecutor
+from concurrent.futures import ThreadPoolExecutor as ProcessPoolExecutor   # threads: zlib releases the GIL while it compresses, and a
+# fork of a process that holds an initialised HIP runtime, torch and feeder threads can deadlock (ADVICE r04) — the callers are such processes
 
 
 def _gz_member(args):

@@ -83,27 +83,28 @@ void enable_peer(const ibu_ctx* puller, int peer) {
 
 // Evenly spaced samples of every shard, IN PROPORTION to its size (a shard of 1e3 records beside one of 1e9 does not get the
 // same say: ADVICE r03), `budget` in all — one strided copy per shard.
+int32_t sample_one(ibu_ctx_t* ctx, const ibu_sort_shard_t& shard, size_t total, size_t budget, std::vector<Rec>& out) {
+  const size_t n = shard.n;
+  size_t want = total ? (size_t)(((long double)budget * n) / total) + 1 : 0;
+  if (want > n) want = n;
+  if (!want) { out.clear(); return IBU_OK; }
+  // one strided copy: the stride is an integer, so the COUNT is what gives way — take = n / stride samples, centred, reach
+  // within half a stride of both ends.  (Round 4 fixed the count and floored the stride: 513 samples at stride 5 of 3001
+  // records never saw the top 15 % of a sorted shard, and the last owner of 33 received 5.6 shares.)
+  const size_t stride = (n + want - 1) / want;             // >= 1
+  const size_t take = n / stride;                          // 1 .. want
+  const size_t first = (n - take * stride) / 2 + stride / 2;
+  try { out.resize(take); } catch (...) { return caught_io("ibu_sort_records_contexts"); }
+  IBU_HIP(hipSetDevice(ctx->device));
+  IBU_HIP(hipMemcpy2DAsync(out.data(), kRec, static_cast<const uint8_t*>(shard.d_records) + kRec * first, stride * kRec, kRec, take,
+                           hipMemcpyDeviceToHost, ctx->stream));
+  IBU_HIP(hipStreamSynchronize(ctx->stream));
+  return IBU_OK;
+}
 int32_t sample_shards(ibu_ctx_t* const* ctxs, const ibu_sort_shard_t* shards, size_t W, size_t budget, std::vector<std::vector<Rec>>& samp) {
   size_t total = 0;
   for (size_t i = 0; i < W; ++i) total += shards[i].n;
-  return on_every_context(W, [&](size_t i) -> int32_t {
-    const size_t n = shards[i].n;
-    size_t want = total ? (size_t)(((long double)budget * n) / total) + 1 : 0;
-    if (want > n) want = n;
-    if (!want) { samp[i].clear(); return IBU_OK; }
-    // one strided copy: the stride is an integer, so the COUNT is what gives way — take = n / stride samples, centred, reach
-    // within half a stride of both ends.  (Round 4 fixed the count and floored the stride: 513 samples at stride 5 of 3001
-    // records never saw the top 15 % of a sorted shard, and the last owner of 33 received 5.6 shares.)
-    const size_t stride = (n + want - 1) / want;             // >= 1
-    const size_t take = n / stride;                          // 1 .. want
-    const size_t first = (n - take * stride) / 2 + stride / 2;
-    try { samp[i].resize(take); } catch (...) { return caught_io("ibu_sort_records_contexts"); }
-    IBU_HIP(hipSetDevice(ctxs[i]->device));
-    IBU_HIP(hipMemcpy2DAsync(samp[i].data(), kRec, static_cast<const uint8_t*>(shards[i].d_records) + kRec * first, stride * kRec, kRec, take,
-                             hipMemcpyDeviceToHost, ctxs[i]->stream));
-    IBU_HIP(hipStreamSynchronize(ctxs[i]->stream));
-    return IBU_OK;
-  });
+  return on_every_context(W, [&](size_t i) -> int32_t { return sample_one(ctxs[i], shards[i], total, budget, samp[i]); });
 }
 // splitter k = the pooled sample at k / W (W: owners, or the 256 fine ranges of the partition-first form)
 void pick_splitters(std::vector<std::vector<Rec>>& samp, size_t W, std::vector<Rec>& split) {
@@ -322,16 +323,18 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
 // kernels cannot take.  A record's key range goes into the digit side stream, one 24-byte pass of the sort puts the records in range
 // order in the shard's scratch, the owners pull their pieces over their own (dead) records and sort them once.  The census is taken by the
 // partition pass on its way (the stamp kernel reads every record anyway) and shared: no owner runs one of its own.
-int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, size_t total) {
+int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shards, size_t total, std::vector<Rec>& split) {
   const bool trace = trace_sort();
   double t_mark = now_ms(), t_phase[4] = {0, 0, 0, 0};
   auto lap = [&](int k) { const double t = now_ms(); t_phase[k] = t - t_mark; t_mark = t; };
   constexpr size_t F = 256;
-  std::vector<std::vector<Rec>> samp(W);
-  int32_t rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
-  if (rc) return rc;
-  std::vector<Rec> split;
-  pick_splitters(samp, F, split);
+  int32_t rc = IBU_OK;
+  if (split.empty()) {                                          // (the caller has them already when it sampled for the element form's census)
+    std::vector<std::vector<Rec>> samp(W);
+    rc = sample_shards(ctxs, shards, W, sample_budget(W), samp);
+    if (rc) return rc;
+    pick_splitters(samp, F, split);
+  }
   lap(0);
   std::vector<std::vector<uint64_t>> fine(W, std::vector<uint64_t>(F + 1, 0));
   std::vector<std::array<uint64_t, 8>> words(W);
@@ -522,6 +525,8 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
     if (ctxs[0]->cfg.sort_compact != 0 && total > 0 && W <= kPartitionFirstMaxShards) {
       int32_t rc = IBU_OK;
       bool tried_elements = false;
+      std::vector<std::vector<Rec>> samp(W);
+      std::vector<Rec> split;                                   // the 255 splitters of the 256 fine ranges; empty: the form samples for itself
       if (aligned) {
         bool all_exact = true;
         std::vector<char> was_exact(W, 1);
@@ -535,16 +540,15 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
           uint64_t* d_c = static_cast<uint64_t*>(c->d_sort_scratch);
           IBU_HIP(launch_records_census_sample(c->cfg, shards[i].d_records, shards[i].n, d_c, &ex, c->stream));
           IBU_HIP(hipMemcpyAsync(words[i].data(), d_c, 64, hipMemcpyDeviceToHost, c->stream));
-          IBU_HIP(hipStreamSynchronize(c->stream));
           was_exact[i] = ex ? 1 : 0;
-          return IBU_OK;
+          return sample_one(c, shards[i], total, sample_budget(W), samp[i]);   // (synchronises: the census words have arrived too) — one round of threads for both
         });
         if (rc) return rc;
         for (size_t i = 0; i < W; ++i) all_exact = all_exact && was_exact[i];
         combine(&plan);
+        pick_splitters(samp, 256, split);                       // sampled once: a plan miss re-runs the partition pass only
         if (plan.k <= 11) {
           bool covered = true;
-          std::vector<Rec> split;                               // sampled once: a plan miss re-runs the partition pass only
           tried_elements = true;
           rc = sort_partition_first(ctxs, W, shards, plan, total, !all_exact, &words, &covered, split);
           if (rc == IBU_OK && !covered) {
@@ -554,7 +558,7 @@ extern "C" int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ct
           }
         }
       }
-      if (!tried_elements) rc = sort_partition_first_records(ctxs, W, shards, total);   // more than 11 varying key bytes, or buffers the element kernels cannot take
+      if (!tried_elements) rc = sort_partition_first_records(ctxs, W, shards, total, split);   // more than 11 varying key bytes, or buffers the element kernels cannot take
       if (rc != kLandingFailed) return rc;
       if (trace_sort()) fprintf(stderr, "ibu sort: contexts=%zu the range cut does not fit a shard's capacity: falling back to the sort-first form\n", W);
       return sort_sort_first(ctxs, W, shards, plan, false);

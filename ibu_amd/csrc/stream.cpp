@@ -312,9 +312,9 @@ extern "C" int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* 
 // (mmap.rs:312-320) with the batch in HBM
 // ------------------------------------------------------------------------------------------
 // A producer thread owns the source, the pinned slots and the copy stream; the consumer (the caller's thread) owns the order in
-// which batches are taken and the streams that read them.  Slot s goes FREE -> (filled, H2D queued) READY -> (next) HELD ->
-// (release: `consumed[s]` recorded on the caller's stream) RELEASED -> (producer waits for that event) refilled.  The producer
-// fills slots in ring order, so a batch held for long stalls the ring when its turn comes again — never correctness.
+// which batches are taken and the streams that read them.  Slot s goes FREE -> FILLING -> (H2D queued) READY -> (next) HELD ->
+// (release: `consumed[s]` recorded on the caller's stream) RELEASED -> (producer waits for that event) FILLING ...  The producer
+// takes ANY slot the consumer does not hold, so batches held for long (at most slots - 1) never stall the others.
 struct ibu_stream {
   ibu_ctx* ctx = nullptr;
   ibu_header_t header{};
@@ -327,8 +327,9 @@ struct ibu_stream {
   double t0 = 0;
   std::mutex mu;
   std::condition_variable cv;
-  enum : uint8_t { FREE, READY, HELD, RELEASED };
-  struct Slot { uint8_t state = FREE; size_t n = 0; uint64_t first = 0; };
+  enum : uint8_t { FREE, FILLING, READY, HELD, RELEASED };
+  struct Slot { uint8_t state = FREE; size_t n = 0; uint64_t first = 0, seq = 0; };   // seq: when it was released (oldest refilled first)
+  uint64_t release_seq = 0;
   std::vector<Slot> slot;
   std::deque<uint32_t> ready;        // READY slots in stream order
   uint32_t held = 0;
@@ -425,14 +426,28 @@ void stream_produce(ibu_stream* s) {
   uint64_t delivered = 0;
   size_t row = s->start;
   bool eof = s->m ? s->start >= s->end : false;
-  for (size_t k = 0; rc == IBU_OK && !eof; ++k) {
-    const uint32_t si = (uint32_t)(k % r.slots);
+  while (rc == IBU_OK && !eof) {
+    // any slot the consumer does not hold will do (never-used ones first, then the one released longest ago): with slots - 1 batches
+    // held the one slot left keeps the stream moving — filling in ring order would wait for a HELD slot while a free one sat idle
+    uint32_t si = 0;
     bool released = false;
     {
       std::unique_lock<std::mutex> lk(s->mu);
-      s->cv.wait(lk, [&] { return s->stop || s->slot[si].state == ibu_stream::FREE || s->slot[si].state == ibu_stream::RELEASED; });
+      int pick = -1;
+      s->cv.wait(lk, [&] {
+        if (s->stop) return true;
+        pick = -1;
+        for (uint32_t i = 0; i < r.slots && pick < 0; ++i)
+          if (s->slot[i].state == ibu_stream::FREE) pick = (int)i;
+        if (pick < 0)
+          for (uint32_t i = 0; i < r.slots; ++i)
+            if (s->slot[i].state == ibu_stream::RELEASED && (pick < 0 || s->slot[i].seq < s->slot[pick].seq)) pick = (int)i;
+        return pick >= 0;
+      });
       if (s->stop) break;
+      si = (uint32_t)pick;
       released = s->slot[si].state == ibu_stream::RELEASED;
+      s->slot[si].state = ibu_stream::FILLING;
     }
     if (released) {                  // the consumer's work on the slot's previous batch (and so its H2D) is done
       e = hipEventSynchronize(r.consumed[si]);
@@ -468,6 +483,9 @@ void stream_produce(ibu_stream* s) {
       s->stats.batches += 1;
       delivered += n;
       s->cv.notify_all();
+    } else {
+      std::lock_guard<std::mutex> g(s->mu);
+      s->slot[si].state = ibu_stream::FREE;     // nothing came (the end, or an error with no batch in front of it)
     }
     if (src_rc) rc = src_rc;
   }
@@ -534,6 +552,7 @@ int32_t stream_give_back(ibu_stream* s, uint32_t si, hipStream_t st) {
   {
     std::lock_guard<std::mutex> g(s->mu);
     s->slot[si].state = ibu_stream::RELEASED;   // (even when the record failed: the stream must be able to end)
+    s->slot[si].seq = ++s->release_seq;
     --s->held;
     s->cv.notify_all();
   }

@@ -568,8 +568,9 @@ int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* ctx, const 
  *   exactly the records the reference's iterator yields before its Err: whole refills of IBU_DEFAULT_BUFFER_SIZE counted from
  *   where the stream took over; the complete records of the final partial refill are dropped with it (quirk Q8,
  *   reader.rs:232-237).
- * close: stops the producer, waits for the copies in flight and for the context's stream, returns the ring.  Batches still
- *   held are invalid afterwards.  The reader / map stays open and is the caller's to close. */
+ * close: stops the producer (a producer blocked inside the source — a pipe nobody writes to — is waited for: close the writing end
+ *   first), waits for the copies in flight and for the context's stream, returns the ring.  Batches still held are invalid
+ *   afterwards.  The reader / map stays open and is the caller's to close. */
 typedef struct ibu_stream ibu_stream_t;
 int32_t ibu_stream_open_reader(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, ibu_stream_t** out);
 int32_t ibu_stream_open_mmap(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, size_t shard, size_t n_shards,

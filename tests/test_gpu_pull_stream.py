@@ -243,6 +243,30 @@ def test_batches_may_be_held_and_released_in_any_order_but_not_all_of_them(ia, c
     m.close()
 
 
+def test_one_free_slot_keeps_the_stream_moving_while_the_others_are_held(ia, ctx, oracle, tmp_path):
+    """slots - 1 batches held for the whole stream: everything else flows through the one slot left (the producer takes any
+    slot the caller does not hold, not the next one in ring order)."""
+    n = 12 * 4096 + 5
+    p = tmp_path / "one.ibu"
+    recs = _write_file(oracle, p, n)
+    m = ia.MmapReader.new(p)
+    with m.device_stream(ctx, ring=SMALL) as s:                      # 3 slots
+        a, b = s.next_batch(), s.next_batch()
+        host = [a.download().copy(), b.download().copy()]
+        ptrs = {a.ptr, b.ptr}
+        while True:
+            c = s.next_batch()
+            if c is None:
+                break
+            assert c.ptr not in ptrs                                 # always the third slot
+            host.append(c.download().copy())
+            c.release()
+        a.release()
+        b.release()
+    assert np.concatenate(host).tobytes() == recs.tobytes()
+    m.close()
+
+
 def test_the_ring_is_lent_while_a_stream_is_open(ia, ctx, oracle, tmp_path):
     p = tmp_path / "l.ibu"
     _write_file(oracle, p, 10_000)

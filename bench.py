@@ -424,36 +424,44 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
         assert os.path.getsize(path) == file_bytes
 
         best = None
+        dst = ctx.alloc(24 * n)                          # the caller's buffer: the transfer alone (allocation is timed on its own below)
         for rep in range(2):                             # the first call allocates the pinned ring and warms the page cache
             t0 = time.perf_counter()
-            _, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
+            _, dptr, got_n, st = ctx.load_to_device(path, ring=ring, d_records=dst, cap_records=n)
             dt = time.perf_counter() - t0
-            ok = got_n == n and ctx.reduce(dptr, n) == want
-            dec = None
-            if ok and rep == 1 and torch is not None:
-                # decode of the records where the LIBRARY put them (the destination is the library's allocation: placement-probed
-                # under the default option from 1 GiB on) into columns from ibu_device_alloc: the kernel's rate a file-based caller sees
-                cols = [ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)]
-                ms = []
-                for _ in range(3):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(torch.cuda.ExternalStream(ctx.stream))
-                    ctx.decode_ascii(dptr, n, bc_len, umi_len, *cols)
-                    e1.record(torch.cuda.ExternalStream(ctx.stream))
-                    e1.synchronize()
-                    ms.append(e0.elapsed_time(e1))
-                for b in cols:
-                    b.free()
-                gbps = n * (24 + bc_len + umi_len + 8) / (min(ms[1:]) * 1e-3) / 1e9
-                dec = {"decode_ms_on_the_loaded_records": min(ms[1:]), "decode_GBps": gbps, "decode_frac_of_peak": gbps / HBM_PEAK_GBPS,
-                       "arrays": "destination allocated by ibu_load_to_device, columns by ibu_device_alloc (library default placement)"}
-            ctx.free(dptr)
-            if not ok:
+            if not (got_n == n and ctx.reduce(dptr, n) == want):
                 raise LegCheckFailed("e2e: load_to_device returned other records than were written")
-            best = rate(dt, st, first_call_seconds=best["seconds"] if best else None, totals_equal_resident_copy=True)
-            if dec:
-                best["then_decode"] = dec
+            best = rate(dt, st, first_call_seconds=best["seconds"] if best else None, totals_equal_resident_copy=True,
+                        destination="a caller-owned device buffer (no allocation inside the call)")
+        dst.free()
         out["load_to_device"] = best
+        # the same call with the destination allocated by the LIBRARY (placement-probed under the default option from 1 GiB on: up to
+        # four candidates are allocated, a write + read streamed over each, the fastest kept), then one decode of the records where the
+        # library put them into columns from ibu_device_alloc: what a file-based caller that does nothing about placement sees
+        t0 = time.perf_counter()
+        _, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
+        dt = time.perf_counter() - t0
+        if not (got_n == n and ctx.reduce(dptr, n) == want):
+            raise LegCheckFailed("e2e: load_to_device (library-allocated destination) returned other records than were written")
+        lib = rate(dt, st, totals_equal_resident_copy=True,
+                   destination="allocated inside the call, option alloc_probe_tries = 0 (auto); allocating right after large frees "
+                               "waits for the driver to hand out cleared VRAM: profiles/r05_h_alloc_probe_cost.jsonl")
+        if torch is not None:
+            cols = [ctx.alloc(n * bc_len), ctx.alloc(n * umi_len), ctx.alloc(n * 8)]
+            ms = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.ExternalStream(ctx.stream))
+                ctx.decode_ascii(dptr, n, bc_len, umi_len, *cols)
+                e1.record(torch.cuda.ExternalStream(ctx.stream))
+                e1.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            for b in cols:
+                b.free()
+            gbps = n * (24 + bc_len + umi_len + 8) / (min(ms[1:]) * 1e-3) / 1e9
+            lib["then_decode"] = {"decode_ms_on_the_loaded_records": min(ms[1:]), "decode_GBps": gbps, "decode_frac_of_peak": gbps / HBM_PEAK_GBPS}
+        ctx.free(dptr)
+        out["load_to_device_library_allocated"] = lib
 
         m = ia.MmapReader.new(path)
         ndev = ia.device_count()

@@ -72,6 +72,7 @@ struct ibu_ctx {
 namespace ibu {
 int32_t ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_dev);
 void ring_release(ibu_ctx* ctx);
+void stream_orphan(ibu_ctx* ctx);   // stream.cpp: shut down the open ibu_stream_t that holds the ring (ibu_ctx_destroy)
 void codec_ring_release(ibu_ctx* ctx);
 int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hipMalloc, or the probed form under option "alloc_probe_tries"
 // The context's sort scratch (census slots, histograms, digit side stream): grows only; the one allocation a launch path may make.

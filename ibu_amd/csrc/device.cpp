@@ -86,6 +86,7 @@ extern "C" int32_t ibu_ctx_create(int32_t device, ibu_ctx_t** out) {
 extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->ring_lent) stream_orphan(ctx);   // a stream still open on this context: stop its producer before the ring goes
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);

@@ -1145,7 +1145,10 @@ int32_t ibu::reader_read_direct(ibu_reader_t* r, uint8_t* dst, size_t cap_bytes,
   while (read < cap_bytes) {
     size_t got = 0;
     int e = r->inner->read(dst + read, cap_bytes - read, &got);
-    if (e) return src_error(r, e, "read");
+    if (e) {                                           // (reader.rs:225-230: the refill under way is lost with the error, the ones in front of it were yielded)
+      *got_bytes = read - read % IBU_RECORD_SIZE;
+      return src_error(r, e, "read");
+    }
     if (got == 0) { *eof = true; break; }
     read += got;
   }

@@ -14,7 +14,8 @@ int32_t open_plain_file(const char* path, int* fd_out, ibu_header_t* header, siz
 // `cap_bytes` are there or the stream ends, without the detour through the reader's own 1.18 MB buffer (which must be
 // empty: ibu_reader_buffered == 0).  Whole records only: a stream that ends inside a record is TruncatedRecord with the
 // position read_batch would report (reader.rs:232-237), with *got_bytes = the complete record bytes in front of the cut and
-// r->bytes_read unchanged.  *eof: the stream ended (possibly with *got_bytes > 0).
+// r->bytes_read unchanged; a source error likewise leaves in *got_bytes the complete record bytes read in front of it.
+// *eof: the stream ended (possibly with *got_bytes > 0).
 int32_t reader_read_direct(ibu_reader_t* r, uint8_t* dst, size_t cap_bytes, size_t* got_bytes, bool* eof);
 // num_cpus::get()
 size_t host_cores();

@@ -386,12 +386,11 @@ int32_t fill_from_reader(ibu_stream* s, uint8_t* dst, size_t* filled, bool* eof)
     const size_t ask = room / kRefillRecords * kRefill;
     size_t got = 0;
     const int32_t rc = reader_read_direct(rd, dst + n * IBU_RECORD_SIZE, ask, &got, &s->src_eof);
-    if (rc == IBU_ERR_TRUNCATED_RECORD) {              // `got` = the complete record bytes in front of the cut: its whole refills go out
-      *filled = n + got / kRefill * kRefillRecords;
-      *eof = true;
+    if (rc) {                                          // a stream that ends inside a record, or a source error (reader.rs:225-237): `got` = the
+      *filled = n + got / kRefill * kRefillRecords;    // complete record bytes in front of it — their WHOLE refills go out, as the reference's
+      *eof = true;                                     // iterator has yielded them by then; the refill under way is lost with the error
       return rc;
     }
-    if (rc) { *eof = true; return rc; }
     *filled = n + got / IBU_RECORD_SIZE;
     *eof = s->src_eof;               // a short read is the end of the source: this batch is the last
     return IBU_OK;
@@ -621,6 +620,7 @@ extern "C" int32_t ibu_stream_next(ibu_stream_t* s, void* stream, const void** d
   if (!s || !d_records || !n) return err_arg("NULL argument");
   *d_records = nullptr;
   *n = 0;
+  if (!s->ctx) return err_arg("the stream's context has been destroyed");
   IBU_HIP(hipSetDevice(s->ctx->device));
   uint32_t si = 0;
   uint64_t first = 0;
@@ -633,6 +633,7 @@ extern "C" int32_t ibu_stream_next(ibu_stream_t* s, void* stream, const void** d
 
 extern "C" int32_t ibu_stream_release(ibu_stream_t* s, const void* d_records, void* stream) {
   if (!s || !d_records) return err_arg("NULL argument");
+  if (!s->ctx) return err_arg("the stream's context has been destroyed");
   IBU_HIP(hipSetDevice(s->ctx->device));
   Ring& r = s->ctx->ring;
   uint32_t si = r.slots;
@@ -656,8 +657,16 @@ extern "C" int32_t ibu_stream_stats(const ibu_stream_t* s, ibu_stream_stats_t* o
 
 extern "C" void ibu_stream_close(ibu_stream_t* s) {
   if (!s) return;
-  stream_shutdown(s);
+  if (s->ctx) stream_shutdown(s);    // (an orphan — its context was destroyed first — has been shut down already)
   delete s;
+}
+// ibu_ctx_destroy under an open stream: the producer is stopped and joined and the ring given back BEFORE the context frees it; the
+// handle stays valid for ibu_stream_close (every other call on it reports the destroyed context).
+void ibu::stream_orphan(ibu_ctx* ctx) {
+  ibu_stream* s = static_cast<ibu_stream*>(ctx->ring_lent);
+  if (!s) return;
+  stream_shutdown(s);
+  s->ctx = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------

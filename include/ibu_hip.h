@@ -570,7 +570,10 @@ int32_t ibu_writer_write_batch_device_on(ibu_writer_t* w, ibu_ctx_t* ctx, const 
  *   reader.rs:232-237).
  * close: stops the producer (a producer blocked inside the source — a pipe nobody writes to — is waited for: close the writing end
  *   first), waits for the copies in flight and for the context's stream, returns the ring.  Batches still held are invalid
- *   afterwards.  The reader / map stays open and is the caller's to close. */
+ *   afterwards.  The reader / map stays open and is the caller's to close.  ibu_ctx_destroy under an open stream shuts the
+ *   stream down first (producer joined, ring returned); the handle stays valid for ibu_stream_close only.
+ * A source error (Io, Niffler) inside a refill behaves like the truncation: the whole refills in front of it are delivered,
+ *   the refill under way is lost with the error (reader.rs:225-230). */
 typedef struct ibu_stream ibu_stream_t;
 int32_t ibu_stream_open_reader(ibu_reader_t* r, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, ibu_stream_t** out);
 int32_t ibu_stream_open_mmap(const ibu_mmap_t* m, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg, size_t shard, size_t n_shards,

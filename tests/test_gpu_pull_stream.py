@@ -381,3 +381,119 @@ def test_process_device_and_the_pull_stream_are_one_pipeline(ia, ctx, oracle, tm
         st2 = s.stats()
     assert acc == res and st2.records == st.records == n and st2.batches == st.batches == nb
     m.close()
+
+
+def test_destroying_the_context_under_an_open_stream_is_safe(ia, oracle, tmp_path):
+    """ibu_ctx_destroy with a stream still open: the producer is stopped and the ring returned before the context goes; the handle
+    stays closable, every other call on it reports the destroyed context."""
+    p = tmp_path / "o.ibu"
+    _write_file(oracle, p, 50_000)
+    c = ia.Context(0)
+    m = ia.MmapReader.new(p)
+    s = m.device_stream(c, ring=SMALL)
+    b = s.next_batch()
+    assert b.n == 4096
+    c.close()                                                        # destroys the context; the stream becomes an orphan
+    with pytest.raises(ia.IbuError) as e:
+        s.next_batch()
+    assert e.value.kind == "InvalidArg"
+    with pytest.raises(ia.IbuError):
+        b.release()
+    s.close()
+    m.close()
+
+
+@pytest.mark.parametrize("ring", [SMALL, ONE, MID])
+def test_a_source_error_arrives_after_the_whole_refills_in_front_of_it(ia, ctx, oracle, tmp_path, ring):
+    """reader.rs:225-230: `inner.read` failing inside a refill returns the error at once — the refills in front of it were yielded,
+    the one under way is lost.  A file-like source that raises EIO after 3.5 refills: three refills of records, then Io."""
+    n = 6 * REFILL
+    p = tmp_path / "io.ibu"
+    recs = _write_file(oracle, p, n)
+    data = p.read_bytes()
+    fail_at = 32 + 24 * (3 * REFILL + REFILL // 2) + 7
+
+    class Flaky:
+        def __init__(self):
+            self.pos = 0
+
+        def read(self, k):
+            if self.pos >= fail_at:
+                raise OSError(5, "injected")
+            k = min(k, fail_at - self.pos, 100_003)
+            out = data[self.pos:self.pos + k]
+            self.pos += k
+            return out
+
+    r = ia.Reader(Flaky())
+    s = r.device_stream(ctx, ring=ring)
+    got = []
+    with pytest.raises(ia.IbuError) as e:
+        for b in s:
+            with b:
+                got.append(b.download().copy())
+    assert e.value.kind == "Io" and e.value.os_errno == 5
+    assert np.concatenate(got).tobytes() == recs[:3 * REFILL].tobytes()
+    s.close()
+    r.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IBU_FUZZ_SEEDS_STREAM", "24"))))
+def test_pull_stream_fuzz_against_the_oracles_iterator(ia, ctx, oracle, tmp_path, seed):
+    """Seeded fuzz: random sizes, ring shapes, source forms (plain / gzip / BGZF Reader, mmap shards), records already taken by
+    the host iterator, and cuts inside the last record — what the stream delivers (and the error it ends with) is what the
+    oracle's iterator yields on the same bytes."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([0, 1, 5, 4095, 4096, REFILL - 1, REFILL, REFILL + 1, 2 * REFILL + 3, int(rng.integers(1, 400_000))]))
+    lens = [(16, 12), (32, 32), (5, 7), (31, 1)][seed % 4]
+    ring = {"slots": int(rng.integers(2, 6)), "slot_records": int(rng.choice([128, 1000, 4096, REFILL - 128, REFILL, REFILL + 128, 3 * REFILL, 200_000])),
+            "feeder_threads": int(rng.integers(1, 5))}
+    p = tmp_path / "f.ibu"
+    recs = _write_file(oracle, p, n, *lens)
+    cut = int(rng.choice([0, 0, int(rng.integers(1, 24)), 24 * int(rng.integers(0, 3)) + int(rng.integers(1, 24))])) if n else 0
+    cut = min(cut, 24 * n - 1) if n else 0
+    if cut:
+        with open(p, "r+b") as f:
+            f.truncate(32 + 24 * n - cut)
+    form = ["plain", "gzip", "bgzf", "mmap"][int(rng.integers(0, 4))]
+    if form == "mmap" and cut % 24:
+        form = "plain"                                               # a map refuses such a file at open (InvalidMapSize)
+    want, err = _oracle_iterate(oracle, p)
+    taken = int(rng.integers(0, 20)) if form != "mmap" and len(want) > 40 else 0
+    got = []
+    if form == "mmap":
+        m = ia.MmapReader.new(p)
+        nsh = int(rng.integers(1, 5))
+        for sh in range(nsh):
+            with m.device_stream(ctx, shard=sh, n_shards=nsh, ring=ring) as s:
+                for b in s:
+                    with b:
+                        got.extend(_as_tuples(b.download()))
+        m.close()
+        assert got == want and err is None
+        return
+    path = p
+    if form == "gzip":
+        path = tmp_path / "f.ibu.gz"
+        path.write_bytes(gzip.compress(p.read_bytes(), 1))
+    elif form == "bgzf":
+        from tests.bgzf import bgzf_compress
+        path = tmp_path / "f.ibu.bgz"
+        path.write_bytes(bgzf_compress(p.read_bytes()))
+    r = ia.Reader.from_path(path)
+    head = [tuple(next(r)) for _ in range(taken)]
+    s = r.device_stream(ctx, ring=ring)
+    seen_err = None
+    try:
+        for b in s:
+            with b:
+                got.extend(_as_tuples(b.download()))
+    except ia.IbuError as e:
+        seen_err = e
+    s.close()
+    r.close()
+    assert head + got == want, (seed, form, n, cut, ring, taken, len(got), len(want))
+    if err is None:
+        assert seen_err is None
+    else:
+        assert seen_err is not None and seen_err.kind == err.name and seen_err.pos == err.a

@@ -63,9 +63,11 @@ def parse(argv=None):
                    help="candidates per resident array for the library's placement probing (ibu_device_alloc_probed: all "
                         "candidates of an array held at once, a write and a read streamed over each, the fastest kept, the "
                         "others freed) BEFORE the timed region; every probe is printed.  0 (default) = as many as fit, at most "
-                        "16: 3-5 for the arrays of 1e9 records on one GPU, 16 for the shards of an 8-GPU run.  1 = plain "
-                        "ibu_device_alloc (what a caller that does not probe gets; also measured and reported in every run "
-                        "as value_first_placement).  See place_leg()")
+                        "16: 3-5 for the arrays of 1e9 records on one GPU, 16 for the shards of an 8-GPU run.  1 = no bench-side "
+                        "probing: on one GPU the arrays then come from plain ibu_device_alloc calls under the LIBRARY's default "
+                        "option (alloc_probe_tries = auto since round 5), on several GPUs from plain hipMalloc.  Every run also "
+                        "reports value_first_placement (plain hipMalloc) and, on one GPU, value_library_default_placement.  "
+                        "See place_leg()")
     # rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never used by the driver):
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: collectives on CPU tensors")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo)")

@@ -62,9 +62,11 @@ extern "C" const char* ibu_status_name(int32_t s) {
     default: return "Unknown";
   }
 }
-extern "C" const char* ibu_version(void) { return "ibu_hip 0.1.0 (format v2, reference ibu 0.2.1, gfx950)"; }
+extern "C" const char* ibu_version(void) { return "ibu_hip 0.5.0 (format v2, reference ibu 0.2.1, gfx950)"; }
 // 2: + device_copy, barcode_counts, decode_to_host, write_ascii_batch, ctx_set_option
 // 3: ibu_decode_sink_t.cap_records (layout change), + lower_bound_records, "base_order" / "sort_variant" options
+// 4: ibu_stream_stats_t + numa_node / ring_node (layout change), + ibu_stream_* (pull stream), ibu_ctx_numa, ibu_numa_of_pci, options "numa",
+//    "peer_access", "alloc_probe_tries" = 0 (auto, the new default)
 extern "C" uint32_t ibu_abi_revision(void) { return 4; }
 extern "C" void ibu_free(void* p) { free(p); }
 

@@ -63,6 +63,9 @@ struct ibu_ctx {
   ibu::Ring ring;
   ibu::CodecRing cring;
   void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
+  std::vector<hipStream_t> pull_streams;   // the multi-GPU sort's pulls: one stream per peer link in use at once (created on demand, multi_sort.cpp)
+  std::vector<hipEvent_t> pull_events;
+  int force_pull_streams = 0;      // option "sort_pull_streams" (test knob): 1 = pieces of same-device peers travel on their own pull streams too
   int peer_access = 1;             // option "peer_access": 0 = never enable direct peer access for this context's pulls (the runtime stages the copies)
   int numa_mode = 1;               // option "numa": 1 = auto (feed threads and the pinned ring on the device's node), 0 = off
   char pci_bus_id[32] = {0};       // "0000:c1:00.0"

@@ -92,6 +92,8 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
   ring_release(ctx);
   codec_ring_release(ctx);
+  for (hipStream_t ps : ctx->pull_streams) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+  for (hipEvent_t pe : ctx->pull_events) (void)hipEventDestroy(pe);
   if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
   if (ctx->d_runs_scratch) (void)hipFree(ctx->d_runs_scratch);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
@@ -138,6 +140,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
   if (strcmp(key, "alloc_probe_tries") == 0) {
     if (value < 0 || value > IBU_ALLOC_PROBE_MAX) return err_arg("alloc_probe_tries must be 0 (auto) .. 16");
     ctx->cfg.alloc_probe_tries = (int)value;
+    return IBU_OK;
+  }
+  if (strcmp(key, "sort_pull_streams") == 0) {
+    if (value != 0 && value != 1) return err_arg("sort_pull_streams must be 0 or 1");
+    ctx->force_pull_streams = (int)value;
     return IBU_OK;
   }
   if (strcmp(key, "peer_access") == 0) {

@@ -81,6 +81,45 @@ void enable_peer(const ibu_ctx* puller, int peer) {
   (void)hipGetLastError();
 }
 
+// xGMI is point to point: a GPU has one link to each peer, and copies queued on ONE stream run one after the other — one link busy,
+// six idle.  An owner's pulls therefore go out on one stream PER PEER DEVICE (up to kPullStreams, created on demand and kept by the
+// context), so that the links carry their pieces at the same time; the context's own stream then waits for all of them.  Pieces
+// that live on the owner's own device are device-local copies and stay on the context's stream.
+constexpr size_t kPullStreams = 7;
+// (option "sort_pull_streams" = 1, a test knob: same-device peers — a rehearsal on one GPU — get their own streams too, by shard number,
+// so that the fork / join of the pull streams runs where there is only one device)
+int32_t pull_stream_for(ibu_ctx* c, int peer_device, size_t peer_shard, hipStream_t* out) {
+  if (peer_device == c->device && !c->force_pull_streams) { *out = c->stream; return IBU_OK; }
+  const size_t slot = (c->force_pull_streams ? peer_shard : (size_t)peer_device) % kPullStreams;
+  while (c->pull_streams.size() <= slot) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    IBU_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipStreamDestroy(st); return hip_fail(e, "hipEventCreateWithFlags"); }
+    try { c->pull_streams.push_back(st); c->pull_events.push_back(ev); }
+    catch (...) { (void)hipStreamDestroy(st); (void)hipEventDestroy(ev); return caught_io("ibu_sort_records_contexts"); }
+  }
+  *out = c->pull_streams[slot];
+  return IBU_OK;
+}
+// the context's stream continues only when every pull stream has delivered
+int32_t join_pull_streams(ibu_ctx* c) {
+  for (size_t k = 0; k < c->pull_streams.size(); ++k) {
+    IBU_HIP(hipEventRecord(c->pull_events[k], c->pull_streams[k]));
+    IBU_HIP(hipStreamWaitEvent(c->stream, c->pull_events[k], 0));
+  }
+  return IBU_OK;
+}
+// ... and a pull stream starts only behind what the context's stream has queued so far (the owner's own earlier work on the
+// buffers the pulls write)
+int32_t fork_pull_streams(ibu_ctx* c, hipEvent_t scratch_event) {
+  if (c->pull_streams.empty()) return IBU_OK;
+  IBU_HIP(hipEventRecord(scratch_event, c->stream));
+  for (hipStream_t ps : c->pull_streams) IBU_HIP(hipStreamWaitEvent(ps, scratch_event, 0));
+  return IBU_OK;
+}
+
 // Evenly spaced samples of every shard, IN PROPORTION to its size (a shard of 1e3 records beside one of 1e9 does not get the
 // same say: ADVICE r03), `budget` in all — one strided copy per shard.
 int32_t sample_one(ibu_ctx_t* ctx, const ibu_sort_shard_t& shard, size_t total, size_t budget, std::vector<Rec>& out) {
@@ -166,8 +205,8 @@ void cut_owners(const ibu_sort_shard_t* shards, size_t W, const std::vector<std:
     for (size_t j = 0; j <= W; ++j) bound[i][j] = fine[i][cut[j]];
 }
 
-// The exchange and the owners' sorts without a join between them.  pull(j, i, cnt, first, land): queue owner j's copy of `cnt`
-// units of shard i, from unit `first` of its partitioned scratch to unit `land` at the owner, on ctxs[j]->stream.
+// The exchange and the owners' sorts without a join between them.  pull(j, i, cnt, first, land, stream): queue owner j's copy of `cnt`
+// units of shard i, from unit `first` of its partitioned scratch to unit `land` at the owner, on `stream` (one per peer device).
 // sort(j): queue owner j's sort on ctxs[j]->stream (may synchronise that stream itself).  What orders them:
 //   - owner j's sort follows its own pulls in its stream;
 //   - the sort overwrites shard j's scratch, which the OTHER owners read: it waits (hipStreamWaitEvent, across devices) for the
@@ -183,13 +222,23 @@ int32_t exchange_then_sort(ibu_ctx_t* const* ctxs, size_t W, const std::vector<s
   int32_t rc = on_every_context(W, [&](size_t j) -> int32_t {
     IBU_HIP(hipSetDevice(ctxs[j]->device));
     IBU_HIP(hipEventCreateWithFlags(&pulled[j], hipEventDisableTiming));
+    for (size_t i = 0; i < W; ++i) {                            // streams for the peers this owner pulls from, before anything is queued on them
+      hipStream_t ps;
+      if (bound[i][j + 1] > bound[i][j]) { const int32_t r = pull_stream_for(ctxs[j], ctxs[i]->device, i, &ps); if (r) return r; }
+    }
+    int32_t r = fork_pull_streams(ctxs[j], pulled[j]);          // (the event is free until it is recorded for good below)
+    if (r) return r;
     for (size_t i = 0; i < W; ++i) {
       const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
       if (!cnt) continue;
       enable_peer(ctxs[j], ctxs[i]->device);
-      const int32_t r = pull(j, i, cnt, (size_t)bound[i][j], land[j][i]);
+      hipStream_t ps;
+      r = pull_stream_for(ctxs[j], ctxs[i]->device, i, &ps);
+      if (!r) r = pull(j, i, cnt, (size_t)bound[i][j], land[j][i], ps);
       if (r) return r;
     }
+    r = join_pull_streams(ctxs[j]);
+    if (r) return r;
     IBU_HIP(hipEventRecord(pulled[j], ctxs[j]->stream));
     return IBU_OK;
   });
@@ -294,9 +343,9 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   double t_enq = 0;
   rc = exchange_then_sort(
       ctxs, W, bound, land,
-      [&](size_t j, size_t i, size_t cnt, size_t first, size_t at) -> int32_t {
+      [&](size_t j, size_t i, size_t cnt, size_t first, size_t at, hipStream_t ps) -> int32_t {
         const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + 12 * (shards[i].capacity + first);
-        IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_tmp) + 12 * at, ctxs[j]->device, src, ctxs[i]->device, 12 * cnt, ctxs[j]->stream));
+        IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_tmp) + 12 * at, ctxs[j]->device, src, ctxs[i]->device, 12 * cnt, ps));
         return IBU_OK;
       },
       [&](size_t j) -> int32_t {
@@ -378,9 +427,9 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   double t_enq = 0;
   rc = exchange_then_sort(
       ctxs, W, bound, land,
-      [&](size_t j, size_t i, size_t cnt, size_t first, size_t at) -> int32_t {
+      [&](size_t j, size_t i, size_t cnt, size_t first, size_t at, hipStream_t ps) -> int32_t {
         const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + kRec * first;
-        IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_records) + kRec * at, ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ctxs[j]->stream));
+        IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_records) + kRec * at, ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ps));
         return IBU_OK;
       },
       [&](size_t j) -> int32_t {
@@ -454,9 +503,14 @@ int32_t sort_sort_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t* shar
       const size_t cnt = (size_t)(bound[i][j + 1] - bound[i][j]);
       if (!cnt) continue;
       enable_peer(ctxs[j], ctxs[i]->device);
+      hipStream_t ps;                                           // one stream per peer device: the links carry their pieces at the same time
+      int32_t r = pull_stream_for(ctxs[j], ctxs[i]->device, i, &ps);   // (everything queued on the context's stream so far has completed: joined above)
+      if (r) return r;
       const uint8_t* src = static_cast<const uint8_t*>(compact ? shards[i].d_tmp : shards[i].d_records) + wire * bound[i][j];
-      IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ctxs[j]->stream));
+      IBU_HIP(hipMemcpyPeerAsync(t + wire * land[j][i], ctxs[j]->device, src, ctxs[i]->device, wire * cnt, ps));
     }
+    int32_t r = join_pull_streams(ctxs[j]);
+    if (r) return r;
     IBU_HIP(hipStreamSynchronize(ctxs[j]->stream));
     return IBU_OK;
   });

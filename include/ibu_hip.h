@@ -299,6 +299,9 @@ int32_t ibu_device_count(int32_t* n);
  *   "peer_access"    0 | 1  the multi-GPU sort's pulls (ibu_sort_records_contexts): 1 (default) = the pulling context enables direct
  *                           peer access to the shard's device where the topology has it (copies go over xGMI without staging; it
  *                           stays enabled for the process), 0 = never: the runtime stages the copies through the host.
+ *   "sort_pull_streams" 0 | 1  test knob of the multi-GPU sort: its pulls travel on one stream per PEER DEVICE (xGMI is point to point:
+ *                           copies queued on one stream would use one link at a time); 1 = peers on the puller's own device get
+ *                           such streams too, so that a rehearsal on one GPU runs the fork / join of those streams.
  *   "trace_rows"     0 | 1  tests: one stderr line per kernel launch of the streaming entry points saying how many rows took
  *                           the tiled and how many the one-thread-per-row kernel.  A context starts with the value the
  *                           environment variable IBU_TRACE_ROWS had when the library first created a context (read once).
@@ -430,7 +433,8 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * sampled ranges, so an owner's load is quantised to about total / 256 — 3 % of a share with 8 shards, 12 % with 32 —; the
  * sort-first form cuts at sampled quantiles of sorted shards, a few percent at any shard count.  In the partition-first forms the
  * host joins its worker threads where it needs every shard's answer (samples, range counts) and once at the end; the exchange and
- * the owners' sorts are ordered on the devices (stream order and cross-device events).
+ * the owners' sorts are ordered on the devices (stream order and cross-device events).  An owner's pulls go out on one stream per
+ * peer device, so that the point-to-point links carry their pieces at the same time.
  * One host thread per context; the first error in context order is the call's.  A shard that would receive more than its
  * capacity: IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) before anything has moved between
  * shards: every shard still holds its own records (untouched, or sorted locally on the sort-first path) — leave headroom for

@@ -1091,6 +1091,9 @@ def test_sort_records_contexts_fuzz(ia, oracle, seed):
     try:
         shards, at = [], 0
         for c, n in zip(ctxs, counts):
+            c.set_option("sort_pull_streams", seed % 2)            # odd seeds: the pulls on per-peer streams, as between distinct GPUs
+            if seed % 7 == 3:
+                c.set_option("sort_compact", 0)                    # (on the first context this selects the sort-first form)
             d, t = c.alloc(24 * cap), c.alloc(24 * cap)
             if n:
                 d.upload(recs[at:at + n])
@@ -1180,20 +1183,22 @@ def test_sort_records_contexts_falls_back_when_the_range_cut_does_not_fit(ia, or
 def test_sort_records_contexts_orders_exchange_and_sorts_on_the_devices(ia, oracle, capfd):
     """The partition-first forms join their host threads where the host needs every shard's answer and once at the end; the
     exchange and the owners' sorts are chained by stream order and events (no join in between).  Also with direct peer access
-    switched off on every context (option "peer_access" = 0: the branch a topology without it takes)."""
+    switched off on every context (option "peer_access" = 0: the branch a topology without it takes), and with the pulls on one
+    stream per peer (option "sort_pull_streams" = 1: what distinct devices get, so that their links work at the same time)."""
     k, n_each = 8, 150_000
     total = k * n_each
     for lens in ((16, 12), (32, 32)):
         recs = oracle.generate(SEED + 808, 0, total, *lens)
         np.random.default_rng(808).shuffle(recs)
         want = oracle.sort_records(recs).tobytes()
-        for peer in (1, 0):
+        for peer, own_streams in ((1, 0), (0, 0), (1, 1)):
             cap = n_each * 5 // 4
             ctxs = [ia.Context(0) for _ in range(k)]
             try:
                 shards = []
                 for i, c in enumerate(ctxs):
                     c.set_option("peer_access", peer)
+                    c.set_option("sort_pull_streams", own_streams)   # 1: the per-peer pull streams a multi-GPU run uses, forced on one GPU
                     d, t = c.alloc(24 * cap), c.alloc(24 * cap)
                     d.upload(recs[i * n_each:(i + 1) * n_each])
                     shards.append((d, t, n_each, cap))

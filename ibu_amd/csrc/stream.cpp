@@ -333,7 +333,7 @@ struct ibu_stream {
   std::vector<Slot> slot;
   std::deque<uint32_t> ready;        // READY slots in stream order
   uint32_t held = 0;
-  bool stop = false, done = false;
+  bool stop = false, done = false, started = false;
   int32_t rc = IBU_OK;               // the source's error, delivered after the batches in front of it
   ibu_error_detail_t detail{};
   ibu_stream_stats_t stats{};
@@ -418,6 +418,11 @@ void stream_produce(ibu_stream* s) {
   Ring& r = ctx->ring;
   (void)pthread_setname_np(pthread_self(), "ibu-feed");
   RunOnNode on_node(feed_place(ctx));   // this thread and every thread it starts (feeders, inflate workers) on the device's node
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    s->started = true;               // name and affinity are in place: ibu_stream_open_* returns only now (what ibu_ctx_numa and a
+    s->cv.notify_all();              // look at /proc/self/task say is true from the first moment the caller holds the handle)
+  }
   int32_t rc = IBU_OK;
   hipError_t e = hipSetDevice(ctx->device);
   if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
@@ -514,6 +519,8 @@ int32_t stream_open(ibu_ctx* ctx, const ibu_ring_config_t* cfg, ibu_stream* s) {
     ctx->ring_lent = nullptr;
     return caught_io("ibu_stream_open");
   }
+  std::unique_lock<std::mutex> lk(s->mu);
+  s->cv.wait(lk, [&] { return s->started; });
   return IBU_OK;
 }
 

@@ -373,6 +373,8 @@ class Reader:
         return DeviceStream._open(lambda out: lib.ibu_stream_open_reader(self._r, ctx._c, _ring(ring), out), ctx, self)
 
     def close(self):
+        for st in list(getattr(self, "_streams", ())):   # a producer thread must not outlive the reader it reads
+            st.close()
         if getattr(self, "_r", None):
             lib.ibu_reader_close(self._r)
             self._r = None
@@ -554,6 +556,8 @@ class MmapReader:
         return bc, umi, idx, st
 
     def close(self):
+        for st in list(getattr(self, "_streams", ())):   # a producer thread must not outlive the map it copies from
+            st.close()
         if getattr(self, "_m", None):
             lib.ibu_mmap_close(self._m)
             self._m = None
@@ -678,7 +682,10 @@ class DeviceStream:
         out = C.c_void_p()
         _check(call(C.byref(out)))
         s = cls.__new__(cls)
-        s._s, s.ctx, s._source = out, ctx, source   # the source (Reader / MmapReader) must outlive the stream
+        s._s, s.ctx, s._source = out, ctx, source   # the source (Reader / MmapReader) must outlive the stream:
+        if not hasattr(source, "_streams"):         # closing the source closes the streams still open on it first
+            source._streams = weakref.WeakSet()
+        source._streams.add(s)
         return s
 
     def header(self):

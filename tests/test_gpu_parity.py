@@ -737,6 +737,55 @@ def test_full_size_sort_and_decode_against_the_oracle_on_key_ranges_1e9(ia, ctx,
         b_.free()
 
 
+def test_launch_functions_can_be_captured_into_a_hip_graph(ia, oracle):
+    """include/ibu_hip.h: "Launch functions are asynchronous, allocate nothing and never synchronise (graph-capturable)".  The
+    hot path's launches (K2 decode, K3 encode, K1 / K1', column unpack / pack, K4 reduce, the copy) are captured ONCE into a
+    hipGraph (through torch's graph capture on a side stream) and replayed over new input: every replay's outputs are the
+    oracle's for the records then in the buffer — head-peel and tail kernels included (n is not a multiple of the tile and the
+    record buffer starts at an odd record)."""
+    torch = pytest.importorskip("torch")
+    n, bc_len, umi_len = 100_003, 16, 12
+    c = ia.Context(0)
+    try:
+        side = torch.cuda.Stream()
+        st = side.cuda_stream
+        big = c.alloc(24 * (n + 1))
+        recs = ia.DeviceBuffer.wrap(c, big.ptr + 24, 24 * n)         # 8- but not 16-byte aligned: peeled rows
+        bc, umi, idx, back = c.alloc(n * bc_len), c.alloc(n * umi_len), c.alloc(n * 8), c.alloc(n * 24)
+        c0, c1, c2, codes, asc, copy = c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 12), c.alloc(n * 24)
+
+        def launches():
+            c.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
+            c.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back, stream=st)
+            c.deserialize(recs, n, c0, c1, c2, stream=st)
+            c.serialize(c0, c1, c2, n, copy, stream=st)
+            c.unpack_2bit(c1, n, 12, asc, stream=st)
+            c.pack_2bit(asc, n, 12, codes, stream=st)
+            c.reduce(recs, n, stream=st, reset=True, fetch=False)
+
+        c.generate(SEED, 0, n, bc_len, umi_len, recs, stream=st)
+        launches()                                                   # warm-up outside the capture: module load, occupancy queries
+        c.synchronize(st)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            launches()
+        for seed in (SEED + 1, SEED + 2):
+            c.generate(seed, 7, n, bc_len, umi_len, recs, stream=st)  # new input, same buffers; not part of the graph
+            c.synchronize(st)
+            g.replay()
+            torch.cuda.synchronize()
+            want = oracle.generate(seed, 7, n, bc_len, umi_len)
+            wbc, wumi, widx = oracle.decode_records(want, bc_len, umi_len)
+            assert bc.download().tobytes() == wbc.tobytes() and umi.download().tobytes() == wumi.tobytes()
+            assert idx.download(np.uint64).tobytes() == widx.tobytes()
+            assert back.download().tobytes() == want.tobytes() == copy.download().tobytes()
+            assert codes.download(np.uint64).tobytes() == want["umi"].tobytes()
+            assert c.reduce_fetch(st) == oracle.reduce_records(want)
+            c.codec_status(st)
+    finally:
+        c.close()
+
+
 def test_generate_into_an_8_byte_aligned_buffer(ia, ctx, oracle):
     """Not 16-B aligned: every record takes the one-thread-per-record kernel; same bytes."""
     n = 10_007

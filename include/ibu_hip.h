@@ -18,7 +18,8 @@
  *   - nothing throws or aborts across this boundary.
  *   - host pointers are `h_` / unprefixed; device pointers are prefixed `d_`.  `stream` is a
  *     hipStream_t passed as void* (NULL = the context's own stream).  Launch functions are
- *     asynchronous, allocate nothing and never synchronise (graph-capturable).
+ *     asynchronous, allocate nothing and never synchronise: they can be captured into a hipGraph and replayed
+ *     (tests/test_gpu_parity.py::test_launch_functions_can_be_captured_into_a_hip_graph).
  *   - the caller owns every buffer it passes; the library owns only what *_open/_create
  *     returned, until the matching *_close/_destroy.
  *

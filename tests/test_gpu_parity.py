@@ -737,53 +737,67 @@ def test_full_size_sort_and_decode_against_the_oracle_on_key_ranges_1e9(ia, ctx,
         b_.free()
 
 
-def test_launch_functions_can_be_captured_into_a_hip_graph(ia, oracle):
+_GRAPH_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                       # before the library: both must bind the HIP runtime torch ships (as bench.py does)
+sys.path.insert(0, sys.argv[1])
+import ibu_amd as ia
+from oracle import oracle
+SEED = 0x1B00002
+n, bc_len, umi_len = 100_003, 16, 12
+c = ia.Context(0)
+side = torch.cuda.Stream()
+st = side.cuda_stream
+big = c.alloc(24 * (n + 1))
+recs = ia.DeviceBuffer.wrap(c, big.ptr + 24, 24 * n)         # 8- but not 16-byte aligned: peeled rows
+bc, umi, idx, back = c.alloc(n * bc_len), c.alloc(n * umi_len), c.alloc(n * 8), c.alloc(n * 24)
+c0, c1, c2, codes, asc, copy = c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 12), c.alloc(n * 24)
+
+def launches():
+    c.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
+    c.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back, stream=st)
+    c.deserialize(recs, n, c0, c1, c2, stream=st)
+    c.serialize(c0, c1, c2, n, copy, stream=st)
+    c.unpack_2bit(c1, n, 12, asc, stream=st)
+    c.pack_2bit(asc, n, 12, codes, stream=st)
+    c.reduce(recs, n, stream=st, reset=True, fetch=False)
+
+c.generate(SEED, 0, n, bc_len, umi_len, recs, stream=st)
+launches()                                                   # warm-up outside the capture: module load, occupancy queries
+c.synchronize(st)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=side):
+    launches()
+for seed in (SEED + 1, SEED + 2):
+    c.generate(seed, 7, n, bc_len, umi_len, recs, stream=st)  # new input, same buffers; not part of the graph
+    c.synchronize(st)
+    g.replay()
+    torch.cuda.synchronize()
+    want = oracle.generate(seed, 7, n, bc_len, umi_len)
+    wbc, wumi, widx = oracle.decode_records(want, bc_len, umi_len)
+    assert bc.download().tobytes() == wbc.tobytes() and umi.download().tobytes() == wumi.tobytes()
+    assert idx.download(np.uint64).tobytes() == widx.tobytes()
+    assert back.download().tobytes() == want.tobytes() == copy.download().tobytes()
+    assert codes.download(np.uint64).tobytes() == want["umi"].tobytes()
+    assert c.reduce_fetch(st) == oracle.reduce_records(want)
+    c.codec_status(st)
+c.close()
+print("GRAPH_OK")
+"""
+
+
+def test_launch_functions_can_be_captured_into_a_hip_graph():
     """include/ibu_hip.h: "Launch functions are asynchronous, allocate nothing and never synchronise (graph-capturable)".  The
-    hot path's launches (K2 decode, K3 encode, K1 / K1', column unpack / pack, K4 reduce, the copy) are captured ONCE into a
-    hipGraph (through torch's graph capture on a side stream) and replayed over new input: every replay's outputs are the
-    oracle's for the records then in the buffer — head-peel and tail kernels included (n is not a multiple of the tile and the
-    record buffer starts at an odd record)."""
-    torch = pytest.importorskip("torch")
-    n, bc_len, umi_len = 100_003, 16, 12
-    c = ia.Context(0)
-    try:
-        side = torch.cuda.Stream()
-        st = side.cuda_stream
-        big = c.alloc(24 * (n + 1))
-        recs = ia.DeviceBuffer.wrap(c, big.ptr + 24, 24 * n)         # 8- but not 16-byte aligned: peeled rows
-        bc, umi, idx, back = c.alloc(n * bc_len), c.alloc(n * umi_len), c.alloc(n * 8), c.alloc(n * 24)
-        c0, c1, c2, codes, asc, copy = c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 8), c.alloc(n * 12), c.alloc(n * 24)
-
-        def launches():
-            c.decode_ascii(recs, n, bc_len, umi_len, bc, umi, idx, stream=st)
-            c.encode_ascii(bc, umi, idx, n, bc_len, umi_len, back, stream=st)
-            c.deserialize(recs, n, c0, c1, c2, stream=st)
-            c.serialize(c0, c1, c2, n, copy, stream=st)
-            c.unpack_2bit(c1, n, 12, asc, stream=st)
-            c.pack_2bit(asc, n, 12, codes, stream=st)
-            c.reduce(recs, n, stream=st, reset=True, fetch=False)
-
-        c.generate(SEED, 0, n, bc_len, umi_len, recs, stream=st)
-        launches()                                                   # warm-up outside the capture: module load, occupancy queries
-        c.synchronize(st)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            launches()
-        for seed in (SEED + 1, SEED + 2):
-            c.generate(seed, 7, n, bc_len, umi_len, recs, stream=st)  # new input, same buffers; not part of the graph
-            c.synchronize(st)
-            g.replay()
-            torch.cuda.synchronize()
-            want = oracle.generate(seed, 7, n, bc_len, umi_len)
-            wbc, wumi, widx = oracle.decode_records(want, bc_len, umi_len)
-            assert bc.download().tobytes() == wbc.tobytes() and umi.download().tobytes() == wumi.tobytes()
-            assert idx.download(np.uint64).tobytes() == widx.tobytes()
-            assert back.download().tobytes() == want.tobytes() == copy.download().tobytes()
-            assert codes.download(np.uint64).tobytes() == want["umi"].tobytes()
-            assert c.reduce_fetch(st) == oracle.reduce_records(want)
-            c.codec_status(st)
-    finally:
-        c.close()
+    hot path's launches (K2 decode, K3 encode, K1 / K1', column unpack / pack, K4 reduce) are captured ONCE into a hipGraph
+    (through torch's graph capture on a side stream) and replayed over new input: every replay's outputs are the oracle's for the
+    records then in the buffer — head-peel and tail kernels included (n is not a multiple of the tile and the record buffer starts
+    at an odd record).  In a process of its own: torch must bind the HIP runtime before the library does."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GRAPH_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_generate_into_an_8_byte_aligned_buffer(ia, ctx, oracle):

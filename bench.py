@@ -425,27 +425,33 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
         d.free()
         assert os.path.getsize(path) == file_bytes
 
-        best = None
         dst = ctx.alloc(24 * n)                          # the caller's buffer: the transfer alone (allocation is timed on its own below)
-        for rep in range(2):                             # the first call allocates the pinned ring and warms the page cache
+        calls = []
+        for rep in range(3):                             # (the pinned ring exists already: write_batch_device above allocated it)
             t0 = time.perf_counter()
             _, dptr, got_n, st = ctx.load_to_device(path, ring=ring, d_records=dst, cap_records=n)
-            dt = time.perf_counter() - t0
+            calls.append(time.perf_counter() - t0)
             if not (got_n == n and ctx.reduce(dptr, n) == want):
                 raise LegCheckFailed("e2e: load_to_device returned other records than were written")
-            best = rate(dt, st, first_call_seconds=best["seconds"] if best else None, totals_equal_resident_copy=True,
-                        destination="a caller-owned device buffer (no allocation inside the call)")
         dst.free()
-        out["load_to_device"] = best
+        # the fastest of three calls, all three in the line: right after the legs above freed ~200 GB a call has been seen to take
+        # twice as long as its neighbours (0.046 / 0.098 s in profiles r05_r) — presumably the driver clearing the freed VRAM with the
+        # DMA engines the H2D copies use; the mmap leg further down, a second later, runs at the link's rate again
+        out["load_to_device"] = rate(min(calls), st, calls_seconds=[round(c_, 4) for c_ in calls], totals_equal_resident_copy=True,
+                                     destination="a caller-owned device buffer (no allocation inside the call)")
         # the same call with the destination allocated by the LIBRARY (placement-probed under the default option from 1 GiB on: up to
         # four candidates are allocated, a write + read streamed over each, the fastest kept), then one decode of the records where the
         # library put them into columns from ibu_device_alloc: what a file-based caller that does nothing about placement sees
-        t0 = time.perf_counter()
-        _, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
-        dt = time.perf_counter() - t0
-        if not (got_n == n and ctx.reduce(dptr, n) == want):
-            raise LegCheckFailed("e2e: load_to_device (library-allocated destination) returned other records than were written")
-        lib = rate(dt, st, totals_equal_resident_copy=True,
+        lib_calls = []
+        for rep in range(2):
+            t0 = time.perf_counter()
+            _, dptr, got_n, st = ctx.load_to_device(path, ring=ring)
+            lib_calls.append(time.perf_counter() - t0)
+            if not (got_n == n and ctx.reduce(dptr, n) == want):
+                raise LegCheckFailed("e2e: load_to_device (library-allocated destination) returned other records than were written")
+            if rep == 0:
+                ctx.free(dptr)
+        lib = rate(min(lib_calls), st, calls_seconds=[round(c_, 4) for c_ in lib_calls], totals_equal_resident_copy=True,
                    destination="allocated inside the call, option alloc_probe_tries = 0 (auto); allocating right after large frees "
                                "waits for the driver to hand out cleared VRAM: profiles/r05_h_alloc_probe_cost.jsonl")
         if torch is not None:

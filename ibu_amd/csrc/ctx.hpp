@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -63,6 +64,9 @@ struct ibu_ctx {
   ibu::Ring ring;
   ibu::CodecRing cring;
   void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
+  std::thread loser_free;          // placement probing: the candidates not kept are freed off the caller's path (hipFree of a touched
+                                   // gigabyte-sized block has been seen to take 35-65 ms: profiles/README.md r05_t); joined by the next
+                                   // probing allocation and by ibu_ctx_destroy
   std::vector<hipStream_t> pull_streams;   // the multi-GPU sort's pulls: one stream per peer link in use at once (created on demand, multi_sort.cpp)
   std::vector<hipEvent_t> pull_events;
   int force_pull_streams = 0;      // option "sort_pull_streams" (test knob): 1 = pieces of same-device peers travel on their own pull streams too

@@ -7,6 +7,8 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "ctx.hpp"
 
 using namespace ibu;
@@ -87,6 +89,7 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->ring_lent) stream_orphan(ctx);   // a stream still open on this context: stop its producer before the ring goes
+  if (ctx->loser_free.joinable()) ctx->loser_free.join();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
@@ -199,6 +202,8 @@ extern "C" int32_t ibu_device_alloc(ibu_ctx_t* ctx, size_t bytes, void** d_ptr) 
 // Option "alloc_probe_tries": how many candidates an allocation of `bytes` draws.  Auto (0) probes only what is worth it and
 // cannot hurt: at least 1 GiB (the arrays whose placement the streaming kernels feel; smaller ones are ring slots and scratch
 // tables) and at least three candidates fitting the free memory at once (so that the candidates never push a caller out of memory).
+static int32_t alloc_probed_impl(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, void** d_ptr, ibu_alloc_probe_t* report, double alloc_budget_ms,
+                                 double* slow_ms);
 static uint32_t probe_tries_for(const ibu_ctx* ctx, size_t bytes) {
   const int t = ctx->cfg.alloc_probe_tries;
   if (t == 1) return 1;
@@ -213,11 +218,19 @@ int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
   const uint32_t tries = probe_tries_for(ctx, bytes);
   if (tries > 1) {
     ibu_alloc_probe_t rep;
-    const int32_t rc = ibu_device_alloc_probed(ctx, bytes, tries, d_ptr, &rep);
+    // auto: a candidate may take 10 ms + 2 ms per GB to allocate (the runtime's usual 0.1-1 ms with a wide margin); beyond that the
+    // driver is busy handing out cleared memory and drawing more candidates would multiply the wait, not the choice
+    const double budget = ctx->cfg.alloc_probe_tries == 0 ? 10.0 + 2.0 * ((double)bytes / 1e9) : 0.0;
+    double slow = 0;
+    const int32_t rc = alloc_probed_impl(ctx, bytes, tries, d_ptr, &rep, budget, &slow);
     if (rc == IBU_OK && trace_sort()) {
-      fprintf(stderr, "ibu alloc: %zu bytes probed: %u candidates, kept #%u (ms:", bytes, rep.tries, rep.chosen);
-      for (uint32_t k = 0; k < rep.tries; ++k) fprintf(stderr, " %.3f", rep.ms[k]);
-      fprintf(stderr, ")\n");
+      if (rep.tries > 1) {
+        fprintf(stderr, "ibu alloc: %zu bytes probed: %u candidates, kept #%u (ms:", bytes, rep.tries, rep.chosen);
+        for (uint32_t k = 0; k < rep.tries; ++k) fprintf(stderr, " %.3f", rep.ms[k]);
+        fprintf(stderr, ")%s\n", slow > 0 ? "; the drawing stopped at a slow allocation" : "");
+      } else {
+        fprintf(stderr, "ibu alloc: %zu bytes not probed: the allocation took %.1f ms (the driver is handing out memory slowly)\n", bytes, slow);
+      }
     }
     return rc;
   }
@@ -231,10 +244,15 @@ int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
 // the allocator has to hand out different pages —, stream a write and a read over each (the write-only generator kernel and the
 // read-only reduce kernel over the whole range, timed with events on the context's stream, second run of two), keep the
 // fastest, free the rest.  Allocation stops quietly at the first candidate that does not fit.  The contents are unspecified.
-extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, void** d_ptr, ibu_alloc_probe_t* report) {
+// alloc_budget_ms > 0 (the auto mode): a candidate whose hipMalloc took longer than that ends the drawing — what costs in probing is
+// not the measuring (0.8 ms per GB and candidate) but the driver handing out memory slowly (right after large frees it clears VRAM:
+// seconds for 24 GB, profiles/README.md r05_h), and every further candidate would pay that again.  *slow_ms: that allocation's time.
+static int32_t alloc_probed_impl(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, void** d_ptr, ibu_alloc_probe_t* report, double alloc_budget_ms,
+                                 double* slow_ms) {
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;
   if (!d_ptr) return err_arg("d_ptr is NULL");
+  if (slow_ms) *slow_ms = 0;
   if (report) memset(report, 0, sizeof *report);
   if (tries < 1) tries = 1;
   if (tries > IBU_ALLOC_PROBE_MAX) tries = IBU_ALLOC_PROBE_MAX;
@@ -244,12 +262,20 @@ extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_
   float ms[IBU_ALLOC_PROBE_MAX] = {0};
   uint32_t got = 0;
   for (; got < tries; ++got) {
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&cand[got], bytes ? bytes : 16);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       cand[got] = nullptr;
       if (got == 0) return hip_fail(e, "hipMalloc");
       break;                                    // the candidates that exist are the field
+    }
+    const double ms_alloc = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (trace_sort() && tries > 1) fprintf(stderr, "ibu alloc: candidate %u of %zu bytes: hipMalloc %.2f ms\n", got, bytes, ms_alloc);
+    if (alloc_budget_ms > 0 && ms_alloc > alloc_budget_ms) {   // the driver is slow right now: no further candidates
+      if (slow_ms) *slow_ms = ms_alloc;
+      ++got;
+      break;
     }
   }
   uint32_t best = 0;
@@ -281,8 +307,31 @@ extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_
     }
     for (uint32_t k = 1; k < got; ++k)
       if (ms[k] < ms[best]) best = k;
-    for (uint32_t k = 0; k < got; ++k)
-      if (k != best) (void)hipFree(cand[k]);
+    // The candidates not kept go back on a helper thread: hipFree of a block kernels have touched takes tens of milliseconds per
+    // gigabyte-sized block in a busy process (three losers of 2.4 GB: 100-200 ms, four times the load they were probed for), and
+    // nothing the caller does next depends on it.  One helper at a time per context; the next probing allocation and
+    // ibu_ctx_destroy join it.
+    if (ctx->loser_free.joinable()) ctx->loser_free.join();
+    std::vector<void*> losers;
+    bool deferred = false;
+    try {
+      for (uint32_t k = 0; k < got; ++k)
+        if (k != best) losers.push_back(cand[k]);
+      const int dev = ctx->device;
+      const bool trace = trace_sort();
+      ctx->loser_free = std::thread([losers, dev, trace] {
+        const auto tf = std::chrono::steady_clock::now();
+        (void)hipSetDevice(dev);
+        for (void* q : losers) (void)hipFree(q);
+        if (trace) fprintf(stderr, "ibu alloc: freed the %zu candidates not kept in %.2f ms (helper thread)\n", losers.size(),
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf).count());
+      });
+      deferred = true;
+    } catch (...) {
+    }
+    if (!deferred)
+      for (uint32_t k = 0; k < got; ++k)
+        if (k != best) (void)hipFree(cand[k]);
   }
   *d_ptr = cand[best];
   if (report) {
@@ -291,6 +340,9 @@ extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_
     for (uint32_t k = 0; k < got; ++k) report->ms[k] = ms[k];
   }
   return IBU_OK;
+}
+extern "C" int32_t ibu_device_alloc_probed(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, void** d_ptr, ibu_alloc_probe_t* report) {
+  return alloc_probed_impl(ctx, bytes, tries, d_ptr, report, 0, nullptr);
 }
 extern "C" int32_t ibu_device_free(ibu_ctx_t* ctx, void* d_ptr) {
   int32_t rc = check_ctx(ctx);

@@ -284,10 +284,15 @@ int32_t ibu_device_count(int32_t* n);
  *                           resident — ibu_device_alloc, the destination of ibu_load_to_device, the context's sort scratch.
  *                           0 = auto (default): an allocation of at least 1 GiB of which at least three candidates fit in the
  *                           device's free memory draws up to four and keeps the fastest, anything else is a plain
- *                           allocation; 1 = never probe; k > 1 = allocations of at least 256 MiB draw k candidates.  What
+ *                           allocation; the drawing ends early at a candidate whose hipMalloc took longer than 10 ms + 2 ms
+ *                           per GB (the driver hands out memory slowly right after large frees: more candidates would
+ *                           multiply that wait, not the choice); 1 = never probe; k > 1 = allocations of at least 256 MiB
+ *                           draw k candidates, however long they take.  What
  *                           probing is and why: ibu_device_alloc_probed.  What it costs: a write + read of every candidate
- *                           (~0.3 ms per GB each, twice), the candidates' memory for that long (k x bytes at the peak), and
- *                           one synchronisation of the context's stream per probed allocation.  It never touches the reduce
+ *                           (~0.3 ms per GB each, twice), the candidates' memory (k x bytes at the peak; the ones not kept
+ *                           are freed by a helper thread right after the choice — the driver clears VRAM when it is freed,
+ *                           15-25 GB/s, which a caller need not wait for; the next probing allocation and ibu_ctx_destroy
+ *                           join that thread), and one synchronisation of the context's stream per probed allocation.  It never touches the reduce
  *                           accumulator (reset / reduce ... / fetch may span allocations).  IBU_TRACE_SORT=1 prints what was
  *                           drawn and chosen.
  *   "numa"           0 | 1  1 = auto (default): the context looks up the NUMA node its device hangs off (PCI bus id ->

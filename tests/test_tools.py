@@ -36,7 +36,7 @@ def test_pmc_traffic_merges_every_process_and_lists_the_sort_kernels(tmp_path):
 
 def test_committed_pmc_traffic_json_is_this_rounds(tmp_path):
     doc = json.load(open(os.path.join(PROFILES, "pmc_traffic.json")))
-    assert doc["_round"].startswith("r04") and doc["sort"], "profiles/pmc_traffic.json must carry a non-empty sort section"
+    assert doc["_round"].startswith("r05") and doc["sort"], "profiles/pmc_traffic.json must carry a non-empty sort section"
     rt = doc["runtime_length_31_31"]                            # the runtime-length kernels move algorithmic bytes: the code stream lives in LDS
     assert abs(rt["decode_31_31"]["hbm_bytes_per_record"] - 94) < 0.3 and abs(rt["encode_31_31"]["hbm_bytes_per_record"] - 94) < 0.3
     assert abs(rt["unpack"]["hbm_bytes_per_record"] - 39) < 0.2 and abs(rt["pack"]["hbm_bytes_per_record"] - 39) < 0.2

@@ -262,7 +262,13 @@ def place_leg(make, tries, set_bytes, torch, dev, sharers=1, ctx=None, library_d
         # arrays of 1 GiB and more draw up to four candidates when three fit): the same five arrays from plain ctx.alloc calls
         first.free()
         t0 = time.perf_counter()
-        first = make(1)
+        try:
+            first = make(1)
+        except Exception as e:                           # the headline must not die on a side measurement: plain arrays again
+            info["library_default_error"] = f"{type(e).__name__}: {e}"
+            ctx.set_option("alloc_probe_tries", 1)
+            first = make(1)
+            ctx.set_option("alloc_probe_tries", 0)
         alloc_s = time.perf_counter() - t0
         dprobe = first.probe()
         info.update(library_default_probe_ms_decode_encode=[round(v, 3) for v in dprobe],

@@ -90,13 +90,24 @@ hipError_t launch_expand(const LaunchCfg&, const CompactPlan& pl, const void* el
 // (d_starts: u64[256] in `scratch`, the first element of every range); received elements -> sorted records.
 hipError_t launch_estimate_prefix(const LaunchCfg&, const void* recs, size_t n, size_t n_scale, void* tmp, const CompactPlan& pl,
                                   uint32_t* prefix_passes, hipStream_t st);
+// What the host needs from a partition pass — the range starts (u64[256]) and, where taken, the census words (u64[8]) — exists as soon
+// as the pass's small scan kernel has run, BEFORE its scatter kernel (a third of the pass's time) has: with `early` the launcher copies
+// both into pinned host memory right there and records `ready` behind the copies, so that the caller can plan the exchange while the
+// scatter still runs.
+struct PartitionEarly {
+  uint64_t* h_starts;   // pinned, u64[256]
+  uint64_t* h_words;    // pinned, u64[8] (written only when the census is taken)
+  hipEvent_t ready;
+};
 hipError_t launch_partition_elems(const LaunchCfg&, const CompactPlan& pl, const void* recs, void* elems, size_t n, const void* d_split,
                                   uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
-                                  const uint64_t** d_census /*nullable: the exact census words of these records, accumulated on the way*/, hipStream_t st);
+                                  const uint64_t** d_census /*nullable: the exact census words of these records, accumulated on the way*/, hipStream_t st,
+                                  const PartitionEarly* early = nullptr);
 hipError_t launch_records_census_sample(const LaunchCfg&, const void* recs, size_t n, uint64_t* d_census /*u64[8 x 64]*/, bool* exact, hipStream_t st);
 hipError_t launch_partition_records(const LaunchCfg&, const void* recs, size_t n, const void* d_split /*24-byte records*/, uint32_t nsplit, void* out,
                                     void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
-                                    const uint64_t** d_census /*nullable: the exact OR / AND words of these records, accumulated on the way*/, hipStream_t st);   // the same on 24-byte records (any key)
+                                    const uint64_t** d_census /*nullable: the exact OR / AND words of these records, accumulated on the way*/, hipStream_t st,
+                                    const PartitionEarly* early = nullptr);   // the same on 24-byte records (any key)
 bool sort_elems_supported(const LaunchCfg&, const void* recs, const void* tmp, size_t capacity);
 hipError_t launch_sort_elems(const LaunchCfg&, const CompactPlan& pl, void* recs, void* tmp, size_t n, uint32_t prefix_passes, void* scratch,
                              size_t scratch_bytes, hipStream_t st);

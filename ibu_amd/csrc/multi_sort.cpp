@@ -205,6 +205,36 @@ void cut_owners(const ibu_sort_shard_t* shards, size_t W, const std::vector<std:
     for (size_t j = 0; j <= W; ++j) bound[i][j] = fine[i][cut[j]];
 }
 
+// Events of one call, destroyed on every way out.
+struct EventSet {
+  std::vector<hipEvent_t> ev;
+  std::vector<int> dev;
+  explicit EventSet(size_t n) : ev(n, nullptr), dev(n, 0) {}
+  ~EventSet() {
+    for (size_t i = 0; i < ev.size(); ++i)
+      if (ev[i]) { (void)hipSetDevice(dev[i]); (void)hipEventDestroy(ev[i]); }
+  }
+};
+// A shard's partition pass with its counts handed over early (kernels.h: PartitionEarly): `launch(early)` queues the pass on the
+// context's stream; `done` is recorded behind it; the thread waits only until the counts (and census words) have arrived in pinned
+// memory — the pass's scatter kernel, a third of its time, is still running when this returns.
+template <class Launch>
+int32_t partition_with_early_counts(ibu_ctx* c, Launch launch, hipEvent_t* done, int* done_dev, uint64_t* starts_out /*[256]*/, uint64_t* words_out /*[8] or null*/) {
+  if (!c->h_part) IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_part), 264 * sizeof(uint64_t), hipHostMallocDefault));
+  hipEvent_t ready = nullptr;
+  IBU_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  PartitionEarly early{c->h_part, c->h_part + 256, ready};
+  hipError_t e = launch(&early);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(done, hipEventDisableTiming);
+  if (e == hipSuccess) { *done_dev = c->device; e = hipEventRecord(*done, c->stream); }
+  if (e == hipSuccess) e = hipEventSynchronize(ready);
+  (void)hipEventDestroy(ready);
+  if (e != hipSuccess) return hip_fail(e, "partition pass");
+  memcpy(starts_out, c->h_part, 256 * sizeof(uint64_t));
+  if (words_out) memcpy(words_out, c->h_part + 256, 8 * sizeof(uint64_t));
+  return IBU_OK;
+}
+
 // The exchange and the owners' sorts without a join between them.  pull(j, i, cnt, first, land, stream): queue owner j's copy of `cnt`
 // units of shard i, from unit `first` of its partitioned scratch to unit `land` at the owner, on `stream` (one per peer device).
 // sort(j): queue owner j's sort on ctxs[j]->stream (may synchronise that stream itself).  What orders them:
@@ -216,6 +246,7 @@ void cut_owners(const ibu_sort_shard_t* shards, size_t W, const std::vector<std:
 // One join at the end.  *t_enqueue_ms / *t_total_ms: for the trace.
 template <class Pull, class Sort>
 int32_t exchange_then_sort(ibu_ctx_t* const* ctxs, size_t W, const std::vector<std::vector<uint64_t>>& bound, const std::vector<std::vector<size_t>>& land,
+                           const std::vector<hipEvent_t>& partitioned /*shard i's partition pass has finished (null: nothing was queued)*/,
                            Pull pull, Sort sort, double* t_enqueue_ms) {
   std::vector<hipEvent_t> pulled(W, nullptr);
   const double t0 = now_ms();
@@ -234,7 +265,10 @@ int32_t exchange_then_sort(ibu_ctx_t* const* ctxs, size_t W, const std::vector<s
       enable_peer(ctxs[j], ctxs[i]->device);
       hipStream_t ps;
       r = pull_stream_for(ctxs[j], ctxs[i]->device, i, &ps);
-      if (!r) r = pull(j, i, cnt, (size_t)bound[i][j], land[j][i], ps);
+      if (r) return r;
+      // shard i's scatter may still be running (its counts came back early): the pull waits for it on the device
+      if (partitioned[i] && ps != ctxs[i]->stream) IBU_HIP(hipStreamWaitEvent(ps, partitioned[i], 0));
+      r = pull(j, i, cnt, (size_t)bound[i][j], land[j][i], ps);
       if (r) return r;
     }
     r = join_pull_streams(ctxs[j]);
@@ -291,6 +325,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     if (shards[i].n > shards[big].n) big = i;
   uint32_t prefix_passes = 0;
   std::vector<std::vector<uint64_t>> fine(W, std::vector<uint64_t>(F + 1, 0));
+  EventSet partitioned(W);                                    // shard i's partition pass has finished (its counts arrive earlier)
   const size_t split_bytes = (kRec + 12) * (F - 1) + 512;
   rc = on_every_context(W, [&](size_t i) -> int32_t {
     ibu_ctx_t* c = ctxs[i];
@@ -308,11 +343,14 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
     IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
     IBU_HIP(launch_compact(c->cfg, plan, d_split_recs, F - 1, d_split_elems, st));
     const uint64_t *d_starts = nullptr, *d_words = nullptr;
-    IBU_HIP(launch_partition_elems(c->cfg, plan, shards[i].d_records, t, n, d_split_elems, (uint32_t)(F - 1), t + 12 * shards[i].capacity, c->d_sort_scratch, need,
-                                   &d_starts, guessed ? &d_words : nullptr, st));
-    IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
-    if (guessed) IBU_HIP(hipMemcpyAsync((*exact_words)[i].data(), d_words, 64, hipMemcpyDeviceToHost, st));
-    IBU_HIP(hipStreamSynchronize(st));
+    int32_t pr = partition_with_early_counts(
+        c,
+        [&](const PartitionEarly* early) {
+          return launch_partition_elems(c->cfg, plan, shards[i].d_records, t, n, d_split_elems, (uint32_t)(F - 1), t + 12 * shards[i].capacity, c->d_sort_scratch,
+                                        need, &d_starts, guessed ? &d_words : nullptr, st, early);
+        },
+        &partitioned.ev[i], &partitioned.dev[i], fine[i].data(), guessed ? (*exact_words)[i].data() : nullptr);
+    if (pr) return pr;
     fine[i][F] = n;
     return IBU_OK;
   });
@@ -342,7 +380,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   // 4. every owner sorts what it received, elements -> records, queued behind its pulls and behind the pulls that read ITS upper half
   double t_enq = 0;
   rc = exchange_then_sort(
-      ctxs, W, bound, land,
+      ctxs, W, bound, land, partitioned.ev,
       [&](size_t j, size_t i, size_t cnt, size_t first, size_t at, hipStream_t ps) -> int32_t {
         const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + 12 * (shards[i].capacity + first);
         IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_tmp) + 12 * at, ctxs[j]->device, src, ctxs[i]->device, 12 * cnt, ps));
@@ -361,7 +399,7 @@ int32_t sort_partition_first(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_shard_t*
   if (rc) return rc;
   lap(3);
   if (trace)
-    fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u; host joins: samples, range counts, end; ms: samples %.2f, "
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=12 bytes per record (partition first, prefix_passes=%u; host joins: samples, range counts (handed over before the partition's scatter), end; ms: samples %.2f, "
             "partition %.2f, plan %.2f, exchange+sort %.2f of which enqueueing the pulls %.2f)\n", W, prefix_passes, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_enq);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
@@ -387,6 +425,7 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   lap(0);
   std::vector<std::vector<uint64_t>> fine(W, std::vector<uint64_t>(F + 1, 0));
   std::vector<std::array<uint64_t, 8>> words(W);
+  EventSet partitioned(W);
   const size_t split_bytes = kRec * (F - 1) + 512;
   rc = on_every_context(W, [&](size_t i) -> int32_t {
     ibu_ctx_t* c = ctxs[i];
@@ -400,10 +439,14 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
     uint8_t* d_split_recs = static_cast<uint8_t*>(c->d_sort_scratch) + ((need + 255) & ~(size_t)255);
     IBU_HIP(hipMemcpyAsync(d_split_recs, split.data(), kRec * (F - 1), hipMemcpyHostToDevice, st));
     const uint64_t *d_starts = nullptr, *d_words = nullptr;
-    IBU_HIP(launch_partition_records(c->cfg, shards[i].d_records, n, d_split_recs, (uint32_t)(F - 1), shards[i].d_tmp, c->d_sort_scratch, need, &d_starts, &d_words, st));
-    IBU_HIP(hipMemcpyAsync(fine[i].data(), d_starts, 8 * F, hipMemcpyDeviceToHost, st));
-    IBU_HIP(hipMemcpyAsync(words[i].data(), d_words, 64, hipMemcpyDeviceToHost, st));   // the exact OR / AND words of this shard's records, taken on the way
-    IBU_HIP(hipStreamSynchronize(st));
+    int32_t pr = partition_with_early_counts(
+        c,
+        [&](const PartitionEarly* early) {
+          return launch_partition_records(c->cfg, shards[i].d_records, n, d_split_recs, (uint32_t)(F - 1), shards[i].d_tmp, c->d_sort_scratch, need, &d_starts, &d_words,
+                                          st, early);
+        },
+        &partitioned.ev[i], &partitioned.dev[i], fine[i].data(), words[i].data());   // (the exact OR / AND words of this shard's records, taken on the way)
+    if (pr) return pr;
     fine[i][F] = n;
     return IBU_OK;
   });
@@ -426,7 +469,7 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   // and the owners' sorts, each behind its own pulls and behind the pulls that read ITS scratch
   double t_enq = 0;
   rc = exchange_then_sort(
-      ctxs, W, bound, land,
+      ctxs, W, bound, land, partitioned.ev,
       [&](size_t j, size_t i, size_t cnt, size_t first, size_t at, hipStream_t ps) -> int32_t {
         const uint8_t* src = static_cast<const uint8_t*>(shards[i].d_tmp) + kRec * first;
         IBU_HIP(hipMemcpyPeerAsync(static_cast<uint8_t*>(shards[j].d_records) + kRec * at, ctxs[j]->device, src, ctxs[i]->device, kRec * cnt, ps));
@@ -444,7 +487,7 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   if (rc) return rc;
   lap(3);
   if (trace)
-    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first; host joins: samples, range counts, end; ms: samples %.2f, partition %.2f, "
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first; host joins: samples, range counts (handed over before the partition's scatter), end; ms: samples %.2f, partition %.2f, "
             "plan %.2f, exchange+sort %.2f of which enqueueing the pulls %.2f)\n", W, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_enq);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;

@@ -619,7 +619,7 @@ hipError_t launch_estimate_prefix(const LaunchCfg& cfg, const void* recs, size_t
 }
 hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, const void* recs, void* elems, size_t n, const void* d_split,
                                   uint32_t nsplit, void* out, void* scratch, size_t scratch_bytes, const uint64_t** d_starts,
-                                  const uint64_t** d_census, hipStream_t st) {
+                                  const uint64_t** d_census, hipStream_t st, const PartitionEarly* early) {
   (void)hipGetLastError();
   if (n == 0 || nsplit > 255 || pl.k > 11) return hipErrorInvalidValue;
   if (d_census && (reinterpret_cast<uintptr_t>(recs) & 15u)) return hipErrorInvalidValue;
@@ -652,6 +652,12 @@ hipError_t launch_partition_elems(const LaunchCfg& cfg, const CompactPlan& pl, c
                      counts);
   hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
   hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
+  if (early) {                                                 // the host's share of the pass is complete here: hand it over before the scatter
+    e = hipMemcpyAsync(early->h_starts, binbase, 8 * kBins, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && census) e = hipMemcpyAsync(early->h_words, census, 64, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(early->ready, st);
+    if (e != hipSuccess) return e;
+  }
   if (L.idx64)
     hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
                        (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));
@@ -699,7 +705,8 @@ ibu_k_sort_stamp_records(const u64* __restrict__ recs, u64 n, const u64* __restr
   if constexpr (CENSUS) acc.flush(census, nullptr, ref, any_rows);
 }
 hipError_t launch_partition_records(const LaunchCfg& cfg, const void* recs, size_t n, const void* d_split, uint32_t nsplit, void* out, void* scratch,
-                                    size_t scratch_bytes, const uint64_t** d_starts, const uint64_t** d_census, hipStream_t st) {
+                                    size_t scratch_bytes, const uint64_t** d_starts, const uint64_t** d_census, hipStream_t st,
+                                    const PartitionEarly* early) {
   (void)hipGetLastError();
   if (n == 0 || nsplit > 255) return hipErrorInvalidValue;
   const SweepVariant& sv = pick_variant(cfg);
@@ -736,6 +743,12 @@ hipError_t launch_partition_records(const LaunchCfg& cfg, const void* recs, size
   hipLaunchKernelGGL(sv.counts_bytes, dim3(wave_grid < cap ? wave_grid : cap), dim3(kSortThreads), 0, st, (const uint8_t*)digits, (u64)n, L.ntiles, counts);
   hipLaunchKernelGGL(ibu_k_sort_blocksums, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb, blocksum);
   hipLaunchKernelGGL(ibu_k_sort_blockscan, dim3(1), dim3(kSortThreads), 0, st, (const u32*)blocksum, L.nblocks, blockoff, binbase);
+  if (early) {                                                 // the host's share of the pass is complete here: hand it over before the scatter
+    e = hipMemcpyAsync(early->h_starts, binbase, 8 * kBins, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && census) e = hipMemcpyAsync(early->h_words, census, 64, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(early->ready, st);
+    if (e != hipSuccess) return e;
+  }
   if (L.idx64)
     hipLaunchKernelGGL(ibu_k_sort_tilepos<u64>, dim3(L.nblocks), dim3(kSortThreads), 0, st, (const uint16_t*)counts, L.ntiles, L.tpb,
                        (const u64*)blockoff, (const u64*)binbase, static_cast<u64*>(pos));

@@ -438,8 +438,9 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  * Nothing is sorted twice in the first two.  How even the shares come out: the partition-first forms cut at the boundaries of 256
  * sampled ranges, so an owner's load is quantised to about total / 256 — 3 % of a share with 8 shards, 12 % with 32 —; the
  * sort-first form cuts at sampled quantiles of sorted shards, a few percent at any shard count.  In the partition-first forms the
- * host joins its worker threads where it needs every shard's answer (samples, range counts) and once at the end; the exchange and
- * the owners' sorts are ordered on the devices (stream order and cross-device events).  An owner's pulls go out on one stream per
+ * host joins its worker threads where it needs every shard's answer (samples, range counts — copied out before the partition pass's
+ * scatter kernel has run, so the plan is made while it runs) and once at the end; the exchange and the owners' sorts are ordered on
+ * the devices (a pull waits for the event of the shard it reads, a sort for the pulls that read its scratch).  An owner's pulls go out on one stream per
  * peer device, so that the point-to-point links carry their pieces at the same time.
  * One host thread per context; the first error in context order is the call's.  A shard that would receive more than its
  * capacity: IBU_ERR_INVALID_ARG (detail.a = records it would receive, detail.b = its capacity) before anything has moved between

@@ -1207,7 +1207,7 @@ def test_sort_records_contexts_orders_exchange_and_sorts_on_the_devices(ia, orac
                 trace = capfd.readouterr().err
                 assert b"".join(shards[i][0].download(count=24 * out[i]).tobytes() for i in range(k)) == want
                 if trace:
-                    assert "partition first" in trace and "host joins: samples, range counts, end" in trace, trace
+                    assert "partition first" in trace and "host joins: samples, range counts (handed over before the partition's scatter), end" in trace, trace
             finally:
                 for c in ctxs:
                     c.close()

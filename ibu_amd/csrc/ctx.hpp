@@ -64,6 +64,7 @@ struct ibu_ctx {
   ibu::Ring ring;
   ibu::CodecRing cring;
   void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
+  hipStream_t side_stream = nullptr;   // the multi-GPU sort's shared prefix estimate runs here, beside the pulls (created on first use, kept)
   uint64_t* h_part = nullptr;      // pinned, u64[264]: a partition pass's range starts and census words land here early (multi_sort.cpp)
   std::thread loser_free;          // placement probing: the candidates not kept are freed off the caller's path (hipFree of a touched
                                    // gigabyte-sized block has been seen to take 35-65 ms: profiles/README.md r05_t); joined by the next

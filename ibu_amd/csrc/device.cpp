@@ -104,6 +104,7 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (ctx->d_flag) (void)hipFree(ctx->d_flag);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_part) (void)hipHostFree(ctx->h_part);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);

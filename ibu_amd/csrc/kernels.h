@@ -68,8 +68,12 @@ hipError_t launch_fill2(uint64_t* p, uint64_t v0, uint64_t v1, hipStream_t st);
 // sort.hip
 bool trace_sort();   // IBU_TRACE_SORT set to anything but "" / "0" (read once): one stderr line per sort / probed allocation saying what was chosen
 hipError_t launch_sort_records(const LaunchCfg&, void* recs, void* tmp, size_t n, void* scratch,
-                               size_t scratch_bytes, hipStream_t st, const uint64_t* known_words = nullptr /*u64[6]: OR x 3, AND x 3 of a superset: no census pass*/);
+                               size_t scratch_bytes, hipStream_t st, const uint64_t* known_words = nullptr /*u64[6]: OR x 3, AND x 3 of a superset: no census pass*/,
+                               int known_prefix = -1 /*>= 0: the 24-byte path's prefix length, estimated elsewhere (0 = all passes)*/,
+                               int* only_estimate = nullptr /*non-null: only estimate that prefix length for n_scale records like these*/,
+                               size_t n_scale = 0);
 size_t sort_scratch_bytes(const LaunchCfg&, size_t n);
+size_t sort_prefix_estimate_tables(const LaunchCfg&, size_t n);   // bytes of `tmp` the only_estimate form of launch_sort_records writes (0: none)
 int sort_num_variants();
 int sort_num_compact_variants();
 hipError_t launch_lower_bound(const void* recs, size_t n, const void* keys, size_t k, uint64_t* pos, hipStream_t st);

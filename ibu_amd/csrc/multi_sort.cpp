@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <vector>
 
 #include "common.hpp"
@@ -427,13 +428,17 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   std::vector<std::array<uint64_t, 8>> words(W);
   EventSet partitioned(W);
   const size_t split_bytes = kRec * (F - 1) + 512;
+  size_t big = 0;                                               // the biggest shard: the prefix estimate samples it (below)
+  for (size_t i = 1; i < W; ++i)
+    if (shards[i].n > shards[big].n) big = i;
+  const size_t est_tables = sort_prefix_estimate_tables(ctxs[big]->cfg, shards[big].n);
   rc = on_every_context(W, [&](size_t i) -> int32_t {
     ibu_ctx_t* c = ctxs[i];
     const size_t n = shards[i].n;
     if (!n) return IBU_OK;
     IBU_HIP(hipSetDevice(c->device));
     const size_t need = sort_scratch_bytes(c->cfg, n);
-    int32_t r = ensure_sort_scratch(c, need + split_bytes);   // the splitters ride behind the sort's own scratch
+    int32_t r = ensure_sort_scratch(c, std::max(need + split_bytes, i == big ? est_tables : (size_t)0));   // the splitters ride behind the sort's own scratch
     if (r) return r;
     hipStream_t st = c->stream;
     uint8_t* d_split_recs = static_cast<uint8_t*>(c->d_sort_scratch) + ((need + 255) & ~(size_t)255);
@@ -464,6 +469,29 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
   std::vector<std::vector<size_t>> land(W, std::vector<size_t>(W, 0));
   rc = plan_landing(shards, W, bound, n_out, land, "no shard's records were touched");
   if (rc) return kLandingFailed;
+  // ... and ONE prefix estimate (the prefix + finish path of the owners' sorts: how many leading key bytes leave short runs), as the
+  // element form has had: taken on the biggest shard's partitioned records — a sample of every key range — for `total` records, tables
+  // in that context's sort scratch (idle between its partition pass and its owner's sort), on a stream of its own behind the partition
+  // pass, by a thread of its own: the pulls are queued meanwhile, and an owner asks for the result when it queues its sort, by which
+  // time its pulls are still under way.  (Round 4 and before: W private estimates, each a host round trip at the head of an owner's sort.)
+  std::shared_future<int> shared_prefix;
+  if (shards[big].n >= 2) {
+    try {
+      shared_prefix = std::async(std::launch::async, [&, big]() -> int {
+        ibu_ctx_t* c = ctxs[big];
+        int P = -1;
+        if (hipSetDevice(c->device) != hipSuccess) return -1;
+        if (!c->side_stream && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) { c->side_stream = nullptr; return -1; }   // (creating a stream stalls the threads that are queueing the pulls: once per context)
+        hipStream_t es = c->side_stream;
+        hipError_t e = partitioned.ev[big] ? hipStreamWaitEvent(es, partitioned.ev[big], 0) : hipSuccess;
+        if (e == hipSuccess)
+          e = launch_sort_records(c->cfg, shards[big].d_tmp, c->d_sort_scratch, shards[big].n, c->d_sort_scratch, c->sort_scratch_bytes, es, all_words, -1, &P, total);
+        (void)hipStreamSynchronize(es);
+        if (e != hipSuccess) { (void)hipGetLastError(); return -1; }   // (every owner estimates for itself then)
+        return P;
+      }).share();
+    } catch (...) { return caught_io("ibu_sort_records_contexts"); }
+  }
   lap(2);
   // the exchange — every owner pulls its pieces from the shards' scratch over its own records (partitioned into its scratch: dead) —
   // and the owners' sorts, each behind its own pulls and behind the pulls that read ITS scratch
@@ -477,18 +505,19 @@ int32_t sort_partition_first_records(ibu_ctx_t* const* ctxs, size_t W, ibu_sort_
       },
       [&](size_t j) -> int32_t {
         ibu_ctx_t* c = ctxs[j];
+        const int known_prefix = shared_prefix.valid() ? std::shared_future<int>(shared_prefix).get() : -1;   // (first: the estimate's tables live in a context's sort scratch)
         if (n_out[j] < 2) return IBU_OK;
         int32_t r = ensure_sort_scratch(c, sort_scratch_bytes(c->cfg, n_out[j]));
         if (r) return r;
-        IBU_HIP(launch_sort_records(c->cfg, shards[j].d_records, shards[j].d_tmp, n_out[j], c->d_sort_scratch, c->sort_scratch_bytes, c->stream, all_words));
+        IBU_HIP(launch_sort_records(c->cfg, shards[j].d_records, shards[j].d_tmp, n_out[j], c->d_sort_scratch, c->sort_scratch_bytes, c->stream, all_words, known_prefix));
         return IBU_OK;
       },
       &t_enq);
   if (rc) return rc;
   lap(3);
   if (trace)
-    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first; host joins: samples, range counts (handed over before the partition's scatter), end; ms: samples %.2f, partition %.2f, "
-            "plan %.2f, exchange+sort %.2f of which enqueueing the pulls %.2f)\n", W, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_enq);
+    fprintf(stderr, "ibu sort: contexts=%zu exchange=24 bytes per record (partition first, one prefix estimate for all owners: %d; host joins: samples, range counts (handed over before the partition's scatter), end; ms: samples %.2f, partition %.2f, "
+            "plan %.2f, exchange+sort %.2f of which enqueueing the pulls %.2f)\n", W, shared_prefix.valid() ? shared_prefix.get() : -1, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_enq);
   for (size_t j = 0; j < W; ++j) shards[j].n = n_out[j];
   return IBU_OK;
 }

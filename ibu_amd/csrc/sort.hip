@@ -785,13 +785,24 @@ hipError_t launch_sort_elems(const LaunchCfg& cfg, const CompactPlan& pl, void* 
                                   static_cast<ElemT<3>*>(tmp));
 }
 
+// What launch_sort_records' sampled prefix estimate keeps in the head of `tmp` for n records (0: it would not sample) — for a caller
+// that hands it some other scratch as `tmp` (only_estimate).
+size_t sort_prefix_estimate_tables(const LaunchCfg& cfg, size_t n) {
+  const size_t table_bytes = 128 + (size_t)kPairSlotsMax * 12 * kMaxPrefix;
+  return (cfg.sort_hybrid && n >= 4 * (size_t)32768 && table_bytes <= n * 24) ? table_bytes : 0;
+}
+
 // Not purely asynchronous: the census result comes back to the host (one 64-byte read) to pick the passes; everything
 // after that is queued on `st`.
 // known_words (nullable): census words the caller already has for a SUPERSET of these records (the multi-GPU sort: the partition pass
 // took them over all shards) — OR x 3, AND x 3; no census pass runs, no record is assumed in index order or sorted, and the bytes
 // that vary in the superset get their passes (a byte that happens to be constant here costs one identity pass).
+// known_prefix (with known_words; the multi-GPU sort): >= 0 = the prefix length of the 24-byte prefix + finish path as somebody already
+// estimated it for the WHOLE these records are a key range of (0: all passes); -1: estimate here.  only_estimate (nullable): do nothing
+// but that estimate — for n_scale records like these — and return it in *only_estimate (tmp's head is the table scratch).
 hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size_t n, void* scratch,
-                               size_t scratch_bytes, hipStream_t st, const uint64_t* known_words) {
+                               size_t scratch_bytes, hipStream_t st, const uint64_t* known_words, int known_prefix, int* only_estimate,
+                               size_t n_scale) {
   (void)hipGetLastError();
   if (n < 2) return hipSuccess;
   const SweepVariant& sv = pick_variant(cfg);
@@ -894,7 +905,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
     for (u32 b = 0; b < 8; ++b)
       if ((varying >> (8 * b)) & 255u) passes[npass++] = {(u32)f, 8 * b};   // constant digits: the pass would be the identity
   }
-  if (compact_ok && npass > 0) {
+  if (compact_ok && npass > 0 && !only_estimate) {
     u32 ebytes[16], ne = 0;
     if (speculated) {
       bool covered = true;
@@ -1015,13 +1026,16 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
   {
     // P: ranking inside a segment is quadratic in its length (measured at 1e9 records: 1.5 ms per record of average segment
     // length, against 10.3 ms for one more prefix pass), so the prefix is chosen to leave at most ~8 records per segment
+    const size_t n_est = n_scale ? n_scale : n;               // the size the runs are estimated for
     int P = 1;
-    for (u64 segs = 256; n / segs > 8 && P < 8; segs <<= 8) ++P;
+    for (u64 segs = 256; n_est / segs > 8 && P < 8; segs <<= 8) ++P;
     // ... of WELL-SPREAD keys.  From 2^17 records on the sample ranges say whether they are (ibu_k_sort_sample_pairs_recs: pairs of
     // equal prefix and the most frequent prefix among 3 x 32 Ki sample records, tables in tmp): the shortest prefix with at most
     // ~8 records per run and no heavy prefix is taken, which may be longer than the one n suggests — or none (P = 0: all passes).
     static constexpr size_t kSampleW = 32768;
-    if (cfg.sort_hybrid && n >= 4 * kSampleW && (reinterpret_cast<uintptr_t>(tmp) & 7u) == 0) {
+    if (known_prefix >= 0) {
+      P = known_prefix ? (known_prefix < npass ? known_prefix : npass) : npass;
+    } else if (cfg.sort_hybrid && n >= 4 * kSampleW && (reinterpret_cast<uintptr_t>(tmp) & 7u) == 0) {
       PrefixBytes pb;
       pb = PrefixBytes();
       for (int k = 0; k < npass && k < 24; ++k) { pb.field[k] = (uint8_t)passes[npass - 1 - k].field; pb.shift[k] = (uint8_t)passes[npass - 1 - k].shift; }
@@ -1050,8 +1064,8 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
           e = hipStreamSynchronize(st);
           if (e != hipSuccess) return e;
           for (u32 q = 0; q < (u32)kMaxPrefix && pb.first + q + 1 <= pb.count; ++q) {
-            const double seg = 1.0 + ((double)n / (double)m) * (2.0 * (double)pairs[q] / (double)m);
-            const double heaviest = (double)pairs[kMaxPrefix + q] * ((double)n / (double)m);
+            const double seg = 1.0 + ((double)n_est / (double)m) * (2.0 * (double)pairs[q] / (double)m);
+            const double heaviest = (double)pairs[kMaxPrefix + q] * ((double)n_est / (double)m);
             if (seg <= 8.0 && heaviest <= 128.0) { Pest = (int)(pb.first + q + 1); break; }
           }
         }
@@ -1059,6 +1073,7 @@ hipError_t launch_sort_records(const LaunchCfg& cfg, void* recs, void* tmp, size
         P = Pest ? Pest : npass;                              // npass: never worth it below
       }
     }
+    if (only_estimate) { *only_estimate = P >= npass ? 0 : P; return hipGetLastError(); }
     const int margin = cfg.sort_hybrid == 2 ? 1 : 3;
     if (cfg.sort_hybrid && npass >= P + margin && n < (1ull << 40)) {
       u32* d_overflow = reinterpret_cast<u32*>(sc + L.misc);

@@ -431,7 +431,8 @@ int32_t ibu_sort_records(ibu_ctx_t* ctx, void* d_records, void* d_tmp, size_t n,
  *     kernels, the owners are cut on the exact counts at range boundaries, pull their pieces (12 bytes per record on the links)
  *     and sort them straight into records;
  *   partition first on records — any other key or alignment, at most 32 shards: the same on 24-byte records (their key range in
- *     the digit side stream, one 24-byte pass into the shard's scratch, the owners pull over their own records and sort once);
+ *     the digit side stream, one 24-byte pass into the shard's scratch, the owners pull over their own records and sort once —
+ *     on the census words that pass took over all shards and on one sampled prefix estimate made for all owners, not one each);
  *   sort first — more than 32 shards, option "sort_compact" = 0 on ctxs[0], or a range cut of the first two forms that does not
  *     fit a shard's capacity: every shard sorted where it lives, cut at n_ctxs - 1 splitters by binary search, 24-byte records
  *     exchanged (12-byte elements when at most 12 bytes vary), owners sort again.

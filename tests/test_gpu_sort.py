@@ -1211,3 +1211,44 @@ def test_sort_records_contexts_orders_exchange_and_sorts_on_the_devices(ia, orac
             finally:
                 for c in ctxs:
                     c.close()
+
+
+@pytest.mark.parametrize("kind", ["random", "whitelist"])
+def test_sort_records_contexts_wide_keys_share_one_prefix_estimate(ia, oracle, capfd, kind):
+    """Wide keys (the 24-byte partition-first form): the owners' sorts take ONE sampled prefix estimate, made on the biggest shard's
+    partitioned records for the whole, instead of one each — big enough that the estimate samples (1.05 M records
+    hold its tables), with well-spread keys and with barcodes from a short whitelist (long runs of equal barcode: the estimate must
+    reach into the UMI or give up, and every owner follows it)."""
+    import re
+    k, n_each = 4, 1_200_000
+    total = k * n_each
+    recs = oracle.generate(SEED + 909, 0, total, 32, 32)
+    rng = np.random.default_rng(909)
+    if kind == "whitelist":
+        recs["barcode"] = recs["barcode"][rng.integers(0, 3000, total)]
+    rng.shuffle(recs)
+    want = oracle.sort_records(recs).tobytes()
+    cap = n_each * 5 // 4
+    ctxs = [ia.Context(0) for _ in range(k)]
+    try:
+        shards = []
+        for i, c in enumerate(ctxs):
+            d, t = c.alloc(24 * cap), c.alloc(24 * cap)
+            d.upload(recs[i * n_each:(i + 1) * n_each])
+            shards.append((d, t, n_each, cap))
+        capfd.readouterr()
+        out = ia.Context.sort_records_contexts(ctxs, shards)
+        trace = capfd.readouterr().err
+        assert sum(out) == total
+        assert b"".join(shards[i][0].download(count=24 * out[i]).tobytes() for i in range(k)) == want
+        if trace:
+            m = re.search(r"one prefix estimate for all owners: (-?\d+)", trace)
+            assert m and int(m.group(1)) >= 0, trace
+            shared = int(m.group(1))
+            owners = [int(x) for x in re.findall(r"path=prefix\+finish prefix_passes=(\d+)", trace)]
+            if shared > 0:
+                assert owners and all(p == shared for p in owners), trace      # every owner took the shared length
+            assert trace.count("sample estimate") <= 1, trace                  # ... and none sampled for itself
+    finally:
+        for c in ctxs:
+            c.close()

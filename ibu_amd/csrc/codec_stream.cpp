@@ -76,9 +76,9 @@ int32_t codec_ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg) {
     IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_aos[i]), slot_records * IBU_RECORD_SIZE, hflags));
     IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_col[i]), slot_records * kMaxCols, hflags));
     IBU_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.h_status[i]), 2 * sizeof(uint64_t), hipHostMallocDefault));
-    IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.d_aos[i]), slot_records * IBU_RECORD_SIZE));
-    IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.d_col[i]), slot_records * kMaxCols));
-    IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.d_status[i]), 2 * sizeof(uint64_t)));
+    IBU_HIP(ctx_malloc(ctx, reinterpret_cast<void**>(&r.d_aos[i]), slot_records * IBU_RECORD_SIZE));
+    IBU_HIP(ctx_malloc(ctx, reinterpret_cast<void**>(&r.d_col[i]), slot_records * kMaxCols));
+    IBU_HIP(ctx_malloc(ctx, reinterpret_cast<void**>(&r.d_status[i]), 2 * sizeof(uint64_t)));
   }
   return IBU_OK;
 }

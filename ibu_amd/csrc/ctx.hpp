@@ -85,6 +85,10 @@ void stream_orphan(ibu_ctx* ctx);   // stream.cpp: shut down the open ibu_stream
 void codec_ring_release(ibu_ctx* ctx);
 int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hipMalloc, or the probed form under option "alloc_probe_tries"
 // The context's sort scratch (census slots, histograms, digit side stream): grows only; the one allocation a launch path may make.
+// hipMalloc for the library's own device memory.  The candidates a placement probe did not keep are freed on a helper thread
+// (ctx->loser_free): until it has finished their memory is still taken, and an allocation that fails for want of memory while it
+// runs waits for it and tries once more — a caller never sees an out-of-memory error the synchronous free would not have given.
+hipError_t ctx_malloc(ibu_ctx* ctx, void** p, size_t bytes);   // device.cpp
 inline int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   if (need > ctx->sort_scratch_bytes) {
     if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));

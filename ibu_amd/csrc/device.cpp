@@ -145,6 +145,7 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
   if (strcmp(key, "alloc_probe_tries") == 0) {
     if (value < 0 || value > IBU_ALLOC_PROBE_MAX) return err_arg("alloc_probe_tries must be 0 (auto) .. 16");
     ctx->cfg.alloc_probe_tries = (int)value;
+    if (ctx->loser_free.joinable()) ctx->loser_free.join();   // (documented: setting the option waits for candidates still being freed)
     return IBU_OK;
   }
   if (strcmp(key, "sort_pull_streams") == 0) {
@@ -216,6 +217,16 @@ static uint32_t probe_tries_for(const ibu_ctx* ctx, size_t bytes) {
   const size_t fit = free_b / bytes;
   return fit < 3 ? 1u : (fit < 4 ? (uint32_t)fit : 4u);
 }
+hipError_t ibu::ctx_malloc(ibu_ctx* ctx, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e == hipErrorOutOfMemory && ctx->loser_free.joinable()) {
+    (void)hipGetLastError();
+    ctx->loser_free.join();
+    e = hipMalloc(p, bytes ? bytes : 16);
+    if (trace_sort()) fprintf(stderr, "ibu alloc: %zu bytes did not fit while candidates were being freed: waited for them, %s\n", bytes, e == hipSuccess ? "fits now" : "still does not fit");
+  }
+  return e;
+}
 int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
   const uint32_t tries = probe_tries_for(ctx, bytes);
   if (tries > 1) {
@@ -236,7 +247,7 @@ int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
     }
     return rc;
   }
-  IBU_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+  IBU_HIP(ctx_malloc(ctx, d_ptr, bytes));
   return IBU_OK;
 }
 // Placement probing behind the ABI (round 3; bench.py did this in Python in round 2).  On this part the rate of a streaming
@@ -265,7 +276,7 @@ static int32_t alloc_probed_impl(ibu_ctx_t* ctx, size_t bytes, uint32_t tries, v
   uint32_t got = 0;
   for (; got < tries; ++got) {
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(&cand[got], bytes ? bytes : 16);
+    hipError_t e = got == 0 ? ctx_malloc(ctx, &cand[got], bytes) : hipMalloc(&cand[got], bytes ? bytes : 16);   // (further candidates: what fits now)
     if (e != hipSuccess) {
       (void)hipGetLastError();
       cand[got] = nullptr;
@@ -636,7 +647,7 @@ extern "C" int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_recor
     if (ctx->d_runs_scratch) IBU_HIP(hipFree(ctx->d_runs_scratch));
     ctx->d_runs_scratch = nullptr;
     ctx->runs_scratch_bytes = 0;
-    IBU_HIP(hipMalloc(&ctx->d_runs_scratch, need));
+    IBU_HIP(ctx_malloc(ctx, &ctx->d_runs_scratch, need));
     ctx->runs_scratch_bytes = need;
   }
   IBU_HIP(launch_runs_emit(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->d_runs_scratch, runs, pairs, d_barcodes,

@@ -189,7 +189,7 @@ int32_t ibu::ring_ensure(ibu_ctx* ctx, const ibu_ring_config_t* cfg, bool need_d
   r.node = node_of_range(r.pinned[0], slot_bytes);
   if (need_dev) {
     r.dev.assign(slots, nullptr);
-    for (uint32_t i = 0; i < slots; ++i) IBU_HIP(hipMalloc(reinterpret_cast<void**>(&r.dev[i]), slot_bytes));
+    for (uint32_t i = 0; i < slots; ++i) IBU_HIP(ctx_malloc(ctx, reinterpret_cast<void**>(&r.dev[i]), slot_bytes));
   }
   r.slots = slots;
   r.slot_bytes = slot_bytes;

@@ -292,7 +292,10 @@ int32_t ibu_device_count(int32_t* n);
  *                           (~0.3 ms per GB each, twice), the candidates' memory (k x bytes at the peak; the ones not kept
  *                           are freed by a helper thread right after the choice — the driver clears VRAM when it is freed,
  *                           15-25 GB/s, which a caller need not wait for; the next probing allocation and ibu_ctx_destroy
- *                           join that thread), and one synchronisation of the context's stream per probed allocation.  It never touches the reduce
+ *                           join that thread, and so does any allocation of the LIBRARY's that would otherwise fail for want
+ *                           of memory — it then tries once more; a caller about to allocate with an allocator of its own
+ *                           can wait for that memory by setting this option, to any value), and one synchronisation of the
+ *                           context's stream per probed allocation.  It never touches the reduce
  *                           accumulator (reset / reduce ... / fetch may span allocations).  IBU_TRACE_SORT=1 prints what was
  *                           drawn and chosen.
  *   "numa"           0 | 1  1 = auto (default): the context looks up the NUMA node its device hangs off (PCI bus id ->

@@ -598,3 +598,37 @@ def test_probed_allocations_leave_the_reduce_accumulator_alone(ia, oracle, capfd
         plain.free()
     finally:
         c.close()
+
+
+def test_an_allocation_waits_for_candidates_still_being_freed_instead_of_failing(ia, capfd):
+    """The candidates a placement probe did not keep are freed on a helper thread (the driver clears VRAM at free time: seconds for
+    tens of GB).  Until it is done their memory is still taken: an allocation of the library's that does not fit in the meantime
+    waits for the helper and tries again — the caller sees the result the synchronous free would have given, not an out-of-memory
+    error.  Three candidates of 0.3 of the free memory each, then the same size again at once."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free_b, total_b = C.c_size_t(0), C.c_size_t(0)
+    c = ia.Context(0)
+    try:
+        assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
+        size = (int(free_b.value * 0.30) // 4096) * 4096           # three fit, a fourth does not; two kept ones do
+        assert size >= (1 << 30)
+        c.set_option("alloc_probe_tries", 3)
+        capfd.readouterr()
+        a = c.alloc(size)                                          # three candidates, two of them on their way back
+        b = c.alloc(size)                                          # 0.1 of the memory is free right now unless the helper has finished
+        err = capfd.readouterr().err
+        n = 1_000_003
+        c.generate(SEED, 0, n, 16, 12, b)                          # ordinary memory
+        assert c.reduce(b, n)["count"] == n
+        if os.environ.get("IBU_TRACE_SORT", "") not in ("", "0"):
+            assert "bytes probed: 3 candidates" in err, err
+            # (whether the second call had to wait depends on how fast the driver cleared 0.6 of the memory; when it had to, it says so)
+            assert "still does not fit" not in err, err
+        a.free()
+        b.free()
+        c.set_option("alloc_probe_tries", 0)                       # (setting the option waits for whatever is still being freed)
+        assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
+        assert free_b.value >= 3 * size                            # everything is back
+    finally:
+        c.close()

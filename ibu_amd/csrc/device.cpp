@@ -632,14 +632,17 @@ extern "C" int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_recor
   hipStream_t st = pick_stream(ctx, stream);
   rc = ensure_sort_scratch(ctx, runs_scratch_bytes(n));
   if (rc) return rc;
-  IBU_HIP(launch_runs_count(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes, st));
+  const bool size_query = !d_barcodes && !d_counts && cap == 0;
+  // (with outputs to fill, the count pass keeps every segment's first few run heads: the emit pass then reads the records again only
+  // where runs are short — k_aggregate.hip)
+  IBU_HIP(launch_runs_count(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->sort_scratch_bytes, !size_query, st));
   IBU_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_sort_scratch, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   IBU_HIP(hipStreamSynchronize(st));
   const uint64_t* tot = reinterpret_cast<const uint64_t*>(ctx->h_pinned);
   const uint64_t runs = tot[0], pairs = tot[1];
   *n_barcodes = runs;
   if (n_barcode_umi_pairs) *n_barcode_umi_pairs = pairs;
-  if (!d_barcodes && !d_counts && cap == 0) return IBU_OK;  // size query
+  if (size_query) return IBU_OK;
   if (!d_barcodes || !d_counts) return err_arg("d_barcodes / d_counts are NULL");
   if (runs > cap) return err_arg("output capacity is smaller than the number of distinct barcodes (see *n_barcodes)");
   const size_t need = runs_emit_scratch_bytes(runs);
@@ -650,7 +653,7 @@ extern "C" int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_recor
     IBU_HIP(ctx_malloc(ctx, &ctx->d_runs_scratch, need));
     ctx->runs_scratch_bytes = need;
   }
-  IBU_HIP(launch_runs_emit(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, ctx->d_runs_scratch, runs, pairs, d_barcodes,
+  IBU_HIP(launch_runs_emit(ctx->cfg, d_sorted_records, n, ctx->d_sort_scratch, true, ctx->d_runs_scratch, runs, pairs, d_barcodes,
                            d_counts, d_unique_umis, st));
   return IBU_OK;
 }

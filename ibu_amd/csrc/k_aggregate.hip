@@ -26,7 +26,16 @@ static constexpr int kSortWaves = kSortThreads / kWave;
 // run's barcode, first record and pair rank with plain stores, and a last small kernel turns neighbouring entries into
 // counts (no atomics anywhere: the first version used two per run and took 1 s on 0.9e9 runs of length one).
 // =====================================================================================================
+//
+// Round 5: ONE read of the records where runs are long.  The count pass also keeps the first kStashHeads run heads of every segment
+// (barcode, row inside the segment, pair rank inside the segment: 16 bytes each, plain stores — there are few) in a stash in the
+// scratch; the emit pass serves a segment with that many heads or fewer FROM THE STASH (a few lanes, no record read) and walks only
+// the others again.  Whitelist barcodes (1e5 runs in 1e9 records, 0.8 heads per segment): 24 B/record instead of 48; every record
+// its own barcode: as before.
+// =====================================================================================================
 static constexpr int kSegRecs = 8192;
+static constexpr u32 kStashHeads = 32;
+struct __attribute__((aligned(16))) RunStash { u64 barcode; u32 row_off; u32 pair_local; };
 
 __device__ __forceinline__ u64 shfl_up64(u64 v) {
   u32 lo = __shfl_up((u32)v, 1), hi = __shfl_up((u32)(v >> 32), 1);
@@ -46,6 +55,9 @@ __device__ __forceinline__ void run_heads(const u64* __restrict__ recs, u64 i, u
 
 struct SegPlan { u64 head, main, n; u32 nseg; };            // rows [0, head) | [head, head + main) tiled | rest
 static inline u32 runs_nseg(size_t main_rows) { return (u32)((main_rows + kSegRecs - 1) / kSegRecs) + 2; }
+__device__ __forceinline__ u64 seg_first_row(const SegPlan& sp, u32 seg) {
+  return seg == 0 ? 0 : (seg == sp.nseg - 1 ? sp.head + sp.main : sp.head + (u64)(seg - 1) * kSegRecs);
+}
 
 // One wave walks one segment and hands every run head to `emit(k, barcode, row, pair_rank)`; returns the number of
 // barcode heads / pair heads through c1 / c2.  EMIT = false: counting only (p1, p2 unused).
@@ -120,14 +132,43 @@ ibu_k_runs_count(const u64* __restrict__ recs, SegPlan sp, u32* __restrict__ seg
   runs_segment<false>(recs, sp, seg, lds + wib * kTileBytes, lane, 0, 0, c1, c2, [](u64, u64, u64, u64) {});
   if (lane == 0) { seg_heads[seg] = (u32)c1; seg_heads[sp.nseg + seg] = (u32)c2; }
 }
+// ... and keeping the segment's first kStashHeads heads for the emit pass (see the top of the file)
+extern "C" __global__ void __launch_bounds__(kSortThreads, 8)
+ibu_k_runs_count_stash(const u64* __restrict__ recs, SegPlan sp, u32* __restrict__ seg_heads /*[2][nseg]*/, RunStash* __restrict__ stash /*[nseg][kStashHeads]*/) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kSortWaves * kTileBytes];
+  const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
+  const u32 seg = blockIdx.x * kSortWaves + wib;
+  if (seg >= sp.nseg) return;                               // wave-uniform
+  u64 c1, c2;
+  const u64 row0 = seg_first_row(sp, seg);
+  RunStash* mine = stash + (size_t)seg * kStashHeads;
+  runs_segment<true>(recs, sp, seg, lds + wib * kTileBytes, lane, 0, 0, c1, c2, [=](u64 k, u64 b, u64 row, u64 q) {
+    if (k < kStashHeads) { RunStash e; e.barcode = b; e.row_off = (u32)(row - row0); e.pair_local = (u32)q; mine[k] = e; }
+  });
+  if (lane == 0) { seg_heads[seg] = (u32)c1; seg_heads[sp.nseg + seg] = (u32)c2; }
+}
 
 extern "C" __global__ void __launch_bounds__(kSortThreads, 8)
 ibu_k_runs_emit(const u64* __restrict__ recs, SegPlan sp, const u64* __restrict__ seg_base /*[2][nseg], scanned*/,
+                const u32* __restrict__ seg_heads /*[2][nseg]*/, const RunStash* __restrict__ stash /*[nseg][kStashHeads] or null*/,
                 u64* __restrict__ barcodes, u64* __restrict__ starts, u64* __restrict__ pair_rank) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kSortWaves * kTileBytes];
   const u32 lane = threadIdx.x & (kWave - 1), wib = threadIdx.x >> 6;
   const u32 seg = blockIdx.x * kSortWaves + wib;
   if (seg >= sp.nseg) return;
+  if (stash) {                                              // wave-uniform: the heads the count pass kept are all of them
+    const u32 heads = seg_heads[seg];
+    if (heads <= kStashHeads) {
+      if (lane < heads) {
+        const RunStash e = stash[(size_t)seg * kStashHeads + lane];
+        const u64 k = seg_base[seg] + lane;
+        barcodes[k] = e.barcode;
+        starts[k] = seg_first_row(sp, seg) + e.row_off;
+        if (pair_rank) pair_rank[k] = seg_base[sp.nseg + seg] + e.pair_local;
+      }
+      return;
+    }
+  }
   u64 c1, c2;
   // seg_base: runs / pairs that start before this segment
   runs_segment<true>(recs, sp, seg, lds + wib * kTileBytes, lane, seg_base[seg], seg_base[sp.nseg + seg], c1, c2,
@@ -178,34 +219,42 @@ static SegPlan seg_plan(const LaunchCfg& cfg, const void* recs, size_t n) {
   const RowSplit rs = split_rows(cfg, span, 1, n, kTileRecs);    // an 8-B aligned base peels exactly one record
   return {(u64)rs.head, (u64)rs.main, (u64)n, runs_nseg(rs.main)};
 }
-size_t runs_scratch_bytes(size_t n) {
-  const size_t nseg = runs_nseg(n);                          // main <= n
-  return 64 + (2 * sizeof(u32) + 2 * sizeof(u64)) * nseg + 8;   // totals u64[2] | seg_heads u32[2][nseg] | pad | seg_base u64[2][nseg]
-}
 static inline size_t seg_base_offset(u32 nseg) { return 64 + 2 * sizeof(u32) * (size_t)nseg + ((2 * sizeof(u32) * (size_t)nseg) & 4); }
+static inline size_t stash_offset(u32 nseg) { return (seg_base_offset(nseg) + 2 * sizeof(u64) * (size_t)nseg + 15) & ~(size_t)15; }
+size_t runs_scratch_bytes(size_t n) {
+  const u32 nseg = runs_nseg(n);                             // main <= n
+  return stash_offset(nseg) + sizeof(RunStash) * kStashHeads * (size_t)nseg;   // totals u64[2] | seg_heads u32[2][nseg] | pad | seg_base u64[2][nseg] | pad | stash
+}
 // Pass 1 + scan.  Leaves the scanned table in `scratch`; totals[0] = runs, totals[1] = (barcode, umi) pairs
 // are read back by the caller from scratch[0..15] (u64 each).
-hipError_t launch_runs_count(const LaunchCfg& cfg, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st) {
+// keep_heads: the emit pass follows (launch_runs_emit with from_stash = true); false: a size query.
+hipError_t launch_runs_count(const LaunchCfg& cfg, const void* recs, size_t n, void* scratch, size_t scratch_bytes, bool keep_heads, hipStream_t st) {
   (void)hipGetLastError();
   if (n == 0 || n / kSegRecs + 2 >= (1ull << 31) || scratch_bytes < runs_scratch_bytes(n)) return hipErrorInvalidValue;
   const SegPlan sp = seg_plan(cfg, recs, n);
   u64* totals = static_cast<u64*>(scratch);
   u32* heads = reinterpret_cast<u32*>(static_cast<uint8_t*>(scratch) + 64);
   u64* base = reinterpret_cast<u64*>(static_cast<uint8_t*>(scratch) + seg_base_offset(sp.nseg));
-  hipLaunchKernelGGL(ibu_k_runs_count, dim3((sp.nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs, sp,
-                     heads);
+  if (keep_heads)
+    hipLaunchKernelGGL(ibu_k_runs_count_stash, dim3((sp.nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs, sp,
+                       heads, reinterpret_cast<RunStash*>(static_cast<uint8_t*>(scratch) + stash_offset(sp.nseg)));
+  else
+    hipLaunchKernelGGL(ibu_k_runs_count, dim3((sp.nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs, sp,
+                       heads);
   hipLaunchKernelGGL(ibu_k_runs_scan, dim3(2), dim3(kSortThreads), 0, st, (const u32*)heads, sp.nseg, base, totals);
   return hipGetLastError();
 }
-hipError_t launch_runs_emit(const LaunchCfg& cfg, const void* recs, size_t n, const void* scratch, void* run_scratch, uint64_t n_runs,
+hipError_t launch_runs_emit(const LaunchCfg& cfg, const void* recs, size_t n, const void* scratch, bool from_stash, void* run_scratch, uint64_t n_runs,
                             uint64_t n_pairs, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq, hipStream_t st) {
   (void)hipGetLastError();
   const SegPlan sp = seg_plan(cfg, recs, n);
+  const u32* heads = reinterpret_cast<const u32*>(static_cast<const uint8_t*>(scratch) + 64);
   const u64* base = reinterpret_cast<const u64*>(static_cast<const uint8_t*>(scratch) + seg_base_offset(sp.nseg));
+  const RunStash* stash = from_stash ? reinterpret_cast<const RunStash*>(static_cast<const uint8_t*>(scratch) + stash_offset(sp.nseg)) : nullptr;
   u64* starts = static_cast<u64*>(run_scratch);             // n_runs entries each (run_scratch_bytes)
   u64* pair_rank = uniq ? starts + n_runs : nullptr;
   hipLaunchKernelGGL(ibu_k_runs_emit, dim3((sp.nseg + kSortWaves - 1) / kSortWaves), dim3(kSortThreads), 0, st, (const u64*)recs, sp,
-                     base, (u64*)barcodes, starts, pair_rank);
+                     base, heads, stash, (u64*)barcodes, starts, pair_rank);
   u64 blocks = (n_runs + 255) / 256;
   const u64 cap = (u64)cfg.cus * 8;
   if (blocks > cap) blocks = cap;

@@ -117,9 +117,9 @@ hipError_t launch_sort_elems(const LaunchCfg&, const CompactPlan& pl, void* recs
                              size_t scratch_bytes, hipStream_t st);
 // per-barcode run-length aggregation of sorted records (k_aggregate.hip)
 size_t runs_scratch_bytes(size_t n);
-hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, hipStream_t st);
+hipError_t launch_runs_count(const LaunchCfg&, const void* recs, size_t n, void* scratch, size_t scratch_bytes, bool keep_heads, hipStream_t st);
 size_t runs_emit_scratch_bytes(uint64_t n_runs);
-hipError_t launch_runs_emit(const LaunchCfg&, const void* recs, size_t n, const void* scratch, void* run_scratch, uint64_t n_runs,
+hipError_t launch_runs_emit(const LaunchCfg&, const void* recs, size_t n, const void* scratch, bool from_stash, void* run_scratch, uint64_t n_runs,
                             uint64_t n_pairs, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq, hipStream_t st);
 
 }  // namespace ibu

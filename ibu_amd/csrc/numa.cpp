@@ -78,10 +78,17 @@ PreferNode::PreferNode(int node) {
   if (node < 0 || node >= 1024) return;
   unsigned long mask[16] = {0};
   mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+  if (syscall(SYS_get_mempolicy, &saved_mode_, saved_mask_, (unsigned long)(sizeof saved_mask_ * 8), nullptr, 0ul) != 0) {
+    saved_mode_ = 0;                   // (cannot ask: the default policy comes back afterwards)
+    memset(saved_mask_, 0, sizeof saved_mask_);
+  }
   active_ = syscall(SYS_set_mempolicy, 1 /*MPOL_PREFERRED*/, mask, (unsigned long)(sizeof mask * 8)) == 0;
 }
 PreferNode::~PreferNode() {
-  if (active_) (void)syscall(SYS_set_mempolicy, 0 /*MPOL_DEFAULT*/, nullptr, 0ul);
+  if (!active_) return;
+  if (saved_mode_ == 0 /*MPOL_DEFAULT*/ ||
+      syscall(SYS_set_mempolicy, saved_mode_, saved_mask_, (unsigned long)(sizeof saved_mask_ * 8)) != 0)
+    (void)syscall(SYS_set_mempolicy, 0 /*MPOL_DEFAULT*/, nullptr, 0ul);
 }
 
 RunOnNode::RunOnNode(const NumaPlace& place) {

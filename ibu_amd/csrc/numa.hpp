@@ -34,6 +34,8 @@ class PreferNode {
   bool active() const { return active_; }
  private:
   bool active_ = false;
+  int saved_mode_ = 0;                 // the thread's policy before (a process under `numactl --interleave` gets it back)
+  unsigned long saved_mask_[16] = {0};
 };
 // For the lifetime of the object the calling thread (and every thread it starts: affinity is inherited) runs on place.cpus.
 class RunOnNode {

@@ -470,7 +470,10 @@ int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ctxs, ibu_sor
  * pairs.  Size query: d_barcodes = d_counts = NULL and cap = 0.  cap too small: IBU_ERR_INVALID_ARG with
  * *n_barcodes set.  The input must be sorted (ibu_sort_records / a file whose header says sorted);
  * unsorted input yields the run-length encoding of the barcode column instead.  Synchronises `stream`
- * once (the counts come back to size the output).  n < 2^40. */
+ * once (the counts come back to size the output).  n < 2^40.  Reads the records once where barcodes
+ * repeat (at most 32 run heads per 8192 records: the count pass keeps them), twice where they do not;
+ * the size query alone is one read — a caller that knows a bound (its whitelist) skips it and passes
+ * that bound as cap. */
 int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, uint64_t* d_barcodes,
                            uint64_t* d_counts, uint64_t* d_unique_umis, size_t cap, size_t* n_barcodes,
                            size_t* n_barcode_umi_pairs, void* stream);

@@ -756,6 +756,51 @@ def test_barcode_counts(ctx, oracle, ia, n, n_barcodes, n_umis):
     assert u2 is None and b2.tobytes() == wb.tobytes() and c2.tobytes() == wc.tobytes()
 
 
+@pytest.mark.parametrize("peel", [0, 1])
+def test_barcode_counts_serves_sparse_segments_from_the_stash_and_walks_the_dense_ones(ctx, oracle, ia, peel):
+    """The count pass keeps the first 32 run heads of every 8192-record segment; the emit pass writes a segment with at most 32 heads
+    from that stash and reads the records again only for the others.  Segments with 0 (one run goes on), 1, 31, 32, 33, 34, 64 and
+    8192 heads side by side, a run that crosses a segment boundary or a new one starting exactly on it, with and without the peeled
+    first record (which shifts every segment by one row)."""
+    import ctypes as C
+    rng = np.random.default_rng(3232 + peel)
+    seg = 8192
+    heads_per_seg = [1, 0, 31, 32, 33, 0, 34, 64, 8192, 2, 32, 0, 33, 1, 5]
+    starts_new = [True, False, True, False, True, False, False, True, True, False, True, False, True, True, False]   # a head on the segment's first row
+    bc = np.empty(0, np.uint64)
+    cur = 10
+    for h, first in zip(heads_per_seg, starts_new):
+        col = np.full(seg, cur, np.uint64)
+        if h:
+            rows = np.arange(seg) if h == seg else np.sort(rng.choice(np.arange(1, seg), h - (1 if first else 0), replace=False))
+            if first and h != seg:
+                rows = np.concatenate(([0], rows))
+            step = np.zeros(seg, np.uint64)
+            step[rows] = rng.integers(1, 1000, len(rows)).astype(np.uint64)
+            col = cur + np.cumsum(step)
+            cur = int(col[-1])
+        bc = np.concatenate((bc, col.astype(np.uint64)))
+    tail = np.full(77, cur + 5, np.uint64)                         # the n % 128 rest: one more run
+    bc = np.concatenate((np.full(peel, 3, np.uint64), bc, tail))
+    n = len(bc)
+    recs = np.empty(n, dtype=ia.REC_DTYPE)
+    recs["barcode"] = bc
+    recs["umi"] = rng.integers(0, 6, n, dtype=np.uint64)
+    recs["index"] = np.arange(n, dtype=np.uint64)
+    srt = oracle.sort_records(recs)
+    assert srt["barcode"].tobytes() == bc.tobytes()                # (the construction is sorted by barcode already)
+    buf = ctx.alloc(24 * (n + 2))
+    base = buf.ptr + (24 if peel else 0)                          # peel = 1: start at an odd record (8- not 16-byte aligned)
+    ia.lib.ibu_memcpy_h2d(ctx._c, C.c_void_p(base), srt.ctypes.data_as(C.c_void_p), 24 * n, None)
+    ctx.synchronize()
+    b, c, u = ctx.barcode_counts(base, n)
+    wb, wc, wu = oracle.barcode_counts(srt)
+    assert (b.tobytes(), c.tobytes(), u.tobytes()) == (wb.tobytes(), wc.tobytes(), wu.tobytes())
+    b2, c2, _ = ctx.barcode_counts(base, n, unique_umis=False)
+    assert (b2.tobytes(), c2.tobytes()) == (wb.tobytes(), wc.tobytes())
+    buf.free()
+
+
 @pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 255, 8192 + 1, 8192 + 128 + 5, 3 * 8192 + 129, 100_001])
 @pytest.mark.parametrize("n_barcodes,n_umis", [(1, 1), (5, 2), (1 << 40, 1 << 20)])
 def test_barcode_counts_of_a_shard_at_an_odd_record(ctx, oracle, ia, n, n_barcodes, n_umis):

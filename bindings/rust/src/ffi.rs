@@ -75,6 +75,18 @@ pub struct ibu_alloc_probe_t {
     pub ms: [f32; 16],
 }
 
+/// One BGZF block as `ibu_bgzf_scan` describes it and `ibu_inflate_blocks_device` inflates it.
+#[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct ibu_inflate_block_t {
+    pub comp_offset: u64,
+    pub out_offset: i64,
+    pub comp_len: u32,
+    pub out_len: u32,
+    pub crc32: u32,
+    pub reserved: u32,
+}
+
 /// One shard of `ibu_sort_records_contexts`: `n` records in `d_records` (room for `capacity`), `d_tmp` = capacity * 24 bytes.
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
@@ -184,6 +196,10 @@ extern "C" {
     pub fn ibu_barcode_counts(ctx: *mut ibu_ctx_t, d_sorted_records: *const c_void, n: usize, d_barcodes: *mut u64,
                               d_counts: *mut u64, d_unique_umis: *mut u64, cap: usize, n_barcodes: *mut usize,
                               n_barcode_umi_pairs: *mut usize, stream: *mut c_void) -> i32;
+    pub fn ibu_bgzf_scan(buf: *const u8, len: usize, is_final: i32, blocks: *mut ibu_inflate_block_t, cap: usize, n_blocks: *mut usize,
+                         consumed: *mut usize, out_bytes: *mut u64) -> i32;
+    pub fn ibu_inflate_blocks_device(ctx: *mut ibu_ctx_t, d_comp: *const c_void, d_blocks: *const ibu_inflate_block_t, n: usize,
+                                     d_out: *mut c_void, d_status: *mut u32, d_first_bad: *mut u32, stream: *mut c_void) -> i32;
     pub fn ibu_mmap_decode_to_host(m: *const ibu_mmap_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t, shard: usize,
                                    n_shards: usize, h_bc_ascii: *mut u8, h_umi_ascii: *mut u8, h_index: *mut u64,
                                    stats: *mut ibu_stream_stats_t) -> i32;

@@ -729,6 +729,19 @@ class DeviceStream:
         self.close()
 
 
+def bgzf_scan(buf, final=True, cap=None):
+    """ibu_bgzf_scan over `buf` (bytes-like): (ctypes array of ibu_inflate_block_t, consumed bytes, uncompressed bytes, status).
+    status is 0 or 2 = IBU_ERR_NIFFLER (the blocks in front of the bad spot are described)."""
+    from ._lib import CInflateBlock
+    a = np.frombuffer(buf, dtype=np.uint8)
+    cap = int(cap) if cap is not None else len(a) // 28 + 1
+    blocks = (CInflateBlock * max(cap, 1))()
+    n, consumed, out_bytes = C.c_size_t(), C.c_size_t(), C.c_uint64()
+    rc = lib.ibu_bgzf_scan(_hptr(a) if len(a) else None, len(a), 1 if final else 0, blocks, cap, C.byref(n), C.byref(consumed), C.byref(out_bytes))
+    return (CInflateBlock * n.value).from_buffer_copy(bytes(blocks)[:n.value * C.sizeof(CInflateBlock)]) if n.value else (CInflateBlock * 0)(), \
+        consumed.value, out_bytes.value, rc
+
+
 def numa_of_pci(pci_bus_id, sysfs_root=None):
     """(node, cpulist, usable_cpus) of a PCI function from a sysfs tree (ibu_numa_of_pci); node -1 = the platform does not say."""
     node, usable, buf = C.c_int32(), C.c_int32(), C.create_string_buffer(256)
@@ -860,6 +873,25 @@ class Context:
                                       C.byref(nb), C.byref(npairs), stream))
         self.synchronize(stream)
         return (d_b.download(np.uint64), d_c.download(np.uint64), d_u.download(np.uint64) if d_u else None)
+
+    def inflate_blocks(self, d_comp, blocks, d_out, stream=None):
+        """ibu_inflate_blocks_device: the deflate blocks `blocks` (a ctypes array of ibu_inflate_block_t, or what bgzf_scan
+        returned) of the compressed bytes at d_comp -> d_out.  Returns (status per block as numpy u32, first bad block or None);
+        synchronises."""
+        n = len(blocks)
+        if n == 0:
+            return np.empty(0, np.uint32), None
+        raw = np.frombuffer(bytes(blocks), dtype=np.uint8) if not isinstance(blocks, np.ndarray) else blocks.view(np.uint8)
+        d_blocks = self.upload(raw)
+        d_status = self.alloc(4 * n + 4)
+        first = np.full(1, 0xFFFFFFFF, np.uint32)
+        _check(lib.ibu_memcpy_h2d(self._c, d_status.ptr + 4 * n, _hptr(first), 4, stream))
+        _check(lib.ibu_inflate_blocks_device(self._c, _dptr(d_comp), d_blocks.ptr, n, _dptr(d_out), d_status.ptr, d_status.ptr + 4 * n, stream))
+        self.synchronize(stream)
+        st = d_status.download(np.uint32)
+        d_blocks.free()
+        d_status.free()
+        return st[:n].copy(), (None if st[n] == 0xFFFFFFFF else int(st[n]))
 
     def lower_bound(self, d_sorted_records, n, d_keys, k, d_pos, stream=None):
         """d_pos[j] (u64, device) = first position whose record is >= key j (24-byte records in d_keys); asynchronous."""

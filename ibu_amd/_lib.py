@@ -48,6 +48,11 @@ class CKeyPlan(C.Structure):  # ibu_key_plan_t
     _fields_ = [("csel", (u32 * 3) * 4), ("xsel", (u32 * 2) * 6), ("k", u32), ("index_bytes", u32), ("base", u64 * 3)]
 
 
+class CInflateBlock(C.Structure):  # ibu_inflate_block_t
+    _fields_ = [("comp_offset", C.c_uint64), ("out_offset", C.c_int64), ("comp_len", C.c_uint32), ("out_len", C.c_uint32),
+                ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class CSortShard(C.Structure):  # ibu_sort_shard_t
     _fields_ = [("d_records", C.c_void_p), ("d_tmp", C.c_void_p), ("n", C.c_size_t), ("capacity", C.c_size_t)]
 
@@ -137,6 +142,8 @@ SIGNATURES = {
     "ibu_mmap_decode_to_host": (i32, [vp, vp, vp, sz, sz, vp, vp, vp, vp]),
     "ibu_writer_write_ascii_batch": (i32, [vp, vp, vp, vp, vp, vp, u64, sz, u32, u32, vp]),
     "ibu_barcode_counts": (i32, [vp, vp, sz, vp, vp, vp, sz, P(sz), P(sz), vp]),
+    "ibu_bgzf_scan": (i32, [vp, sz, i32, P(CInflateBlock), sz, P(sz), P(sz), P(C.c_uint64)]),
+    "ibu_inflate_blocks_device": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
     "ibu_device_alloc": (i32, [vp, sz, P(vp)]),
     "ibu_device_alloc_probed": (i32, [vp, sz, u32, P(vp), P(CAllocProbe)]),
     "ibu_device_free": (i32, [vp, vp]),

@@ -9,6 +9,7 @@
 
 #include <chrono>
 
+#include <cstddef>
 #include "ctx.hpp"
 
 using namespace ibu;
@@ -571,6 +572,20 @@ extern "C" int32_t ibu_records_first_mismatch(ibu_ctx_t* ctx, const void* d_a, c
 static_assert(sizeof(ibu_key_plan_t) == sizeof(ibu::CompactPlan) && offsetof(ibu_key_plan_t, base) == offsetof(ibu::CompactPlan, base) &&
                   offsetof(ibu_key_plan_t, k) == offsetof(ibu::CompactPlan, k),
               "ibu_key_plan_t is the kernels' CompactPlan");
+static_assert(sizeof(ibu_inflate_block_t) == sizeof(InflateBlockDesc) && offsetof(ibu_inflate_block_t, crc32) == offsetof(InflateBlockDesc, crc) &&
+              offsetof(ibu_inflate_block_t, out_offset) == offsetof(InflateBlockDesc, ooff) && IBU_INFLATE_PAD == kInflatePad,
+              "ibu_inflate_block_t is the kernel's descriptor");
+extern "C" int32_t ibu_inflate_blocks_device(ibu_ctx_t* ctx, const void* d_comp, const ibu_inflate_block_t* d_blocks, size_t n, void* d_out,
+                                             uint32_t* d_status, uint32_t* d_first_bad, void* stream) {
+  int32_t rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n == 0) return IBU_OK;
+  if (!d_comp || !d_blocks || !d_out || !d_status || !d_first_bad) return err_arg("NULL argument");
+  if (n >= (1ull << 31)) return err_arg("fewer than 2^31 blocks per call");
+  IBU_HIP(launch_inflate_blocks(ctx->cfg, d_comp, reinterpret_cast<const InflateBlockDesc*>(d_blocks), n, d_out, d_status, d_first_bad,
+                                pick_stream(ctx, stream)));
+  return IBU_OK;
+}
 extern "C" int32_t ibu_records_census(ibu_ctx_t* ctx, const void* d_records, size_t n, uint64_t out[8], void* stream) {
   int32_t rc = check_ctx(ctx);
   if (rc) return rc;

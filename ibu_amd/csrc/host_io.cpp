@@ -896,6 +896,53 @@ int32_t writer_make(std::unique_ptr<Sink> sink, MemSink* mem, const ibu_header_t
 
 }  // namespace
 
+// The walk over BGZF block headers (the rule of BgzfSource::refill above, without the inflating): see include/ibu_hip.h.
+extern "C" int32_t ibu_bgzf_scan(const uint8_t* buf, size_t len, int32_t final, ibu_inflate_block_t* blocks, size_t cap, size_t* n_blocks,
+                                 size_t* consumed, uint64_t* out_bytes) {
+  if (!n_blocks || !consumed) return err_arg("n_blocks / consumed is NULL");
+  *n_blocks = 0;
+  *consumed = 0;
+  if (out_bytes) *out_bytes = 0;
+  if ((!buf && len) || (!blocks && cap)) return err_arg("NULL argument");
+  size_t pos = 0, nb = 0;
+  uint64_t total = 0;
+  int32_t rc = IBU_OK;
+  while (pos < len && nb < cap) {
+    const size_t avail = len - pos;
+    const uint8_t* hd = buf + pos;
+    if (avail < 12) { if (final) rc = err_niffler("the stream ends inside a BGZF block header"); break; }
+    const bool bgzf_like = hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8 && (hd[3] & 4);
+    if (!bgzf_like) { rc = err_niffler("not a BGZF block (a gzip member without the BC extra field)"); break; }
+    const size_t xlen = (size_t)(hd[10] | (hd[11] << 8));
+    if (avail < 12 + xlen) { if (final) rc = err_niffler("the stream ends inside a BGZF block header"); break; }
+    size_t bsize = 0;
+    for (size_t p = 0; p + 4 <= xlen;) {
+      const uint8_t* extra = hd + 12;
+      const size_t slen = (size_t)(extra[p + 2] | (extra[p + 3] << 8));
+      if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = (size_t)(extra[p + 4] | (extra[p + 5] << 8)) + 1;
+      p += 4 + slen;
+    }
+    if (bsize < 12 + 2 + xlen + 8) { rc = err_niffler("not a BGZF block (no usable BC extra field)"); break; }
+    if (avail < bsize) { if (final) rc = err_niffler("the stream ends inside a BGZF block"); break; }
+    const uint8_t* tr = hd + bsize - 8;
+    ibu_inflate_block_t b;
+    b.comp_offset = pos + 12 + xlen;
+    b.comp_len = (uint32_t)(bsize - 12 - xlen - 8);
+    b.crc32 = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+    b.out_len = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+    b.reserved = 0;
+    if (b.out_len > 65536) { rc = err_niffler("a BGZF block announces more than 64 KiB"); break; }
+    b.out_offset = (int64_t)total;
+    total += b.out_len;
+    blocks[nb++] = b;
+    pos += bsize;
+  }
+  *n_blocks = nb;
+  *consumed = pos;
+  if (out_bytes) *out_bytes = total;
+  return rc;
+}
+
 extern "C" int32_t ibu_writer_open_callback(ibu_write_fn wr, ibu_flush_fn fl, void* user, const ibu_header_t* header,
                                             ibu_writer_t** out) {
   if (!wr) return err_arg("write callback is NULL");

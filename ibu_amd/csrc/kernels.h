@@ -122,4 +122,13 @@ size_t runs_emit_scratch_bytes(uint64_t n_runs);
 hipError_t launch_runs_emit(const LaunchCfg&, const void* recs, size_t n, const void* scratch, bool from_stash, void* run_scratch, uint64_t n_runs,
                             uint64_t n_pairs, uint64_t* barcodes, uint64_t* counts, uint64_t* uniq, hipStream_t st);
 
+// DEFLATE blocks inflated on the device, one wave per block (k_inflate.hip).  The compressed bytes must be readable 2 KiB past the
+// last block (kInflatePad); block i's output goes to d_out_base + ooff (signed: a block that begins in front of the window a batch
+// keeps lands in the headroom before it).  d_status[i]: 0 good, 1 not a valid deflate stream of these sizes, 2 CRC-32 mismatch;
+// *d_first_bad (the caller sets it to 0xFFFFFFFF): the lowest bad block.
+struct InflateBlockDesc { uint64_t coff; int64_t ooff; uint32_t clen, isize, crc, reserved; };
+constexpr size_t kInflatePad = 2048;
+hipError_t launch_inflate_blocks(const LaunchCfg&, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
+                                 uint32_t* d_status, uint32_t* d_first_bad, hipStream_t st);
+
 }  // namespace ibu

@@ -477,6 +477,30 @@ int32_t ibu_sort_records_contexts(ibu_ctx_t* const* ctxs, size_t n_ctxs, ibu_sor
 int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t n, uint64_t* d_barcodes,
                            uint64_t* d_counts, uint64_t* d_unique_umis, size_t cap, size_t* n_barcodes,
                            size_t* n_barcode_umi_pairs, void* stream);
+/* BGZF / DEFLATE on the device (k_inflate.hip).  A bgzip file — to niffler (src/io/reader.rs:345-352) a gzip stream of many
+ * members — is a chain of independent deflate blocks of at most 64 KiB whose compressed and uncompressed sizes stand in their
+ * headers and trailers: the blocks can be found without inflating them, their COMPRESSED bytes can cross the PCIe link (half the
+ * bytes of a records file) and every block can go to a wave of its own.
+ * ibu_bgzf_scan (host): walks the block headers in buf[0, len) and describes up to `cap` whole blocks: comp_offset / comp_len = the
+ * raw deflate bytes inside the member, out_len and crc32 from its trailer, out_offset = the sum of the out_len before it.
+ * *consumed = bytes of buf the described blocks cover (the next call starts there), *out_bytes = their uncompressed size.  A
+ * member that is not a BGZF block, or one that is cut off with final != 0: IBU_ERR_NIFFLER (the blocks in front of it are
+ * described, *n_blocks says how many); a block that is not whole yet with final == 0 ends the walk quietly.
+ * ibu_inflate_blocks_device: inflates the n blocks d_blocks describes (device memory, comp_offset relative to d_comp, out_offset
+ * — signed — relative to d_out) — d_comp must be readable IBU_INFLATE_PAD bytes past the last block's end — and verifies length,
+ * the end of the deflate stream on the block's last byte and the CRC-32, exactly as the host decoder does.  d_status[i] = 0 good /
+ * 1 not a valid deflate stream of these sizes / 2 CRC-32 mismatch; *d_first_bad (device; the caller sets it to 0xFFFFFFFF) = the
+ * lowest bad block.  A block writes only its own out_len bytes.  Asynchronous on `stream`. */
+#define IBU_INFLATE_PAD 2048
+typedef struct ibu_inflate_block {
+  uint64_t comp_offset;
+  int64_t out_offset;
+  uint32_t comp_len, out_len, crc32, reserved;
+} ibu_inflate_block_t;
+int32_t ibu_bgzf_scan(const uint8_t* buf, size_t len, int32_t final, ibu_inflate_block_t* blocks, size_t cap, size_t* n_blocks,
+                      size_t* consumed, uint64_t* out_bytes);
+int32_t ibu_inflate_blocks_device(ibu_ctx_t* ctx, const void* d_comp, const ibu_inflate_block_t* d_blocks, size_t n, void* d_out,
+                                  uint32_t* d_status, uint32_t* d_first_bad, void* stream);
 /* For each of the k key records d_keys[j] (24 B each): the first position p in the SORTED device records with
  * records[p] >= key under ibu_record_cmp (record.rs:58), i.e. slice::partition_point(|r| r < key); n if there is none.
  * Positions land in d_pos[0..k) on the device; asynchronous on `stream`.  This is the splitter search of the

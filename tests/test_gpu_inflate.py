@@ -1,0 +1,205 @@
+"""GPU parity for the device DEFLATE decoder (k_inflate.hip) behind ibu_bgzf_scan / ibu_inflate_blocks_device: the blocks of BGZF
+streams written by zlib at every level and strategy inflate on the device to the bytes zlib's own inflate gives, a block is
+accepted exactly when the host decoder accepts it (length, end of the deflate stream on the block's last byte, CRC-32), and
+nothing is written outside a block's own output range.  The reference reads such files as multi-member gzip through niffler
+(src/io/reader.rs:345-352); the oracle for the bytes is zlib (the record-stream parity of the whole path: test_gpu_streams.py,
+test_gpu_pull_stream.py)."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from tests.bgzf import bgzf_compress
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x1B00007
+PAD = 2048
+GUARD = 4096
+NIFFLER = 2          # IBU_ERR_NIFFLER (include/ibu_hip.h)
+
+
+@pytest.fixture(scope="module")
+def ia():
+    import ibu_amd
+    return ibu_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ia):
+    c = ia.Context(0)
+    yield c
+    c.close()
+
+
+def _bgzf(data, block=0xFF00, level=1, strategy=zlib.Z_DEFAULT_STRATEGY, eof=True):
+    out = bytearray()
+    for off in range(0, len(data), block):
+        chunk = data[off:off + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        cd = c.compress(chunk) + c.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(cd) + 25)
+        out += cd + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    if eof:
+        out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    return bytes(out)
+
+
+def _inflate_on_device(ia, ctx, comp, blocks, out_bytes):
+    """-> (output bytes, status array, first bad, guard zones intact)"""
+    d_comp = ctx.alloc(len(comp) + PAD)
+    d_comp.upload(np.frombuffer(comp, np.uint8))
+    d_out = ctx.alloc(out_bytes + 2 * GUARD)
+    d_out.upload(np.full(out_bytes + 2 * GUARD, 0xA5, np.uint8))
+    st, first = ctx.inflate_blocks(d_comp, blocks, d_out.ptr + GUARD)
+    got = d_out.download(np.uint8)
+    d_comp.free()
+    d_out.free()
+    guards_ok = bool((got[:GUARD] == 0xA5).all() and (got[GUARD + out_bytes:] == 0xA5).all())
+    return got[GUARD:GUARD + out_bytes].tobytes(), st, first, guards_ok
+
+
+def _kinds(oracle, rng):
+    recs = oracle.generate(SEED, 0, 40_000, 16, 12)
+    period = rng.integers(0, 256, 20_000, dtype=np.uint8).tobytes()
+    words = [bytes(rng.integers(97, 123, rng.integers(2, 9), dtype=np.uint8)) for _ in range(300)]
+    text = b" ".join(words[i] for i in rng.integers(0, 300, 60_000))
+    return {
+        "records": recs.tobytes(),
+        "random": rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes(),          # incompressible: stored blocks
+        "zeros": bytes(150_000),                                                      # distance 1, length 258
+        "far": period * 9,                                                            # matches 20 000 bytes back: the global read-back
+        "text": text,                                                                 # long codes, short and long distances
+        "skewed": bytes(rng.choice(np.array([0, 0, 0, 0, 0, 0, 0, 1, 2, 255], np.uint8), 180_000)),
+        "one": b"x",
+        "empty": b"",
+    }
+
+
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                            (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE),
+                                            (9, zlib.Z_FILTERED)])
+def test_blocks_inflate_to_what_zlib_gives(ia, ctx, oracle, level, strategy):
+    rng = np.random.default_rng(SEED + level + 16 * strategy)
+    for name, data in _kinds(oracle, rng).items():
+        for block in (0xFF00, 4093):
+            comp = _bgzf(data, block=block, level=level, strategy=strategy)
+            blocks, consumed, out_bytes, rc = ia.bgzf_scan(comp)
+            assert rc == 0 and consumed == len(comp) and out_bytes == len(data), (name, level, strategy)
+            assert len(blocks) == (len(data) + block - 1) // block + 1                  # + the empty EOF block
+            got, st, first, guards = _inflate_on_device(ia, ctx, comp, blocks, len(data))
+            assert first is None and not st.any(), (name, level, strategy, block, st.nonzero()[0][:5], first)
+            assert got == data, (name, level, strategy, block)
+            assert guards
+            if len(data) > 200_000:
+                break
+
+
+def test_scan_describes_whole_blocks_and_names_what_is_not_bgzf(ia):
+    data = bytes(range(256)) * 1000
+    comp = bgzf_compress(data, level=1)
+    blocks, consumed, out_bytes, rc = ia.bgzf_scan(comp)
+    assert rc == 0 and consumed == len(comp) and out_bytes == len(data)
+    pos = 0
+    for b in blocks:                                                  # the descriptors are the members' own fields
+        assert b.comp_offset == pos + 18 and comp[pos:pos + 4] == b"\x1f\x8b\x08\x04"
+        bsize = struct.unpack_from("<H", comp, pos + 16)[0] + 1
+        assert b.comp_len == bsize - 26
+        assert (b.crc32, b.out_len) == struct.unpack_from("<II", comp, pos + bsize - 8)
+        pos += bsize
+    assert [b.out_offset for b in blocks] == list(np.cumsum([0] + [b.out_len for b in blocks])[:-1])
+    # a buffer that ends inside a block: more may come (final = 0) / the stream is cut off (final = 1)
+    cut = len(comp) - 40
+    b0, c0, o0, rc0 = ia.bgzf_scan(comp[:cut], final=False)
+    assert rc0 == 0 and len(b0) == len(blocks) - 2 and c0 == blocks[len(b0)].comp_offset - 18
+    b1, c1, o1, rc1 = ia.bgzf_scan(comp[:cut], final=True)
+    assert rc1 == NIFFLER and len(b1) == len(b0) and c1 == c0 and o1 == o0
+    # cap: the walk stops after `cap` blocks and says where
+    b2, c2, _, rc2 = ia.bgzf_scan(comp, cap=3)
+    assert rc2 == 0 and len(b2) == 3 and c2 == blocks[3].comp_offset - 18
+    # an ordinary gzip member is not a BGZF block
+    import gzip
+    b3, c3, _, rc3 = ia.bgzf_scan(gzip.compress(data[:1000]))
+    assert rc3 == NIFFLER and len(b3) == 0 and c3 == 0
+    assert ia.bgzf_scan(b"")[3] == 0
+
+
+def test_a_bad_block_is_named_and_its_neighbours_are_not_touched(ia, ctx, oracle):
+    recs = oracle.generate(SEED, 0, 30_000, 16, 12).tobytes()
+    block = 0xFF00
+    good = _bgzf(recs, block=block, level=6)
+    blocks, _, out_bytes, _ = ia.bgzf_scan(good)
+    nb = len(blocks)
+    rng = np.random.default_rng(SEED)
+    for trial in range(12):
+        comp = bytearray(good)
+        victim = int(rng.integers(0, nb - 1))
+        b = blocks[victim]
+        kind = trial % 4
+        if kind == 0:                                                 # a flipped bit somewhere in the deflate data
+            at = b.comp_offset + int(rng.integers(0, b.comp_len))
+            comp[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                                               # the trailer's CRC
+            struct.pack_into("<I", comp, b.comp_offset + b.comp_len, b.crc32 ^ 0x10)
+        elif kind == 2:                                               # the trailer's length: one too many
+            struct.pack_into("<I", comp, b.comp_offset + b.comp_len + 4, b.out_len + 1)
+        else:                                                         # a block cut short by a byte (its last byte belongs to the next one now)
+            pass
+        bl, _, ob, rc = ia.bgzf_scan(bytes(comp))
+        assert rc == 0 and len(bl) == nb
+        if kind == 3:
+            bl[victim].comp_len -= 1
+        got, st, first, guards = _inflate_on_device(ia, ctx, bytes(comp), bl, ob)
+        assert guards
+        # zlib on the same block: does it take it?
+        bb = bl[victim]
+        try:
+            d = zlib.decompressobj(-15)
+            o = d.decompress(bytes(comp[bb.comp_offset:bb.comp_offset + bb.comp_len]))
+            zl_ok = d.eof and not d.unused_data and len(o) == bb.out_len and zlib.crc32(o) == bb.crc32
+        except zlib.error:
+            zl_ok = False
+        assert (st[victim] == 0) == zl_ok, (trial, kind, st[victim])
+        if kind == 1:
+            assert st[victim] == 2
+        others = np.delete(st, victim)
+        assert not others.any()
+        assert first == (None if zl_ok else victim)
+        for i, x in enumerate(bl):                                    # every good block's bytes are right
+            if i != victim or zl_ok:
+                assert got[x.out_offset:x.out_offset + x.out_len] == recs[blocks[i].out_offset:blocks[i].out_offset + blocks[i].out_len], (trial, i)
+
+
+def test_noise_ends_every_wave(ia, ctx):
+    """Random bytes as deflate data: every block is refused (or, once in a long while, is a valid tiny stream), no wave spins, nothing
+    is written outside the blocks' output ranges."""
+    rng = np.random.default_rng(SEED + 9)
+    nb, clen, olen = 512, 3000, 8192
+    comp = rng.integers(0, 256, nb * clen, dtype=np.uint8).tobytes()
+    from ibu_amd._lib import CInflateBlock
+    blocks = (CInflateBlock * nb)()
+    for i in range(nb):
+        blocks[i].comp_offset, blocks[i].comp_len, blocks[i].out_offset, blocks[i].out_len, blocks[i].crc32 = i * clen, clen, i * olen, olen, 0
+    got, st, first, guards = _inflate_on_device(ia, ctx, comp, blocks, nb * olen)
+    assert guards and st.all() and first == 0
+
+
+def test_a_window_of_blocks_lands_around_a_slot(ia, ctx, oracle):
+    """out_offset is signed: the first block of a batch may begin in front of the bytes the batch keeps (it lands in the headroom),
+    the last may end behind them — what the stream does with a slot of whole refills."""
+    data = oracle.generate(SEED, 0, 20_000, 16, 12).tobytes()
+    comp = _bgzf(data, block=50_000, level=1)
+    blocks, _, out_bytes, _ = ia.bgzf_scan(comp)
+    shift = 12_345                                                    # the slot begins 12 345 bytes into the first block
+    for b in blocks:
+        b.out_offset -= shift
+    d_comp = ctx.alloc(len(comp) + PAD)
+    d_comp.upload(np.frombuffer(comp, np.uint8))
+    d_out = ctx.alloc(out_bytes + 65536)
+    st, first = ctx.inflate_blocks(d_comp, blocks, d_out.ptr + shift)
+    assert first is None and not st.any()
+    assert d_out.download(np.uint8)[:out_bytes].tobytes() == data
+    d_comp.free()
+    d_out.free()

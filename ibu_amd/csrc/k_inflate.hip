@@ -1,41 +1,58 @@
-// k_inflate.hip — DEFLATE blocks (RFC 1951) inflated ON THE DEVICE, one wave per block: the device half of BGZF ingest (the
-// reference reads gzip through niffler, src/io/reader.rs:345-352; a bgzip file is a chain of independent members of at most 64 KiB
-// whose sizes stand in their headers, so the COMPRESSED bytes can cross the PCIe link — half of them for a records file — and a
-// block each goes to a wave).  Launcher: launch_inflate_blocks (kernels.h); C ABI: ibu_inflate_blocks_device (device.cpp); the
-// host walk over the block headers: ibu_bgzf_scan (host_io.cpp).  The host decoder with the same acceptance rules: pgzip.cpp.
+// k_inflate.hip — DEFLATE blocks (RFC 1951) inflated ON THE DEVICE: the device half of BGZF ingest (the reference reads gzip through
+// niffler, src/io/reader.rs:345-352; a bgzip file is a chain of independent members of at most 64 KiB whose sizes stand in their
+// headers, so the COMPRESSED bytes can cross the PCIe link — half of them for a records file — and the blocks inflate side by side).
+// Launcher: launch_inflate_blocks (kernels.h); C ABI: ibu_inflate_blocks_device (device.cpp); the host walk over the block headers:
+// ibu_bgzf_scan (host_io.cpp).  The host decoder with the same acceptance rules: pgzip.cpp.
 //
-// A wave decodes its block SEQUENTIALLY — every lane runs the same symbol loop on the same (wave-uniform) state, so there is no
-// divergence and nothing to broadcast — and uses its lanes where the work is wide:
-//   - the compressed bytes are staged through a 1 KiB ring in LDS, 256 bytes per load instruction, the next chunk always
-//     requested one chunk ahead (its dword sits in a register until there is room), so a bit-buffer refill is three LDS reads;
-//   - the decode tables live in LDS: 2^10 literal/length and 2^8 distance entries that resolve a code of up to 10 / 8 bits,
-//     length or distance extra bits included, in one lookup; the rare longer codes are decoded canonically (counts per length and
-//     the symbols in code order: 15 steps at most).  The tables are BUILT by the wave in parallel: code ranks by __ballot /
-//     popcount per length, every lane fills the entries of its symbols;
-//   - the output goes through a 4 KiB ring in LDS: a match of up to 3584 bytes back copies inside it, 64 bytes per step (the
-//     source of a match that overlaps its destination is periodic, so every lane reads bytes that existed before the match); a
-//     match from further back reads the block's own output back from global memory (flushed long before: the flush runs 256
-//     bytes behind the write position at most).  Full 256-byte chunks leave the ring as one dword store per lane;
-//   - the CRC-32 of the output is checked by the same wave: every lane takes 1/64 of the block, the partial values are combined
-//     with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction.
+// ONE LANE PER BLOCK.  Inflating is sequential inside a block and a CU issues about one instruction per cycle whatever the
+// instruction does: a wave that decodes ONE block with wave-uniform state (the first form, round 5: tables of 2^10 entries and both
+// rings in LDS, 12 blocks in flight per CU, the symbol loop on the scalar unit) spends that issue rate on one symbol at a time —
+// 16.7 ms per 64 KiB block, 12 GB/s for the chip, the same on the vector and on the scalar unit.  Here every lane runs the decoder
+// on a block of its own, 64 blocks per wave, so an instruction advances up to 64 symbols.  What makes that fit:
+//   - no lookup tables: a code is decoded canonically, bit by bit, from the counts per code length — fifteen 10-bit counts packed in
+//     five registers per code, the decode loop unrolled so that it never reads memory — and the symbols in code order (one LDS read
+//     per symbol; literal/length symbols as a byte plus a ninth bit in a 288-bit flag word);
+//   - the compressed bytes come a dword at a time from global memory, always one dword ahead (the next one sits in a register when
+//     the bit buffer runs low, and its 64-byte line stays in L1 / L2 for the 15 reads that follow);
+//   - the output goes through a 256-byte ring per lane in LDS: literals and matches of up to 128 bytes back never touch global
+//     memory, full 64-byte pieces leave the ring as 16 dword stores; a match from further back reads the lane's own earlier
+//     output from global memory (a wave's vector memory operations execute in order: the byte a lane stored is the byte it loads).
+//     The code lengths of a dynamic header are parsed in the same LDS (the ring's pending bytes go out first and come back after);
+//   - everything a lane keeps in LDS is laid out lane-interleaved (element k of lane L at k * 64 + L: lanes that read the same
+//     element hit different banks): 704 bytes per lane, 45 KB per wave, three waves (192 blocks) per CU;
+//   - divergence (one lane in a literal, the next in a match, a third building its tables) costs instructions, not correctness: no
+//     lane waits for another inside the decoder.
+// (Second form, same round: symbols and counts in LDS, bytes straight to global memory, no prefetch — 0.23 s for 1e8 records, every
+// wave step waiting for some lane's global load or store.)
+// When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
+// block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
 // the block's last compressed byte, the output has the announced length, the CRC matches; any invalid code, distance or size
 // makes the block bad (status 1), a wrong CRC status 2.  Every loop consumes input or produces output and both are bounded by
-// the descriptor, so a wave leaves any input — random bytes included — after at most 8 x comp_len + a few iterations.
+// the descriptor, so a lane leaves any input — random bytes included — after at most 8 x comp_len + a few iterations.
 #include "kcommon.hpp"
 #include "kernels.h"
 
 namespace ibu {
 namespace {
 
-constexpr int kInfThreads = 256, kInfWaves = kInfThreads / kWave;
-constexpr u32 kInRing = 1024, kOutRing = 4096, kNear = 3584;
-constexpr u32 kLitRoot = 10, kDistRoot = 8;
-constexpr u32 K_LIT = 0, K_BASE = 1, K_EOB = 2, K_LONG = 3, K_BAD = 4;
+constexpr int kInfThreads = kWave;                           // one wave per workgroup: its LDS is the 64 lanes' tables
+constexpr u32 kDistSyms = 32;
 
-// Decode-table entry (the host decoder's layout): bits 0-7 the stream bits this step consumes (code + extra bits), bits 8-11 the
-// code length alone (where the extra bits start), bits 12-14 the kind, bits 16-31 the payload (literal, base length / distance).
-__device__ __forceinline__ u32 mk(u32 payload, u32 f, u32 kind, u32 nbits) { return (payload << 16) | (kind << 12) | (f << 8) | nbits; }
+// per-wave LDS, lane-interleaved
+struct InfLds {
+  uint8_t sym_lo[320 * kWave];           // literal/length symbols in code order, low 8 bits: [k * 64 + lane]; k in [288, 320): construct()'s
+                                         // position per length (u16[16])
+  u32 sym_hi[9 * kWave];                 // bit k of the lane's 288 bits: symbol k of the order is >= 256
+  uint8_t sym_dist[kDistSyms * kWave];   // distance symbols (and the code-length code's) in code order
+  u32 ring[80 * kWave];                  // dword d of lane L at [d * 64 + L]: bytes [0, 256) the output ring; bytes [0, 320) the code lengths of a
+                                         // header while it is read
+  uint16_t base[29 + 30];                // length / distance bases, then their extra bits (shared by the lanes)
+  uint8_t extra[29 + 30];
+  uint8_t clorder[19];
+  u32 crc_tab[256];
+};
+constexpr u32 kRing = 256, kNear = 128, kPiece = 64;
 
 __device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -43,124 +60,7 @@ __device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 
 __device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-__device__ __forceinline__ u32 lit_entry(u32 sym, u32 nb) {
-  if (sym < 256) return mk(sym, 0, K_LIT, nb);
-  if (sym == 256) return mk(0, 0, K_EOB, nb);
-  if (sym < 286) return mk(kLenBase[sym - 257], nb, K_BASE, nb + kLenExtra[sym - 257]);
-  return mk(0, 0, K_BAD, nb);
-}
-__device__ __forceinline__ u32 dist_entry(u32 sym, u32 nb) {
-  if (sym < 30) return mk(kDistBase[sym], nb, K_BASE, nb + kDistExtra[sym]);
-  return mk(0, 0, K_BAD, nb);
-}
-
-// Everything the symbol loop computes is the same in all 64 lanes.  Said to the compiler (readfirstlane at every LDS read whose
-// address is uniform), the bit buffer, the table entries and the positions live in SGPRs and the loop runs on the scalar unit; left
-// unsaid, every one of its ~90 instructions per symbol is a vector instruction over 64 identical lanes (first version: 16.7 ms per
-// 64 KiB block, 12 GB/s for the chip).
-__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
-
-struct InfWave {                         // one wave's slice of LDS: 11 584 bytes
-  u32 lit[1u << kLitRoot];
-  u32 dist[1u << kDistRoot];
-  u32 in[kInRing / 4];
-  u32 out[kOutRing / 4];
-  uint16_t perm_lit[288];                // symbols in code order (by length, then value): the canonical decode of long codes
-  uint16_t perm_dist[32];
-  uint16_t cnt_lit[16], cnt_dist[16];    // codes per length
-  uint16_t cl[128];                      // the code-length code: symbol << 8 | length
-  uint8_t lens[352];                     // [0, 316): code lengths of a dynamic header; [320, 339): those of the code-length code
-};
-
-// The canonical decode tables of one code, built by the wave: lens[0, n) in LDS (n <= 320), root P.  false: a code set zlib rejects.
-__device__ __forceinline__ bool build_tables(const uint8_t* lens, u32 n, u32 P, bool is_dist, u32* tab, uint16_t* cnts, uint16_t* perm, u32 lane) {
-  const u64 lt = (1ull << lane) - 1;
-  u32 run[16];                                              // codes of each length seen so far (wave-uniform)
-#pragma unroll
-  for (int l = 0; l < 16; ++l) run[l] = 0;
-  u32 my_len[5], my_rank[5];
-#pragma unroll
-  for (int c = 0; c < 5; ++c) {
-    const u32 s = 64 * c + lane;
-    const u32 li = s < n ? lens[s] : 0;
-    u32 rk = 0;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) {
-      const u64 m = __ballot(li == (u32)l);
-      if (li == (u32)l) rk = run[l] + (u32)__popcll(m & lt);
-      run[l] += (u32)__popcll(m);
-    }
-    my_len[c] = li;
-    my_rank[c] = rk;
-  }
-  u32 maxlen = 0;
-#pragma unroll
-  for (int l = 1; l < 16; ++l)
-    if (run[l]) maxlen = l;
-  const u32 root = 1u << P;
-  for (u32 i = lane; i < root; i += kWave) tab[i] = mk(0, 0, K_BAD, 1);
-  if (lane < 16) cnts[lane] = 0;
-  if (maxlen == 0) { wave_lds_fence(); return is_dist; }    // no codes at all: literals only (allowed for distances)
-  int left = 1;
-#pragma unroll
-  for (int l = 1; l < 16; ++l) {
-    left = 2 * left - (int)run[l];
-    if (left < 0) return false;                             // over-subscribed
-  }
-  if (left > 0 && maxlen != 1) return false;                // incomplete (allowed: a single 1-bit code)
-  u32 next[16], offs[16];                                   // first code / first position in `perm` of each length
-  {
-    u32 code = 0, o = 0;
-    next[0] = offs[0] = 0;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) {
-      code = (code + (l > 1 ? run[l - 1] : 0u)) << 1;
-      next[l] = code;
-      offs[l] = o;
-      o += run[l];
-    }
-  }
-  wave_lds_fence();                                         // the BAD fill above is in place before the entries
-#pragma unroll
-  for (int l = 1; l < 16; ++l)
-    if (lane == 0) cnts[l] = (uint16_t)run[l];
-#pragma unroll
-  for (int c = 0; c < 5; ++c) {
-    const u32 s = 64 * c + lane, l = my_len[c];
-    if (l == 0) continue;
-    u32 nx = 0, of = 0;
-#pragma unroll
-    for (int k = 1; k < 16; ++k)
-      if (l == (u32)k) { nx = next[k]; of = offs[k]; }
-    perm[of + my_rank[c]] = (uint16_t)s;
-    const u32 code = nx + my_rank[c];
-    const u32 r = __brev(code) >> (32 - l);                 // LSB-first streams: the code as the bit buffer shows it
-    if (l <= P) {
-      const u32 e = is_dist ? dist_entry(s, l) : lit_entry(s, l);
-      for (u32 i = r; i < root; i += 1u << l) tab[i] = e;
-    } else {
-      tab[r & (root - 1)] = mk(0, 0, K_LONG, 0);
-    }
-  }
-  wave_lds_fence();
-  return true;
-}
-
-// A code longer than the root table resolves: the canonical decode, one bit at a time.  0xFFFF: no such code.
-__device__ __forceinline__ u32 slow_symbol(const uint16_t* cnts, const uint16_t* perm, u64 buf, u32* nbits) {
-  u32 code = 0, first = 0, index = 0;
-  for (u32 len = 1; len <= 15; ++len) {
-    code |= (u32)(buf >> (len - 1)) & 1u;
-    const u32 c = uni(cnts[len]);
-    if (code < first + c) { *nbits = len; return uni(perm[index + (code - first)]); }
-    index += c;
-    first = (first + c) << 1;
-    code <<= 1;
-  }
-  return 0xFFFFu;
-}
-
-struct Crc32Pow { u32 x2n[32]; };                            // x^(2^k) mod P, reflected (host_io.cpp fills it)
+struct Crc32Pow { u32 x2n[32]; };                            // x^(2^k) mod P, reflected (the launcher fills it)
 
 __device__ __forceinline__ u32 multmodp(u32 a, u32 b) {      // a(x) b(x) mod P(x), reflected CRC-32
   u32 m = 1u << 31, p = 0;
@@ -184,152 +84,180 @@ __device__ __forceinline__ u32 x8nmodp(const Crc32Pow& pw, u32 n) {   // x^(8 n)
   return p;
 }
 
-struct Inflate {                                             // the decoder of one block: every field wave-uniform except `pre`
-  InfWave* w;
+// One lane's decoder.
+struct LaneInflate {
+  InfLds* w;
+  u32 lane;
   const uint8_t* comp;                                       // the block's compressed bytes (readable 2 KiB past clen)
-  uint8_t* out;                                              // where its output goes
-  u32 lane, clen, isize;
-  u64 buf;
-  u32 cnt, ipos, in_loaded, pre;
-  u32 opos, flushed;
+  uint8_t* out;
+  u32 clen, isize;
+  u64 buf;                                                   // cnt valid low bits
+  u32 cnt, ipos, nxt;                                        // nxt: the dword at comp + ipos, already loaded
+  u32 opos, flushed, rbase;                                  // ring: bytes [max(rbase, opos - 256 + pending), opos) are in it; [flushed, opos) not yet in global memory
+  u32 cl[5], cd[5];                                          // codes per length 1 .. 15, 10 bits each, three to a word: literal/length and distance code
 
-  __device__ __forceinline__ u32 gload(u32 off) const {
+  // ---- LDS columns ----
+  __device__ __forceinline__ uint8_t* ring8(u32 b) const { return reinterpret_cast<uint8_t*>(w->ring) + (((b >> 2) * kWave + lane) << 2) + (b & 3); }
+  __device__ __forceinline__ uint8_t& lens(u32 s) const { return *ring8(s); }
+  __device__ __forceinline__ uint16_t& offs(u32 l) const { return *reinterpret_cast<uint16_t*>(w->sym_lo + (288 + 2 * l) * kWave + 2 * (lane & 31) + (lane >> 5) * kWave); }
+  __device__ __forceinline__ u32 lit_symbol(u32 k) const {
+    return (u32)w->sym_lo[k * kWave + lane] | (((w->sym_hi[(k >> 5) * kWave + lane] >> (k & 31)) & 1u) << 8);
+  }
+
+  // ---- input ----
+  __device__ __forceinline__ u32 load32(u32 at) const {
     u32 v;
-    __builtin_memcpy(&v, comp + off + 4 * lane, 4);
+    __builtin_memcpy(&v, comp + at, 4);
     return v;
   }
-  __device__ __forceinline__ void in_fill() {                // at least 512 staged bytes in front of ipos; the next chunk requested
-    if (in_loaded >= ipos + 512) return;
-    do {
-      w->in[((in_loaded & (kInRing - 1)) >> 2) + lane] = pre;
-      in_loaded += 256;
-      pre = gload(in_loaded);
-    } while (in_loaded < ipos + 512);
-    wave_lds_fence();
+  __device__ __forceinline__ void in_start(u32 p) { buf = 0; cnt = 0; ipos = p; nxt = load32(p); }
+  __device__ __forceinline__ void need(u32 n) {              // n <= 32
+    if (cnt < n) {
+      buf |= (u64)nxt << cnt;
+      cnt += 32;
+      ipos += 4;
+      nxt = load32(ipos);                                    // wanted ~4 symbols from now
+    }
   }
-  __device__ __forceinline__ void in_start(u32 p) {          // (re)start reading at byte p of the compressed block
-    in_loaded = p & ~255u;
-    pre = gload(in_loaded);
-    buf = 0;
-    cnt = 0;
-    ipos = p;
+  __device__ __forceinline__ u32 bits(u32 n) {
+    need(n);
+    const u32 v = (u32)(buf & ((1ull << n) - 1));
+    buf >>= n;
+    cnt -= n;
+    return v;
   }
-  __device__ __forceinline__ u64 in_read64(u32 p) const {
-    const u32 i = (p & (kInRing - 1)) >> 2, sh = 8 * (p & 3);
-    const u32 a = uni(w->in[i]), b = uni(w->in[(i + 1) & (kInRing / 4 - 1)]), c = uni(w->in[(i + 2) & (kInRing / 4 - 1)]);
-    const u64 lo = ((u64)b << 32) | a;
-    return sh ? (lo >> sh) | ((u64)c << (64 - sh)) : lo;
-  }
-  // buf holds cnt valid low bits; what lies above them is zero or the true upcoming bits (a refill ORs the same bits again)
-  __device__ __forceinline__ void refill() {
-    in_fill();
-    buf |= in_read64(ipos) << cnt;
-    ipos += (63 - cnt) >> 3;
-    cnt |= 56;
-  }
-  __device__ __forceinline__ void drop(u32 k) { buf >>= k; cnt -= k; }
-  __device__ __forceinline__ u32 take(u32 k) { const u32 v = (u32)(buf & ((1ull << k) - 1)); drop(k); return v; }
   __device__ __forceinline__ u32 bitpos() const { return ipos * 8 - cnt; }
 
-  __device__ __forceinline__ void flush_full() {             // whole 256-byte chunks of the ring -> global, a dword per lane
-    if (opos - flushed < 256) return;
-    wave_lds_fence();
-    do {
-      const u32 v = w->out[((flushed & (kOutRing - 1)) >> 2) + lane];
-      __builtin_memcpy(out + flushed + 4 * lane, &v, 4);
-      flushed += 256;
-    } while (opos - flushed >= 256);
-  }
-  __device__ __forceinline__ void flush_rest() {
-    wave_lds_fence();
-    const uint8_t* ring = reinterpret_cast<const uint8_t*>(w->out);
-    for (u32 p = flushed + lane; p < opos; p += kWave) out[p] = ring[p & (kOutRing - 1)];
-    flushed = opos;
-  }
-  // `len` bytes from `dist` back.  The source of an overlapping match is periodic with period dist: every lane reads a byte that
-  // existed before the match began.
-  __device__ __forceinline__ bool copy_match(u32 len, u32 dist) {
-    if (dist > opos || opos + len > isize) return false;
-    uint8_t* ring = reinterpret_cast<uint8_t*>(w->out);
-    const bool plain = dist >= len;
-    if (dist <= kNear) {
-      wave_lds_fence();
-      for (u32 done = 0; done < len; done += kWave) {
-        const u32 i = done + lane;
-        if (i < len) {
-          const u32 off = plain ? i : i % dist;
-          ring[(opos + i) & (kOutRing - 1)] = ring[(opos - dist + off) & (kOutRing - 1)];
-        }
+  // the position in code order of the next code, from the packed counts: 15 unrolled steps, no memory.  -1: no such code.
+  __device__ __forceinline__ int decode_index(const u32 (&c5)[5]) {
+    need(15);
+    u32 code = 0, first = 0, index = 0, b = (u32)buf;
+#pragma unroll
+    for (int len = 1; len <= 15; ++len) {
+      code |= b & 1u;
+      b >>= 1;
+      const u32 c = (c5[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u;
+      if (code < first + c) {
+        buf >>= len;
+        cnt -= len;
+        return (int)(index + (code - first));
       }
-    } else {                                                 // from the block's own output in global memory: flushed long ago
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... and the flush stores have landed
-      for (u32 done = 0; done < len; done += kWave) {
-        const u32 i = done + lane;
-        if (i < len) {
-          const u32 off = plain ? i : i % dist;
-          ring[(opos + i) & (kOutRing - 1)] = __builtin_nontemporal_load(out + (opos - dist + off));
-        }
+      index += c;
+      first = (first + c) << 1;
+      code <<= 1;
+    }
+    return -1;
+  }
+
+  // Counts (packed into c5) and symbol order of the code with lengths lens[at, at + n).  How complete it is: 0 complete, > 0 codes left
+  // over, < 0 over-subscribed; *maxlen = the longest code.  store(k, s): symbol s is the k-th in code order.
+  template <class Store>
+  __device__ __forceinline__ int construct(u32 (&c5)[5], u32 at, u32 n, u32* maxlen, Store store) {
+    for (u32 l = 0; l < 16; ++l) offs(l) = 0;
+    for (u32 s = 0; s < n; ++s) offs(lens(at + s))++;
+    int left = 1;
+    u32 ml = 0, o = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c5[k] = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+      const u32 c = offs(l);
+      c5[(l - 1) / 3] |= c << (10 * ((l - 1) % 3));
+      if (c) ml = l;
+      if (left >= 0) left = 2 * left - (int)c;              // (stays negative once over-subscribed)
+      offs(l) = (uint16_t)o;
+      o += c;
+    }
+    *maxlen = ml;
+    if (left < 0) return left;
+    for (u32 s = 0; s < n; ++s) {
+      const u32 l = lens(at + s);
+      if (l) {
+        const u32 k = offs(l);
+        offs(l) = (uint16_t)(k + 1);
+        store(k, s);
       }
     }
-    opos += len;
-    flush_full();
+    return left;
+  }
+  // the host decoder's acceptance of a code set (pgzip.cpp, build_table)
+  __device__ __forceinline__ bool accept(int left, u32 maxlen, bool is_dist) const {
+    if (maxlen == 0) return is_dist;                         // no codes at all: literals only (allowed for distances)
+    if (left < 0) return false;                              // over-subscribed
+    return left == 0 || maxlen == 1;                         // incomplete: only a single 1-bit code
+  }
+  __device__ __forceinline__ bool build_lit(u32 at, u32 n) {
+    for (u32 k = 0; k < 9; ++k) w->sym_hi[k * kWave + lane] = 0;
+    u32 ml = 0;
+    const int left = construct(cl, at, n, &ml, [&](u32 k, u32 s) {
+      w->sym_lo[k * kWave + lane] = (uint8_t)s;
+      if (s >= 256) w->sym_hi[(k >> 5) * kWave + lane] |= 1u << (k & 31);
+    });
+    return accept(left, ml, false);
+  }
+  __device__ __forceinline__ bool build_dist(u32 at, u32 n) {
+    u32 ml = 0;
+    const int left = construct(cd, at, n, &ml, [&](u32 k, u32 s) { w->sym_dist[k * kWave + lane] = (uint8_t)s; });
+    return accept(left, ml, true);
+  }
+
+  // ---- output ----
+  __device__ __forceinline__ void flush_pieces() {           // whole 64-byte pieces of the ring -> global memory
+    while (opos - flushed >= kPiece) {
+      const u32 d0 = (flushed & (kRing - 1)) >> 2;           // (flushed is a multiple of 64)
+#pragma unroll
+      for (u32 d = 0; d < kPiece / 4; ++d) {
+        const u32 v = w->ring[(d0 + d) * kWave + lane];
+        __builtin_memcpy(out + flushed + 4 * d, &v, 4);
+      }
+      flushed += kPiece;
+    }
+  }
+  __device__ __forceinline__ void put_pending() {            // the bytes behind the last whole piece -> global memory (they stay pending)
+    for (u32 p = flushed; p < opos; ++p) out[p] = *ring8(p & (kRing - 1));
+  }
+  __device__ __forceinline__ void get_pending() {            // ... and back into the ring (the header's code lengths were parsed over them)
+    for (u32 p = flushed; p < opos; ++p) *ring8(p & (kRing - 1)) = out[p];
+    rbase = opos;                                            // nothing older is in the ring any more
+  }
+  __device__ __forceinline__ bool copy_match(u32 len, u32 dist) {
+    if (dist > opos || opos + len > isize) return false;
+    const bool near = dist <= kNear && dist <= opos - rbase;
+    while (len) {                                            // at most 64 bytes, then the whole pieces leave: 127 pending + 128 back fit the ring
+      const u32 n = len < kPiece ? len : kPiece;
+      if (near) {
+        for (u32 i = 0; i < n; ++i) *ring8((opos + i) & (kRing - 1)) = *ring8((opos + i - dist) & (kRing - 1));
+      } else {                                               // further back than the ring reaches: flushed long ago (pending < 128 <= dist ... or rbase)
+        for (u32 i = 0; i < n; ++i) {
+          const u32 src = opos + i - dist;
+          *ring8((opos + i) & (kRing - 1)) = src < flushed ? out[src] : *ring8(src & (kRing - 1));
+        }
+      }
+      opos += n;
+      len -= n;
+      flush_pieces();
+    }
     return true;
   }
 
-  // the code lengths of a dynamic block -> tables.  Behind the 3 block bits.
   __device__ __forceinline__ bool parse_dynamic() {
-    refill();
-    const u32 hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
+    const u32 hlit = bits(5) + 257, hdist = bits(5) + 1, hclen = bits(4) + 4;
     if (hlit > 286 || hdist > 30) return false;
-    uint8_t* cll = w->lens + 320;
-    if (lane < 19) cll[lane] = 0;
-    wave_lds_fence();
-    refill();
-    for (u32 i = 0; i < hclen; ++i) {
-      if (cnt < 3) refill();
-      const u32 v = take(3);
-      if (lane == 0) cll[kClOrder[i]] = (uint8_t)v;
-    }
-    wave_lds_fence();
-    {                                                        // the code-length code: 19 symbols of at most 7 bits, built serially
-      u32 count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const u32 mine = lane < 19 ? cll[lane] : 0;
-#pragma unroll
-      for (int l = 1; l < 8; ++l) count[l] = (u32)__popcll(__ballot(mine == (u32)l));
-      int left = 1;
-#pragma unroll
-      for (int l = 1; l < 8; ++l) {
-        left = 2 * left - (int)count[l];
-        if (left < 0) return false;
-      }
-      if (left > 0) return false;                            // zlib: an incomplete code-length code is always an error
-      u32 next[8], code = 0;
-      next[0] = 0;
-#pragma unroll
-      for (int l = 1; l < 8; ++l) { code = (code + (l > 1 ? count[l - 1] : 0u)) << 1; next[l] = code; }
-      // rank among the symbols of the same length, in symbol order
-      const u64 lt = (1ull << lane) - 1;
-      u32 rk = 0, nx = 0;
-#pragma unroll
-      for (int l = 1; l < 8; ++l) {
-        const u64 m = __ballot(mine == (u32)l);
-        if (mine == (u32)l) { rk = (u32)__popcll(m & lt); nx = next[l]; }
-      }
-      if (mine) {
-        const u32 r = __brev(nx + rk) >> (32 - mine);
-        for (u32 i = r; i < 128; i += 1u << mine) w->cl[i] = (uint16_t)((lane << 8) | mine);
-      }
-      wave_lds_fence();
+    put_pending();                                           // the code lengths are parsed in the ring's LDS
+    for (u32 i = 0; i < 19; ++i) lens(i) = 0;
+    for (u32 i = 0; i < hclen; ++i) lens(w->clorder[i]) = (uint8_t)bits(3);
+    {                                                        // the code-length code (in the distance code's place): an incomplete one is always an error
+      u32 ml = 0;
+      if (construct(cd, 0, 19, &ml, [&](u32 k, u32 s) { w->sym_dist[k * kWave + lane] = (uint8_t)s; }) != 0) return false;
     }
     const u32 total = hlit + hdist;
     u32 i = 0, prev = 0;
     while (i < total) {
-      refill();
-      const u32 e = uni(w->cl[buf & 127]);
-      drop(e & 0xFF);
-      const u32 sym = e >> 8;
+      const int k = decode_index(cd);
+      if (k < 0) return false;
+      const u32 sym = w->sym_dist[(u32)k * kWave + lane];
       if (sym < 16) {
-        if (lane == 0) w->lens[i] = (uint8_t)sym;
+        lens(i) = (uint8_t)sym;
         prev = sym;
         ++i;
         continue;
@@ -338,103 +266,77 @@ struct Inflate {                                             // the decoder of o
       if (sym == 16) {
         if (i == 0) return false;
         val = prev;
-        rep = 3 + take(2);
-      } else if (sym == 17) rep = 3 + take(3);
-      else rep = 11 + take(7);
+        rep = 3 + bits(2);
+      } else if (sym == 17) rep = 3 + bits(3);
+      else rep = 11 + bits(7);
       if (i + rep > total) return false;
-      if (lane < rep) w->lens[i + lane] = (uint8_t)val;
-      if (lane + 64 < rep) w->lens[i + lane + 64] = (uint8_t)val;
-      if (lane + 128 < rep) w->lens[i + lane + 128] = (uint8_t)val;
+      for (u32 k2 = 0; k2 < rep; ++k2) lens(i + k2) = (uint8_t)val;
       prev = val;
       i += rep;
     }
-    wave_lds_fence();
-    if (uni(w->lens[256]) == 0) return false;                // no end-of-block code
-    if (!build_tables(w->lens, hlit, kLitRoot, false, w->lit, w->cnt_lit, w->perm_lit, lane)) return false;
-    if (!build_tables(w->lens + hlit, hdist, kDistRoot, true, w->dist, w->cnt_dist, w->perm_dist, lane)) return false;
-    return true;
+    if (lens(256) == 0) return false;                        // no end-of-block code
+    const bool ok = build_lit(0, hlit) && build_dist(hlit, hdist);
+    get_pending();
+    return ok;
   }
   __device__ __forceinline__ bool fixed_tables() {
-    for (u32 s = lane; s < 288; s += kWave) w->lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
-    if (lane < 32) w->lens[288 + lane] = 5;
-    wave_lds_fence();
-    if (!build_tables(w->lens, 288, kLitRoot, false, w->lit, w->cnt_lit, w->perm_lit, lane)) return false;
-    return build_tables(w->lens + 288, 32, kDistRoot, true, w->dist, w->cnt_dist, w->perm_dist, lane);
+    put_pending();
+    for (u32 s = 0; s < 288; ++s) lens(s) = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
+    for (u32 s = 0; s < 32; ++s) lens(288 + s) = 5;
+    const bool ok = build_lit(0, 288) && build_dist(288, 32);
+    get_pending();
+    return ok;
   }
-
   // a stored block behind its 3 header bits: to the byte boundary, LEN / NLEN, LEN bytes as they are
   __device__ __forceinline__ bool stored() {
-    drop(cnt & 7);
-    if (cnt < 32) refill();
-    const u32 len = take(16), nlen = take(16);
+    const u32 skip = cnt & 7;                                // (ipos * 8 is a byte boundary: the bits in the buffer say where we are)
+    buf >>= skip;
+    cnt -= skip;
+    const u32 len = bits(16), nlen = bits(16);
     if ((len ^ nlen) != 0xFFFFu) return false;
-    const u32 p = bitpos() >> 3;                             // (a byte boundary)
+    const u32 p = bitpos() >> 3;
     if (p + len > clen || opos + len > isize) return false;
-    uint8_t* ring = reinterpret_cast<uint8_t*>(w->out);
-    const u32 base = opos;
-    for (u32 done = 0; done < len; done += kWave) {
-      const u32 i = done + lane;
-      if (i < len) ring[(base + i) & (kOutRing - 1)] = comp[p + i];
-      opos = base + (len - done < kWave ? len : done + kWave);
-      flush_full();
+    for (u32 i = 0; i < len; ++i) {
+      *ring8(opos & (kRing - 1)) = comp[p + i];
+      ++opos;
+      if (opos - flushed >= kPiece) flush_pieces();
     }
     in_start(p + len);
     return true;
   }
-
-  // the symbols of a Huffman block up to its end-of-block code
   __device__ __forceinline__ bool symbols() {
     const u32 lim = clen * 8;
     for (;;) {
-      if (cnt < 48) refill();
       if (bitpos() > lim) return false;                      // ran past the block's last byte
-      u32 e = uni(w->lit[buf & ((1u << kLitRoot) - 1)]);
-      u32 kind = (e >> 12) & 7u;
-      if (kind == K_LONG) {
-        u32 nb = 0;
-        const u32 sym = slow_symbol(w->cnt_lit, w->perm_lit, buf, &nb);
-        if (sym == 0xFFFFu) return false;
-        e = lit_entry(sym, nb);
-        kind = (e >> 12) & 7u;
-      }
-      if (kind == K_LIT) {
+      const int k = decode_index(cl);
+      if (k < 0) return false;
+      const u32 sym = lit_symbol((u32)k);
+      if (sym < 256) {
         if (opos >= isize) return false;
-        drop(e & 0xFFu);
-        if (lane == 0) reinterpret_cast<uint8_t*>(w->out)[opos & (kOutRing - 1)] = (uint8_t)(e >> 16);
+        *ring8(opos & (kRing - 1)) = (uint8_t)sym;
         ++opos;
-        flush_full();
+        if (opos - flushed >= kPiece) flush_pieces();
         continue;
       }
-      if (kind == K_EOB) { drop(e & 0xFFu); return true; }
-      if (kind != K_BASE) return false;
-      const u32 lf = (e >> 8) & 15u, lb = e & 0xFFu;
-      const u32 len = (e >> 16) + ((u32)(buf >> lf) & ((1u << (lb - lf)) - 1));
-      drop(lb);
-      u32 d = uni(w->dist[buf & ((1u << kDistRoot) - 1)]);
-      u32 dk = (d >> 12) & 7u;
-      if (dk == K_LONG) {
-        u32 nb = 0;
-        const u32 sym = slow_symbol(w->cnt_dist, w->perm_dist, buf, &nb);
-        if (sym == 0xFFFFu) return false;
-        d = dist_entry(sym, nb);
-        dk = (d >> 12) & 7u;
-      }
-      if (dk != K_BASE) return false;
-      const u32 df = (d >> 8) & 15u, db = d & 0xFFu;
-      const u32 dist = (d >> 16) + ((u32)(buf >> df) & ((1u << (db - df)) - 1));
-      drop(db);
+      if (sym == 256) return true;
+      const u32 ls = sym - 257;
+      if (ls >= 29) return false;
+      const u32 len = w->base[ls] + bits(w->extra[ls]);
+      const int kd = decode_index(cd);
+      if (kd < 0) return false;
+      const u32 ds = w->sym_dist[(u32)kd * kWave + lane];
+      if (ds >= 30) return false;
+      const u32 dist = w->base[29 + ds] + bits(w->extra[29 + ds]);
       if (!copy_match(len, dist)) return false;
     }
   }
-
   // 0: the block is what its descriptor says; 1: it is not
   __device__ __forceinline__ u32 run() {
     in_start(0);
-    opos = flushed = 0;
+    opos = flushed = rbase = 0;
     for (;;) {
-      refill();
       if (bitpos() + 3 > clen * 8) return 1;
-      const u32 last = take(1), type = take(2);
+      const u32 last = bits(1), type = bits(2);
       bool ok;
       if (type == 0) ok = stored();
       else if (type == 1) ok = fixed_tables() && symbols();
@@ -444,7 +346,7 @@ struct Inflate {                                             // the decoder of o
       if (last) break;
     }
     if (opos != isize || ((bitpos() + 7) >> 3) != clen) return 1;
-    flush_rest();
+    put_pending();
     return 0;
   }
 };
@@ -454,42 +356,62 @@ struct Inflate {                                             // the decoder of o
 __global__ void __launch_bounds__(kInfThreads)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
                      u32* __restrict__ status, u32* __restrict__ first_bad, Crc32Pow pw) {
-  __shared__ InfWave lds[kInfWaves];
-  __shared__ u32 crc_tab[256];
-  {
-    u32 c = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  InfLds* w = reinterpret_cast<InfLds*>(lds_raw);
+  const u32 lane = threadIdx.x;
+  for (u32 i = lane; i < 29 + 30; i += kWave) {
+    w->base[i] = i < 29 ? kLenBase[i] : kDistBase[i - 29];
+    w->extra[i] = i < 29 ? kLenExtra[i] : kDistExtra[i - 29];
+  }
+  if (lane < 19) w->clorder[lane] = kClOrder[lane];
+  for (u32 i = lane; i < 256; i += kWave) {
+    u32 c = i;
 #pragma unroll
     for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
-    crc_tab[threadIdx.x] = c;
+    w->crc_tab[i] = c;
   }
   __syncthreads();
-  const u32 lane = threadIdx.x & (kWave - 1), wib = uni(threadIdx.x >> 6);
-  const u32 nwaves = gridDim.x * kInfWaves;
-  for (u32 b = blockIdx.x * kInfWaves + wib; b < nblocks; b += nwaves) {
-    const InflateBlockDesc bd = blocks[b];
-    Inflate s;
-    s.w = &lds[wib];
-    s.comp = comp + bd.coff;
-    s.out = out_base + bd.ooff;
-    s.lane = lane;
-    s.clen = bd.clen;
-    s.isize = bd.isize;
-    u32 st = bd.isize > 65536u ? 1u : s.run();
-    if (st == 0 && bd.isize) {                               // CRC-32 of what was written
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const u32 chunk = (bd.isize + kWave - 1) / kWave;
-      const u32 a = lane * chunk < bd.isize ? lane * chunk : bd.isize, e = a + chunk < bd.isize ? a + chunk : bd.isize;
-      u32 crc = 0xFFFFFFFFu;
-      for (u32 p = a; p < e; ++p) crc = crc_tab[(crc ^ __builtin_nontemporal_load(s.out + p)) & 255u] ^ (crc >> 8);
-      crc ^= 0xFFFFFFFFu;
-      u32 v = e > a ? multmodp(x8nmodp(pw, bd.isize - e), crc) : 0u;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) v ^= __shfl_xor(v, m);
-      if (v != bd.crc) st = 2;
-    } else if (st == 0 && bd.crc != 0) {
-      st = 2;
+  const u32 ngroups = (nblocks + kWave - 1) / kWave;
+  for (u32 g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const u32 b = g * kWave + lane;
+    const bool live = b < nblocks;
+    InflateBlockDesc bd;
+    bd.coff = 0; bd.ooff = 0; bd.clen = 0; bd.isize = 0; bd.crc = 0; bd.reserved = 0;
+    if (live) bd = blocks[b];
+    u32 st = 0;
+    if (live) {
+      LaneInflate s;
+      s.w = w;
+      s.lane = lane;
+      s.comp = comp + bd.coff;
+      s.out = out_base + bd.ooff;
+      s.clen = bd.clen;
+      s.isize = bd.isize;
+      st = bd.isize > 65536u ? 1u : s.run();
     }
-    if (lane == 0) {
+    // the CRC-32 of what each lane wrote, block by block, all lanes on one block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 todo = __ballot(live && st == 0);
+    for (u32 j = 0; j < kWave; ++j) {
+      if (!((todo >> j) & 1ull)) continue;                   // wave-uniform
+      const u32 isz = (u32)__shfl((int)bd.isize, (int)j);
+      const u32 want = (u32)__shfl((int)bd.crc, (int)j);
+      const u32 lo = (u32)__shfl((int)(u32)bd.ooff, (int)j), hi = (u32)__shfl((int)(u32)((u64)bd.ooff >> 32), (int)j);
+      const uint8_t* o = out_base + (int64_t)(((u64)hi << 32) | lo);
+      u32 v = 0;
+      if (isz) {
+        const u32 chunk = (isz + kWave - 1) / kWave;
+        const u32 a = lane * chunk < isz ? lane * chunk : isz, e = a + chunk < isz ? a + chunk : isz;
+        u32 crc = 0xFFFFFFFFu;
+        for (u32 p = a; p < e; ++p) crc = w->crc_tab[(crc ^ __builtin_nontemporal_load(o + p)) & 255u] ^ (crc >> 8);
+        crc ^= 0xFFFFFFFFu;
+        v = e > a ? multmodp(x8nmodp(pw, isz - e), crc) : 0u;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v ^= (u32)__shfl_xor((int)v, m);
+      }
+      if (lane == j && v != want) st = 2;
+    }
+    if (live) {
       status[b] = st;
       if (st) atomicMin(first_bad, b);
     }
@@ -517,9 +439,12 @@ hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const
     for (int n = 1; n < 32; ++n) t.x2n[n] = p = mul(p, p);
     return t;
   }();
-  const u32 want = (u32)((nblocks + kInfWaves - 1) / kInfWaves);
-  const u32 cap = (u32)cfg.cus * 3;                          // 47 KB of LDS per workgroup: three fit a CU
-  hipLaunchKernelGGL(ibu_k_inflate_blocks, dim3(want < cap ? want : cap), dim3(kInfThreads), 0, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
+  const size_t lds = sizeof(InfLds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_inflate_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const u32 want = (u32)((nblocks + kWave - 1) / kWave);
+  const u32 cap = (u32)cfg.cus * 3;                          // 45 KB of LDS per wave: three fit a CU
+  hipLaunchKernelGGL(ibu_k_inflate_blocks, dim3(want < cap ? want : cap), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
                      (uint8_t*)d_out_base, d_status, d_first_bad, pw);
   return hipGetLastError();
 }

@@ -729,17 +729,36 @@ class DeviceStream:
         self.close()
 
 
+INFLATE_BLOCK_DTYPE = np.dtype([("comp_offset", "<u8"), ("out_offset", "<i8"), ("comp_len", "<u4"), ("out_len", "<u4"), ("crc32", "<u4"),
+                                ("reserved", "<u4")])   # ibu_inflate_block_t
+
+
 def bgzf_scan(buf, final=True, cap=None):
     """ibu_bgzf_scan over `buf` (bytes-like): (ctypes array of ibu_inflate_block_t, consumed bytes, uncompressed bytes, status).
-    status is 0 or 2 = IBU_ERR_NIFFLER (the blocks in front of the bad spot are described)."""
+    status is 0 or 2 = IBU_ERR_NIFFLER (the blocks in front of the bad spot are described).  cap: at most that many blocks."""
     from ._lib import CInflateBlock
     a = np.frombuffer(buf, dtype=np.uint8)
-    cap = int(cap) if cap is not None else len(a) // 28 + 1
-    blocks = (CInflateBlock * max(cap, 1))()
-    n, consumed, out_bytes = C.c_size_t(), C.c_size_t(), C.c_uint64()
-    rc = lib.ibu_bgzf_scan(_hptr(a) if len(a) else None, len(a), 1 if final else 0, blocks, cap, C.byref(n), C.byref(consumed), C.byref(out_bytes))
-    return (CInflateBlock * n.value).from_buffer_copy(bytes(blocks)[:n.value * C.sizeof(CInflateBlock)]) if n.value else (CInflateBlock * 0)(), \
-        consumed.value, out_bytes.value, rc
+    step = 1 << 16
+    tmp = (CInflateBlock * step)()
+    parts, pos, total, rc, left = [], 0, 0, 0, (None if cap is None else int(cap))
+    while pos < len(a) and (left is None or left > 0):
+        n, consumed, out_bytes = C.c_size_t(), C.c_size_t(), C.c_uint64()
+        want = step if left is None else min(step, left)
+        rc = lib.ibu_bgzf_scan(_hptr(a[pos:]), len(a) - pos, 1 if final else 0, tmp, want, C.byref(n), C.byref(consumed), C.byref(out_bytes))
+        if n.value:
+            part = np.frombuffer(tmp, dtype=INFLATE_BLOCK_DTYPE, count=n.value).copy()
+            part["comp_offset"] += pos
+            part["out_offset"] += total
+            parts.append(part)
+            if left is not None:
+                left -= n.value
+        pos += consumed.value
+        total += out_bytes.value
+        if rc or consumed.value == 0 or n.value < want:
+            break
+    allb = np.concatenate(parts) if parts else np.empty(0, INFLATE_BLOCK_DTYPE)
+    blocks = (CInflateBlock * len(allb)).from_buffer_copy(allb.tobytes()) if len(allb) else (CInflateBlock * 0)()
+    return blocks, pos, total, rc
 
 
 def numa_of_pci(pci_bus_id, sysfs_root=None):

@@ -582,8 +582,10 @@ extern "C" int32_t ibu_inflate_blocks_device(ibu_ctx_t* ctx, const void* d_comp,
   if (n == 0) return IBU_OK;
   if (!d_comp || !d_blocks || !d_out || !d_status || !d_first_bad) return err_arg("NULL argument");
   if (n >= (1ull << 31)) return err_arg("fewer than 2^31 blocks per call");
+  rc = ensure_sort_scratch(ctx, inflate_scratch_bytes(ctx->cfg, n));   // (the lanes' symbol tables: the context's scratch, as the sort's)
+  if (rc) return rc;
   IBU_HIP(launch_inflate_blocks(ctx->cfg, d_comp, reinterpret_cast<const InflateBlockDesc*>(d_blocks), n, d_out, d_status, d_first_bad,
-                                pick_stream(ctx, stream)));
+                                ctx->d_sort_scratch, ctx->sort_scratch_bytes, pick_stream(ctx, stream)));
   return IBU_OK;
 }
 extern "C" int32_t ibu_records_census(ibu_ctx_t* ctx, const void* d_records, size_t n, uint64_t out[8], void* stream) {

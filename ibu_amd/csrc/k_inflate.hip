@@ -18,12 +18,19 @@
 //     memory, full 64-byte pieces leave the ring as 16 dword stores; a match from further back reads the lane's own earlier
 //     output from global memory (a wave's vector memory operations execute in order: the byte a lane stored is the byte it loads).
 //     The code lengths of a dynamic header are parsed in the same LDS (the ring's pending bytes go out first and come back after);
-//   - everything a lane keeps in LDS is laid out lane-interleaved (element k of lane L at k * 64 + L: lanes that read the same
-//     element hit different banks): 704 bytes per lane, 45 KB per wave, three waves (192 blocks) per CU;
+//   - everything a lane keeps is laid out lane-interleaved (element k of lane L at k * 64 + L: lanes that read the same element hit
+//     different banks / one cache line): the symbol orders in global memory (24 KB per workgroup, in the caller's scratch — read once
+//     per symbol; in LDS they held a CU to three waves), the ring and the header's code lengths in LDS (22 KB per wave: six waves,
+//     384 blocks, per CU);
 //   - divergence (one lane in a literal, the next in a match, a third building its tables) costs instructions, not correctness: no
 //     lane waits for another inside the decoder.
+// Measured (profiles/README.md r05_ai; BGZF level 1 of 16/12 records, ratio 0.50): a wave takes 134 ms for its 64 blocks — a step of
+// the symbol loop is a chain of ~600 dependent instructions under divergence, 4.4 us — so 1e8 records (575 waves, one round) inflate in
+// 0.134 s = 18 GB/s, 3e8 in 0.288 s = 25 GB/s = 1.04 G records/s (the host's 16 inflate threads: 0.40), and a full grid (1536 waves)
+// turns over 47 GB/s.  The streams do NOT use it: a ring slot holds a few hundred blocks, i.e. a handful of waves for 134 ms.
 // (Second form, same round: symbols and counts in LDS, bytes straight to global memory, no prefetch — 0.23 s for 1e8 records, every
-// wave step waiting for some lane's global load or store.)
+// wave step waiting for some lane's global load or store.  Third: this one with the symbol orders in LDS, three waves per CU: 0.124 s
+// for 1e8, 0.359 s for 3e8.)
 // When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
 // block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
@@ -39,14 +46,17 @@ namespace {
 constexpr int kInfThreads = kWave;                           // one wave per workgroup: its LDS is the 64 lanes' tables
 constexpr u32 kDistSyms = 32;
 
-// per-wave LDS, lane-interleaved
-struct InfLds {
-  uint8_t sym_lo[320 * kWave];           // literal/length symbols in code order, low 8 bits: [k * 64 + lane]; k in [288, 320): construct()'s
-                                         // position per length (u16[16])
+// per-wave tables, lane-interleaved.  The symbol orders live in GLOBAL memory (one InfTables per workgroup of the grid, in the caller's
+// scratch: they are read once per symbol, and kept in LDS — 24 KB per wave — they held a CU to three waves; a wave's step is a chain
+// of ~600 dependent instructions, so what a CU needs is waves to interleave); the ring and everything touched per byte stay in LDS.
+struct InfTables {
+  uint8_t sym_lo[288 * kWave];           // literal/length symbols in code order, low 8 bits: [k * 64 + lane]
   u32 sym_hi[9 * kWave];                 // bit k of the lane's 288 bits: symbol k of the order is >= 256
   uint8_t sym_dist[kDistSyms * kWave];   // distance symbols (and the code-length code's) in code order
-  u32 ring[80 * kWave];                  // dword d of lane L at [d * 64 + L]: bytes [0, 256) the output ring; bytes [0, 320) the code lengths of a
-                                         // header while it is read
+};
+struct InfLds {
+  u32 ring[88 * kWave];                  // dword d of lane L at [d * 64 + L]: bytes [0, 256) the output ring; bytes [0, 320) the code lengths of a
+                                         // header while it is read; bytes [320, 352): construct()'s position per length (u16[16])
   uint16_t base[29 + 30];                // length / distance bases, then their extra bits (shared by the lanes)
   uint8_t extra[29 + 30];
   uint8_t clorder[19];
@@ -87,6 +97,7 @@ __device__ __forceinline__ u32 x8nmodp(const Crc32Pow& pw, u32 n) {   // x^(8 n)
 // One lane's decoder.
 struct LaneInflate {
   InfLds* w;
+  InfTables* t;
   u32 lane;
   const uint8_t* comp;                                       // the block's compressed bytes (readable 2 KiB past clen)
   uint8_t* out;
@@ -99,9 +110,9 @@ struct LaneInflate {
   // ---- LDS columns ----
   __device__ __forceinline__ uint8_t* ring8(u32 b) const { return reinterpret_cast<uint8_t*>(w->ring) + (((b >> 2) * kWave + lane) << 2) + (b & 3); }
   __device__ __forceinline__ uint8_t& lens(u32 s) const { return *ring8(s); }
-  __device__ __forceinline__ uint16_t& offs(u32 l) const { return *reinterpret_cast<uint16_t*>(w->sym_lo + (288 + 2 * l) * kWave + 2 * (lane & 31) + (lane >> 5) * kWave); }
+  __device__ __forceinline__ uint16_t& offs(u32 l) const { return *reinterpret_cast<uint16_t*>(ring8(320 + 2 * l)); }
   __device__ __forceinline__ u32 lit_symbol(u32 k) const {
-    return (u32)w->sym_lo[k * kWave + lane] | (((w->sym_hi[(k >> 5) * kWave + lane] >> (k & 31)) & 1u) << 8);
+    return (u32)t->sym_lo[k * kWave + lane] | (((t->sym_hi[(k >> 5) * kWave + lane] >> (k & 31)) & 1u) << 8);
   }
 
   // ---- input ----
@@ -187,17 +198,17 @@ struct LaneInflate {
     return left == 0 || maxlen == 1;                         // incomplete: only a single 1-bit code
   }
   __device__ __forceinline__ bool build_lit(u32 at, u32 n) {
-    for (u32 k = 0; k < 9; ++k) w->sym_hi[k * kWave + lane] = 0;
+    for (u32 k = 0; k < 9; ++k) t->sym_hi[k * kWave + lane] = 0;
     u32 ml = 0;
     const int left = construct(cl, at, n, &ml, [&](u32 k, u32 s) {
-      w->sym_lo[k * kWave + lane] = (uint8_t)s;
-      if (s >= 256) w->sym_hi[(k >> 5) * kWave + lane] |= 1u << (k & 31);
+      t->sym_lo[k * kWave + lane] = (uint8_t)s;
+      if (s >= 256) t->sym_hi[(k >> 5) * kWave + lane] |= 1u << (k & 31);
     });
     return accept(left, ml, false);
   }
   __device__ __forceinline__ bool build_dist(u32 at, u32 n) {
     u32 ml = 0;
-    const int left = construct(cd, at, n, &ml, [&](u32 k, u32 s) { w->sym_dist[k * kWave + lane] = (uint8_t)s; });
+    const int left = construct(cd, at, n, &ml, [&](u32 k, u32 s) { t->sym_dist[k * kWave + lane] = (uint8_t)s; });
     return accept(left, ml, true);
   }
 
@@ -248,14 +259,14 @@ struct LaneInflate {
     for (u32 i = 0; i < hclen; ++i) lens(w->clorder[i]) = (uint8_t)bits(3);
     {                                                        // the code-length code (in the distance code's place): an incomplete one is always an error
       u32 ml = 0;
-      if (construct(cd, 0, 19, &ml, [&](u32 k, u32 s) { w->sym_dist[k * kWave + lane] = (uint8_t)s; }) != 0) return false;
+      if (construct(cd, 0, 19, &ml, [&](u32 k, u32 s) { t->sym_dist[k * kWave + lane] = (uint8_t)s; }) != 0) return false;
     }
     const u32 total = hlit + hdist;
     u32 i = 0, prev = 0;
     while (i < total) {
       const int k = decode_index(cd);
       if (k < 0) return false;
-      const u32 sym = w->sym_dist[(u32)k * kWave + lane];
+      const u32 sym = t->sym_dist[(u32)k * kWave + lane];
       if (sym < 16) {
         lens(i) = (uint8_t)sym;
         prev = sym;
@@ -324,7 +335,7 @@ struct LaneInflate {
       const u32 len = w->base[ls] + bits(w->extra[ls]);
       const int kd = decode_index(cd);
       if (kd < 0) return false;
-      const u32 ds = w->sym_dist[(u32)kd * kWave + lane];
+      const u32 ds = t->sym_dist[(u32)kd * kWave + lane];
       if (ds >= 30) return false;
       const u32 dist = w->base[29 + ds] + bits(w->extra[29 + ds]);
       if (!copy_match(len, dist)) return false;
@@ -355,7 +366,7 @@ struct LaneInflate {
 
 __global__ void __launch_bounds__(kInfThreads)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
-                     u32* __restrict__ status, u32* __restrict__ first_bad, Crc32Pow pw) {
+                     u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, Crc32Pow pw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   InfLds* w = reinterpret_cast<InfLds*>(lds_raw);
   const u32 lane = threadIdx.x;
@@ -382,6 +393,7 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
     if (live) {
       LaneInflate s;
       s.w = w;
+      s.t = tables + blockIdx.x;
       s.lane = lane;
       s.comp = comp + bd.coff;
       s.out = out_base + bd.ooff;
@@ -418,11 +430,17 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
   }
 }
 
+static inline u32 inflate_grid(const LaunchCfg& cfg, size_t nblocks) {
+  const size_t want = (nblocks + kWave - 1) / kWave;
+  const size_t cap = (size_t)cfg.cus * 6;                    // 24 KB of LDS per wave: six fit a CU
+  return (u32)(want < cap ? want : cap);
+}
+size_t inflate_scratch_bytes(const LaunchCfg& cfg, size_t nblocks) { return sizeof(InfTables) * (size_t)inflate_grid(cfg, nblocks); }
 hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
-                                 uint32_t* d_status, uint32_t* d_first_bad, hipStream_t st) {
+                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st) {
   (void)hipGetLastError();
   if (nblocks == 0) return hipSuccess;
-  if (nblocks >= (1ull << 31)) return hipErrorInvalidValue;
+  if (nblocks >= (1ull << 31) || scratch_bytes < inflate_scratch_bytes(cfg, nblocks)) return hipErrorInvalidValue;
   static const Crc32Pow pw = [] {
     Crc32Pow t;
     auto mul = [](u32 a, u32 b) {
@@ -442,10 +460,8 @@ hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const
   const size_t lds = sizeof(InfLds);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_inflate_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const u32 want = (u32)((nblocks + kWave - 1) / kWave);
-  const u32 cap = (u32)cfg.cus * 3;                          // 45 KB of LDS per wave: three fit a CU
-  hipLaunchKernelGGL(ibu_k_inflate_blocks, dim3(want < cap ? want : cap), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
-                     (uint8_t*)d_out_base, d_status, d_first_bad, pw);
+  hipLaunchKernelGGL(ibu_k_inflate_blocks, dim3(inflate_grid(cfg, nblocks)), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
+                     (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), pw);
   return hipGetLastError();
 }
 

@@ -20,17 +20,18 @@
 //     The code lengths of a dynamic header are parsed in the same LDS (the ring's pending bytes go out first and come back after);
 //   - everything a lane keeps is laid out lane-interleaved (element k of lane L at k * 64 + L: lanes that read the same element hit
 //     different banks / one cache line): the symbol orders in global memory (24 KB per workgroup, in the caller's scratch — read once
-//     per symbol; in LDS they held a CU to three waves), the ring and the header's code lengths in LDS (22 KB per wave: six waves,
-//     384 blocks, per CU);
+//     per symbol; in LDS they held a CU to three waves); the ring and the header's code lengths in LDS, lane after lane at an odd
+//     dword stride (a byte's address is base + offset, the lanes' same byte sits in different banks): 23 KB per wave, six waves,
+//     384 blocks, per CU;
 //   - divergence (one lane in a literal, the next in a match, a third building its tables) costs instructions, not correctness: no
 //     lane waits for another inside the decoder.
-// Measured (profiles/README.md r05_ai; BGZF level 1 of 16/12 records, ratio 0.50): a wave takes 134 ms for its 64 blocks — a step of
-// the symbol loop is a chain of ~600 dependent instructions under divergence, 4.4 us — so 1e8 records (575 waves, one round) inflate in
-// 0.134 s = 18 GB/s, 3e8 in 0.288 s = 25 GB/s = 1.04 G records/s (the host's 16 inflate threads: 0.40), and a full grid (1536 waves)
-// turns over 47 GB/s.  The streams do NOT use it: a ring slot holds a few hundred blocks, i.e. a handful of waves for 134 ms.
-// (Second form, same round: symbols and counts in LDS, bytes straight to global memory, no prefetch — 0.23 s for 1e8 records, every
-// wave step waiting for some lane's global load or store.  Third: this one with the symbol orders in LDS, three waves per CU: 0.124 s
-// for 1e8, 0.359 s for 3e8.)
+// Measured (profiles/README.md r05_ad ... r05_ak; BGZF level 1 of 16/12 records, ratio 0.50): a wave takes 68 ms for its 64 blocks, so
+// 1e8 records (575 waves, one round) inflate in 0.068 s = 35 GB/s, 3e8 in 0.143 s = 50 GB/s = 2.1 G records/s (the host's 16 inflate
+// threads: 0.40).  The streams do NOT use it: a ring slot holds a few hundred blocks, i.e. a handful of waves for 68 ms.
+// How it got there, same round: symbols and counts in LDS, bytes straight to global memory, no prefetch — 0.231 s for 1e8 records,
+// every wave step waiting for some lane's global load or store; counts in registers, input one dword ahead, the output ring: 0.124 s;
+// symbol orders to global memory (three -> six waves per CU): 0.134 s but 3e8 from 0.359 to 0.288 s; the CRC pass 16 bytes per load
+// instead of one (it was 25 of a wave's 134 ms): 0.109 s; literal runs batched (symbols() below) and a byte-addressed ring: 0.068 s.
 // When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
 // block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
@@ -54,9 +55,11 @@ struct InfTables {
   u32 sym_hi[9 * kWave];                 // bit k of the lane's 288 bits: symbol k of the order is >= 256
   uint8_t sym_dist[kDistSyms * kWave];   // distance symbols (and the code-length code's) in code order
 };
+constexpr u32 kLaneDwords = 89;
 struct InfLds {
-  u32 ring[88 * kWave];                  // dword d of lane L at [d * 64 + L]: bytes [0, 256) the output ring; bytes [0, 320) the code lengths of a
-                                         // header while it is read; bytes [320, 352): construct()'s position per length (u16[16])
+  u32 ring[kLaneDwords * kWave];         // lane L's 356 bytes at dword L * 89 (an odd stride: the lanes' same byte sits in different banks, and a
+                                         // byte's address is base + offset): [0, 256) the output ring; [0, 320) the code lengths of a header while it
+                                         // is read; [320, 352): construct()'s position per length (u16[16])
   uint16_t base[29 + 30];                // length / distance bases, then their extra bits (shared by the lanes)
   uint8_t extra[29 + 30];
   uint8_t clorder[19];
@@ -98,6 +101,7 @@ __device__ __forceinline__ u32 x8nmodp(const Crc32Pow& pw, u32 n) {   // x^(8 n)
 struct LaneInflate {
   InfLds* w;
   InfTables* t;
+  uint8_t* rb;                                               // this lane's bytes of w->ring
   u32 lane;
   const uint8_t* comp;                                       // the block's compressed bytes (readable 2 KiB past clen)
   uint8_t* out;
@@ -108,7 +112,7 @@ struct LaneInflate {
   u32 cl[5], cd[5];                                          // codes per length 1 .. 15, 10 bits each, three to a word: literal/length and distance code
 
   // ---- LDS columns ----
-  __device__ __forceinline__ uint8_t* ring8(u32 b) const { return reinterpret_cast<uint8_t*>(w->ring) + (((b >> 2) * kWave + lane) << 2) + (b & 3); }
+  __device__ __forceinline__ uint8_t* ring8(u32 b) const { return rb + b; }
   __device__ __forceinline__ uint8_t& lens(u32 s) const { return *ring8(s); }
   __device__ __forceinline__ uint16_t& offs(u32 l) const { return *reinterpret_cast<uint16_t*>(ring8(320 + 2 * l)); }
   __device__ __forceinline__ u32 lit_symbol(u32 k) const {
@@ -215,10 +219,10 @@ struct LaneInflate {
   // ---- output ----
   __device__ __forceinline__ void flush_pieces() {           // whole 64-byte pieces of the ring -> global memory
     while (opos - flushed >= kPiece) {
-      const u32 d0 = (flushed & (kRing - 1)) >> 2;           // (flushed is a multiple of 64)
+      const u32* src = reinterpret_cast<const u32*>(rb + (flushed & (kRing - 1)));   // (flushed is a multiple of 64)
 #pragma unroll
       for (u32 d = 0; d < kPiece / 4; ++d) {
-        const u32 v = w->ring[(d0 + d) * kWave + lane];
+        const u32 v = src[d];
         __builtin_memcpy(out + flushed + 4 * d, &v, 4);
       }
       flushed += kPiece;
@@ -315,22 +319,34 @@ struct LaneInflate {
     in_start(p + len);
     return true;
   }
+  // The symbols of a Huffman block up to its end-of-block code.  Lanes diverge between "literal" and "match": run naively, every step
+  // of the wave pays for both.  So the lanes that are here together first decode LITERALS only — a lane that meets a length symbol (or
+  // the end) parks it — until all of them are parked (or 6 steps have passed); then the parked symbols are served in one go.  With a
+  // match every ~5 symbols a wave then runs the match path every ~5 steps for (nearly) all its lanes, not every step for a fifth.
   __device__ __forceinline__ bool symbols() {
     const u32 lim = clen * 8;
     for (;;) {
-      if (bitpos() > lim) return false;                      // ran past the block's last byte
-      const int k = decode_index(cl);
-      if (k < 0) return false;
-      const u32 sym = lit_symbol((u32)k);
-      if (sym < 256) {
-        if (opos >= isize) return false;
-        *ring8(opos & (kRing - 1)) = (uint8_t)sym;
-        ++opos;
-        if (opos - flushed >= kPiece) flush_pieces();
-        continue;
+      u32 parked = 0xFFFFFFFFu;                              // the non-literal symbol this lane waits with
+      for (u32 step = 0; step < 6; ++step) {
+        if (parked == 0xFFFFFFFFu) {
+          if (bitpos() > lim) return false;                  // ran past the block's last byte
+          const int k = decode_index(cl);
+          if (k < 0) return false;
+          const u32 sym = lit_symbol((u32)k);
+          if (sym < 256) {
+            if (opos >= isize) return false;
+            *ring8(opos & (kRing - 1)) = (uint8_t)sym;
+            ++opos;
+            if (opos - flushed >= kPiece) flush_pieces();
+          } else {
+            parked = sym;
+          }
+        }
+        if (__ballot(parked == 0xFFFFFFFFu) == 0) break;     // (of the lanes that are in this loop together)
       }
-      if (sym == 256) return true;
-      const u32 ls = sym - 257;
+      if (parked == 0xFFFFFFFFu) continue;
+      if (parked == 256) return true;
+      const u32 ls = parked - 257;
       if (ls >= 29) return false;
       const u32 len = w->base[ls] + bits(w->extra[ls]);
       const int kd = decode_index(cd);
@@ -394,6 +410,7 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
       LaneInflate s;
       s.w = w;
       s.t = tables + blockIdx.x;
+      s.rb = reinterpret_cast<uint8_t*>(w->ring + lane * kLaneDwords);
       s.lane = lane;
       s.comp = comp + bd.coff;
       s.out = out_base + bd.ooff;
@@ -415,7 +432,27 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
         const u32 chunk = (isz + kWave - 1) / kWave;
         const u32 a = lane * chunk < isz ? lane * chunk : isz, e = a + chunk < isz ? a + chunk : isz;
         u32 crc = 0xFFFFFFFFu;
-        for (u32 p = a; p < e; ++p) crc = w->crc_tab[(crc ^ __builtin_nontemporal_load(o + p)) & 255u] ^ (crc >> 8);
+        // 16 bytes per load, the next load in flight while these go through the table (a byte per load made this pass 98 of a wave's
+        // 134 ms: 64 blocks x 1024 dependent trips to L2)
+        u32 p = a;
+        u32x4 cur = {0, 0, 0, 0}, nx = {0, 0, 0, 0};
+        if (p + 16 <= e) __builtin_memcpy(&cur, o + p, 16);
+        while (p + 16 <= e) {
+          if (p + 32 <= e) __builtin_memcpy(&nx, o + p + 16, 16);
+          const u32 ws[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u32 x = ws[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              crc = w->crc_tab[(crc ^ x) & 255u] ^ (crc >> 8);
+              x >>= 8;
+            }
+          }
+          cur = nx;
+          p += 16;
+        }
+        for (; p < e; ++p) crc = w->crc_tab[(crc ^ o[p]) & 255u] ^ (crc >> 8);
         crc ^= 0xFFFFFFFFu;
         v = e > a ? multmodp(x8nmodp(pw, isz - e), crc) : 0u;
 #pragma unroll

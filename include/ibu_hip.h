@@ -491,10 +491,10 @@ int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t 
  * the end of the deflate stream on the block's last byte and the CRC-32, exactly as the host decoder does.  d_status[i] = 0 good /
  * 1 not a valid deflate stream of these sizes / 2 CRC-32 mismatch; *d_first_bad (device; the caller sets it to 0xFFFFFFFF) = the
  * lowest bad block.  A block writes only its own out_len bytes.  Asynchronous on `stream`; the lanes' tables live in the context's
- * sort scratch (one call per context at a time, as for the sort).  One LANE per block: 64 blocks per wave, 134 ms per wave on BGZF
- * level 1 of 16/12 records — 18 GB/s of output for 1e8 records, 25 GB/s for 3e8 (the 16 host inflate threads of the same box: 9.6),
- * 47 GB/s once 98 304 blocks (6.4 GB) are in one call.  A building block: the library's own streams keep the host inflate (a ring
- * slot holds too few blocks to fill the device). */
+ * sort scratch (one call per context at a time, as for the sort).  One LANE per block: 64 blocks per wave, 68 ms per wave on BGZF
+ * level 1 of 16/12 records — 35 GB/s of output for 1e8 records, 50 GB/s for 3e8 (the 16 host inflate threads of the same box: 9.6).
+ * A building block: the library's own streams keep the host inflate (a ring slot holds too few blocks to fill the device: a call
+ * wants tens of thousands). */
 #define IBU_INFLATE_PAD 2048
 typedef struct ibu_inflate_block {
   uint64_t comp_offset;

@@ -549,10 +549,37 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
         out["gzip_reader_process_device_decode"] = rate(dt, st, gz_bytes=gz_bytes, gz_ratio=gz_bytes / file_bytes, compress_seconds=tc,
                                                         input="ONE gzip member, level 1 (what `gzip -1` writes), inflated on the host cores",
                                                         totals_equal_resident_copy=True)
+        # the BGZF form of the same file (what `bgzip -l 1` writes) two ways: the Reader (blocks inflated on the host cores, the pull
+        # stream's path) and ibu_load_bgzf_to_device (the COMPRESSED bytes cross the link, every block is inflated on the device)
+        from gzutil import bgzf_parallel
+        bg = path + ".bgzf"
+        t0 = time.perf_counter()
+        bg_bytes = bgzf_parallel(path, bg, level=1, workers=max(2, min(16, usable_cores())))
+        tc = time.perf_counter() - t0
+        r = ia.Reader.from_path(bg)
+        t0 = time.perf_counter()
+        _, st = r.process_device(ctxs[0], ia.PROC_DECODE, sink=(s_bc, s_umi, s_idx, n), ring=ring)
+        dt = time.perf_counter() - t0
+        r.close()
+        out["bgzf_reader_process_device_decode"] = rate(dt, st, bgzf_bytes=bg_bytes, compress_seconds=tc,
+                                                        input="BGZF blocks, level 1, inflated on the host cores (block-parallel)")
+        dst = ctxs[0].alloc(24 * n)
+        calls = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            _, dptr, got_n, st = ctxs[0].load_bgzf_to_device(bg, ring=ring, d_records=dst, cap_records=n)
+            calls.append(time.perf_counter() - t0)
+            if not (got_n == n and ctxs[0].reduce(dptr, n) == want):
+                raise LegCheckFailed("e2e: load_bgzf_to_device returned other records than were written")
+        dst.free()
+        out["bgzf_load_to_device_device_inflate"] = rate(min(calls), st, calls_seconds=[round(c_, 4) for c_ in calls], bgzf_bytes=bg_bytes,
+                                                         bytes_over_the_link=bg_bytes, totals_equal_resident_copy=True,
+                                                         call="ibu_load_bgzf_to_device(ctx, path, ring, &header, &d_records, cap, &n, &stats): "
+                                                              "one lane per BGZF block (k_inflate.hip)")
     finally:
         for c in ctxs:
             c.close()
-        for f in (path, gz):
+        for f in (path, gz, path + ".bgzf"):
             if os.path.exists(f):
                 os.unlink(f)
     out["numa"] = ctx.numa()   # where the device hangs off the host, and where the pinned ring of the runs above landed (option "numa")

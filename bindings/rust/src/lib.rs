@@ -614,6 +614,13 @@ pub mod device {
             check(unsafe { ffi::ibu_load_to_device(self.raw, c.as_ptr(), std::ptr::null(), &mut h, &mut p, 0, &mut n, std::ptr::null_mut()) })?;
             Ok((h, p, n))
         }
+        /// The same for a BGZF (bgzip) file of the records, inflated on the device: the compressed bytes cross the link.
+        pub fn load_bgzf_to_device<P: AsRef<Path>>(&self, path: P) -> Result<(Header, *mut c_void, usize)> {
+            let c = CString::new(path.as_ref().to_string_lossy().as_bytes()).unwrap();
+            let (mut h, mut p, mut n) = (bytemuck::Zeroable::zeroed(), std::ptr::null_mut(), 0usize);
+            check(unsafe { ffi::ibu_load_bgzf_to_device(self.raw, c.as_ptr(), std::ptr::null(), &mut h, &mut p, 0, &mut n, std::ptr::null_mut()) })?;
+            Ok((h, p, n))
+        }
     }
     /// `ibu_stream_t`: iterate to pull one device-resident batch at a time.  An `Err` item is the source's error
     /// (`TruncatedRecord`, `Io`, `Niffler` ...), delivered after the batches in front of it; iteration ends after it.

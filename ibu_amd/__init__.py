@@ -956,6 +956,15 @@ class Context:
                                       C.byref(n), C.byref(st)))
         return Header._wrap(h), p.value, n.value, st
 
+    def load_bgzf_to_device(self, path, ring=None, d_records=None, cap_records=0):
+        """ibu_load_bgzf_to_device: a BGZF file of the records -> device records, inflated on the device (the compressed bytes cross
+        the link) -> (Header, device pointer (int) or the given buffer, n, stats)."""
+        h, n, st = CHeader(), C.c_size_t(), CStreamStats()
+        p = C.c_void_p(_dptr(d_records).value if d_records is not None else None)
+        _check(lib.ibu_load_bgzf_to_device(self._c, str(path).encode(), _ring(ring), C.byref(h), C.byref(p), cap_records,
+                                           C.byref(n), C.byref(st)))
+        return Header._wrap(h), p.value, n.value, st
+
     def free(self, ptr):
         _check(lib.ibu_device_free(self._c, ptr))
 

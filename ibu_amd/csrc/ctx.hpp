@@ -89,6 +89,9 @@ int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hi
 // (ctx->loser_free): until it has finished their memory is still taken, and an allocation that fails for want of memory while it
 // runs waits for it and tries once more — a caller never sees an out-of-memory error the synchronous free would not have given.
 hipError_t ctx_malloc(ibu_ctx* ctx, void** p, size_t bytes);   // device.cpp
+// hipFree of temporaries off the caller's path (the driver clears VRAM at free time: tens of milliseconds per GB): on the context's
+// helper thread, as the candidates of a placement probe; ctx_malloc, the next such call and ibu_ctx_destroy join it.
+void ctx_free_deferred(ibu_ctx* ctx, void* a, void* b, void* c);
 inline int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   if (need > ctx->sort_scratch_bytes) {
     if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));

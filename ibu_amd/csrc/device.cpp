@@ -228,6 +228,22 @@ hipError_t ibu::ctx_malloc(ibu_ctx* ctx, void** p, size_t bytes) {
   }
   return e;
 }
+void ibu::ctx_free_deferred(ibu_ctx* ctx, void* a, void* b, void* c) {
+  if (ctx->loser_free.joinable()) ctx->loser_free.join();
+  const int dev = ctx->device;
+  try {
+    ctx->loser_free = std::thread([a, b, c, dev] {
+      (void)hipSetDevice(dev);
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+      if (c) (void)hipFree(c);
+    });
+  } catch (...) {
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (c) (void)hipFree(c);
+  }
+}
 int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
   const uint32_t tries = probe_tries_for(ctx, bytes);
   if (tries > 1) {

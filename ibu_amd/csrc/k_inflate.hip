@@ -25,13 +25,16 @@
 //     384 blocks, per CU;
 //   - divergence (one lane in a literal, the next in a match, a third building its tables) costs instructions, not correctness: no
 //     lane waits for another inside the decoder.
-// Measured (profiles/README.md r05_ad ... r05_ak; BGZF level 1 of 16/12 records, ratio 0.50): a wave takes 68 ms for its 64 blocks, so
-// 1e8 records (575 waves, one round) inflate in 0.068 s = 35 GB/s, 3e8 in 0.143 s = 50 GB/s = 2.1 G records/s (the host's 16 inflate
-// threads: 0.40).  The streams do NOT use it: a ring slot holds a few hundred blocks, i.e. a handful of waves for 68 ms.
+// Measured (profiles/README.md r05_ad ... r05_ar; BGZF level 1 of 16/12 records, ratio 0.50): a wave takes ~46 ms for its 64 blocks, so
+// 1e8 records (575 waves, one round) inflate in 0.046 s = 52 GB/s, 3e8 in 0.119 s = 60 GB/s = 2.5 G records/s (the host's 16 inflate
+// threads: 0.40).  ibu_load_bgzf_to_device (stream.cpp) is built on it; the STREAMS do not use it: a ring slot holds a few hundred
+// blocks, i.e. a handful of waves for 46 ms.
 // How it got there, same round: symbols and counts in LDS, bytes straight to global memory, no prefetch — 0.231 s for 1e8 records,
 // every wave step waiting for some lane's global load or store; counts in registers, input one dword ahead, the output ring: 0.124 s;
 // symbol orders to global memory (three -> six waves per CU): 0.134 s but 3e8 from 0.359 to 0.288 s; the CRC pass 16 bytes per load
-// instead of one (it was 25 of a wave's 134 ms): 0.109 s; literal runs batched (symbols() below) and a byte-addressed ring: 0.068 s.
+// instead of one (it was 25 of a wave's 134 ms): 0.109 s; literal runs batched (symbols() below) and a byte-addressed ring: 0.068 s;
+// the code lengths tried likeliest first (decode_index): 0.055 s; the symbol orders back in LDS when one round of three waves per CU
+// takes the whole call: 0.046 s (3e8: scratch, six waves, 0.119 s).
 // When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
 // block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
@@ -102,14 +105,17 @@ struct LaneInflate {
   InfLds* w;
   InfTables* t;
   uint8_t* rb;                                               // this lane's bytes of w->ring
-  u32 lane;
+  u32 lane, park_steps;
   const uint8_t* comp;                                       // the block's compressed bytes (readable 2 KiB past clen)
   uint8_t* out;
   u32 clen, isize;
   u64 buf;                                                   // cnt valid low bits
   u32 cnt, ipos, nxt;                                        // nxt: the dword at comp + ipos, already loaded
   u32 opos, flushed, rbase;                                  // ring: bytes [max(rbase, opos - 256 + pending), opos) are in it; [flushed, opos) not yet in global memory
-  u32 cl[5], cd[5];                                          // codes per length 1 .. 15, 10 bits each, three to a word: literal/length and distance code
+  // a canonical code in registers: per length 1 .. 15 the number of codes and the position of its first symbol in code order (10 bits
+  // each, three to a word) and its first code (16 bits, two to a word)
+  struct Code { u32 cnt[5], off[5], first[8]; };
+  Code cl, cd;                                               // literal/length and distance code
 
   // ---- LDS columns ----
   __device__ __forceinline__ uint8_t* ring8(u32 b) const { return rb + b; }
@@ -143,41 +149,51 @@ struct LaneInflate {
   }
   __device__ __forceinline__ u32 bitpos() const { return ipos * 8 - cnt; }
 
-  // the position in code order of the next code, from the packed counts: 15 unrolled steps, no memory.  -1: no such code.
-  __device__ __forceinline__ int decode_index(const u32 (&c5)[5]) {
+  // The position in code order of the next code: no memory, no loop-carried state.  A window of L bits is a code of length L exactly when
+  // first[L] <= window < first[L] + count[L] — whatever order the lengths are tried in (a shorter code's longer windows lie below the
+  // longer lengths' ranges, a longer code's prefixes above the shorter ones').  So the likely lengths go first: a literal of a records
+  // file is 8 or 9 bits, and the wave leaves after the slowest lane's hit — ~3 tries instead of the ~12 steps of counting up from 1.
+  // LIT: the order for literal/length codes; else for distance (and code-length) codes.  -1: no such code.
+  template <bool LIT>
+  __device__ __forceinline__ int decode_index(const Code& c) {
     need(15);
-    u32 code = 0, first = 0, index = 0, b = (u32)buf;
+    const u32 x = __brev((u32)buf) >> 17;                    // the next 15 bits, first bit on top
+    constexpr int kOrderLit[15] = {8, 9, 7, 10, 6, 11, 5, 12, 4, 13, 3, 14, 2, 15, 1};
+    constexpr int kOrderDist[15] = {5, 4, 6, 3, 7, 2, 8, 1, 9, 10, 11, 12, 13, 14, 15};
 #pragma unroll
-    for (int len = 1; len <= 15; ++len) {
-      code |= b & 1u;
-      b >>= 1;
-      const u32 c = (c5[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u;
-      if (code < first + c) {
+    for (int i = 0; i < 15; ++i) {
+      const int len = LIT ? kOrderLit[i] : kOrderDist[i];
+      const u32 cn = (c.cnt[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u;
+      const u32 fi = (c.first[(len - 1) / 2] >> (16 * ((len - 1) % 2))) & 0xFFFFu;
+      const u32 d = (x >> (15 - len)) - fi;
+      if (d < cn) {                                          // (unsigned: a window below `first` wraps to a huge d)
         buf >>= len;
         cnt -= len;
-        return (int)(index + (code - first));
+        return (int)(((c.off[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u) + d);
       }
-      index += c;
-      first = (first + c) << 1;
-      code <<= 1;
     }
     return -1;
   }
 
-  // Counts (packed into c5) and symbol order of the code with lengths lens[at, at + n).  How complete it is: 0 complete, > 0 codes left
+  // Counts, first codes and first positions (packed into cc) and symbol order of the code with lengths lens[at, at + n).  How complete it is: 0 complete, > 0 codes left
   // over, < 0 over-subscribed; *maxlen = the longest code.  store(k, s): symbol s is the k-th in code order.
   template <class Store>
-  __device__ __forceinline__ int construct(u32 (&c5)[5], u32 at, u32 n, u32* maxlen, Store store) {
+  __device__ __forceinline__ int construct(Code& cc, u32 at, u32 n, u32* maxlen, Store store) {
     for (u32 l = 0; l < 16; ++l) offs(l) = 0;
     for (u32 s = 0; s < n; ++s) offs(lens(at + s))++;
     int left = 1;
-    u32 ml = 0, o = 0;
+    u32 ml = 0, o = 0, code = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) c5[k] = 0;
+    for (int k = 0; k < 5; ++k) cc.cnt[k] = cc.off[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cc.first[k] = 0;
 #pragma unroll
     for (int l = 1; l < 16; ++l) {
       const u32 c = offs(l);
-      c5[(l - 1) / 3] |= c << (10 * ((l - 1) % 3));
+      cc.cnt[(l - 1) / 3] |= c << (10 * ((l - 1) % 3));
+      cc.off[(l - 1) / 3] |= (o & 1023u) << (10 * ((l - 1) % 3));
+      cc.first[(l - 1) / 2] |= (code & 0xFFFFu) << (16 * ((l - 1) % 2));   // (a valid code set keeps it below 2^l)
+      code = (code + c) << 1;
       if (c) ml = l;
       if (left >= 0) left = 2 * left - (int)c;              // (stays negative once over-subscribed)
       offs(l) = (uint16_t)o;
@@ -268,7 +284,7 @@ struct LaneInflate {
     const u32 total = hlit + hdist;
     u32 i = 0, prev = 0;
     while (i < total) {
-      const int k = decode_index(cd);
+      const int k = decode_index<false>(cd);
       if (k < 0) return false;
       const u32 sym = t->sym_dist[(u32)k * kWave + lane];
       if (sym < 16) {
@@ -327,10 +343,10 @@ struct LaneInflate {
     const u32 lim = clen * 8;
     for (;;) {
       u32 parked = 0xFFFFFFFFu;                              // the non-literal symbol this lane waits with
-      for (u32 step = 0; step < 6; ++step) {
+      for (u32 step = 0; step < park_steps; ++step) {
         if (parked == 0xFFFFFFFFu) {
           if (bitpos() > lim) return false;                  // ran past the block's last byte
-          const int k = decode_index(cl);
+          const int k = decode_index<true>(cl);
           if (k < 0) return false;
           const u32 sym = lit_symbol((u32)k);
           if (sym < 256) {
@@ -349,7 +365,7 @@ struct LaneInflate {
       const u32 ls = parked - 257;
       if (ls >= 29) return false;
       const u32 len = w->base[ls] + bits(w->extra[ls]);
-      const int kd = decode_index(cd);
+      const int kd = decode_index<false>(cd);
       if (kd < 0) return false;
       const u32 ds = t->sym_dist[(u32)kd * kWave + lane];
       if (ds >= 30) return false;
@@ -380,9 +396,12 @@ struct LaneInflate {
 
 }  // namespace
 
+// TL: the lanes' symbol orders in LDS (47 KB per wave: three waves per CU — the form for inputs that fit one round of them, where the
+// symbol's round trip to L2 is a quarter of a wave's step) instead of global scratch (six waves per CU: the form for large inputs).
+template <bool TL>
 __global__ void __launch_bounds__(kInfThreads)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
-                     u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, Crc32Pow pw) {
+                     u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, u32 park_steps, u32 bpw /*blocks per wave: lanes [0, bpw) decode*/, Crc32Pow pw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   InfLds* w = reinterpret_cast<InfLds*>(lds_raw);
   const u32 lane = threadIdx.x;
@@ -398,10 +417,10 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
     w->crc_tab[i] = c;
   }
   __syncthreads();
-  const u32 ngroups = (nblocks + kWave - 1) / kWave;
+  const u32 ngroups = (nblocks + bpw - 1) / bpw;
   for (u32 g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const u32 b = g * kWave + lane;
-    const bool live = b < nblocks;
+    const u32 b = g * bpw + lane;
+    const bool live = lane < bpw && b < nblocks;
     InflateBlockDesc bd;
     bd.coff = 0; bd.ooff = 0; bd.clen = 0; bd.isize = 0; bd.crc = 0; bd.reserved = 0;
     if (live) bd = blocks[b];
@@ -409,9 +428,10 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
     if (live) {
       LaneInflate s;
       s.w = w;
-      s.t = tables + blockIdx.x;
+      s.t = TL ? reinterpret_cast<InfTables*>(lds_raw + ((sizeof(InfLds) + 15) & ~(size_t)15)) : tables + blockIdx.x;
       s.rb = reinterpret_cast<uint8_t*>(w->ring + lane * kLaneDwords);
       s.lane = lane;
+      s.park_steps = park_steps;
       s.comp = comp + bd.coff;
       s.out = out_base + bd.ooff;
       s.clen = bd.clen;
@@ -467,12 +487,20 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
   }
 }
 
+// Always 64 blocks per wave: a wave's time does not shrink with fewer lanes (3678 blocks dealt five to a wave took 42 ms, 36 766 at 48
+// to a wave 46 ms: the step is a chain of dependent instructions, not divergence), and dense waves leave room for the next launch.
+static inline u32 inflate_bpw(const LaunchCfg&, size_t) { return kWave; }
+// one round of three waves per CU takes everything: the form with the symbol orders in LDS; else six waves per CU, tables in scratch
+static inline bool inflate_tables_in_lds(const LaunchCfg& cfg, size_t nblocks) { return (nblocks + kWave - 1) / kWave <= (size_t)cfg.cus * 3; }
 static inline u32 inflate_grid(const LaunchCfg& cfg, size_t nblocks) {
-  const size_t want = (nblocks + kWave - 1) / kWave;
-  const size_t cap = (size_t)cfg.cus * 6;                    // 24 KB of LDS per wave: six fit a CU
+  const u32 bpw = inflate_bpw(cfg, nblocks);
+  const size_t want = (nblocks + bpw - 1) / bpw;
+  const size_t cap = (size_t)cfg.cus * 6;                    // 23 KB of LDS per wave: six fit a CU
   return (u32)(want < cap ? want : cap);
 }
-size_t inflate_scratch_bytes(const LaunchCfg& cfg, size_t nblocks) { return sizeof(InfTables) * (size_t)inflate_grid(cfg, nblocks); }
+size_t inflate_scratch_bytes(const LaunchCfg& cfg, size_t nblocks) {
+  return inflate_tables_in_lds(cfg, nblocks) ? 16 : sizeof(InfTables) * (size_t)inflate_grid(cfg, nblocks);
+}
 hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
                                  uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st) {
   (void)hipGetLastError();
@@ -494,11 +522,18 @@ hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const
     for (int n = 1; n < 32; ++n) t.x2n[n] = p = mul(p, p);
     return t;
   }();
-  const size_t lds = sizeof(InfLds);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ibu_k_inflate_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool tl = inflate_tables_in_lds(cfg, nblocks);
+  const size_t lds = ((sizeof(InfLds) + 15) & ~(size_t)15) + (tl ? sizeof(InfTables) : 0);
+  const void* fn = tl ? reinterpret_cast<const void*>(ibu_k_inflate_blocks<true>) : reinterpret_cast<const void*>(ibu_k_inflate_blocks<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ibu_k_inflate_blocks, dim3(inflate_grid(cfg, nblocks)), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
-                     (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), pw);
+  const u32 grid = inflate_grid(cfg, nblocks);
+  if (tl)
+    hipLaunchKernelGGL(ibu_k_inflate_blocks<true>, dim3(grid), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
+                       (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), 6u, inflate_bpw(cfg, nblocks), pw);
+  else
+    hipLaunchKernelGGL(ibu_k_inflate_blocks<false>, dim3(grid), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
+                       (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), 6u, inflate_bpw(cfg, nblocks), pw);
   return hipGetLastError();
 }
 

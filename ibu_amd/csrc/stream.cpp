@@ -14,7 +14,10 @@
 // split per call = per GPU) and the streaming Reader (reader.rs:279-306, incl. the gzip path
 // of reader.rs:345-352).
 #include <errno.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -26,6 +29,8 @@
 
 #include "ctx.hpp"
 #include "host_io.hpp"
+#include "kernels.h"
+#include "pgzip.hpp"
 
 using namespace ibu;
 
@@ -254,6 +259,169 @@ extern "C" int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ib
   }
   *n = num;
   if (stats) { stats->records = num; stats->seconds_total = now_s() - t0; }
+  return IBU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// load_to_vec of a BGZF file, inflated on the device (k_inflate.hip): the COMPRESSED bytes cross the link
+// ------------------------------------------------------------------------------------------
+// The result is what ibu_load_to_device gives for the gunzipped file (load_to_vec, reader.rs:510-535: header read and validated,
+// (length - 32) % 24 != 0 -> InvalidMapSize).  The file is mapped, its block headers are walked (ibu_bgzf_scan: no inflating), the
+// blocks that hold the 32 header bytes are inflated on the host, the whole file goes through the pinned ring into a device buffer and
+// the device inflates every block straight to its place in the records: a launch per ~16 Ki blocks behind the copy that completes
+// them, on streams of their own, so the copies run on while the first launches work.  A block is accepted exactly as the host
+// decoder accepts it; anything else — a member that is not a BGZF block, a file that ends inside one, a block that does not inflate
+// to its announced length and CRC — is IBU_ERR_NIFFLER, as from the Reader.
+extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, ibu_header_t* header,
+                                           void** d_records, size_t cap_records, size_t* n, ibu_stream_stats_t* stats) {
+  if (!ctx || !path || !header || !d_records || !n) return err_arg("NULL argument");
+  IBU_HIP(hipSetDevice(ctx->device));
+  RunOnNode on_node(feed_place(ctx));
+  const double t0 = now_s();
+  if (stats) memset(stats, 0, sizeof *stats);
+  int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return err_io(errno, path);
+  struct stat sb;
+  if (fstat(fd, &sb)) { const int e = errno; close(fd); return err_io(e, "metadata"); }
+  const size_t size = (size_t)sb.st_size;
+  if (size == 0) { close(fd); return err_io(0, "read header"); }
+  void* mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  const int map_errno = errno;
+  close(fd);
+  if (mp == MAP_FAILED) return err_io(map_errno, "mmap");
+  struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{mp, size};
+  (void)madvise(mp, size, MADV_SEQUENTIAL);
+  const uint8_t* map = static_cast<const uint8_t*>(mp);
+
+  // 1. the blocks (a cut-off or foreign member: IBU_ERR_NIFFLER from the walk)
+  std::vector<ibu_inflate_block_t> B;
+  uint64_t total = 0;
+  try {
+    std::vector<ibu_inflate_block_t> part(1 << 16);
+    for (size_t pos = 0; pos < size;) {
+      size_t nb = 0, consumed = 0;
+      uint64_t ob = 0;
+      const int32_t rc = ibu_bgzf_scan(map + pos, size - pos, 1, part.data(), part.size(), &nb, &consumed, &ob);
+      for (size_t i = 0; i < nb; ++i) {
+        part[i].comp_offset += pos;
+        part[i].out_offset += (int64_t)total;
+      }
+      B.insert(B.end(), part.begin(), part.begin() + (ptrdiff_t)nb);
+      if (rc) return rc;
+      if (consumed == 0) return err_niffler("the stream ends inside a BGZF block");
+      pos += consumed;
+      total += ob;
+    }
+  } catch (...) { return caught_io("ibu_load_bgzf_to_device"); }
+
+  // 2. the header: the leading blocks, inflated here
+  uint8_t head[IBU_HEADER_SIZE + 65536];
+  size_t lead = 0, lead_bytes = 0;
+  try {
+    pgz::RawInflater raw;
+    std::vector<uint8_t> in;
+    while (lead_bytes < IBU_HEADER_SIZE && lead < B.size()) {
+      const ibu_inflate_block_t& b = B[lead];
+      if (b.out_len) {
+        in.assign(map + b.comp_offset, map + b.comp_offset + b.comp_len);
+        in.resize(b.comp_len + 512, 0);                  // the decoder may read (not use) a few bytes behind the stream
+        uint32_t crc = 0;
+        const int e = raw.inflate(in.data(), b.comp_len, head + lead_bytes, b.out_len, &crc);
+        if (e == ENOMEM) return err_io(ENOMEM, "inflate");
+        if (e || crc != b.crc32) return err_niffler("a BGZF block does not inflate to its announced length and CRC-32");
+      }
+      lead_bytes += b.out_len;
+      ++lead;
+    }
+  } catch (...) { return caught_io("ibu_load_bgzf_to_device"); }
+  if (lead_bytes < IBU_HEADER_SIZE) return err_io(0, "read header");
+  memcpy(header, head, IBU_HEADER_SIZE);
+  int32_t rc = ibu_header_validate(header);
+  if (rc) return rc;
+  if ((total - IBU_HEADER_SIZE) % IBU_RECORD_SIZE != 0) return err_map_size();
+  const size_t num = (size_t)((total - IBU_HEADER_SIZE) / IBU_RECORD_SIZE);
+
+  // 3. the destination
+  bool owned = false;
+  if (*d_records == nullptr) {
+    rc = ctx_alloc(ctx, num * IBU_RECORD_SIZE, d_records);
+    if (rc) return rc;
+    owned = true;
+  } else if (num > cap_records) {
+    return err_arg("device buffer too small for the file");
+  }
+  uint8_t* d_out = static_cast<uint8_t*>(*d_records);
+  void *d_comp = nullptr, *d_desc = nullptr, *d_status = nullptr;
+  constexpr int kStreams = 3;
+  hipStream_t ks[kStreams] = {nullptr, nullptr, nullptr};
+  auto fail = [&](int32_t code) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    for (hipStream_t q : ks)
+      if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    ctx_free_deferred(ctx, d_comp, d_desc, d_status);
+    if (owned) { (void)hipFree(*d_records); *d_records = nullptr; }
+    return code;
+  };
+  if (lead_bytes > IBU_HEADER_SIZE) {                     // the records behind the header in the blocks inflated here
+    hipError_t e = hipMemcpy(d_out, head + IBU_HEADER_SIZE, lead_bytes - IBU_HEADER_SIZE, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy"));
+  }
+  const size_t nrest = B.size() - lead;
+  if (nrest) {
+    // 4. everything else: the file to the device, the blocks inflated where their records belong
+    hipError_t e = ctx_malloc(ctx, &d_comp, size + kInflatePad);
+    if (e == hipSuccess) e = ctx_malloc(ctx, &d_desc, nrest * sizeof(InflateBlockDesc));
+    if (e == hipSuccess) e = ctx_malloc(ctx, &d_status, 4 * nrest + 16);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc"));
+    for (size_t i = lead; i < B.size(); ++i) B[i].out_offset -= IBU_HEADER_SIZE;   // relative to the records
+    uint32_t* d_first_bad = static_cast<uint32_t*>(d_status) + nrest;
+    const uint32_t none = 0xFFFFFFFFu;
+    e = hipMemcpy(d_desc, B.data() + lead, nrest * sizeof(InflateBlockDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_first_bad, &none, 4, hipMemcpyHostToDevice);
+    for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&ks[k], hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
+    rc = ensure_sort_scratch(ctx, 16);
+    if (!rc) rc = ring_ensure(ctx, cfg, false);
+    if (rc) return fail(rc);
+    Ring& r = ctx->ring;
+    constexpr size_t kLaunchBlocks = 16384, kLaunchMax = 32768;   // (<= cus * 3 * 64 blocks per launch: the form with its tables in LDS, no scratch)
+    size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;
+    for (size_t k = 0; up < size; ++k) {
+      const uint32_t sl = (uint32_t)(k % r.slots);
+      const size_t len = size - up < r.slot_bytes ? size - up : r.slot_bytes;
+      e = hipEventSynchronize(r.copied[sl]);
+      if (e != hipSuccess) return fail(hip_fail(e, "hipEventSynchronize"));
+      uint8_t* dst = r.pinned[sl];
+      const uint8_t* src = map + up;
+      parallel_bytes(len, feeder_threads(cfg), [&](size_t off, size_t l) { memcpy(dst + off, src + off, l); return 0; });
+      e = hipMemcpyAsync(static_cast<uint8_t*>(d_comp) + up, dst, len, hipMemcpyHostToDevice, ctx->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(r.copied[sl], ctx->copy_stream);
+      if (e != hipSuccess) return fail(hip_fail(e, "H2D"));
+      up += len;
+      if (stats) { stats->bytes_h2d += len; stats->batches += 1; }
+      while (next_blk < nrest && B[lead + next_blk].comp_offset + B[lead + next_blk].comp_len <= up) ++next_blk;
+      while (next_blk - launch_from >= kLaunchBlocks || (up == size && next_blk > launch_from)) {
+        const size_t cnt = next_blk - launch_from < kLaunchMax ? next_blk - launch_from : kLaunchMax;
+        hipStream_t q = ks[launches++ % kStreams];
+        e = hipStreamWaitEvent(q, r.copied[sl], 0);
+        if (e == hipSuccess)
+          e = launch_inflate_blocks(ctx->cfg, d_comp, static_cast<const InflateBlockDesc*>(d_desc) + launch_from, cnt, d_out,
+                                    static_cast<uint32_t*>(d_status) + launch_from, d_first_bad, ctx->d_sort_scratch, ctx->sort_scratch_bytes, q);
+        if (e != hipSuccess) return fail(hip_fail(e, "inflate"));
+        launch_from += cnt;
+      }
+    }
+    uint32_t first_bad = none;
+    e = hipStreamSynchronize(ctx->copy_stream);
+    for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamSynchronize(ks[k]);
+    if (e == hipSuccess) e = hipMemcpy(&first_bad, d_first_bad, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
+    if (first_bad != none) return fail(err_niffler("a BGZF block does not inflate to its announced length and CRC-32"));
+    for (hipStream_t& q : ks) { (void)hipStreamDestroy(q); q = nullptr; }
+    ctx_free_deferred(ctx, d_comp, d_desc, d_status);
+  }
+  *n = num;
+  if (stats) { stats->records = num; stats->seconds_total = now_s() - t0; stats->numa_node = feed_place(ctx).node; stats->ring_node = ctx->ring.node; }
   return IBU_OK;
 }
 

@@ -430,6 +430,12 @@ class Context {
     check(ibu_load_to_device(c_, path.c_str(), ring, &h, &p, 0, &n, stats));
     return {h, p, n};
   }
+  // The same for a BGZF (bgzip) file of the records, inflated on the device: the compressed bytes cross the link.
+  std::tuple<Header, void*, size_t> load_bgzf_to_device(const std::string& path, const RingConfig* ring = nullptr, StreamStats* stats = nullptr) {
+    Header h; void* p = nullptr; size_t n = 0;
+    check(ibu_load_bgzf_to_device(c_, path.c_str(), ring, &h, &p, 0, &n, stats));
+    return {h, p, n};
+  }
   void* alloc(size_t bytes) { void* p = nullptr; check(ibu_device_alloc(c_, bytes, &p)); return p; }
   // for arrays that stay resident: up to `tries` candidates, the one that streams fastest is kept (ibu_device_alloc_probed)
   void* alloc_probed(size_t bytes, uint32_t tries, AllocProbe* report = nullptr) {

@@ -491,10 +491,11 @@ int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t 
  * the end of the deflate stream on the block's last byte and the CRC-32, exactly as the host decoder does.  d_status[i] = 0 good /
  * 1 not a valid deflate stream of these sizes / 2 CRC-32 mismatch; *d_first_bad (device; the caller sets it to 0xFFFFFFFF) = the
  * lowest bad block.  A block writes only its own out_len bytes.  Asynchronous on `stream`; the lanes' tables live in the context's
- * sort scratch (one call per context at a time, as for the sort).  One LANE per block: 64 blocks per wave, 68 ms per wave on BGZF
- * level 1 of 16/12 records — 35 GB/s of output for 1e8 records, 50 GB/s for 3e8 (the 16 host inflate threads of the same box: 9.6).
- * A building block: the library's own streams keep the host inflate (a ring slot holds too few blocks to fill the device: a call
- * wants tens of thousands). */
+ * sort scratch (calls of more than 49 152 blocks; one such call per context at a time, as for the sort).  One LANE per block: 64
+ * blocks per wave; BGZF level 1 of 16/12 records: 52 GB/s of output for 1e8 records, 60 GB/s for 3e8 (the 16 host inflate threads
+ * of the same box: 9.6).
+ * A wave takes ~46 ms for its 64 blocks whatever the call's size, so a call wants tens of thousands of blocks:
+ * ibu_load_bgzf_to_device (above) is the library's own use of it; the streams keep the host inflate (a ring slot holds too few). */
 #define IBU_INFLATE_PAD 2048
 typedef struct ibu_inflate_block {
   uint64_t comp_offset;
@@ -572,6 +573,16 @@ typedef struct ibu_stream_stats {
 int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg,
                            ibu_header_t* header, void** d_records, size_t cap_records, size_t* n,
                            ibu_stream_stats_t* stats);
+/* The same for a BGZF (bgzip) file of the records, INFLATED ON THE DEVICE: the compressed bytes cross the link (half of them for a
+ * 16/12 records file) and every block inflates straight to its place among the records (ibu_inflate_blocks_device below; one launch
+ * per ~16 Ki blocks behind the copy that completes them).  The result is what ibu_load_to_device gives for the gunzipped file — the
+ * reference's load_to_vec does not decompress (reader.rs:510-535 reads the file as it is; its Reader does, through niffler,
+ * :345-352): this is the bulk form of that Reader path.  Header too short: IBU_ERR_IO; invalid header: as ibu_header_validate;
+ * (length - 32) % 24 != 0: IBU_ERR_INVALID_MAP_SIZE; a member that is not a BGZF block, a file that ends inside one, a block that
+ * does not inflate to its announced length and CRC-32: IBU_ERR_NIFFLER (an ordinary gzip file: use the Reader).  Takes the file
+ * size + 36 bytes per block of device memory for the length of the call. */
+int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, ibu_header_t* header, void** d_records,
+                                size_t cap_records, size_t* n, ibu_stream_stats_t* stats);
 
 /* Device analogue of Writer::write_batch (writer.rs:315-351): n device-resident AoS records
  * are copied back through the ring and appended to the writer (same buffered/direct rules).

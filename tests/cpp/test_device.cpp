@@ -276,6 +276,26 @@ TEST(argument_errors_surface_as_ibu_errors) {
   CHECK_THROWS(Io, ctx().load_to_device("/nonexistent/file.ibu"), {});
 }
 
+TEST(bgzf_file_inflates_on_the_device) {
+  // ibu_load_bgzf_to_device: the compressed bytes cross the link, every block inflates on the device; the result is load_to_vec of the
+  // gunzipped file.  Fixtures from tests/test_cpp.py (the same 50 000 records plain, as BGZF blocks, and that BGZF file cut short).
+  const char* dir = std::getenv("IBU_TEST_COMPRESSED_DIR");
+  if (!dir) return;
+  const std::string d(dir);
+  auto recs = oracle_records(11, 0, 50000, 16, 12);
+  const RingConfig ring{3, 8192, 2, 0};
+  StreamStats st{};
+  auto [h, dptr, n] = ctx().load_bgzf_to_device(d + "/a.bgz", &ring, &st);
+  CHECK(h == Header(16, 12)); CHECK_EQ(n, recs.size()); CHECK_EQ(st.records, (uint64_t)recs.size());
+  std::vector<Record> got(n);
+  ctx().download(static_cast<void*>(got.data()), dptr, n * 24);
+  ctx().free(dptr);
+  CHECK(got == recs);
+  CHECK_THROWS(Niffler, ctx().load_bgzf_to_device(d + "/cut.bgz"), {});     // ends inside a block
+  CHECK_THROWS(Niffler, ctx().load_bgzf_to_device(d + "/a.gz"), {});        // an ordinary gzip member: the Reader's business
+  CHECK_THROWS(Niffler, ctx().load_bgzf_to_device(d + "/plain.ibu"), {});   // not compressed
+}
+
 int main(int argc, char** argv) {
   if (device::device_count() == 0) { std::fprintf(stderr, "no GPU: the device tests cannot run\n"); return 2; }
   return run_all(argc, argv);

@@ -146,8 +146,11 @@ def test_random_example(built, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_device_tests(built, tmp_path):
-    r = _run([os.path.join(built, "test_device")], env={**os.environ, "TMPDIR": str(tmp_path)})
+def test_cpp_device_tests(built, tmp_path, oracle):
+    fx = tmp_path / "compressed"
+    fx.mkdir()
+    _compressed_fixture(fx, oracle)
+    r = _run([os.path.join(built, "test_device")], env={**os.environ, "TMPDIR": str(tmp_path), "IBU_TEST_COMPRESSED_DIR": str(fx)})
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failed" in r.stdout
 

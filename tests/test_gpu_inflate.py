@@ -203,3 +203,79 @@ def test_a_window_of_blocks_lands_around_a_slot(ia, ctx, oracle):
     assert d_out.download(np.uint8)[:out_bytes].tobytes() == data
     d_comp.free()
     d_out.free()
+
+
+# ---- ibu_load_bgzf_to_device: load_to_vec of the gunzipped file, inflated on the device -----------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 1000, 100_003, 1_000_003])
+@pytest.mark.parametrize("block,level", [(0xFF00, 1), (4093, 6), (20, 1), (0xFF00, 0)])
+def test_load_bgzf_to_device_gives_the_records_of_the_gunzipped_file(ia, ctx, oracle, tmp_path, n, block, level):
+    if block == 20 and n > 1000:
+        pytest.skip("tiny blocks only for small files")
+    recs = oracle.generate(SEED + n, 0, n, 16, 12)
+    plain = struct.pack("<IIIIQ8s", 0x21554249, 2, 16, 12, 0, b"\0" * 8) + recs.tobytes()
+    p = tmp_path / "r.ibu.gz"
+    p.write_bytes(_bgzf(plain, block=block, level=level))
+    ring = {"slots": 3, "slot_records": 40_000, "feeder_threads": 3}     # several ring slots per file, block edges off the slot edges
+    h, dptr, got_n, st = ctx.load_bgzf_to_device(str(p), ring=ring)
+    assert (h.bc_len, h.umi_len, got_n) == (16, 12, n)
+    assert st.records == n and st.bytes_h2d == p.stat().st_size
+    if n:
+        got = ia.DeviceBuffer.wrap(ctx, dptr, 24 * n).download().tobytes()
+        assert got == recs.tobytes()
+    ctx.free(dptr)
+    # into the caller's buffer; one record short: refused
+    buf = ctx.alloc(24 * max(n, 1) + 64)
+    buf.upload(np.full(24 * max(n, 1) + 64, 0xA5, np.uint8))
+    _, q, got_n, _ = ctx.load_bgzf_to_device(str(p), ring=ring, d_records=buf, cap_records=n)
+    assert q == buf.ptr and got_n == n
+    whole = buf.download(np.uint8)
+    assert whole[:24 * n].tobytes() == recs.tobytes() and (whole[24 * n:] == 0xA5).all()   # nothing behind the records
+    if n:
+        with pytest.raises(ia.IbuError) as e:
+            ctx.load_bgzf_to_device(str(p), ring=ring, d_records=buf, cap_records=n - 1)
+        assert e.value.kind == "InvalidArg"
+    buf.free()
+
+
+def test_load_bgzf_to_device_refuses_what_the_reader_refuses(ia, ctx, oracle, tmp_path):
+    import gzip
+    n = 50_000
+    recs = oracle.generate(SEED, 0, n, 16, 12)
+    hdr = struct.pack("<IIIIQ8s", 0x21554249, 2, 16, 12, 0, b"\0" * 8)
+    plain = hdr + recs.tobytes()
+    good = _bgzf(plain, level=1)
+    blocks, _, _, _ = ia.bgzf_scan(good)
+
+    def load(data):
+        p = tmp_path / "x.gz"
+        p.write_bytes(data)
+        return ctx.load_bgzf_to_device(str(p))
+
+    def kind_of(data):
+        with pytest.raises(ia.IbuError) as e:
+            load(data)
+        return e.value.kind
+
+    assert kind_of(gzip.compress(plain)) == "Niffler"                       # an ordinary gzip member: the Reader's business
+    assert kind_of(plain) == "Niffler"                                      # not compressed at all
+    assert kind_of(good[:-60]) == "Niffler"                                 # cut inside the last data block's trailer / the EOF block
+    assert kind_of(good[:len(good) // 2]) == "Niffler"                      # cut inside a block
+    assert kind_of(good[:7]) == "Niffler"                                   # cut inside the first header
+    assert kind_of(b"") == "Io"                                             # nothing there: no header to read
+    b = blocks[len(blocks) // 2]
+    bad = bytearray(good)
+    bad[b.comp_offset + b.comp_len // 2] ^= 0x40
+    assert kind_of(bytes(bad)) == "Niffler"                                 # a block that does not inflate (or not to its CRC)
+    bad = bytearray(good)
+    struct.pack_into("<I", bad, b.comp_offset + b.comp_len, b.crc32 ^ 1)
+    assert kind_of(bytes(bad)) == "Niffler"                                 # the trailer's CRC
+    bad = bytearray(good)                                                   # the first block (inflated on the host for the header)
+    struct.pack_into("<I", bad, blocks[0].comp_offset + blocks[0].comp_len, blocks[0].crc32 ^ 1)
+    assert kind_of(bytes(bad)) == "Niffler"
+    assert kind_of(_bgzf(plain + b"\x01\x02\x03")) == "InvalidMapSize"      # (length - 32) % 24 != 0
+    assert kind_of(_bgzf(hdr[:20])) == "Io"                                 # shorter than a header
+    assert kind_of(_bgzf(b"\0" * 32 + recs.tobytes())) == "InvalidMagicNumber"
+    assert kind_of(_bgzf(struct.pack("<IIIIQ8s", 0x21554249, 2, 0, 12, 0, b"\0" * 8))) == "InvalidBarcodeLength"
+    h, dptr, got_n, _ = load(good)                                          # and the file itself loads
+    assert got_n == n
+    ctx.free(dptr)

@@ -64,6 +64,9 @@ struct ibu_ctx {
   ibu::Ring ring;
   ibu::CodecRing cring;
   void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
+  void* d_inflate_stage = nullptr; // ibu_load_bgzf_to_device: the compressed file, the block descriptors and their status words on the device (grows only)
+  size_t inflate_stage_bytes = 0;
+  hipStream_t inflate_streams[3] = {nullptr, nullptr, nullptr};   // ... and the streams its launches go out on (created on first use, kept)
   hipStream_t side_stream = nullptr;   // the multi-GPU sort's shared prefix estimate runs here, beside the pulls (created on first use, kept)
   uint64_t* h_part = nullptr;      // pinned, u64[264]: a partition pass's range starts and census words land here early (multi_sort.cpp)
   std::thread loser_free;          // placement probing: the candidates not kept are freed off the caller's path (hipFree of a touched
@@ -89,9 +92,7 @@ int32_t ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr);   // device.cpp: hi
 // (ctx->loser_free): until it has finished their memory is still taken, and an allocation that fails for want of memory while it
 // runs waits for it and tries once more — a caller never sees an out-of-memory error the synchronous free would not have given.
 hipError_t ctx_malloc(ibu_ctx* ctx, void** p, size_t bytes);   // device.cpp
-// hipFree of temporaries off the caller's path (the driver clears VRAM at free time: tens of milliseconds per GB): on the context's
-// helper thread, as the candidates of a placement probe; ctx_malloc, the next such call and ibu_ctx_destroy join it.
-void ctx_free_deferred(ibu_ctx* ctx, void* a, void* b, void* c);
+
 inline int32_t ensure_sort_scratch(ibu_ctx* ctx, size_t need) {
   if (need > ctx->sort_scratch_bytes) {
     if (ctx->d_sort_scratch) IBU_HIP(hipFree(ctx->d_sort_scratch));

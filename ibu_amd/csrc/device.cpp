@@ -106,6 +106,9 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_part) (void)hipHostFree(ctx->h_part);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  for (hipStream_t q : ctx->inflate_streams)
+    if (q) (void)hipStreamDestroy(q);
+  if (ctx->d_inflate_stage) (void)hipFree(ctx->d_inflate_stage);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -227,22 +230,6 @@ hipError_t ibu::ctx_malloc(ibu_ctx* ctx, void** p, size_t bytes) {
     if (trace_sort()) fprintf(stderr, "ibu alloc: %zu bytes did not fit while candidates were being freed: waited for them, %s\n", bytes, e == hipSuccess ? "fits now" : "still does not fit");
   }
   return e;
-}
-void ibu::ctx_free_deferred(ibu_ctx* ctx, void* a, void* b, void* c) {
-  if (ctx->loser_free.joinable()) ctx->loser_free.join();
-  const int dev = ctx->device;
-  try {
-    ctx->loser_free = std::thread([a, b, c, dev] {
-      (void)hipSetDevice(dev);
-      if (a) (void)hipFree(a);
-      if (b) (void)hipFree(b);
-      if (c) (void)hipFree(c);
-    });
-  } catch (...) {
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    if (c) (void)hipFree(c);
-  }
 }
 int32_t ibu::ctx_alloc(ibu_ctx* ctx, size_t bytes, void** d_ptr) {
   const uint32_t tries = probe_tries_for(ctx, bytes);

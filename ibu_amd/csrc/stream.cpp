@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -292,134 +293,208 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{mp, size};
   (void)madvise(mp, size, MADV_SEQUENTIAL);
   const uint8_t* map = static_cast<const uint8_t*>(mp);
+  double t_mark = now_s(), t_ph[4] = {0, 0, 0, 0};        // (IBU_TRACE_SORT=1: where the call's time went)
+  auto lap = [&](int k) { const double t = now_s(); t_ph[k] += t - t_mark; t_mark = t; };
 
-  // 1. the blocks (a cut-off or foreign member: IBU_ERR_NIFFLER from the walk)
+  // The WALK over the block headers (and the blocks that hold the 32 header bytes, inflated on the host) runs on a thread of its own
+  // while this one already copies the file to the device: the copies need nothing but the file's size.  (In line, the walk's 12.5 ms
+  // of page faults stood in front of a call of 1e8 records that takes 88.)
   std::vector<ibu_inflate_block_t> B;
   uint64_t total = 0;
-  try {
-    std::vector<ibu_inflate_block_t> part(1 << 16);
-    for (size_t pos = 0; pos < size;) {
-      size_t nb = 0, consumed = 0;
-      uint64_t ob = 0;
-      const int32_t rc = ibu_bgzf_scan(map + pos, size - pos, 1, part.data(), part.size(), &nb, &consumed, &ob);
-      for (size_t i = 0; i < nb; ++i) {
-        part[i].comp_offset += pos;
-        part[i].out_offset += (int64_t)total;
-      }
-      B.insert(B.end(), part.begin(), part.begin() + (ptrdiff_t)nb);
-      if (rc) return rc;
-      if (consumed == 0) return err_niffler("the stream ends inside a BGZF block");
-      pos += consumed;
-      total += ob;
-    }
-  } catch (...) { return caught_io("ibu_load_bgzf_to_device"); }
-
-  // 2. the header: the leading blocks, inflated here
   uint8_t head[IBU_HEADER_SIZE + 65536];
   size_t lead = 0, lead_bytes = 0;
-  try {
-    pgz::RawInflater raw;
-    std::vector<uint8_t> in;
-    while (lead_bytes < IBU_HEADER_SIZE && lead < B.size()) {
-      const ibu_inflate_block_t& b = B[lead];
-      if (b.out_len) {
-        in.assign(map + b.comp_offset, map + b.comp_offset + b.comp_len);
-        in.resize(b.comp_len + 512, 0);                  // the decoder may read (not use) a few bytes behind the stream
-        uint32_t crc = 0;
-        const int e = raw.inflate(in.data(), b.comp_len, head + lead_bytes, b.out_len, &crc);
-        if (e == ENOMEM) return err_io(ENOMEM, "inflate");
-        if (e || crc != b.crc32) return err_niffler("a BGZF block does not inflate to its announced length and CRC-32");
+  int32_t walk_rc = IBU_OK;
+  ibu_error_detail_t walk_detail{};
+  std::atomic<bool> walked{false};
+  auto walk = [&]() -> int32_t {
+    try {
+      std::vector<ibu_inflate_block_t> part(1 << 16);
+      for (size_t pos = 0; pos < size;) {                  // 1. the blocks (a cut-off or foreign member: IBU_ERR_NIFFLER from the walk)
+        size_t nb = 0, consumed = 0;
+        uint64_t ob = 0;
+        const int32_t rc = ibu_bgzf_scan(map + pos, size - pos, 1, part.data(), part.size(), &nb, &consumed, &ob);
+        for (size_t i = 0; i < nb; ++i) {
+          part[i].comp_offset += pos;
+          part[i].out_offset += (int64_t)total;
+        }
+        B.insert(B.end(), part.begin(), part.begin() + (ptrdiff_t)nb);
+        if (rc) return rc;
+        if (consumed == 0) return err_niffler("the stream ends inside a BGZF block");
+        pos += consumed;
+        total += ob;
       }
-      lead_bytes += b.out_len;
-      ++lead;
-    }
-  } catch (...) { return caught_io("ibu_load_bgzf_to_device"); }
-  if (lead_bytes < IBU_HEADER_SIZE) return err_io(0, "read header");
-  memcpy(header, head, IBU_HEADER_SIZE);
-  int32_t rc = ibu_header_validate(header);
-  if (rc) return rc;
-  if ((total - IBU_HEADER_SIZE) % IBU_RECORD_SIZE != 0) return err_map_size();
-  const size_t num = (size_t)((total - IBU_HEADER_SIZE) / IBU_RECORD_SIZE);
-
-  // 3. the destination
-  bool owned = false;
-  if (*d_records == nullptr) {
-    rc = ctx_alloc(ctx, num * IBU_RECORD_SIZE, d_records);
+      pgz::RawInflater raw;                                // 2. the header: the leading blocks, inflated here
+      std::vector<uint8_t> in;
+      while (lead_bytes < IBU_HEADER_SIZE && lead < B.size()) {
+        const ibu_inflate_block_t& b = B[lead];
+        if (b.out_len) {
+          in.assign(map + b.comp_offset, map + b.comp_offset + b.comp_len);
+          in.resize(b.comp_len + 512, 0);                  // the decoder may read (not use) a few bytes behind the stream
+          uint32_t crc = 0;
+          const int e = raw.inflate(in.data(), b.comp_len, head + lead_bytes, b.out_len, &crc);
+          if (e == ENOMEM) return err_io(ENOMEM, "inflate");
+          if (e || crc != b.crc32) return err_niffler("a BGZF block does not inflate to its announced length and CRC-32");
+        }
+        lead_bytes += b.out_len;
+        ++lead;
+      }
+    } catch (...) { return caught_io("ibu_load_bgzf_to_device"); }
+    if (lead_bytes < IBU_HEADER_SIZE) return err_io(0, "read header");
+    memcpy(header, head, IBU_HEADER_SIZE);
+    const int32_t rc = ibu_header_validate(header);
     if (rc) return rc;
-    owned = true;
-  } else if (num > cap_records) {
-    return err_arg("device buffer too small for the file");
-  }
-  uint8_t* d_out = static_cast<uint8_t*>(*d_records);
-  void *d_comp = nullptr, *d_desc = nullptr, *d_status = nullptr;
+    if ((total - IBU_HEADER_SIZE) % IBU_RECORD_SIZE != 0) return err_map_size();
+    return IBU_OK;
+  };
+  std::thread walker;
+  auto run_walk = [&] {
+    walk_rc = walk();
+    if (walk_rc) walk_detail = tls_error();                // (the detail lives in the walker's thread: the caller gets a copy)
+    walked.store(true, std::memory_order_release);
+  };
+  try { walker = std::thread(run_walk); } catch (...) { run_walk(); }   // no thread to be had: in line
+  struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_walker{walker};
+
+  bool owned = false;
   constexpr int kStreams = 3;
-  hipStream_t ks[kStreams] = {nullptr, nullptr, nullptr};
+  hipStream_t* ks = ctx->inflate_streams;
   auto fail = [&](int32_t code) {
+    if (walker.joinable()) walker.join();
     (void)hipStreamSynchronize(ctx->copy_stream);
-    for (hipStream_t q : ks)
-      if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-    ctx_free_deferred(ctx, d_comp, d_desc, d_status);
+    for (int k = 0; k < kStreams; ++k)
+      if (ks[k]) (void)hipStreamSynchronize(ks[k]);
     if (owned) { (void)hipFree(*d_records); *d_records = nullptr; }
     return code;
   };
-  if (lead_bytes > IBU_HEADER_SIZE) {                     // the records behind the header in the blocks inflated here
-    hipError_t e = hipMemcpy(d_out, head + IBU_HEADER_SIZE, lead_bytes - IBU_HEADER_SIZE, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy"));
-  }
-  const size_t nrest = B.size() - lead;
-  if (nrest) {
-    // 4. everything else: the file to the device, the blocks inflated where their records belong
-    hipError_t e = ctx_malloc(ctx, &d_comp, size + kInflatePad);
-    if (e == hipSuccess) e = ctx_malloc(ctx, &d_desc, nrest * sizeof(InflateBlockDesc));
-    if (e == hipSuccess) e = ctx_malloc(ctx, &d_status, 4 * nrest + 16);
-    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc"));
-    for (size_t i = lead; i < B.size(); ++i) B[i].out_offset -= IBU_HEADER_SIZE;   // relative to the records
-    uint32_t* d_first_bad = static_cast<uint32_t*>(d_status) + nrest;
-    const uint32_t none = 0xFFFFFFFFu;
-    e = hipMemcpy(d_desc, B.data() + lead, nrest * sizeof(InflateBlockDesc), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_first_bad, &none, 4, hipMemcpyHostToDevice);
-    for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&ks[k], hipStreamNonBlocking);
-    if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
-    rc = ensure_sort_scratch(ctx, 16);
-    if (!rc) rc = ring_ensure(ctx, cfg, false);
-    if (rc) return fail(rc);
-    Ring& r = ctx->ring;
-    constexpr size_t kLaunchBlocks = 16384, kLaunchMax = 32768;   // (<= cus * 3 * 64 blocks per launch: the form with its tables in LDS, no scratch)
-    size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;
-    for (size_t k = 0; up < size; ++k) {
-      const uint32_t sl = (uint32_t)(k % r.slots);
-      const size_t len = size - up < r.slot_bytes ? size - up : r.slot_bytes;
-      e = hipEventSynchronize(r.copied[sl]);
-      if (e != hipSuccess) return fail(hip_fail(e, "hipEventSynchronize"));
-      uint8_t* dst = r.pinned[sl];
-      const uint8_t* src = map + up;
-      parallel_bytes(len, feeder_threads(cfg), [&](size_t off, size_t l) { memcpy(dst + off, src + off, l); return 0; });
-      e = hipMemcpyAsync(static_cast<uint8_t*>(d_comp) + up, dst, len, hipMemcpyHostToDevice, ctx->copy_stream);
-      if (e == hipSuccess) e = hipEventRecord(r.copied[sl], ctx->copy_stream);
-      if (e != hipSuccess) return fail(hip_fail(e, "H2D"));
-      up += len;
-      if (stats) { stats->bytes_h2d += len; stats->batches += 1; }
-      while (next_blk < nrest && B[lead + next_blk].comp_offset + B[lead + next_blk].comp_len <= up) ++next_blk;
-      while (next_blk - launch_from >= kLaunchBlocks || (up == size && next_blk > launch_from)) {
-        const size_t cnt = next_blk - launch_from < kLaunchMax ? next_blk - launch_from : kLaunchMax;
-        hipStream_t q = ks[launches++ % kStreams];
-        e = hipStreamWaitEvent(q, r.copied[sl], 0);
-        if (e == hipSuccess)
-          e = launch_inflate_blocks(ctx->cfg, d_comp, static_cast<const InflateBlockDesc*>(d_desc) + launch_from, cnt, d_out,
-                                    static_cast<uint32_t*>(d_status) + launch_from, d_first_bad, ctx->d_sort_scratch, ctx->sort_scratch_bytes, q);
-        if (e != hipSuccess) return fail(hip_fail(e, "inflate"));
-        launch_from += cnt;
-      }
+  // the staging on the device — the compressed file; the descriptors and status words behind it once their number is known — is the
+  // context's and grows only (freeing 1.2 GB and allocating it again cost a call of 1e8 records 12 of its 104 ms)
+  auto stage = [&](size_t need) -> int32_t {
+    if (need <= ctx->inflate_stage_bytes) return IBU_OK;
+    void* p = nullptr;
+    hipError_t e = ctx_malloc(ctx, &p, need);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    if (ctx->d_inflate_stage) {                            // (the bytes copied so far move along)
+      e = hipMemcpyAsync(p, ctx->d_inflate_stage, ctx->inflate_stage_bytes, hipMemcpyDeviceToDevice, ctx->copy_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+      (void)hipFree(ctx->d_inflate_stage);
+      if (e != hipSuccess) { (void)hipFree(p); ctx->d_inflate_stage = nullptr; ctx->inflate_stage_bytes = 0; return hip_fail(e, "hipMemcpy"); }
     }
-    uint32_t first_bad = none;
-    e = hipStreamSynchronize(ctx->copy_stream);
-    for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamSynchronize(ks[k]);
-    if (e == hipSuccess) e = hipMemcpy(&first_bad, d_first_bad, 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
-    if (first_bad != none) return fail(err_niffler("a BGZF block does not inflate to its announced length and CRC-32"));
-    for (hipStream_t& q : ks) { (void)hipStreamDestroy(q); q = nullptr; }
-    ctx_free_deferred(ctx, d_comp, d_desc, d_status);
+    ctx->d_inflate_stage = p;
+    ctx->inflate_stage_bytes = need;
+    return IBU_OK;
+  };
+  const size_t comp_room = (size + kInflatePad + 255) & ~(size_t)255;
+  // (room for the descriptors of a file of ordinary 64 KiB blocks right away: no second allocation in the usual case)
+  int32_t rc = stage(comp_room + 40 * (size / 8192 + 64));
+  if (!rc) rc = ensure_sort_scratch(ctx, 16);
+  if (!rc) rc = ring_ensure(ctx, cfg, false);
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < kStreams && e == hipSuccess && !rc; ++k)
+    if (!ks[k]) e = hipStreamCreateWithFlags(&ks[k], hipStreamNonBlocking);
+  if (!rc && e != hipSuccess) rc = hip_fail(e, "hipStreamCreate");
+  if (rc) return fail(rc);
+  Ring& r = ctx->ring;
+  lap(0);
+
+  // What the walk's result allows, once it is there: the destination, the descriptors on the device
+  size_t num = 0, nrest = 0;
+  uint8_t* d_out = nullptr;
+  InflateBlockDesc* d_desc = nullptr;
+  uint32_t *d_status = nullptr, *d_first_bad = nullptr;
+  const uint32_t none = 0xFFFFFFFFu;
+  bool prepared = false;
+  auto prepare = [&]() -> int32_t {
+    if (walker.joinable()) walker.join();
+    if (walk_rc) { tls_error() = walk_detail; return walk_rc; }
+    num = (size_t)((total - IBU_HEADER_SIZE) / IBU_RECORD_SIZE);
+    if (*d_records == nullptr) {
+      const int32_t arc = ctx_alloc(ctx, num * IBU_RECORD_SIZE, d_records);
+      if (arc) return arc;
+      owned = true;
+    } else if (num > cap_records) {
+      return err_arg("device buffer too small for the file");
+    }
+    d_out = static_cast<uint8_t*>(*d_records);
+    nrest = B.size() - lead;
+    const size_t desc_room = (nrest * sizeof(InflateBlockDesc) + 255) & ~(size_t)255;
+    const int32_t src = stage(comp_room + desc_room + 4 * nrest + 16);
+    if (src) return src;
+    d_desc = reinterpret_cast<InflateBlockDesc*>(static_cast<uint8_t*>(ctx->d_inflate_stage) + comp_room);
+    d_status = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_desc) + desc_room);
+    d_first_bad = d_status + nrest;
+    for (size_t i = lead; i < B.size(); ++i) B[i].out_offset -= IBU_HEADER_SIZE;   // relative to the records
+    hipError_t pe = hipSuccess;
+    if (lead_bytes > IBU_HEADER_SIZE)                      // the records behind the header in the blocks inflated on the host
+      pe = hipMemcpy(d_out, head + IBU_HEADER_SIZE, lead_bytes - IBU_HEADER_SIZE, hipMemcpyHostToDevice);
+    if (pe == hipSuccess && nrest) pe = hipMemcpy(d_desc, B.data() + lead, nrest * sizeof(InflateBlockDesc), hipMemcpyHostToDevice);
+    if (pe == hipSuccess) pe = hipMemcpy(d_first_bad, &none, 4, hipMemcpyHostToDevice);
+    if (pe != hipSuccess) return hip_fail(pe, "hipMemcpy");
+    prepared = true;
+    return IBU_OK;
+  };
+
+  // The whole file to the device through the pinned ring; the blocks inflated where their records belong: a launch per full round of
+  // the decoder (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records) behind the copy that completes them, on streams of
+  // their own, and one for what is left at the end.  (A wave takes its ~46 ms whatever the launch's size, and two launches in flight
+  // were seen to run one after the other: 16 Ki blocks per launch made a file of 36 766 blocks 118 ms instead of 88.)
+  const size_t kLaunchBlocks = (size_t)ctx->cfg.cus * 3 * 64, kLaunchMax = kLaunchBlocks;   // (the form with its tables in LDS: no scratch)
+  size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;
+  uint32_t last_slot = 0;
+  auto launch_ready = [&](bool all) -> int32_t {
+    while (next_blk < nrest && B[lead + next_blk].comp_offset + B[lead + next_blk].comp_len <= up) ++next_blk;
+    while (next_blk - launch_from >= kLaunchBlocks || (all && next_blk > launch_from)) {
+      const size_t cnt = next_blk - launch_from < kLaunchMax ? next_blk - launch_from : kLaunchMax;
+      hipStream_t q = ks[launches++ % kStreams];
+      hipError_t le = hipStreamWaitEvent(q, r.copied[last_slot], 0);
+      if (le == hipSuccess)
+        le = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc + launch_from, cnt, d_out, d_status + launch_from, d_first_bad,
+                                   ctx->d_sort_scratch, ctx->sort_scratch_bytes, q);
+      if (le != hipSuccess) return hip_fail(le, "inflate");
+      launch_from += cnt;
+    }
+    return IBU_OK;
+  };
+  for (size_t k = 0; up < size; ++k) {
+    const uint32_t sl = (uint32_t)(k % r.slots);
+    const size_t len = size - up < r.slot_bytes ? size - up : r.slot_bytes;
+    e = hipEventSynchronize(r.copied[sl]);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipEventSynchronize"));
+    uint8_t* dst = r.pinned[sl];
+    const uint8_t* src = map + up;
+    parallel_bytes(len, feeder_threads(cfg), [&](size_t off, size_t l) { memcpy(dst + off, src + off, l); return 0; });
+    e = hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_inflate_stage) + up, dst, len, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(r.copied[sl], ctx->copy_stream);
+    if (e != hipSuccess) return fail(hip_fail(e, "H2D"));
+    up += len;
+    last_slot = sl;
+    if (stats) { stats->bytes_h2d += len; stats->batches += 1; }
+    if (!prepared && walked.load(std::memory_order_acquire)) {
+      rc = prepare();
+      if (rc) return fail(rc);
+    }
+    if (prepared) {
+      rc = launch_ready(false);
+      if (rc) return fail(rc);
+    }
   }
+  lap(1);
+  if (!prepared) {
+    rc = prepare();
+    if (rc) return fail(rc);
+  }
+  rc = launch_ready(true);
+  if (rc) return fail(rc);
+  lap(2);
+  uint32_t first_bad = none;
+  e = hipStreamSynchronize(ctx->copy_stream);
+  for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamSynchronize(ks[k]);
+  if (e == hipSuccess) e = hipMemcpy(&first_bad, d_first_bad, 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
+  if (first_bad != none) return fail(err_niffler("a BGZF block does not inflate to its announced length and CRC-32"));
+  lap(3);
+  if (trace_sort())
+    fprintf(stderr, "ibu load_bgzf: %zu blocks, %zu launches; ms: staging %.2f, copies (the walk beside them) and early launches %.2f, walk's results to the "
+            "device + last launches %.2f, waiting for them %.2f\n", B.size(), launches, 1e3 * t_ph[0], 1e3 * t_ph[1], 1e3 * t_ph[2], 1e3 * t_ph[3]);
   *n = num;
   if (stats) { stats->records = num; stats->seconds_total = now_s() - t0; stats->numa_node = feed_place(ctx).node; stats->ring_node = ctx->ring.node; }
   return IBU_OK;

@@ -14,9 +14,10 @@
 //     per symbol; literal/length symbols as a byte plus a ninth bit in a 288-bit flag word);
 //   - the compressed bytes come a dword at a time from global memory, always one dword ahead (the next one sits in a register when
 //     the bit buffer runs low, and its 64-byte line stays in L1 / L2 for the 15 reads that follow);
-//   - the output goes through a 256-byte ring per lane in LDS: literals and matches of up to 128 bytes back never touch global
-//     memory, full 64-byte pieces leave the ring as 16 dword stores; a match from further back reads the lane's own earlier
-//     output from global memory (a wave's vector memory operations execute in order: the byte a lane stored is the byte it loads).
+//   - the output goes through a 256-byte ring per lane in LDS: literals and matches of up to 64 bytes back never touch global
+//     memory; whole 32-byte pieces leave the ring as 8 dword stores, for all lanes together once one of them holds 96 bytes; a match
+//     from further back reads the lane's own earlier output from global memory (a wave's vector memory operations execute in order:
+//     the byte a lane stored is the byte it loads).
 //     The code lengths of a dynamic header are parsed in the same LDS (the ring's pending bytes go out first and come back after);
 //   - everything a lane keeps is laid out lane-interleaved (element k of lane L at k * 64 + L: lanes that read the same element hit
 //     different banks / one cache line): the symbol orders in global memory (24 KB per workgroup, in the caller's scratch — read once
@@ -34,7 +35,9 @@
 // symbol orders to global memory (three -> six waves per CU): 0.134 s but 3e8 from 0.359 to 0.288 s; the CRC pass 16 bytes per load
 // instead of one (it was 25 of a wave's 134 ms): 0.109 s; literal runs batched (symbols() below) and a byte-addressed ring: 0.068 s;
 // the code lengths tried likeliest first (decode_index): 0.055 s; the symbol orders back in LDS when one round of three waves per CU
-// takes the whole call: 0.046 s (3e8: scratch, six waves, 0.119 s).
+// takes the whole call: 0.046 s (3e8: scratch, six waves, 0.119 s).  SQ counters of that form (r05_az): a step of the wave is ~330
+// instructions (170 vector, 130 scalar — the bookkeeping of divergent branches —, 34 branches, 11 LDS, 3 global) in ~2840 cycles: one wave
+// per SIMD, 8.6 cycles from one instruction to the next.  Flushing the ring for all lanes at once instead of lane by lane changed nothing.
 // When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
 // block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
@@ -68,7 +71,7 @@ struct InfLds {
   uint8_t clorder[19];
   u32 crc_tab[256];
 };
-constexpr u32 kRing = 256, kNear = 128, kPiece = 64;
+constexpr u32 kRing = 256, kNear = 64, kPiece = 32, kChunk = 64, kHigh = 96;
 
 __device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -233,9 +236,13 @@ struct LaneInflate {
   }
 
   // ---- output ----
-  __device__ __forceinline__ void flush_pieces() {           // whole 64-byte pieces of the ring -> global memory
+  // Whole 32-byte pieces of the ring -> global memory, for ALL the lanes that are here together as soon as ONE of them holds 96 bytes:
+  // the flush is 8 LDS reads and 8 stores behind a branch, and taken lane by lane (each at its own 64th byte) some lane took it at
+  // nearly every step of the wave.  Pending bytes stay below 96 + 64 (a match's chunk), 64 bytes of history behind them: the ring's 256.
+  __device__ __forceinline__ void flush_if_due() {
+    if (__ballot(opos - flushed >= kHigh) == 0) return;
     while (opos - flushed >= kPiece) {
-      const u32* src = reinterpret_cast<const u32*>(rb + (flushed & (kRing - 1)));   // (flushed is a multiple of 64)
+      const u32* src = reinterpret_cast<const u32*>(rb + (flushed & (kRing - 1)));   // (flushed is a multiple of 32)
 #pragma unroll
       for (u32 d = 0; d < kPiece / 4; ++d) {
         const u32 v = src[d];
@@ -254,11 +261,11 @@ struct LaneInflate {
   __device__ __forceinline__ bool copy_match(u32 len, u32 dist) {
     if (dist > opos || opos + len > isize) return false;
     const bool near = dist <= kNear && dist <= opos - rbase;
-    while (len) {                                            // at most 64 bytes, then the whole pieces leave: 127 pending + 128 back fit the ring
-      const u32 n = len < kPiece ? len : kPiece;
+    while (len) {                                            // at most 64 bytes, then (if some lane is due) the whole pieces leave
+      const u32 n = len < kChunk ? len : kChunk;
       if (near) {
         for (u32 i = 0; i < n; ++i) *ring8((opos + i) & (kRing - 1)) = *ring8((opos + i - dist) & (kRing - 1));
-      } else {                                               // further back than the ring reaches: flushed long ago (pending < 128 <= dist ... or rbase)
+      } else {                                               // further back than the ring is good for: from global memory what has left it
         for (u32 i = 0; i < n; ++i) {
           const u32 src = opos + i - dist;
           *ring8((opos + i) & (kRing - 1)) = src < flushed ? out[src] : *ring8(src & (kRing - 1));
@@ -266,7 +273,7 @@ struct LaneInflate {
       }
       opos += n;
       len -= n;
-      flush_pieces();
+      flush_if_due();
     }
     return true;
   }
@@ -330,7 +337,7 @@ struct LaneInflate {
     for (u32 i = 0; i < len; ++i) {
       *ring8(opos & (kRing - 1)) = comp[p + i];
       ++opos;
-      if (opos - flushed >= kPiece) flush_pieces();
+      flush_if_due();
     }
     in_start(p + len);
     return true;
@@ -353,7 +360,7 @@ struct LaneInflate {
             if (opos >= isize) return false;
             *ring8(opos & (kRing - 1)) = (uint8_t)sym;
             ++opos;
-            if (opos - flushed >= kPiece) flush_pieces();
+            flush_if_due();
           } else {
             parked = sym;
           }

@@ -38,6 +38,7 @@
 // takes the whole call: 0.046 s (3e8: scratch, six waves, 0.119 s).  SQ counters of that form (r05_az): a step of the wave is ~330
 // instructions (170 vector, 130 scalar — the bookkeeping of divergent branches —, 34 branches, 11 LDS, 3 global) in ~2840 cycles: one wave
 // per SIMD, 8.6 cycles from one instruction to the next.  Flushing the ring for all lanes at once instead of lane by lane changed nothing.
+// So the scratch form took the header's code lengths out of LDS as well: eight waves per CU, two to a SIMD — 3e8 records 0.0747 s = 96 GB/s.
 // When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
 // block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
@@ -60,12 +61,17 @@ struct InfTables {
   uint8_t sym_lo[288 * kWave];           // literal/length symbols in code order, low 8 bits: [k * 64 + lane]
   u32 sym_hi[9 * kWave];                 // bit k of the lane's 288 bits: symbol k of the order is >= 256
   uint8_t sym_dist[kDistSyms * kWave];   // distance symbols (and the code-length code's) in code order
+  uint8_t lens[320 * kWave];             // (the form with its tables in scratch) the code lengths of the header being read
 };
-constexpr u32 kLaneDwords = 89;
+// A lane's LDS: [0, 256) the output ring, then construct()'s position per length (u16[16]).  TL (the form for calls of one round, its
+// symbol orders in LDS too): the code lengths of a header being read share the lane's bytes [0, 320) with the ring, the positions sit
+// at [320, 352) — 89 dwords per lane.  Else the code lengths live in the scratch beside the symbol orders and a lane needs 73 dwords:
+// 18.7 KB per wave, EIGHT waves per CU, two to a SIMD (r05_az: one wave per SIMD waits 8.6 cycles from one instruction to the next).
+// Both strides are odd: the lanes' same byte sits in different banks, and a byte's address is base + offset.
+template <bool TL> struct LaneLds { static constexpr u32 kDwords = TL ? 89 : 73, kOffs = TL ? 320 : 256; };
+template <bool TL>
 struct InfLds {
-  u32 ring[kLaneDwords * kWave];         // lane L's 356 bytes at dword L * 89 (an odd stride: the lanes' same byte sits in different banks, and a
-                                         // byte's address is base + offset): [0, 256) the output ring; [0, 320) the code lengths of a header while it
-                                         // is read; [320, 352): construct()'s position per length (u16[16])
+  u32 ring[LaneLds<TL>::kDwords * kWave];
   uint16_t base[29 + 30];                // length / distance bases, then their extra bits (shared by the lanes)
   uint8_t extra[29 + 30];
   uint8_t clorder[19];
@@ -104,8 +110,9 @@ __device__ __forceinline__ u32 x8nmodp(const Crc32Pow& pw, u32 n) {   // x^(8 n)
 }
 
 // One lane's decoder.
+template <bool TL>
 struct LaneInflate {
-  InfLds* w;
+  InfLds<TL>* w;
   InfTables* t;
   uint8_t* rb;                                               // this lane's bytes of w->ring
   u32 lane, park_steps;
@@ -122,8 +129,8 @@ struct LaneInflate {
 
   // ---- LDS columns ----
   __device__ __forceinline__ uint8_t* ring8(u32 b) const { return rb + b; }
-  __device__ __forceinline__ uint8_t& lens(u32 s) const { return *ring8(s); }
-  __device__ __forceinline__ uint16_t& offs(u32 l) const { return *reinterpret_cast<uint16_t*>(ring8(320 + 2 * l)); }
+  __device__ __forceinline__ uint8_t& lens(u32 s) const { return TL ? *ring8(s) : t->lens[s * kWave + lane]; }
+  __device__ __forceinline__ uint16_t& offs(u32 l) const { return *reinterpret_cast<uint16_t*>(ring8(LaneLds<TL>::kOffs + 2 * l)); }
   __device__ __forceinline__ u32 lit_symbol(u32 k) const {
     return (u32)t->sym_lo[k * kWave + lane] | (((t->sym_hi[(k >> 5) * kWave + lane] >> (k & 31)) & 1u) << 8);
   }
@@ -281,7 +288,7 @@ struct LaneInflate {
   __device__ __forceinline__ bool parse_dynamic() {
     const u32 hlit = bits(5) + 257, hdist = bits(5) + 1, hclen = bits(4) + 4;
     if (hlit > 286 || hdist > 30) return false;
-    put_pending();                                           // the code lengths are parsed in the ring's LDS
+    if (TL) put_pending();                                   // the code lengths are parsed in the ring's LDS
     for (u32 i = 0; i < 19; ++i) lens(i) = 0;
     for (u32 i = 0; i < hclen; ++i) lens(w->clorder[i]) = (uint8_t)bits(3);
     {                                                        // the code-length code (in the distance code's place): an incomplete one is always an error
@@ -314,15 +321,15 @@ struct LaneInflate {
     }
     if (lens(256) == 0) return false;                        // no end-of-block code
     const bool ok = build_lit(0, hlit) && build_dist(hlit, hdist);
-    get_pending();
+    if (TL) get_pending();
     return ok;
   }
   __device__ __forceinline__ bool fixed_tables() {
-    put_pending();
+    if (TL) put_pending();
     for (u32 s = 0; s < 288; ++s) lens(s) = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
     for (u32 s = 0; s < 32; ++s) lens(288 + s) = 5;
     const bool ok = build_lit(0, 288) && build_dist(288, 32);
-    get_pending();
+    if (TL) get_pending();
     return ok;
   }
   // a stored block behind its 3 header bits: to the byte boundary, LEN / NLEN, LEN bytes as they are
@@ -410,7 +417,7 @@ __global__ void __launch_bounds__(kInfThreads)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
                      u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, u32 park_steps, u32 bpw /*blocks per wave: lanes [0, bpw) decode*/, Crc32Pow pw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  InfLds* w = reinterpret_cast<InfLds*>(lds_raw);
+  InfLds<TL>* w = reinterpret_cast<InfLds<TL>*>(lds_raw);
   const u32 lane = threadIdx.x;
   for (u32 i = lane; i < 29 + 30; i += kWave) {
     w->base[i] = i < 29 ? kLenBase[i] : kDistBase[i - 29];
@@ -433,10 +440,10 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
     if (live) bd = blocks[b];
     u32 st = 0;
     if (live) {
-      LaneInflate s;
+      LaneInflate<TL> s;
       s.w = w;
-      s.t = TL ? reinterpret_cast<InfTables*>(lds_raw + ((sizeof(InfLds) + 15) & ~(size_t)15)) : tables + blockIdx.x;
-      s.rb = reinterpret_cast<uint8_t*>(w->ring + lane * kLaneDwords);
+      s.t = TL ? reinterpret_cast<InfTables*>(lds_raw + ((sizeof(InfLds<TL>) + 15) & ~(size_t)15)) : tables + blockIdx.x;
+      s.rb = reinterpret_cast<uint8_t*>(w->ring + lane * LaneLds<TL>::kDwords);
       s.lane = lane;
       s.park_steps = park_steps;
       s.comp = comp + bd.coff;
@@ -502,17 +509,19 @@ static inline bool inflate_tables_in_lds(const LaunchCfg& cfg, size_t nblocks) {
 static inline u32 inflate_grid(const LaunchCfg& cfg, size_t nblocks) {
   const u32 bpw = inflate_bpw(cfg, nblocks);
   const size_t want = (nblocks + bpw - 1) / bpw;
-  const size_t cap = (size_t)cfg.cus * 6;                    // 23 KB of LDS per wave: six fit a CU
+  const size_t cap = (size_t)cfg.cus * 8;                    // 20 KB of LDS per wave: eight fit a CU
   return (u32)(want < cap ? want : cap);
 }
-size_t inflate_scratch_bytes(const LaunchCfg& cfg, size_t nblocks) {
-  return inflate_tables_in_lds(cfg, nblocks) ? 16 : sizeof(InfTables) * (size_t)inflate_grid(cfg, nblocks);
+// form: 0 = by size (one round of three waves per CU holds the call: symbol orders in LDS, the shortest wave; else in scratch, eight
+// waves per CU, the highest rate); 2 = in scratch whatever the size (launches that are to run beside each other: 20 KB of LDS a wave)
+size_t inflate_scratch_bytes(const LaunchCfg& cfg, size_t nblocks, int form) {
+  return form != 2 && inflate_tables_in_lds(cfg, nblocks) ? 16 : sizeof(InfTables) * (size_t)inflate_grid(cfg, nblocks);
 }
 hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
-                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st) {
+                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st, int form) {
   (void)hipGetLastError();
   if (nblocks == 0) return hipSuccess;
-  if (nblocks >= (1ull << 31) || scratch_bytes < inflate_scratch_bytes(cfg, nblocks)) return hipErrorInvalidValue;
+  if (nblocks >= (1ull << 31) || scratch_bytes < inflate_scratch_bytes(cfg, nblocks, form)) return hipErrorInvalidValue;
   static const Crc32Pow pw = [] {
     Crc32Pow t;
     auto mul = [](u32 a, u32 b) {
@@ -529,8 +538,8 @@ hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const
     for (int n = 1; n < 32; ++n) t.x2n[n] = p = mul(p, p);
     return t;
   }();
-  const bool tl = inflate_tables_in_lds(cfg, nblocks);
-  const size_t lds = ((sizeof(InfLds) + 15) & ~(size_t)15) + (tl ? sizeof(InfTables) : 0);
+  const bool tl = form != 2 && inflate_tables_in_lds(cfg, nblocks);
+  const size_t lds = tl ? ((sizeof(InfLds<true>) + 15) & ~(size_t)15) + sizeof(InfTables) - sizeof(((InfTables*)nullptr)->lens) : sizeof(InfLds<false>);
   const void* fn = tl ? reinterpret_cast<const void*>(ibu_k_inflate_blocks<true>) : reinterpret_cast<const void*>(ibu_k_inflate_blocks<false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -128,8 +128,9 @@ hipError_t launch_runs_emit(const LaunchCfg&, const void* recs, size_t n, const 
 // *d_first_bad (the caller sets it to 0xFFFFFFFF): the lowest bad block.
 struct InflateBlockDesc { uint64_t coff; int64_t ooff; uint32_t clen, isize, crc, reserved; };
 constexpr size_t kInflatePad = 2048;
-size_t inflate_scratch_bytes(const LaunchCfg&, size_t nblocks);   // the lanes' symbol tables (24 KB per workgroup of the grid)
+// form 0: by size; 2: the lanes' tables in scratch whatever the size (k_inflate.hip)
+size_t inflate_scratch_bytes(const LaunchCfg&, size_t nblocks, int form = 0);   // the lanes' tables (44 KB per workgroup of the grid; 16 bytes for the LDS form)
 hipError_t launch_inflate_blocks(const LaunchCfg&, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
-                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st);
+                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st, int form = 0);
 
 }  // namespace ibu

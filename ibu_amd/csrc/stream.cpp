@@ -401,6 +401,8 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   uint8_t* d_out = nullptr;
   InflateBlockDesc* d_desc = nullptr;
   uint32_t *d_status = nullptr, *d_first_bad = nullptr;
+  uint8_t* d_tables = nullptr;                             // the lanes' tables of a launch in the decoder's scratch form, behind the status words
+  size_t tables_room = 0;
   const uint32_t none = 0xFFFFFFFFu;
   bool prepared = false;
   auto prepare = [&]() -> int32_t {
@@ -417,11 +419,14 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
     d_out = static_cast<uint8_t*>(*d_records);
     nrest = B.size() - lead;
     const size_t desc_room = (nrest * sizeof(InflateBlockDesc) + 255) & ~(size_t)255;
-    const int32_t src = stage(comp_room + desc_room + 4 * nrest + 16);
+    const size_t status_room = (4 * nrest + 16 + 255) & ~(size_t)255;
+    tables_room = nrest > (size_t)ctx->cfg.cus * 3 * 64 ? inflate_scratch_bytes(ctx->cfg, (size_t)ctx->cfg.cus * 8 * 64, 2) : 256;   // (the short form needs none)
+    const int32_t src = stage(comp_room + desc_room + status_room + tables_room);
     if (src) return src;
     d_desc = reinterpret_cast<InflateBlockDesc*>(static_cast<uint8_t*>(ctx->d_inflate_stage) + comp_room);
     d_status = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_desc) + desc_room);
     d_first_bad = d_status + nrest;
+    d_tables = reinterpret_cast<uint8_t*>(d_status) + status_room;
     for (size_t i = lead; i < B.size(); ++i) B[i].out_offset -= IBU_HEADER_SIZE;   // relative to the records
     hipError_t pe = hipSuccess;
     if (lead_bytes > IBU_HEADER_SIZE)                      // the records behind the header in the blocks inflated on the host
@@ -433,26 +438,40 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
     return IBU_OK;
   };
 
-  // The whole file to the device through the pinned ring; the blocks inflated where their records belong: a launch per full round of
-  // the decoder (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records) behind the copy that completes them, on streams of
-  // their own, and one for what is left at the end.  (A wave takes its ~46 ms whatever the launch's size, and two launches in flight
-  // were seen to run one after the other: 16 Ki blocks per launch made a file of 36 766 blocks 118 ms instead of 88.)
-  const size_t kLaunchBlocks = (size_t)ctx->cfg.cus * 3 * 64, kLaunchMax = kLaunchBlocks;   // (the form with its tables in LDS: no scratch)
+  // The whole file to the device through the pinned ring; the blocks inflated where their records belong.  A file of at most one
+  // round of the decoder's short form (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records): ONE launch behind the last
+  // copy — a wave takes its ~46 ms whatever the launch's size.  A larger file: launches run one after the other on this device (seen
+  // with 16 Ki- and 32 Ki-block launches on three streams: each waited for the one before), so a launch takes EVERYTHING that has
+  // arrived as soon as the launch before it has finished (the first: once 32 Ki blocks are there) — up to a full grid of the decoder's
+  // other form (tables in scratch, eight waves per CU: 131 072 blocks in ~75 ms) — and the copies run on beside it.
+  const size_t kOneLaunch = (size_t)ctx->cfg.cus * 3 * 64, kFirst = 32768, kGrid = (size_t)ctx->cfg.cus * 8 * 64;
   size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;
   uint32_t last_slot = 0;
+  bool in_flight = false;
   auto launch_ready = [&](bool all) -> int32_t {
+    const bool streamed = nrest > kOneLaunch;
     while (next_blk < nrest && B[lead + next_blk].comp_offset + B[lead + next_blk].comp_len <= up) ++next_blk;
-    while (next_blk - launch_from >= kLaunchBlocks || (all && next_blk > launch_from)) {
-      const size_t cnt = next_blk - launch_from < kLaunchMax ? next_blk - launch_from : kLaunchMax;
-      hipStream_t q = ks[launches++ % kStreams];
+    for (;;) {
+      const size_t left = next_blk - launch_from;
+      if (left == 0 || (!all && (!streamed || left < kFirst))) return IBU_OK;
+      if (in_flight) {                                     // the launch before this one: done? (at the end: wait for it)
+        hipError_t qe = all ? hipEventSynchronize(r.consumed[0]) : hipEventQuery(r.consumed[0]);
+        if (qe == hipErrorNotReady) return IBU_OK;
+        if (qe != hipSuccess) return hip_fail(qe, "hipEventQuery");
+        in_flight = false;
+      }
+      const size_t cnt = left < kGrid ? left : kGrid;
+      hipStream_t q = ks[0];
+      ++launches;
       hipError_t le = hipStreamWaitEvent(q, r.copied[last_slot], 0);
       if (le == hipSuccess)
-        le = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc + launch_from, cnt, d_out, d_status + launch_from, d_first_bad,
-                                   ctx->d_sort_scratch, ctx->sort_scratch_bytes, q);
+        le = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc + launch_from, cnt, d_out, d_status + launch_from, d_first_bad, d_tables,
+                                   tables_room, q, streamed && cnt > kOneLaunch ? 2 : 0);
+      if (le == hipSuccess) le = hipEventRecord(r.consumed[0], q);
       if (le != hipSuccess) return hip_fail(le, "inflate");
+      in_flight = true;
       launch_from += cnt;
     }
-    return IBU_OK;
   };
   for (size_t k = 0; up < size; ++k) {
     const uint32_t sl = (uint32_t)(k % r.slots);

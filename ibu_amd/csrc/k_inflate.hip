@@ -170,19 +170,36 @@ struct LaneInflate {
     const u32 x = __brev((u32)buf) >> 17;                    // the next 15 bits, first bit on top
     constexpr int kOrderLit[15] = {8, 9, 7, 10, 6, 11, 5, 12, 4, 13, 3, 14, 2, 15, 1};
     constexpr int kOrderDist[15] = {5, 4, 6, 3, 7, 2, 8, 1, 9, 10, 11, 12, 13, 14, 15};
+    // the four likeliest lengths without a branch (exactly one length can hit: the selects do not fight), the rest one by one
+    u32 hit_len = 0, hit_idx = 0;
 #pragma unroll
-    for (int i = 0; i < 15; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int len = LIT ? kOrderLit[i] : kOrderDist[i];
       const u32 cn = (c.cnt[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u;
       const u32 fi = (c.first[(len - 1) / 2] >> (16 * ((len - 1) % 2))) & 0xFFFFu;
       const u32 d = (x >> (15 - len)) - fi;
-      if (d < cn) {                                          // (unsigned: a window below `first` wraps to a huge d)
-        buf >>= len;
-        cnt -= len;
-        return (int)(((c.off[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u) + d);
-      }
+      const bool h = d < cn;                                 // (unsigned: a window below `first` wraps to a huge d)
+      hit_len = h ? (u32)len : hit_len;
+      hit_idx = h ? ((c.off[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u) + d : hit_idx;
     }
-    return -1;
+    if (hit_len == 0) {
+#pragma unroll
+      for (int i = 4; i < 15; ++i) {
+        const int len = LIT ? kOrderLit[i] : kOrderDist[i];
+        const u32 cn = (c.cnt[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u;
+        const u32 fi = (c.first[(len - 1) / 2] >> (16 * ((len - 1) % 2))) & 0xFFFFu;
+        const u32 d = (x >> (15 - len)) - fi;
+        if (d < cn) {
+          hit_len = (u32)len;
+          hit_idx = ((c.off[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 1023u) + d;
+          break;
+        }
+      }
+      if (hit_len == 0) return -1;
+    }
+    buf >>= hit_len;
+    cnt -= hit_len;
+    return (int)hit_idx;
   }
 
   // Counts, first codes and first positions (packed into cc) and symbol order of the code with lengths lens[at, at + n).  How complete it is: 0 complete, > 0 codes left
@@ -357,16 +374,17 @@ struct LaneInflate {
     const u32 lim = clen * 8;
     for (;;) {
       u32 parked = 0xFFFFFFFFu;                              // the non-literal symbol this lane waits with
-      for (u32 step = 0; step < park_steps; ++step) {
+      bool bad = false;                                      // checked once per run of literals: a lane that has gone wrong writes no further
+      for (u32 step = 0; step < park_steps; ++step) {        // byte (the position stops) and reads at most 6 x 2 bytes of the padding
         if (parked == 0xFFFFFFFFu) {
-          if (bitpos() > lim) return false;                  // ran past the block's last byte
+          bad |= bitpos() > lim;                             // ran past the block's last byte
           const int k = decode_index<true>(cl);
-          if (k < 0) return false;
-          const u32 sym = lit_symbol((u32)k);
+          bad |= k < 0;
+          const u32 sym = lit_symbol(k < 0 ? 0u : (u32)k);
           if (sym < 256) {
-            if (opos >= isize) return false;
+            bad |= opos >= isize;
             *ring8(opos & (kRing - 1)) = (uint8_t)sym;
-            ++opos;
+            opos += bad ? 0u : 1u;
             flush_if_due();
           } else {
             parked = sym;
@@ -374,6 +392,7 @@ struct LaneInflate {
         }
         if (__ballot(parked == 0xFFFFFFFFu) == 0) break;     // (of the lanes that are in this loop together)
       }
+      if (bad) return false;
       if (parked == 0xFFFFFFFFu) continue;
       if (parked == 256) return true;
       const u32 ls = parked - 257;
@@ -413,7 +432,7 @@ struct LaneInflate {
 // TL: the lanes' symbol orders in LDS (47 KB per wave: three waves per CU — the form for inputs that fit one round of them, where the
 // symbol's round trip to L2 is a quarter of a wave's step) instead of global scratch (six waves per CU: the form for large inputs).
 template <bool TL>
-__global__ void __launch_bounds__(kInfThreads)
+__global__ void __launch_bounds__(kInfThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))   // (two waves to a SIMD: 256 registers each — the scratch form sits right at that)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
                      u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, u32 park_steps, u32 bpw /*blocks per wave: lanes [0, bpw) decode*/, Crc32Pow pw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];

@@ -304,12 +304,86 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   uint8_t head[IBU_HEADER_SIZE + 65536];
   size_t lead = 0, lead_bytes = 0;
   int32_t walk_rc = IBU_OK;
+  bool walked_in_pieces = false;
   ibu_error_detail_t walk_detail{};
   std::atomic<bool> walked{false};
+  // The walk, in pieces side by side.  A block's start cannot be computed without the blocks in front of it, but it can be GUESSED: every
+  // piece but the first looks for the 16 bytes a bgzip header begins with (1f 8b 08 04 .. 06 00 'B' 'C' 02 00) at or behind its first
+  // byte and walks the chain from there to the end of its piece.  The guesses are then checked: piece i's chain must END exactly where
+  // piece i + 1's began — where it does not (the signature inside compressed data, an unusual extra field), or anything at all is off,
+  // the plain walk from byte 0 below decides, errors included.  (184 k blocks of a 6 GB file: 60 ms of page faults in one thread.)
+  auto walk_pieces = [&]() -> bool {
+    const size_t T = 8;
+    if (size < (T << 22)) return false;                    // (small files: the plain walk)
+    struct Piece { size_t begin = 0, end = 0; bool ok = false; uint64_t out = 0; std::vector<ibu_inflate_block_t> blocks; };
+    std::vector<Piece> pc(T);
+    auto run = [&](size_t i) {
+      Piece& P = pc[i];
+      try {
+        const size_t lo = size / T * i, hi = i + 1 == T ? size : size / T * (i + 1);
+        size_t pos = lo;
+        if (i) {                                           // the first header-like spot at or behind lo
+          const uint8_t sig_a[4] = {0x1f, 0x8b, 0x08, 0x04}, sig_b[6] = {0x06, 0x00, 'B', 'C', 0x02, 0x00};
+          for (;; ++pos) {
+            if (pos + 18 > size || pos >= hi) return;      // none in this piece: give up (the plain walk decides)
+            if (memcmp(map + pos, sig_a, 4) == 0 && memcmp(map + pos + 10, sig_b, 6) == 0) break;
+          }
+        }
+        P.begin = pos;
+        std::vector<ibu_inflate_block_t> part(1 << 14);
+        while (pos < hi) {
+          size_t nb = 0, consumed = 0, cap = part.size();
+          uint64_t ob = 0;
+          if (ibu_bgzf_scan(map + pos, size - pos, 1, part.data(), cap, &nb, &consumed, &ob) != IBU_OK || consumed == 0) return;
+          size_t keep = 0, bytes = 0;                      // only the blocks that START inside the piece
+          uint64_t outb = 0;
+          for (; keep < nb; ++keep) {
+            const size_t start = pos + (size_t)part[keep].comp_offset - 18;   // (bgzip's header: 18 bytes; checked again when the pieces are joined)
+            if (start >= hi) break;
+            bytes = (size_t)part[keep].comp_offset + part[keep].comp_len + 8;
+            part[keep].comp_offset += pos;
+            part[keep].out_offset += (int64_t)P.out;
+            outb = (uint64_t)(part[keep].out_offset - (int64_t)P.out) + part[keep].out_len;
+          }
+          P.blocks.insert(P.blocks.end(), part.begin(), part.begin() + (ptrdiff_t)keep);
+          P.out += outb;
+          pos += bytes;
+          if (keep < nb || keep == 0) break;
+        }
+        P.end = pos;
+        P.ok = true;
+      } catch (...) {}
+    };
+    {
+      std::vector<std::thread> th;
+      try { for (size_t i = 1; i < T; ++i) th.emplace_back(run, i); } catch (...) {}
+      const size_t started = th.size();
+      run(0);
+      for (auto& t : th) t.join();
+      if (started != T - 1) return false;
+    }
+    size_t nblocks = 0;
+    for (size_t i = 0; i < T; ++i) {
+      if (!pc[i].ok || (i == 0 && pc[i].begin != 0) || (i && pc[i].begin != pc[i - 1].end)) return false;
+      nblocks += pc[i].blocks.size();
+    }
+    if (pc[T - 1].end != size) return false;
+    B.reserve(nblocks);
+    for (size_t i = 0; i < T; ++i) {
+      for (ibu_inflate_block_t& b : pc[i].blocks) b.out_offset += (int64_t)total;
+      B.insert(B.end(), pc[i].blocks.begin(), pc[i].blocks.end());
+      total += pc[i].out;
+    }
+    return true;
+  };
   auto walk = [&]() -> int32_t {
     try {
-      std::vector<ibu_inflate_block_t> part(1 << 16);
-      for (size_t pos = 0; pos < size;) {                  // 1. the blocks (a cut-off or foreign member: IBU_ERR_NIFFLER from the walk)
+      bool have = false;
+      try { have = walk_pieces(); } catch (...) { have = false; }
+      if (!have) { B.clear(); total = 0; }
+      walked_in_pieces = have;
+      std::vector<ibu_inflate_block_t> part(have ? 1 : 1 << 16);
+      for (size_t pos = have ? size : 0; pos < size;) {    // 1. the blocks (a cut-off or foreign member: IBU_ERR_NIFFLER from the walk)
         size_t nb = 0, consumed = 0;
         uint64_t ob = 0;
         const int32_t rc = ibu_bgzf_scan(map + pos, size - pos, 1, part.data(), part.size(), &nb, &consumed, &ob);
@@ -441,10 +515,11 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   // The whole file to the device through the pinned ring; the blocks inflated where their records belong.  A file of at most one
   // round of the decoder's short form (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records): ONE launch behind the last
   // copy — a wave takes its ~46 ms whatever the launch's size.  A larger file: launches run one after the other on this device (seen
-  // with 16 Ki- and 32 Ki-block launches on three streams: each waited for the one before), so a launch takes EVERYTHING that has
-  // arrived as soon as the launch before it has finished (the first: once 32 Ki blocks are there) — up to a full grid of the decoder's
-  // other form (tables in scratch, eight waves per CU: 131 072 blocks in ~75 ms) — and the copies run on beside it.
-  const size_t kOneLaunch = (size_t)ctx->cfg.cus * 3 * 64, kFirst = 32768, kGrid = (size_t)ctx->cfg.cus * 8 * 64;
+  // with 16 Ki- and 32 Ki-block launches on three streams: each waited for the one before), and a launch costs its waves' 45-75 ms
+  // whatever its size: so the first launch waits for a FULL grid of the decoder's other form (tables in scratch, eight waves per CU:
+  // 131 072 blocks in ~75 ms), every later one takes everything that has arrived once the launch before it has finished, and the
+  // copies run on beside them.  (First launch at 32 Ki blocks: 5e8 records in three launches 0.228 s; at a full grid: two, 0.19.)
+  const size_t kOneLaunch = (size_t)ctx->cfg.cus * 3 * 64, kGrid = (size_t)ctx->cfg.cus * 8 * 64, kFirst = kGrid;
   size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;
   uint32_t last_slot = 0;
   bool in_flight = false;
@@ -512,8 +587,8 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   if (first_bad != none) return fail(err_niffler("a BGZF block does not inflate to its announced length and CRC-32"));
   lap(3);
   if (trace_sort())
-    fprintf(stderr, "ibu load_bgzf: %zu blocks, %zu launches; ms: staging %.2f, copies (the walk beside them) and early launches %.2f, walk's results to the "
-            "device + last launches %.2f, waiting for them %.2f\n", B.size(), launches, 1e3 * t_ph[0], 1e3 * t_ph[1], 1e3 * t_ph[2], 1e3 * t_ph[3]);
+    fprintf(stderr, "ibu load_bgzf: %zu blocks (walked %s), %zu launches; ms: staging %.2f, copies (the walk beside them) and early launches %.2f, walk's results to the "
+            "device + last launches %.2f, waiting for them %.2f\n", B.size(), walked_in_pieces ? "in 8 pieces side by side" : "in one go", launches, 1e3 * t_ph[0], 1e3 * t_ph[1], 1e3 * t_ph[2], 1e3 * t_ph[3]);
   *n = num;
   if (stats) { stats->records = num; stats->seconds_total = now_s() - t0; stats->numa_node = feed_place(ctx).node; stats->ring_node = ctx->ring.node; }
   return IBU_OK;

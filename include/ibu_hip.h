@@ -492,7 +492,7 @@ int32_t ibu_barcode_counts(ibu_ctx_t* ctx, const void* d_sorted_records, size_t 
  * 1 not a valid deflate stream of these sizes / 2 CRC-32 mismatch; *d_first_bad (device; the caller sets it to 0xFFFFFFFF) = the
  * lowest bad block.  A block writes only its own out_len bytes.  Asynchronous on `stream`; the lanes' tables live in the context's
  * sort scratch (calls of more than 49 152 blocks; one such call per context at a time, as for the sort).  One LANE per block: 64
- * blocks per wave; BGZF level 1 of 16/12 records: 52 GB/s of output for 1e8 records, 96 GB/s for 3e8 (the 16 host inflate threads
+ * blocks per wave; BGZF level 1 of 16/12 records: 53 GB/s of output for 1e8 records, 100 GB/s for 3e8 (the 16 host inflate threads
  * of the same box: 9.6).
  * A wave takes ~46 ms for its 64 blocks whatever the call's size, so a call wants tens of thousands of blocks:
  * ibu_load_bgzf_to_device (above) is the library's own use of it; the streams keep the host inflate (a ring slot holds too few). */
@@ -575,8 +575,8 @@ int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_conf
                            ibu_stream_stats_t* stats);
 /* The same for a BGZF (bgzip) file of the records, INFLATED ON THE DEVICE: the compressed bytes cross the link (half of them for a
  * 16/12 records file) and every block inflates straight to its place among the records (ibu_inflate_blocks_device below; the block
- * headers are walked on a thread of their own while the copies run; 1e8 records: 0.075 s against 0.25 s through the Reader, 5e8:
- * 0.24 s against 1.36 s — the plain file: 0.22 s).  The result is what ibu_load_to_device gives for the gunzipped file — the
+ * headers are walked on a thread of their own while the copies run; 1e8 records: 0.074 s against 0.25 s through the Reader, 5e8:
+ * 0.23 s against 1.36 s — the plain file: 0.22 s).  The result is what ibu_load_to_device gives for the gunzipped file — the
  * reference's load_to_vec does not decompress (reader.rs:510-535 reads the file as it is; its Reader does, through niffler,
  * :345-352): this is the bulk form of that Reader path.  Header too short: IBU_ERR_IO; invalid header: as ibu_header_validate;
  * (length - 32) % 24 != 0: IBU_ERR_INVALID_MAP_SIZE; a member that is not a BGZF block, a file that ends inside one, a block that

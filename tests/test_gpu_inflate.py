@@ -279,3 +279,36 @@ def test_load_bgzf_to_device_refuses_what_the_reader_refuses(ia, ctx, oracle, tm
     h, dptr, got_n, _ = load(good)                                          # and the file itself loads
     assert got_n == n
     ctx.free(dptr)
+
+
+@pytest.mark.parametrize("kind", ["records", "decoys"])
+def test_load_bgzf_to_device_walks_a_large_file_in_pieces(ia, oracle, tmp_path, capfd, kind):
+    """From 32 MiB of BGZF on, the block headers are walked in eight pieces side by side, every piece from a GUESSED block start (the
+    bytes a bgzip header begins with); the guesses are checked against the chain in front of them and anything off sends the call back
+    to the plain walk.  "decoys": stored blocks (level 0) of records whose bytes spell that header thousands of times — every piece's
+    first guess is wrong, the result must not be."""
+    import os
+    n = 2_000_003
+    recs = oracle.generate(SEED + 77, 0, n, 32, 32)
+    level = 1
+    if kind == "decoys":
+        level = 0                                                   # stored: the records' bytes stand in the file as they are
+        raw = recs.view(np.uint8).reshape(n, 24)
+        decoy = np.frombuffer(bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00, 0x11, 0x22, 0, 0, 0, 0, 0, 0]), np.uint8)
+        raw[::97] = decoy
+    plain = struct.pack("<IIIIQ8s", 0x21554249, 2, 32, 32, 0, b"\0" * 8) + recs.tobytes()
+    p = tmp_path / "big.ibu.gz"
+    p.write_bytes(_bgzf(plain, level=level))
+    assert p.stat().st_size >= 32 << 20
+    c = ia.Context(0)
+    try:
+        capfd.readouterr()
+        h, dptr, got_n, st = c.load_bgzf_to_device(str(p), ring={"slots": 3, "slot_records": 1 << 19, "feeder_threads": 4})
+        err = capfd.readouterr().err
+        assert got_n == n and (h.bc_len, h.umi_len) == (32, 32)
+        assert ia.DeviceBuffer.wrap(c, dptr, 24 * n).download().tobytes() == recs.tobytes()
+        c.free(dptr)
+        if os.environ.get("IBU_TRACE_SORT", "") not in ("", "0"):
+            assert ("walked in 8 pieces side by side" if kind == "records" else "walked in one go") in err, err
+    finally:
+        c.close()

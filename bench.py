@@ -571,7 +571,22 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
             calls.append(time.perf_counter() - t0)
             if not (got_n == n and ctxs[0].reduce(dptr, n) == want):
                 raise LegCheckFailed("e2e: load_bgzf_to_device returned other records than were written")
+        # ... and all the way to the ASCII columns (what the two Reader legs above deliver): the load, then K2 over the loaded records
+        t0 = time.perf_counter()
+        _, dptr, got_n, _ = ctxs[0].load_bgzf_to_device(bg, ring=ring, d_records=dst, cap_records=n)
+        ctxs[0].decode_ascii(dptr, n, bc_len, umi_len, s_bc, s_umi, s_idx)
+        ctxs[0].synchronize()
+        dt_cols = time.perf_counter() - t0
+        back = ctxs[0].alloc(24 * n)
+        ctxs[0].encode_ascii(s_bc, s_umi, s_idx, n, bc_len, umi_len, back)
+        ctxs[0].codec_status()
+        ok = ctxs[0].reduce(back, n) == want
+        back.free()
         dst.free()
+        if not ok:
+            raise LegCheckFailed("e2e: BGZF load -> DECODE does not reproduce the records written")
+        out["bgzf_load_to_device_then_decode"] = rate(dt_cols, None, totals_equal_resident_copy=True,
+                                                      what="ibu_load_bgzf_to_device + ibu_decode_ascii: BGZF file -> ASCII columns on the device")
         out["bgzf_load_to_device_device_inflate"] = rate(min(calls), st, calls_seconds=[round(c_, 4) for c_ in calls], bgzf_bytes=bg_bytes,
                                                          bytes_over_the_link=bg_bytes, totals_equal_resident_copy=True,
                                                          call="ibu_load_bgzf_to_device(ctx, path, ring, &header, &d_records, cap, &n, &stats): "

@@ -255,6 +255,9 @@ extern "C" {
     pub fn ibu_load_bgzf_to_device(ctx: *mut ibu_ctx_t, path: *const c_char, cfg: *const ibu_ring_config_t,
                               header: *mut ibu_header_t, d_records: *mut *mut c_void, cap_records: usize,
                               n: *mut usize, stats: *mut ibu_stream_stats_t) -> i32;
+    pub fn ibu_load_bgzf_shard_to_device(ctx: *mut ibu_ctx_t, path: *const c_char, cfg: *const ibu_ring_config_t, shard: usize, n_shards: usize,
+                                         header: *mut ibu_header_t, d_records: *mut *mut c_void, cap_records: usize, n: *mut usize,
+                                         first_record: *mut u64, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_writer_write_batch_device(w: *mut ibu_writer_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,
                                          d_records: *const c_void, n: usize, stats: *mut ibu_stream_stats_t) -> i32;
     pub fn ibu_writer_write_batch_device_on(w: *mut ibu_writer_t, ctx: *mut ibu_ctx_t, cfg: *const ibu_ring_config_t,

@@ -621,6 +621,15 @@ pub mod device {
             check(unsafe { ffi::ibu_load_bgzf_to_device(self.raw, c.as_ptr(), std::ptr::null(), &mut h, &mut p, 0, &mut n, std::ptr::null_mut()) })?;
             Ok((h, p, n))
         }
+        /// Shard `shard` of `n_shards` of a BGZF file's records (the split of `process_parallel`): `(header, device pointer, n, first record)`.
+        pub fn load_bgzf_shard_to_device<P: AsRef<Path>>(&self, path: P, shard: usize, n_shards: usize) -> Result<(Header, *mut c_void, usize, u64)> {
+            let c = CString::new(path.as_ref().to_string_lossy().as_bytes()).unwrap();
+            let (mut h, mut p, mut n, mut first) = (bytemuck::Zeroable::zeroed(), std::ptr::null_mut(), 0usize, 0u64);
+            check(unsafe {
+                ffi::ibu_load_bgzf_shard_to_device(self.raw, c.as_ptr(), std::ptr::null(), shard, n_shards, &mut h, &mut p, 0, &mut n, &mut first, std::ptr::null_mut())
+            })?;
+            Ok((h, p, n, first))
+        }
     }
     /// `ibu_stream_t`: iterate to pull one device-resident batch at a time.  An `Err` item is the source's error
     /// (`TruncatedRecord`, `Io`, `Niffler` ...), delivered after the batches in front of it; iteration ends after it.

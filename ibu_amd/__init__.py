@@ -965,6 +965,15 @@ class Context:
                                            C.byref(n), C.byref(st)))
         return Header._wrap(h), p.value, n.value, st
 
+    def load_bgzf_shard_to_device(self, path, shard, n_shards, ring=None, d_records=None, cap_records=0):
+        """ibu_load_bgzf_shard_to_device: shard `shard` of `n_shards` of the file's records (the split of process_parallel)
+        -> (Header, device pointer, n, first record's number, stats)."""
+        h, n, first, st = CHeader(), C.c_size_t(), C.c_uint64(), CStreamStats()
+        p = C.c_void_p(_dptr(d_records).value if d_records is not None else None)
+        _check(lib.ibu_load_bgzf_shard_to_device(self._c, str(path).encode(), _ring(ring), shard, n_shards, C.byref(h), C.byref(p), cap_records,
+                                                 C.byref(n), C.byref(first), C.byref(st)))
+        return Header._wrap(h), p.value, n.value, first.value, st
+
     def free(self, ptr):
         _check(lib.ibu_device_free(self._c, ptr))
 

@@ -170,6 +170,7 @@ SIGNATURES = {
     "ibu_records_expand": (i32, [vp, P(CKeyPlan), vp, sz, vp, vp]),
     "ibu_load_to_device": (i32, [vp, C.c_char_p, P(CRingConfig), P(CHeader), P(vp), sz, P(sz), P(CStreamStats)]),
     "ibu_load_bgzf_to_device": (i32, [vp, C.c_char_p, P(CRingConfig), P(CHeader), P(vp), sz, P(sz), P(CStreamStats)]),
+    "ibu_load_bgzf_shard_to_device": (i32, [vp, C.c_char_p, P(CRingConfig), sz, sz, P(CHeader), P(vp), sz, P(sz), P(C.c_uint64), P(CStreamStats)]),
     "ibu_writer_write_batch_device": (i32, [vp, vp, P(CRingConfig), vp, sz, P(CStreamStats)]),
     "ibu_writer_write_batch_device_on": (i32, [vp, vp, P(CRingConfig), vp, sz, vp, P(CStreamStats)]),
     "ibu_mmap_process_device": (i32, [vp, vp, P(CRingConfig), i32, sz, sz, vp, P(CStreamStats)]),

@@ -275,7 +275,16 @@ extern "C" int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ib
 // to its announced length and CRC — is IBU_ERR_NIFFLER, as from the Reader.
 extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, ibu_header_t* header,
                                            void** d_records, size_t cap_records, size_t* n, ibu_stream_stats_t* stats) {
+  return ibu_load_bgzf_shard_to_device(ctx, path, cfg, 0, 1, header, d_records, cap_records, n, nullptr, stats);
+}
+// Shard `shard` of `n_shards` of the file's records (the split of process_parallel, mmap.rs:297-307): the blocks that lie wholly inside
+// the shard's bytes are copied and inflated on the device, the (at most two) blocks that straddle its ends are inflated on the host and
+// their part copied — as the blocks holding the header always are.  Every device of a node loads its own range of the same file.
+extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, size_t shard, size_t n_shards,
+                                                 ibu_header_t* header, void** d_records, size_t cap_records, size_t* n, uint64_t* first_record,
+                                                 ibu_stream_stats_t* stats) {
   if (!ctx || !path || !header || !d_records || !n) return err_arg("NULL argument");
+  if (n_shards == 0 || shard >= n_shards) return err_arg("shard out of range");
   IBU_HIP(hipSetDevice(ctx->device));
   RunOnNode on_node(feed_place(ctx));
   const double t0 = now_s();
@@ -457,9 +466,9 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
     ctx->inflate_stage_bytes = need;
     return IBU_OK;
   };
-  const size_t comp_room = (size + kInflatePad + 255) & ~(size_t)255;
-  // (room for the descriptors of a file of ordinary 64 KiB blocks right away: no second allocation in the usual case)
-  int32_t rc = stage(comp_room + 40 * (size / 8192 + 64));
+  // (one shard of one: room for the whole file and the descriptors of a file of ordinary 64 KiB blocks right away, so that the copies
+  // can start at once and nothing is allocated a second time in the usual case)
+  int32_t rc = n_shards == 1 ? stage(((size + kInflatePad + 255) & ~(size_t)255) + 40 * (size / 8192 + 64)) : IBU_OK;
   if (!rc) rc = ensure_sort_scratch(ctx, 16);
   if (!rc) rc = ring_ensure(ctx, cfg, false);
   hipError_t e = hipSuccess;
@@ -470,8 +479,10 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   Ring& r = ctx->ring;
   lap(0);
 
-  // What the walk's result allows, once it is there: the destination, the descriptors on the device
-  size_t num = 0, nrest = 0;
+  // What the walk's result allows, once it is there: the shard's range, the destination, the descriptors on the device
+  size_t num = 0, nrest = 0, dev_first = 0;                // device blocks: B[dev_first, dev_first + nrest)
+  size_t cbeg = 0, cend = size;                            // the file bytes that go to the device (one shard of one: all, so that the copies
+  uint64_t rec_first = 0;                                  // can start before the walk is done)
   uint8_t* d_out = nullptr;
   InflateBlockDesc* d_desc = nullptr;
   uint32_t *d_status = nullptr, *d_first_bad = nullptr;
@@ -482,16 +493,58 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
   auto prepare = [&]() -> int32_t {
     if (walker.joinable()) walker.join();
     if (walk_rc) { tls_error() = walk_detail; return walk_rc; }
-    num = (size_t)((total - IBU_HEADER_SIZE) / IBU_RECORD_SIZE);
+    const size_t num_all = (size_t)((total - IBU_HEADER_SIZE) / IBU_RECORD_SIZE);
+    size_t rs = 0, re = 0;
+    int32_t prc = ibu_shard_range(num_all, n_shards, shard, &rs, &re);
+    if (prc) return prc;
+    num = re - rs;
+    rec_first = rs;
+    const uint64_t lo = IBU_HEADER_SIZE + (uint64_t)IBU_RECORD_SIZE * rs, hi = IBU_HEADER_SIZE + (uint64_t)IBU_RECORD_SIZE * re;   // the shard's bytes
     if (*d_records == nullptr) {
       const int32_t arc = ctx_alloc(ctx, num * IBU_RECORD_SIZE, d_records);
       if (arc) return arc;
       owned = true;
     } else if (num > cap_records) {
-      return err_arg("device buffer too small for the file");
+      return err_arg("device buffer too small for the shard");
     }
     d_out = static_cast<uint8_t*>(*d_records);
-    nrest = B.size() - lead;
+    // the blocks wholly inside [lo, hi): the device's; what straddles an end (and the header's blocks): inflated here
+    size_t dev_end = lead;
+    dev_first = lead;
+    while (dev_first < B.size() && (uint64_t)B[dev_first].out_offset < lo) ++dev_first;
+    dev_end = dev_first;
+    while (dev_end < B.size() && (uint64_t)B[dev_end].out_offset + B[dev_end].out_len <= hi) ++dev_end;
+    nrest = dev_end - dev_first;
+    hipError_t pe = hipSuccess;
+    auto put = [&](const uint8_t* bytes, uint64_t at, uint64_t len) {   // bytes [at, at + len) of the stream, as far as they are the shard's
+      const uint64_t a = at < lo ? lo : at, z = at + len > hi ? hi : at + len;
+      if (a < z && pe == hipSuccess) pe = hipMemcpy(d_out + (a - lo), bytes + (a - at), z - a, hipMemcpyHostToDevice);
+    };
+    put(head, 0, lead_bytes);                              // the records behind the header in the blocks inflated for it
+    {
+      pgz::RawInflater raw;
+      std::vector<uint8_t> in, outb(65536);
+      const size_t edge[2] = {dev_first > lead ? dev_first - 1 : (size_t)-1, dev_end < B.size() ? dev_end : (size_t)-1};
+      for (int k = 0; k < 2 && num; ++k) {
+        const size_t i = edge[k];
+        if (i == (size_t)-1 || i < lead || (k == 1 && edge[0] == i)) continue;
+        const ibu_inflate_block_t& b = B[i];
+        if (!b.out_len || (uint64_t)b.out_offset >= hi || (uint64_t)b.out_offset + b.out_len <= lo) continue;
+        in.assign(map + b.comp_offset, map + b.comp_offset + b.comp_len);
+        in.resize(b.comp_len + 512, 0);
+        uint32_t crc = 0;
+        const int ie = raw.inflate(in.data(), b.comp_len, outb.data(), b.out_len, &crc);
+        if (ie == ENOMEM) return err_io(ENOMEM, "inflate");
+        if (ie || crc != b.crc32) return err_niffler("a BGZF block does not inflate to its announced length and CRC-32");
+        put(outb.data(), (uint64_t)b.out_offset, b.out_len);
+      }
+    }
+    if (pe != hipSuccess) return hip_fail(pe, "hipMemcpy");
+    if (n_shards > 1) {                                    // only the device blocks' bytes cross the link
+      cbeg = nrest ? (size_t)B[dev_first].comp_offset : 0;
+      cend = nrest ? (size_t)(B[dev_end - 1].comp_offset + B[dev_end - 1].comp_len) : 0;
+    }
+    const size_t comp_room = (cend - cbeg + kInflatePad + 255) & ~(size_t)255;
     const size_t desc_room = (nrest * sizeof(InflateBlockDesc) + 255) & ~(size_t)255;
     const size_t status_room = (4 * nrest + 16 + 255) & ~(size_t)255;
     tables_room = nrest > (size_t)ctx->cfg.cus * 3 * 64 ? inflate_scratch_bytes(ctx->cfg, (size_t)ctx->cfg.cus * 8 * 64, 2) : 256;   // (the short form needs none)
@@ -501,31 +554,31 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
     d_status = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_desc) + desc_room);
     d_first_bad = d_status + nrest;
     d_tables = reinterpret_cast<uint8_t*>(d_status) + status_room;
-    for (size_t i = lead; i < B.size(); ++i) B[i].out_offset -= IBU_HEADER_SIZE;   // relative to the records
-    hipError_t pe = hipSuccess;
-    if (lead_bytes > IBU_HEADER_SIZE)                      // the records behind the header in the blocks inflated on the host
-      pe = hipMemcpy(d_out, head + IBU_HEADER_SIZE, lead_bytes - IBU_HEADER_SIZE, hipMemcpyHostToDevice);
-    if (pe == hipSuccess && nrest) pe = hipMemcpy(d_desc, B.data() + lead, nrest * sizeof(InflateBlockDesc), hipMemcpyHostToDevice);
+    for (size_t i = dev_first; i < dev_end; ++i) {         // relative to the shard's records / to the bytes on the device
+      B[i].out_offset -= (int64_t)lo;
+      B[i].comp_offset -= cbeg;
+    }
+    if (nrest) pe = hipMemcpy(d_desc, B.data() + dev_first, nrest * sizeof(InflateBlockDesc), hipMemcpyHostToDevice);
     if (pe == hipSuccess) pe = hipMemcpy(d_first_bad, &none, 4, hipMemcpyHostToDevice);
     if (pe != hipSuccess) return hip_fail(pe, "hipMemcpy");
     prepared = true;
     return IBU_OK;
   };
 
-  // The whole file to the device through the pinned ring; the blocks inflated where their records belong.  A file of at most one
-  // round of the decoder's short form (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records): ONE launch behind the last
-  // copy — a wave takes its ~46 ms whatever the launch's size.  A larger file: launches run one after the other on this device (seen
-  // with 16 Ki- and 32 Ki-block launches on three streams: each waited for the one before), and a launch costs its waves' 45-75 ms
-  // whatever its size: so the first launch waits for a FULL grid of the decoder's other form (tables in scratch, eight waves per CU:
-  // 131 072 blocks in ~75 ms), every later one takes everything that has arrived once the launch before it has finished, and the
-  // copies run on beside them.  (First launch at 32 Ki blocks: 5e8 records in three launches 0.228 s; at a full grid: two, 0.19.)
+  // The file's bytes to the device through the pinned ring; the blocks inflated where their records belong.  At most one round of the
+  // decoder's short form (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records): ONE launch behind the last copy — a wave
+  // takes its ~46 ms whatever the launch's size.  More: launches run one after the other on this device (seen with 16 Ki- and 32 Ki-block
+  // launches on three streams: each waited for the one before), and a launch costs its waves' 45-75 ms whatever its size: so the first
+  // launch waits for a FULL grid of the decoder's other form (tables in scratch, eight waves per CU: 131 072 blocks in ~75 ms), every
+  // later one takes everything that has arrived once the launch before it has finished, and the copies run on beside them.
+  // (First launch at 32 Ki blocks: 5e8 records in three launches 0.228 s; at a full grid: two, 0.228 s as well.)
   const size_t kOneLaunch = (size_t)ctx->cfg.cus * 3 * 64, kGrid = (size_t)ctx->cfg.cus * 8 * 64, kFirst = kGrid;
-  size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;
+  size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;   // up: file bytes [cbeg, up) are on their way
   uint32_t last_slot = 0;
   bool in_flight = false;
   auto launch_ready = [&](bool all) -> int32_t {
     const bool streamed = nrest > kOneLaunch;
-    while (next_blk < nrest && B[lead + next_blk].comp_offset + B[lead + next_blk].comp_len <= up) ++next_blk;
+    while (next_blk < nrest && cbeg + B[dev_first + next_blk].comp_offset + B[dev_first + next_blk].comp_len <= up) ++next_blk;
     for (;;) {
       const size_t left = next_blk - launch_from;
       if (left == 0 || (!all && (!streamed || left < kFirst))) return IBU_OK;
@@ -548,15 +601,20 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
       launch_from += cnt;
     }
   };
-  for (size_t k = 0; up < size; ++k) {
+  if (n_shards > 1) {                                      // a shard's bytes are known only after the walk
+    rc = prepare();
+    if (rc) return fail(rc);
+  }
+  up = cbeg;
+  for (size_t k = 0; up < cend; ++k) {
     const uint32_t sl = (uint32_t)(k % r.slots);
-    const size_t len = size - up < r.slot_bytes ? size - up : r.slot_bytes;
+    const size_t len = cend - up < r.slot_bytes ? cend - up : r.slot_bytes;
     e = hipEventSynchronize(r.copied[sl]);
     if (e != hipSuccess) return fail(hip_fail(e, "hipEventSynchronize"));
     uint8_t* dst = r.pinned[sl];
     const uint8_t* src = map + up;
     parallel_bytes(len, feeder_threads(cfg), [&](size_t off, size_t l) { memcpy(dst + off, src + off, l); return 0; });
-    e = hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_inflate_stage) + up, dst, len, hipMemcpyHostToDevice, ctx->copy_stream);
+    e = hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_inflate_stage) + (up - cbeg), dst, len, hipMemcpyHostToDevice, ctx->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(r.copied[sl], ctx->copy_stream);
     if (e != hipSuccess) return fail(hip_fail(e, "H2D"));
     up += len;
@@ -590,6 +648,7 @@ extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, con
     fprintf(stderr, "ibu load_bgzf: %zu blocks (walked %s), %zu launches; ms: staging %.2f, copies (the walk beside them) and early launches %.2f, walk's results to the "
             "device + last launches %.2f, waiting for them %.2f\n", B.size(), walked_in_pieces ? "in 8 pieces side by side" : "in one go", launches, 1e3 * t_ph[0], 1e3 * t_ph[1], 1e3 * t_ph[2], 1e3 * t_ph[3]);
   *n = num;
+  if (first_record) *first_record = rec_first;
   if (stats) { stats->records = num; stats->seconds_total = now_s() - t0; stats->numa_node = feed_place(ctx).node; stats->ring_node = ctx->ring.node; }
   return IBU_OK;
 }

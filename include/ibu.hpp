@@ -436,6 +436,13 @@ class Context {
     check(ibu_load_bgzf_to_device(c_, path.c_str(), ring, &h, &p, 0, &n, stats));
     return {h, p, n};
   }
+  // ... shard `shard` of `n_shards` of its records (the split of process_parallel) -> (header, device pointer, n, first record's number)
+  std::tuple<Header, void*, size_t, uint64_t> load_bgzf_shard_to_device(const std::string& path, size_t shard, size_t n_shards,
+                                                                        const RingConfig* ring = nullptr, StreamStats* stats = nullptr) {
+    Header h; void* p = nullptr; size_t n = 0; uint64_t first = 0;
+    check(ibu_load_bgzf_shard_to_device(c_, path.c_str(), ring, shard, n_shards, &h, &p, 0, &n, &first, stats));
+    return {h, p, n, first};
+  }
   void* alloc(size_t bytes) { void* p = nullptr; check(ibu_device_alloc(c_, bytes, &p)); return p; }
   // for arrays that stay resident: up to `tries` candidates, the one that streams fastest is kept (ibu_device_alloc_probed)
   void* alloc_probed(size_t bytes, uint32_t tries, AllocProbe* report = nullptr) {

@@ -584,6 +584,13 @@ int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_conf
  * the file size + 36 bytes per block of device memory as staging until it is destroyed (it grows only). */
 int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, ibu_header_t* header, void** d_records,
                                 size_t cap_records, size_t* n, ibu_stream_stats_t* stats);
+/* ... and shard `shard` of `n_shards` of its records — the contiguous range ibu_shard_range gives (the split of process_parallel,
+ * mmap.rs:297-307), *first_record (nullable) = its first record's number: every device of a node loads its own range of the same file,
+ * only that range's blocks cross its link (the at most two blocks that straddle the range's ends are inflated on the host, like the
+ * blocks that hold the header).  ibu_load_bgzf_to_device is shard 0 of 1. */
+int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, size_t shard, size_t n_shards,
+                                      ibu_header_t* header, void** d_records, size_t cap_records, size_t* n, uint64_t* first_record,
+                                      ibu_stream_stats_t* stats);
 
 /* Device analogue of Writer::write_batch (writer.rs:315-351): n device-resident AoS records
  * are copied back through the ring and appended to the writer (same buffered/direct rules).

@@ -291,6 +291,19 @@ TEST(bgzf_file_inflates_on_the_device) {
   ctx().download(static_cast<void*>(got.data()), dptr, n * 24);
   ctx().free(dptr);
   CHECK(got == recs);
+  {  // two shards of the same file: the ranges of process_parallel, each loaded on its own
+    size_t at = 0;
+    for (size_t sh = 0; sh < 2; ++sh) {
+      auto [hs, ps, ns, first] = ctx().load_bgzf_shard_to_device(d + "/a.bgz", sh, 2, &ring);
+      CHECK(hs == Header(16, 12)); CHECK_EQ(first, (uint64_t)at); CHECK_EQ(ns, sh ? recs.size() - recs.size() / 2 : recs.size() / 2);
+      std::vector<Record> part(ns);
+      ctx().download(static_cast<void*>(part.data()), ps, ns * 24);
+      ctx().free(ps);
+      CHECK(std::equal(part.begin(), part.end(), recs.begin() + (ptrdiff_t)at));
+      at += ns;
+    }
+    CHECK_EQ(at, recs.size());
+  }
   CHECK_THROWS(Niffler, ctx().load_bgzf_to_device(d + "/cut.bgz"), {});     // ends inside a block
   CHECK_THROWS(Niffler, ctx().load_bgzf_to_device(d + "/a.gz"), {});        // an ordinary gzip member: the Reader's business
   CHECK_THROWS(Niffler, ctx().load_bgzf_to_device(d + "/plain.ibu"), {});   // not compressed

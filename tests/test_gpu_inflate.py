@@ -312,3 +312,40 @@ def test_load_bgzf_to_device_walks_a_large_file_in_pieces(ia, oracle, tmp_path, 
             assert ("walked in 8 pieces side by side" if kind == "records" else "walked in one go") in err, err
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n,block,level", [(1_000_003, 0xFF00, 1), (100_003, 4093, 6), (777, 20, 1), (5, 0xFF00, 1), (0, 0xFF00, 1)])
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_load_bgzf_shards_are_the_ranges_of_process_parallel(ia, ctx, oracle, tmp_path, n, block, level, n_shards):
+    """Every device of a node loads its own range of the same BGZF file: shard i of k is records [i * (n / k), (i + 1) * (n / k)) with
+    the remainder in the last (mmap.rs:297-307); the blocks wholly inside a range inflate on the device, the two that straddle its
+    ends (and the header's) on the host; nothing is written outside the shard's buffer."""
+    recs = oracle.generate(SEED + 5 * n, 0, n, 16, 12)
+    plain = struct.pack("<IIIIQ8s", 0x21554249, 2, 16, 12, 0, b"\0" * 8) + recs.tobytes()
+    p = tmp_path / "s.ibu.gz"
+    p.write_bytes(_bgzf(plain, block=block, level=level))
+    ring = {"slots": 3, "slot_records": 30_000, "feeder_threads": 3}
+    per = n // n_shards
+    got_all = b""
+    for i in range(n_shards):
+        want_first, want_n = i * per, (per if i + 1 < n_shards else n - per * (n_shards - 1))
+        buf = ctx.alloc(24 * want_n + 128)
+        buf.upload(np.full(24 * want_n + 128, 0x5A, np.uint8))
+        h, q, got_n, first, st = ctx.load_bgzf_shard_to_device(str(p), i, n_shards, ring=ring, d_records=buf.ptr + 64, cap_records=want_n)
+        assert (got_n, first) == (want_n, want_first) and (h.bc_len, h.umi_len) == (16, 12), (i, got_n, first)
+        whole = buf.download(np.uint8)
+        assert (whole[:64] == 0x5A).all() and (whole[64 + 24 * want_n:] == 0x5A).all()
+        assert st.bytes_h2d <= p.stat().st_size
+        got_all += whole[64:64 + 24 * want_n].tobytes()
+        buf.free()
+    assert got_all == recs.tobytes()
+    with pytest.raises(ia.IbuError) as e:
+        ctx.load_bgzf_shard_to_device(str(p), n_shards, n_shards)
+    assert e.value.kind == "InvalidArg"
+    # the library allocates a shard's buffer as well
+    h, q, got_n, first, _ = ctx.load_bgzf_shard_to_device(str(p), n_shards - 1, n_shards, ring=ring)
+    assert first == per * (n_shards - 1) and got_n == n - first
+    if got_n:
+        assert ia.DeviceBuffer.wrap(ctx, q, 24 * got_n).download().tobytes() == recs[first:].tobytes()
+    if q:
+        ctx.free(q)

@@ -152,6 +152,16 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     if (ctx->loser_free.joinable()) ctx->loser_free.join();   // (documented: setting the option waits for candidates still being freed)
     return IBU_OK;
   }
+  if (strcmp(key, "release_staging") == 0) {             // one-shot: the device staging ibu_load_bgzf_*_to_device keeps (the compressed file's size) goes back now
+    if (value != 1) return err_arg("release_staging must be 1");
+    IBU_HIP(hipSetDevice(ctx->device));
+    for (hipStream_t q : ctx->inflate_streams)
+      if (q) IBU_HIP(hipStreamSynchronize(q));
+    if (ctx->d_inflate_stage) IBU_HIP(hipFree(ctx->d_inflate_stage));
+    ctx->d_inflate_stage = nullptr;
+    ctx->inflate_stage_bytes = 0;
+    return IBU_OK;
+  }
   if (strcmp(key, "sort_pull_streams") == 0) {
     if (value != 0 && value != 1) return err_arg("sort_pull_streams must be 0 or 1");
     ctx->force_pull_streams = (int)value;

@@ -298,6 +298,8 @@ int32_t ibu_device_count(int32_t* n);
  *                           context's stream per probed allocation.  It never touches the reduce
  *                           accumulator (reset / reduce ... / fetch may span allocations).  IBU_TRACE_SORT=1 prints what was
  *                           drawn and chosen.
+ *   "release_staging"    1  one-shot: frees the device staging ibu_load_bgzf_to_device / _shard_ keep between calls (the size of the
+ *                           compressed bytes of the largest load so far); the next load allocates it again.
  *   "numa"           0 | 1  1 = auto (default): the context looks up the NUMA node its device hangs off (PCI bus id ->
  *                           /sys/bus/pci/devices/<bdf>/numa_node -> that node's cpulist) and keeps its host side there: the pinned
  *                           ring is allocated under a preferred-node policy, the threads that fill it (the stream producer and its
@@ -581,7 +583,9 @@ int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_conf
  * :345-352): this is the bulk form of that Reader path.  Header too short: IBU_ERR_IO; invalid header: as ibu_header_validate;
  * (length - 32) % 24 != 0: IBU_ERR_INVALID_MAP_SIZE; a member that is not a BGZF block, a file that ends inside one, a block that
  * does not inflate to its announced length and CRC-32: IBU_ERR_NIFFLER (an ordinary gzip file: use the Reader).  The context keeps
- * the file size + 36 bytes per block of device memory as staging until it is destroyed (it grows only). */
+ * the file size + 36 bytes per block of device memory as staging until it is destroyed (it grows only; option "release_staging" frees
+ * it).  A file larger than the device's memory is loaded range by range with the _shard_ form below (every call walks the block
+ * headers again: 10 ms per 6 GB). */
 int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, ibu_header_t* header, void** d_records,
                                 size_t cap_records, size_t* n, ibu_stream_stats_t* stats);
 /* ... and shard `shard` of `n_shards` of its records — the contiguous range ibu_shard_range gives (the split of process_parallel,

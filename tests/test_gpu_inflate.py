@@ -279,6 +279,12 @@ def test_load_bgzf_to_device_refuses_what_the_reader_refuses(ia, ctx, oracle, tm
     h, dptr, got_n, _ = load(good)                                          # and the file itself loads
     assert got_n == n
     ctx.free(dptr)
+    ctx.set_option("release_staging", 1)                                    # the staging goes back; the next load allocates it again
+    with pytest.raises(ia.IbuError):
+        ctx.set_option("release_staging", 0)
+    h, dptr, got_n, _ = load(good)
+    assert got_n == n and ia.DeviceBuffer.wrap(ctx, dptr, 24 * n).download().tobytes() == recs.tobytes()
+    ctx.free(dptr)
 
 
 @pytest.mark.parametrize("kind", ["records", "decoys"])

@@ -4,14 +4,12 @@ accepted exactly when the host decoder accepts it (length, end of the deflate st
 nothing is written outside a block's own output range.  The reference reads such files as multi-member gzip through niffler
 (src/io/reader.rs:345-352); the oracle for the bytes is zlib (the record-stream parity of the whole path: test_gpu_streams.py,
 test_gpu_pull_stream.py)."""
-import ctypes as C
 import struct
 import zlib
 
 import numpy as np
 import pytest
 
-from tests.bgzf import bgzf_compress
 
 pytestmark = pytest.mark.gpu
 

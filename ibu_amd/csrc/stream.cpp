@@ -267,10 +267,10 @@ extern "C" int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ib
 // load_to_vec of a BGZF file, inflated on the device (k_inflate.hip): the COMPRESSED bytes cross the link
 // ------------------------------------------------------------------------------------------
 // The result is what ibu_load_to_device gives for the gunzipped file (load_to_vec, reader.rs:510-535: header read and validated,
-// (length - 32) % 24 != 0 -> InvalidMapSize).  The file is mapped, its block headers are walked (ibu_bgzf_scan: no inflating), the
-// blocks that hold the 32 header bytes are inflated on the host, the whole file goes through the pinned ring into a device buffer and
-// the device inflates every block straight to its place in the records: a launch per ~16 Ki blocks behind the copy that completes
-// them, on streams of their own, so the copies run on while the first launches work.  A block is accepted exactly as the host
+// (length - 32) % 24 != 0 -> InvalidMapSize).  The file is mapped; a thread walks its block headers (ibu_bgzf_scan: no inflating; large
+// files in eight pieces side by side) and inflates the blocks that hold the 32 header bytes on the host, while the calling thread
+// already sends the file through the pinned ring into a device buffer; the device then inflates every block straight to its place in
+// the records (the launch policy: further down).  A block is accepted exactly as the host
 // decoder accepts it; anything else — a member that is not a BGZF block, a file that ends inside one, a block that does not inflate
 // to its announced length and CRC — is IBU_ERR_NIFFLER, as from the Reader.
 extern "C" int32_t ibu_load_bgzf_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_config_t* cfg, ibu_header_t* header,

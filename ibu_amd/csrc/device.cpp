@@ -109,6 +109,7 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   for (hipStream_t q : ctx->inflate_streams)
     if (q) (void)hipStreamDestroy(q);
   if (ctx->d_inflate_stage) (void)hipFree(ctx->d_inflate_stage);
+  if (ctx->h_inflate_marks) (void)hipHostFree(ctx->h_inflate_marks);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -150,6 +151,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     if (value < 0 || value > IBU_ALLOC_PROBE_MAX) return err_arg("alloc_probe_tries must be 0 (auto) .. 16");
     ctx->cfg.alloc_probe_tries = (int)value;
     if (ctx->loser_free.joinable()) ctx->loser_free.join();   // (documented: setting the option waits for candidates still being freed)
+    return IBU_OK;
+  }
+  if (strcmp(key, "inflate_one_launch") == 0) {          // a test knob: the block count from which a BGZF load launches its decoder ahead of the copies
+    if (value < 0 || value > (int64_t)ctx->cfg.cus * 3 * 64) return err_arg("inflate_one_launch must be 0 (default) .. one round of the decoder's short form");
+    ctx->inflate_one_launch = (size_t)value;
     return IBU_OK;
   }
   if (strcmp(key, "release_staging") == 0) {             // one-shot: the device staging ibu_load_bgzf_*_to_device keeps (the compressed file's size) goes back now

@@ -434,7 +434,8 @@ struct LaneInflate {
 template <bool TL>
 __global__ void __launch_bounds__(kInfThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))   // (two waves to a SIMD: 256 registers each — the scratch form sits right at that)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
-                     u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, u32 park_steps, u32 bpw /*blocks per wave: lanes [0, bpw) decode*/, Crc32Pow pw) {
+                     u32* __restrict__ status, u32* __restrict__ first_bad, InfTables* __restrict__ tables /*[gridDim.x]*/, u32 park_steps, u32 bpw /*blocks per wave: lanes [0, bpw) decode*/,
+                     const unsigned long long* ready /*nullable: compressed bytes that have arrived so far*/, unsigned long long ready_total, Crc32Pow pw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   InfLds<TL>* w = reinterpret_cast<InfLds<TL>*>(lds_raw);
   const u32 lane = threadIdx.x;
@@ -458,7 +459,34 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
     bd.coff = 0; bd.ooff = 0; bd.clen = 0; bd.isize = 0; bd.crc = 0; bd.reserved = 0;
     if (live) bd = blocks[b];
     u32 st = 0;
-    if (live) {
+    bool arrived = true;
+    if (ready) {
+      // The launch may run AHEAD of the copies that bring its input (ibu_load_bgzf_*_to_device, large files): `*ready` = how many
+      // compressed bytes are on the device so far, written by the copy stream behind every piece.  A wave waits — all 64 lanes for the
+      // last of their blocks, plus the 4 KiB a lane may read (not use) past its block, so that no line is cached before it is final —
+      // looking at a word in PINNED HOST memory that the host's thread writes when it has seen a piece's copy complete (a word in device
+      // memory written by the copy stream never changed for a running kernel: ordinary device memory is coherent with the copy engine
+      // at kernel boundaries only, and in fine-grained device memory the 8-byte copies themselves waited for the kernel to end), asleep
+      // 14 ... 220 us between looks (each one a read over the link), and for ~4 s at most: whatever happens to the host, every wave ends
+      // (status 3: its input never came).
+      unsigned long long need = live ? bd.coff + bd.clen + 4096ull : 0ull;
+      if (need > ready_total) need = ready_total;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const u32 lo = (u32)__shfl_xor((int)(u32)need, m), hi = (u32)__shfl_xor((int)(u32)(need >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        need = o > need ? o : need;
+      }
+      u32 naps = 0, nap = 4;                               // (a nap: 127 x 64 cycles, ~3.4 us)
+      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+        if (naps > 1200000u) { arrived = false; break; }   // ~4 s asleep
+        for (u32 k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(127);
+        naps += nap;
+        if (nap < 64) nap *= 2;                            // back off to a look every ~220 us: 2048 waves looking every 27 us halved the copies' rate
+      }
+      if (!arrived && live) st = 3;
+    }
+    if (live && arrived) {
       LaneInflate<TL> s;
       s.w = w;
       s.t = TL ? reinterpret_cast<InfTables*>(lds_raw + ((sizeof(InfLds<TL>) + 15) & ~(size_t)15)) : tables + blockIdx.x;
@@ -537,7 +565,8 @@ size_t inflate_scratch_bytes(const LaunchCfg& cfg, size_t nblocks, int form) {
   return form != 2 && inflate_tables_in_lds(cfg, nblocks) ? 16 : sizeof(InfTables) * (size_t)inflate_grid(cfg, nblocks);
 }
 hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
-                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st, int form) {
+                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st, int form,
+                                 const uint64_t* d_ready, uint64_t ready_total) {
   (void)hipGetLastError();
   if (nblocks == 0) return hipSuccess;
   if (nblocks >= (1ull << 31) || scratch_bytes < inflate_scratch_bytes(cfg, nblocks, form)) return hipErrorInvalidValue;
@@ -565,10 +594,12 @@ hipError_t launch_inflate_blocks(const LaunchCfg& cfg, const void* d_comp, const
   const u32 grid = inflate_grid(cfg, nblocks);
   if (tl)
     hipLaunchKernelGGL(ibu_k_inflate_blocks<true>, dim3(grid), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
-                       (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), 6u, inflate_bpw(cfg, nblocks), pw);
+                       (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), 6u, inflate_bpw(cfg, nblocks),
+                       reinterpret_cast<const unsigned long long*>(d_ready), (unsigned long long)ready_total, pw);
   else
     hipLaunchKernelGGL(ibu_k_inflate_blocks<false>, dim3(grid), dim3(kInfThreads), lds, st, (const uint8_t*)d_comp, d_blocks, (u32)nblocks,
-                       (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), 6u, inflate_bpw(cfg, nblocks), pw);
+                       (uint8_t*)d_out_base, d_status, d_first_bad, static_cast<InfTables*>(scratch), 6u, inflate_bpw(cfg, nblocks),
+                       reinterpret_cast<const unsigned long long*>(d_ready), (unsigned long long)ready_total, pw);
   return hipGetLastError();
 }
 

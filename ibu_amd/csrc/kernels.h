@@ -131,6 +131,8 @@ constexpr size_t kInflatePad = 2048;
 // form 0: by size; 2: the lanes' tables in scratch whatever the size (k_inflate.hip)
 size_t inflate_scratch_bytes(const LaunchCfg&, size_t nblocks, int form = 0);   // the lanes' tables (44 KB per workgroup of the grid; 16 bytes for the LDS form)
 hipError_t launch_inflate_blocks(const LaunchCfg&, const void* d_comp, const InflateBlockDesc* d_blocks, size_t nblocks, void* d_out_base,
-                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st, int form = 0);
+                                 uint32_t* d_status, uint32_t* d_first_bad, void* scratch, size_t scratch_bytes, hipStream_t st, int form = 0,
+                                 const uint64_t* d_ready = nullptr /*the launch runs ahead of its input: compressed bytes arrived so far (status 3: never came)*/,
+                                 uint64_t ready_total = 0);
 
 }  // namespace ibu

@@ -441,8 +441,13 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
   bool owned = false;
   constexpr int kStreams = 3;
   hipStream_t* ks = ctx->inflate_streams;
+  uint64_t* d_ready = nullptr;                             // (a launch that runs ahead of its input: see below)
+  bool ahead = false;
+  constexpr size_t kInflateMarks = 8;
   auto fail = [&](int32_t code) {
     if (walker.joinable()) walker.join();
+    if (ahead && d_ready)                                  // its waves must not wait for bytes that will not come
+      __atomic_store_n(d_ready, ~0ull, __ATOMIC_RELEASE);
     (void)hipStreamSynchronize(ctx->copy_stream);
     for (int k = 0; k < kStreams; ++k)
       if (ks[k]) (void)hipStreamSynchronize(ks[k]);
@@ -547,19 +552,26 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
     const size_t comp_room = (cend - cbeg + kInflatePad + 255) & ~(size_t)255;
     const size_t desc_room = (nrest * sizeof(InflateBlockDesc) + 255) & ~(size_t)255;
     const size_t status_room = (4 * nrest + 16 + 255) & ~(size_t)255;
-    tables_room = nrest > (size_t)ctx->cfg.cus * 3 * 64 ? inflate_scratch_bytes(ctx->cfg, (size_t)ctx->cfg.cus * 8 * 64, 2) : 256;   // (the short form needs none)
-    const int32_t src = stage(comp_room + desc_room + status_room + tables_room);
+    tables_room = nrest > (ctx->inflate_one_launch ? ctx->inflate_one_launch : (size_t)ctx->cfg.cus * 3 * 64)
+                      ? inflate_scratch_bytes(ctx->cfg, nrest, 2) : 256;   // (the short form needs none)
+    const int32_t src = stage(comp_room + desc_room + status_room + 256 + tables_room);
     if (src) return src;
     d_desc = reinterpret_cast<InflateBlockDesc*>(static_cast<uint8_t*>(ctx->d_inflate_stage) + comp_room);
     d_status = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_desc) + desc_room);
     d_first_bad = d_status + nrest;
-    d_tables = reinterpret_cast<uint8_t*>(d_status) + status_room;
+    d_tables = reinterpret_cast<uint8_t*>(d_status) + status_room + 256;
+    if (!ctx->h_inflate_marks) {
+      hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_inflate_marks), kInflateMarks * sizeof(uint64_t), hipHostMallocDefault);
+      if (he != hipSuccess) { ctx->h_inflate_marks = nullptr; return hip_fail(he, "hipHostMalloc"); }
+    }
+    d_ready = ctx->h_inflate_marks;                        // (pinned host memory: the device reads it over the link)
     for (size_t i = dev_first; i < dev_end; ++i) {         // relative to the shard's records / to the bytes on the device
       B[i].out_offset -= (int64_t)lo;
       B[i].comp_offset -= cbeg;
     }
     if (nrest) pe = hipMemcpy(d_desc, B.data() + dev_first, nrest * sizeof(InflateBlockDesc), hipMemcpyHostToDevice);
     if (pe == hipSuccess) pe = hipMemcpy(d_first_bad, &none, 4, hipMemcpyHostToDevice);
+    __atomic_store_n(d_ready, 0ull, __ATOMIC_RELEASE);
     if (pe != hipSuccess) return hip_fail(pe, "hipMemcpy");
     prepared = true;
     return IBU_OK;
@@ -567,39 +579,38 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
 
   // The file's bytes to the device through the pinned ring; the blocks inflated where their records belong.  At most one round of the
   // decoder's short form (three waves of 64 blocks per CU: 49 152 blocks, 3 GB of records): ONE launch behind the last copy — a wave
-  // takes its ~46 ms whatever the launch's size.  More: launches run one after the other on this device (seen with 16 Ki- and 32 Ki-block
-  // launches on three streams: each waited for the one before), and a launch costs its waves' 45-75 ms whatever its size: so the first
-  // launch waits for a FULL grid of the decoder's other form (tables in scratch, eight waves per CU: 131 072 blocks in ~75 ms), every
-  // later one takes everything that has arrived once the launch before it has finished, and the copies run on beside them.
-  // (First launch at 32 Ki blocks: 5e8 records in three launches 0.228 s; at a full grid: two, 0.228 s as well.)
-  const size_t kOneLaunch = (size_t)ctx->cfg.cus * 3 * 64, kGrid = (size_t)ctx->cfg.cus * 8 * 64, kFirst = kGrid;
-  size_t up = 0, next_blk = 0, launch_from = 0, launches = 0;   // up: file bytes [cbeg, up) are on their way
+  // takes its ~45 ms whatever the launch's size, so the call ends that long after its last byte has arrived either way.  More: ONE launch
+  // as well, but AHEAD of the copies — as soon as the walk's results are on the device — in the decoder's other form (tables in scratch,
+  // eight waves per CU): its waves take the blocks in file order and each waits until the copy stream has said that its blocks are there
+  // (`d_ready`, written behind every piece; k_inflate.hip), so the device inflates at the rate the bytes come in.  (Launches behind the
+  // copies instead — of 16 Ki or 32 Ki blocks on three streams, or of everything that had arrived once the one before was done — ran one
+  // after the other, each for its waves' 45-75 ms: 5e8 records 0.343 / 0.306 / 0.228 s.)
+  const size_t kOneLaunch = ctx->inflate_one_launch ? ctx->inflate_one_launch : (size_t)ctx->cfg.cus * 3 * 64;
+  size_t up = 0, launches = 0;                             // up: file bytes [cbeg, up) are on their way
   uint32_t last_slot = 0;
-  bool in_flight = false;
+  std::vector<size_t> piece_end;                           // piece k of the copies ends at this file byte
+  auto publish = [&](size_t done_upto) {                   // the host has SEEN the copies up to this file byte complete: the launch may use them
+    if (ahead) __atomic_store_n(d_ready, (uint64_t)(done_upto - cbeg), __ATOMIC_RELEASE);
+  };
   auto launch_ready = [&](bool all) -> int32_t {
-    const bool streamed = nrest > kOneLaunch;
-    while (next_blk < nrest && cbeg + B[dev_first + next_blk].comp_offset + B[dev_first + next_blk].comp_len <= up) ++next_blk;
-    for (;;) {
-      const size_t left = next_blk - launch_from;
-      if (left == 0 || (!all && (!streamed || left < kFirst))) return IBU_OK;
-      if (in_flight) {                                     // the launch before this one: done? (at the end: wait for it)
-        hipError_t qe = all ? hipEventSynchronize(r.consumed[0]) : hipEventQuery(r.consumed[0]);
-        if (qe == hipErrorNotReady) return IBU_OK;
-        if (qe != hipSuccess) return hip_fail(qe, "hipEventQuery");
-        in_flight = false;
-      }
-      const size_t cnt = left < kGrid ? left : kGrid;
-      hipStream_t q = ks[0];
-      ++launches;
-      hipError_t le = hipStreamWaitEvent(q, r.copied[last_slot], 0);
+    if (launches || nrest == 0) return IBU_OK;
+    const bool streamed = nrest > kOneLaunch && d_ready;
+    if (!streamed && !all) return IBU_OK;
+    hipStream_t q = ks[0];
+    hipError_t le = hipSuccess;
+    if (streamed) {
+      ahead = true;
+      le = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc, nrest, d_out, d_status, d_first_bad, d_tables, tables_room, q, 2, d_ready,
+                                   cend - cbeg);
+    } else {
+      le = hipStreamWaitEvent(q, r.copied[last_slot], 0);
       if (le == hipSuccess)
-        le = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc + launch_from, cnt, d_out, d_status + launch_from, d_first_bad, d_tables,
-                                   tables_room, q, streamed && cnt > kOneLaunch ? 2 : 0);
-      if (le == hipSuccess) le = hipEventRecord(r.consumed[0], q);
-      if (le != hipSuccess) return hip_fail(le, "inflate");
-      in_flight = true;
-      launch_from += cnt;
+        le = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc, nrest, d_out, d_status, d_first_bad, d_tables, tables_room, q,
+                                   nrest > (size_t)ctx->cfg.cus * 3 * 64 ? 2 : 0);
     }
+    if (le != hipSuccess) return hip_fail(le, "inflate");
+    ++launches;
+    return IBU_OK;
   };
   if (n_shards > 1) {                                      // a shard's bytes are known only after the walk
     rc = prepare();
@@ -611,6 +622,7 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
     const size_t len = cend - up < r.slot_bytes ? cend - up : r.slot_bytes;
     e = hipEventSynchronize(r.copied[sl]);
     if (e != hipSuccess) return fail(hip_fail(e, "hipEventSynchronize"));
+    if (k >= r.slots) publish(piece_end[k - r.slots]);     // (this slot's previous piece has landed: so has everything in front of it)
     uint8_t* dst = r.pinned[sl];
     const uint8_t* src = map + up;
     parallel_bytes(len, feeder_threads(cfg), [&](size_t off, size_t l) { memcpy(dst + off, src + off, l); return 0; });
@@ -620,6 +632,7 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
     up += len;
     last_slot = sl;
     if (stats) { stats->bytes_h2d += len; stats->batches += 1; }
+    try { piece_end.push_back(up); } catch (...) { return fail(caught_io("ibu_load_bgzf_to_device")); }
     if (!prepared && walked.load(std::memory_order_acquire)) {
       rc = prepare();
       if (rc) return fail(rc);
@@ -639,10 +652,19 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
   lap(2);
   uint32_t first_bad = none;
   e = hipStreamSynchronize(ctx->copy_stream);
+  if (e == hipSuccess) publish(cend);                      // every byte is there
   for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamSynchronize(ks[k]);
   if (e == hipSuccess) e = hipMemcpy(&first_bad, d_first_bad, 4, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
-  if (first_bad != none) return fail(err_niffler("a BGZF block does not inflate to its announced length and CRC-32"));
+  if (first_bad != none) {
+    if (trace_sort()) {
+      uint32_t st1 = 0;
+      (void)hipMemcpy(&st1, d_status + first_bad, 4, hipMemcpyDeviceToHost);
+      fprintf(stderr, "ibu load_bgzf: block %u of the device's %zu refused (status %u: 1 not a deflate stream of these sizes, 2 CRC-32, 3 its bytes never arrived)\n",
+              first_bad, nrest, st1);
+    }
+    return fail(err_niffler("a BGZF block does not inflate to its announced length and CRC-32"));
+  }
   lap(3);
   if (trace_sort())
     fprintf(stderr, "ibu load_bgzf: %zu blocks (walked %s), %zu launches; ms: staging %.2f, copies (the walk beside them) and early launches %.2f, walk's results to the "

@@ -298,6 +298,9 @@ int32_t ibu_device_count(int32_t* n);
  *                           context's stream per probed allocation.  It never touches the reduce
  *                           accumulator (reset / reduce ... / fetch may span allocations).  IBU_TRACE_SORT=1 prints what was
  *                           drawn and chosen.
+ *   "inflate_one_launch" 0..49152  a test knob: ibu_load_bgzf_*_to_device launches its decoder AHEAD of the copies (the waves wait for
+ *                           their blocks to arrive) for files of more blocks than this; 0 (default) = one round of the decoder's short
+ *                           form, 49 152 blocks: smaller files get one launch behind the last copy.
  *   "release_staging"    1  one-shot: frees the device staging ibu_load_bgzf_to_device / _shard_ keep between calls (the size of the
  *                           compressed bytes of the largest load so far); the next load allocates it again.
  *   "numa"           0 | 1  1 = auto (default): the context looks up the NUMA node its device hangs off (PCI bus id ->
@@ -577,8 +580,9 @@ int32_t ibu_load_to_device(ibu_ctx_t* ctx, const char* path, const ibu_ring_conf
                            ibu_stream_stats_t* stats);
 /* The same for a BGZF (bgzip) file of the records, INFLATED ON THE DEVICE: the compressed bytes cross the link (half of them for a
  * 16/12 records file) and every block inflates straight to its place among the records (ibu_inflate_blocks_device below; the block
- * headers are walked on a thread of their own while the copies run; 1e8 records: 0.074 s against 0.25 s through the Reader, 5e8:
- * 0.23 s against 1.36 s — the plain file: 0.22 s).  The result is what ibu_load_to_device gives for the gunzipped file — the
+ * headers are walked on a thread of their own while the copies run; 1e8 records: 0.074 s against 0.25 s through the Reader; 1e9:
+ * 0.31 s — the PLAIN file of the same records: 0.44 s; large files get one launch of the decoder ahead of the copies whose waves wait
+ * for their blocks to arrive).  The result is what ibu_load_to_device gives for the gunzipped file — the
  * reference's load_to_vec does not decompress (reader.rs:510-535 reads the file as it is; its Reader does, through niffler,
  * :345-352): this is the bulk form of that Reader path.  Header too short: IBU_ERR_IO; invalid header: as ibu_header_validate;
  * (length - 32) % 24 != 0: IBU_ERR_INVALID_MAP_SIZE; a member that is not a BGZF block, a file that ends inside one, a block that

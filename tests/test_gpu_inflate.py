@@ -324,3 +324,43 @@ def test_load_bgzf_shards_are_the_ranges_of_process_parallel(ia, ctx, oracle, tm
         assert ia.DeviceBuffer.wrap(ctx, q, 24 * got_n).download().tobytes() == recs[first:].tobytes()
     if q:
         ctx.free(q)
+
+
+@pytest.mark.parametrize("n,block", [(200_003, 0xFF00), (50_001, 4093), (3_000, 20)])
+def test_load_bgzf_with_the_decoder_launched_ahead_of_the_copies(ia, oracle, tmp_path, n, block):
+    """Large files get ONE launch of the decoder ahead of the copies: its waves wait (asleep, reading past the caches, for a bounded
+    time) until the copy stream has said that their blocks have arrived.  Forced here for small files (option "inflate_one_launch"),
+    with ring slots much smaller than the file so that the launch really is ahead; whole file and shards; a corrupt block still
+    fails the call."""
+    recs = oracle.generate(SEED + 3 * n, 0, n, 16, 12)
+    plain = struct.pack("<IIIIQ8s", 0x21554249, 2, 16, 12, 0, b"\0" * 8) + recs.tobytes()
+    good = _bgzf(plain, block=block, level=1)
+    p = tmp_path / "ahead.ibu.gz"
+    p.write_bytes(good)
+    c = ia.Context(0)
+    try:
+        c.set_option("inflate_one_launch", 8)
+        ring = {"slots": 3, "slot_records": 8_000, "feeder_threads": 2}
+        for rep in range(2):                                           # (the second call: staging and marks reused)
+            h, dptr, got_n, st = c.load_bgzf_to_device(str(p), ring=ring)
+            assert got_n == n and ia.DeviceBuffer.wrap(c, dptr, 24 * n).download().tobytes() == recs.tobytes()
+            c.free(dptr)
+        got = b""
+        for i in range(3):
+            h, q, k, first, _ = c.load_bgzf_shard_to_device(str(p), i, 3, ring=ring)
+            got += ia.DeviceBuffer.wrap(c, q, 24 * k).download().tobytes() if k else b""
+            if q:
+                c.free(q)
+        assert got == recs.tobytes()
+        blocks, _, _, _ = ia.bgzf_scan(good)
+        b = blocks[len(blocks) * 2 // 3]
+        bad = bytearray(good)
+        struct.pack_into("<I", bad, b.comp_offset + b.comp_len, b.crc32 ^ 4)
+        p.write_bytes(bytes(bad))
+        with pytest.raises(ia.IbuError) as e:
+            c.load_bgzf_to_device(str(p), ring=ring)
+        assert e.value.kind == "Niffler"
+        with pytest.raises(ia.IbuError):
+            c.set_option("inflate_one_launch", 1 << 20)
+    finally:
+        c.close()

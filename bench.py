@@ -52,6 +52,9 @@ def parse(argv=None):
     p.add_argument("--no-sort-leg", action="store_true", help="skip the sort + per-barcode aggregation leg on one GPU")
     p.add_argument("--no-e2e-leg", action="store_true", help="skip the file -> result (PCIe-inclusive) leg on one GPU")
     p.add_argument("--e2e-records", type=float, default=1e8, help="records of the e2e leg's file (24 B each)")
+    p.add_argument("--bgzf-large-records", type=float, default=5e8,
+                   help="records of the e2e leg's LARGE BGZF file (ibu_load_bgzf_to_device with its decoder launched ahead of the copies, beside "
+                        "the plain file of the same records; 12 + 6 GB in the e2e directory, ~20 s); 0 = skip")
     p.add_argument("--e2e-dir", default=None, help="where the e2e leg writes its files (default: the system temp dir)")
     p.add_argument("--bc-len", type=int, default=16)
     p.add_argument("--umi-len", type=int, default=12)
@@ -602,6 +605,54 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
     return out
 
 
+def bgzf_large_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir):
+    """ibu_load_bgzf_to_device on a file large enough for its launch AHEAD of the copies (more than 49 152 blocks): a file of `n` synthetic
+    records written from device memory, compressed to BGZF blocks on the host cores (tools/gzutil.py: what `bgzip -l 1` writes), loaded
+    with the compressed bytes crossing the link and every block inflated on the device — beside the PLAIN file of the same records through
+    ibu_load_to_device.  Both results checked with K4 against the resident records.  Outside the timed region, never part of `value`."""
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gzutil import bgzf_parallel
+    n = int(n)
+    ring = {"slots": 4, "slot_records": 4 << 20, "feeder_threads": 8}
+    d = ctx.alloc(24 * n)
+    path = os.path.join(tmpdir or tempfile.gettempdir(), f"ibu_bench_big_{os.getpid()}.ibu")
+    bg = path + ".bgzf"
+    out = {"workload": f"{n:.3g} records bc_len={bc_len} umi_len={umi_len}: a {24 * n / 1e9:.1f} GB file and its BGZF form (level 1) in {tmpdir or tempfile.gettempdir()}"}
+    try:
+        ctx.generate(seed, 0, n, bc_len, umi_len, d)
+        want = ctx.reduce(d, n)
+        w = ia.Writer.from_path(path, ia.Header(bc_len, umi_len))
+        w.write_batch_device(ctx, d, n, ring=ring)
+        w.finish()
+        w.close()
+        t0 = time.perf_counter()
+        bg_bytes = bgzf_parallel(path, bg, level=1, workers=max(2, min(16, usable_cores())))
+        out["host_compress_seconds"] = round(time.perf_counter() - t0, 2)
+        out["bgzf_bytes"] = bg_bytes
+        for name, call in (("load_bgzf_to_device", lambda: ctx.load_bgzf_to_device(bg, ring=ring, d_records=d, cap_records=n)),
+                           ("load_to_device_plain_file", lambda: ctx.load_to_device(path, ring=ring, d_records=d, cap_records=n))):
+            ts = []
+            for _ in range(3):
+                ctx.generate(1, 0, min(n, 1 << 20), bc_len, umi_len, d)   # (the destination's head holds something else before every load)
+                t0 = time.perf_counter()
+                _, dptr, got_n, _ = call()
+                ts.append(time.perf_counter() - t0)
+                if not (got_n == n and ctx.reduce(dptr, n) == want):
+                    raise LegCheckFailed(f"bgzf_large: {name} returned other records than were written")
+            out[name] = {"seconds": min(ts), "calls_seconds": [round(t, 4) for t in ts], "records_per_s": n / min(ts), "GBps_of_records": 24 * n / min(ts) / 1e9,
+                         "totals_equal_resident_copy": True}
+        out["load_bgzf_to_device"]["GBps_over_the_link"] = bg_bytes / out["load_bgzf_to_device"]["seconds"] / 1e9
+        out["bgzf_over_plain"] = out["load_to_device_plain_file"]["seconds"] / out["load_bgzf_to_device"]["seconds"]
+    finally:
+        d.free()
+        for f in (path, bg):
+            if os.path.exists(f):
+                os.unlink(f)
+    return out
+
+
 def sort_contexts_rehearsal(ia, n, bc_len, umi_len, seed, k=8, rounds=3):
     """ibu_sort_records_contexts — the sort over several GPUs behind ONE call of the C ABI — REHEARSED with k contexts that all
     sit on this one GPU (the call allows it): the k shards' kernels share the device and the exchange is a device-local copy, so
@@ -902,6 +953,12 @@ def main():
             e2e = e2e_leg(ctx, ibu_amd, args.e2e_records, bc_len, umi_len, args.seed, args.e2e_dir, torch=torch)
         except Exception as e:  # the headline stands on its own: a failure here is reported, not fatal
             e2e = {"error": f"{type(e).__name__}: {e}"}
+        if args.bgzf_large_records > 0:
+            try:
+                torch.cuda.empty_cache()
+                e2e["bgzf_large"] = bgzf_large_leg(ctx, ibu_amd, args.bgzf_large_records, bc_len, umi_len, args.seed, args.e2e_dir)
+            except Exception as e:
+                e2e["bgzf_large"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         bpr = 24 + bc_len + umi_len + 8
@@ -967,7 +1024,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
         failed = [k for k, leg_ in (("sort_leg", sort_leg), ("e2e", e2e)) if isinstance(leg_, dict) and
-                  (str(leg_.get("error", "")).startswith("LegCheckFailed") or str(leg_.get("contexts_rehearsal", {}).get("error", "")).startswith("LegCheckFailed"))]
+                  (str(leg_.get("error", "")).startswith("LegCheckFailed") or str(leg_.get("contexts_rehearsal", {}).get("error", "")).startswith("LegCheckFailed")
+                   or str(leg_.get("bgzf_large", {}).get("error", "")).startswith("LegCheckFailed"))]
         if failed:                                   # the line is out; a WRONG result in a side leg still fails the run
             exit_code = 3
             print(f"bench.py: correctness check failed in {failed}", file=sys.stderr)

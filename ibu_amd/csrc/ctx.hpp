@@ -66,6 +66,7 @@ struct ibu_ctx {
   void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
   void* d_inflate_stage = nullptr; // ibu_load_bgzf_to_device: the compressed file, the block descriptors and their status words on the device (grows only)
   size_t inflate_stage_bytes = 0;
+  uint32_t load_piece_delay_ms = 0; // option "load_piece_delay_ms" (a test knob): ibu_load_bgzf_*_to_device sleeps that long before every piece it copies — a slow disk
   size_t inflate_one_launch = 0;   // option "inflate_one_launch": files of more blocks than this get the launch that runs ahead of the copies (0: one round of the short form)
   uint64_t* h_inflate_marks = nullptr; // pinned: [0] = the compressed bytes whose copies the host has seen complete — what a launch that runs ahead of its input looks at
   hipStream_t inflate_streams[3] = {nullptr, nullptr, nullptr};   // ... and the streams its launches go out on (created on first use, kept)

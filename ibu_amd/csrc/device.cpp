@@ -158,6 +158,11 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->inflate_one_launch = (size_t)value;
     return IBU_OK;
   }
+  if (strcmp(key, "load_piece_delay_ms") == 0) {         // a test knob: a slow source for the BGZF loads
+    if (value < 0 || value > 10000) return err_arg("load_piece_delay_ms must be 0 .. 10000");
+    ctx->load_piece_delay_ms = (uint32_t)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "release_staging") == 0) {             // one-shot: the device staging ibu_load_bgzf_*_to_device keeps (the compressed file's size) goes back now
     if (value != 1) return err_arg("release_staging must be 1");
     IBU_HIP(hipSetDevice(ctx->device));

@@ -468,7 +468,7 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
       // memory written by the copy stream never changed for a running kernel: ordinary device memory is coherent with the copy engine
       // at kernel boundaries only, and in fine-grained device memory the 8-byte copies themselves waited for the kernel to end), asleep
       // 14 ... 220 us between looks (each one a read over the link), and for ~4 s at most: whatever happens to the host, every wave ends
-      // (status 3: its input never came).
+      // (status 3: its input never came — the caller inflates what such waves left once everything has arrived: a slow disk is no error).
       unsigned long long need = live ? bd.coff + bd.clen + 4096ull : 0ull;
       if (need > ready_total) need = ready_total;
 #pragma unroll

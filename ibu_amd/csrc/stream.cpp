@@ -620,6 +620,7 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
   for (size_t k = 0; up < cend; ++k) {
     const uint32_t sl = (uint32_t)(k % r.slots);
     const size_t len = cend - up < r.slot_bytes ? cend - up : r.slot_bytes;
+    if (ctx->load_piece_delay_ms) std::this_thread::sleep_for(std::chrono::milliseconds(ctx->load_piece_delay_ms));
     e = hipEventSynchronize(r.copied[sl]);
     if (e != hipSuccess) return fail(hip_fail(e, "hipEventSynchronize"));
     if (k >= r.slots) publish(piece_end[k - r.slots]);     // (this slot's previous piece has landed: so has everything in front of it)
@@ -656,6 +657,36 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
   for (int k = 0; k < kStreams && e == hipSuccess; ++k) e = hipStreamSynchronize(ks[k]);
   if (e == hipSuccess) e = hipMemcpy(&first_bad, d_first_bad, 4, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
+  if (first_bad != none && ahead) {
+    // Waves of the launch that ran ahead give up after ~4 s without their blocks (status 3): a slow source, not a bad file.  Everything
+    // is on the device now: those blocks — from the first of them on — go through a plain launch.  A block that was REFUSED stays refused.
+    try {
+      std::vector<uint32_t> stv(nrest);
+      e = hipMemcpy(stv.data(), d_status, 4 * nrest, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy"));
+      size_t late = nrest;
+      bool refused = false;
+      for (size_t i = 0; i < nrest; ++i) {
+        if (stv[i] == 3) { if (late == nrest) late = i; }
+        else if (stv[i]) refused = true;
+      }
+      if (!refused && late < nrest) {
+        if (trace_sort()) fprintf(stderr, "ibu load_bgzf: the bytes of blocks %zu ... came later than the waves waited: inflating them now\n", late);
+        e = hipMemcpy(d_first_bad, &none, 4, hipMemcpyHostToDevice);
+        ahead = false;                                      // (fail() has nothing to release any more)
+        for (size_t at = late; at < nrest && e == hipSuccess;) {
+          const size_t cnt = nrest - at < (size_t)ctx->cfg.cus * 8 * 64 ? nrest - at : (size_t)ctx->cfg.cus * 8 * 64;
+          e = launch_inflate_blocks(ctx->cfg, ctx->d_inflate_stage, d_desc + at, cnt, d_out, d_status + at, d_first_bad, d_tables, tables_room, ks[0],
+                                    cnt > (size_t)ctx->cfg.cus * 3 * 64 ? 2 : 0);
+          at += cnt;
+          ++launches;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ks[0]);
+        if (e == hipSuccess) e = hipMemcpy(&first_bad, d_first_bad, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(hip_fail(e, "ibu_load_bgzf_to_device"));
+      }
+    } catch (...) { return fail(caught_io("ibu_load_bgzf_to_device")); }
+  }
   if (first_bad != none) {
     if (trace_sort()) {
       uint32_t st1 = 0;

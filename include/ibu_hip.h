@@ -301,6 +301,8 @@ int32_t ibu_device_count(int32_t* n);
  *   "inflate_one_launch" 0..49152  a test knob: ibu_load_bgzf_*_to_device launches its decoder AHEAD of the copies (the waves wait for
  *                           their blocks to arrive) for files of more blocks than this; 0 (default) = one round of the decoder's short
  *                           form, 49 152 blocks: smaller files get one launch behind the last copy.
+ *   "load_piece_delay_ms" 0..10000  a test knob: the BGZF loads sleep that long before every piece they copy (a slow source: the waves
+ *                           of a launch that runs ahead give up after ~4 s, and what they left is inflated once everything has arrived).
  *   "release_staging"    1  one-shot: frees the device staging ibu_load_bgzf_to_device / _shard_ keep between calls (the size of the
  *                           compressed bytes of the largest load so far); the next load allocates it again.
  *   "numa"           0 | 1  1 = auto (default): the context looks up the NUMA node its device hangs off (PCI bus id ->

@@ -364,3 +364,28 @@ def test_load_bgzf_with_the_decoder_launched_ahead_of_the_copies(ia, oracle, tmp
             c.set_option("inflate_one_launch", 1 << 20)
     finally:
         c.close()
+
+
+def test_load_bgzf_from_a_source_slower_than_the_waves_wait(ia, oracle, tmp_path, capfd):
+    """The waves of the launch that runs ahead of the copies give up after ~4 s without their blocks — a disk that slow is no reason to
+    fail: what they left is inflated once everything has arrived.  1.6 s before each of five pieces."""
+    import os
+    n = 120_001
+    recs = oracle.generate(SEED + 31, 0, n, 16, 12)
+    plain = struct.pack("<IIIIQ8s", 0x21554249, 2, 16, 12, 0, b"\0" * 8) + recs.tobytes()
+    p = tmp_path / "slow.ibu.gz"
+    p.write_bytes(_bgzf(plain, level=1))
+    c = ia.Context(0)
+    try:
+        c.set_option("inflate_one_launch", 4)
+        c.set_option("load_piece_delay_ms", 1600)
+        ring = {"slots": 2, "slot_records": 14_000, "feeder_threads": 2}   # 1.44 MB of BGZF in pieces of 336 KB
+        capfd.readouterr()
+        h, dptr, got_n, st = c.load_bgzf_to_device(str(p), ring=ring)
+        err = capfd.readouterr().err
+        assert got_n == n and ia.DeviceBuffer.wrap(c, dptr, 24 * n).download().tobytes() == recs.tobytes()
+        c.free(dptr)
+        if os.environ.get("IBU_TRACE_SORT", "") not in ("", "0"):
+            assert "came later than the waves waited" in err, err
+    finally:
+        c.close()

@@ -2,49 +2,47 @@
 // niffler, src/io/reader.rs:345-352; a bgzip file is a chain of independent members of at most 64 KiB whose sizes stand in their
 // headers, so the COMPRESSED bytes can cross the PCIe link — half of them for a records file — and the blocks inflate side by side).
 // Launcher: launch_inflate_blocks (kernels.h); C ABI: ibu_inflate_blocks_device (device.cpp); the host walk over the block headers:
-// ibu_bgzf_scan (host_io.cpp).  The host decoder with the same acceptance rules: pgzip.cpp.
+// ibu_bgzf_scan (host_io.cpp); the library's user: ibu_load_bgzf_*_to_device (stream.cpp).  The host decoder with the same
+// acceptance rules: pgzip.cpp.
 //
-// ONE LANE PER BLOCK.  Inflating is sequential inside a block and a CU issues about one instruction per cycle whatever the
-// instruction does: a wave that decodes ONE block with wave-uniform state (the first form, round 5: tables of 2^10 entries and both
-// rings in LDS, 12 blocks in flight per CU, the symbol loop on the scalar unit) spends that issue rate on one symbol at a time —
-// 16.7 ms per 64 KiB block, 12 GB/s for the chip, the same on the vector and on the scalar unit.  Here every lane runs the decoder
-// on a block of its own, 64 blocks per wave, so an instruction advances up to 64 symbols.  What makes that fit:
-//   - no lookup tables: a code is decoded canonically, bit by bit, from the counts per code length — fifteen 10-bit counts packed in
-//     five registers per code, the decode loop unrolled so that it never reads memory — and the symbols in code order (one LDS read
-//     per symbol; literal/length symbols as a byte plus a ninth bit in a 288-bit flag word);
-//   - the compressed bytes come a dword at a time from global memory, always one dword ahead (the next one sits in a register when
-//     the bit buffer runs low, and its 64-byte line stays in L1 / L2 for the 15 reads that follow);
+// ONE LANE PER BLOCK, 64 blocks per wave.  Inflating is sequential inside a block, and a CU issues about one instruction per cycle
+// whatever the instruction does: a wave that decodes ONE block with wave-uniform state (the first form: 2^10-entry tables and both
+// rings in LDS, 12 blocks in flight per CU) spends that rate on one symbol at a time — 16.7 ms per block, 12 GB/s for the chip, the
+// same on the vector and on the scalar unit.  With a block per lane an instruction advances up to 64 symbols.  What makes that fit:
+//   - no lookup tables.  A canonical code lives in registers: per code length the number of codes, the first code and the position of
+//     its first symbol in code order (10 + 16 + 10 bits, packed: 18 registers a code).  A window of L bits is a code of length L exactly
+//     when first[L] <= window < first[L] + count[L] — in whatever order the lengths are tried — so the likeliest lengths (8, 9, 7, 10
+//     for a literal of a records file) are tested first, the first four without a branch (decode_index).  The symbols in code order
+//     are the only table: 288 + 32 bytes and a 288-bit flag word (the ninth bit) per lane, one read per symbol;
+//   - the compressed bytes come a dword at a time from global memory, always one dword ahead (its 64-byte line stays in L1 / L2 for
+//     the 15 reads that follow);
 //   - the output goes through a 256-byte ring per lane in LDS: literals and matches of up to 64 bytes back never touch global
 //     memory; whole 32-byte pieces leave the ring as 8 dword stores, for all lanes together once one of them holds 96 bytes; a match
 //     from further back reads the lane's own earlier output from global memory (a wave's vector memory operations execute in order:
-//     the byte a lane stored is the byte it loads).
-//     The code lengths of a dynamic header are parsed in the same LDS (the ring's pending bytes go out first and come back after);
-//   - everything a lane keeps is laid out lane-interleaved (element k of lane L at k * 64 + L: lanes that read the same element hit
-//     different banks / one cache line): the symbol orders in global memory (24 KB per workgroup, in the caller's scratch — read once
-//     per symbol; in LDS they held a CU to three waves); the ring and the header's code lengths in LDS, lane after lane at an odd
-//     dword stride (a byte's address is base + offset, the lanes' same byte sits in different banks): 23 KB per wave, six waves,
-//     384 blocks, per CU;
-//   - divergence (one lane in a literal, the next in a match, a third building its tables) costs instructions, not correctness: no
-//     lane waits for another inside the decoder.
-// Measured (profiles/README.md r05_ad ... r05_ar; BGZF level 1 of 16/12 records, ratio 0.50): a wave takes ~46 ms for its 64 blocks, so
-// 1e8 records (575 waves, one round) inflate in 0.046 s = 52 GB/s, 3e8 in 0.119 s = 60 GB/s = 2.5 G records/s (the host's 16 inflate
-// threads: 0.40).  ibu_load_bgzf_to_device (stream.cpp) is built on it; the STREAMS do not use it: a ring slot holds a few hundred
-// blocks, i.e. a handful of waves for 46 ms.
-// How it got there, same round: symbols and counts in LDS, bytes straight to global memory, no prefetch — 0.231 s for 1e8 records,
-// every wave step waiting for some lane's global load or store; counts in registers, input one dword ahead, the output ring: 0.124 s;
-// symbol orders to global memory (three -> six waves per CU): 0.134 s but 3e8 from 0.359 to 0.288 s; the CRC pass 16 bytes per load
-// instead of one (it was 25 of a wave's 134 ms): 0.109 s; literal runs batched (symbols() below) and a byte-addressed ring: 0.068 s;
-// the code lengths tried likeliest first (decode_index): 0.055 s; the symbol orders back in LDS when one round of three waves per CU
-// takes the whole call: 0.046 s (3e8: scratch, six waves, 0.119 s).  SQ counters of that form (r05_az): a step of the wave is ~330
-// instructions (170 vector, 130 scalar — the bookkeeping of divergent branches —, 34 branches, 11 LDS, 3 global) in ~2840 cycles: one wave
-// per SIMD, 8.6 cycles from one instruction to the next.  Flushing the ring for all lanes at once instead of lane by lane changed nothing.
-// So the scratch form took the header's code lengths out of LDS as well: eight waves per CU, two to a SIMD — 3e8 records 0.0747 s = 96 GB/s.
+//     the byte a lane stored is the byte it loads);
+//   - lanes diverge between "literal" and "match": the lanes first decode literals only, parking the length symbol they meet, and
+//     serve the parked symbols together (symbols()); the error checks of a run of literals are made once, behind it;
+//   - a lane's LDS sits lane after lane at an odd dword stride (a byte's address is base + offset, the lanes' same byte in different
+//     banks); what is indexed by symbol is lane-interleaved (element k of lane L at k * 64 + L).
+// TWO FORMS of the same kernel (template TL).  TL: the symbol orders in LDS too (47 KB a wave, three waves per CU) — the shortest wave
+// (~45 ms for its 64 blocks), taken when one round of those waves holds the whole call (49 152 blocks).  Else: symbol orders and the
+// header's code lengths in the caller's scratch, 20 KB of LDS a wave, EIGHT waves per CU, two to a SIMD — a wave takes ~72 ms there,
+// but 2048 run at once: the highest rate.  A wave's step is a chain of ~330 dependent instructions in ~2840 cycles with one wave per
+// SIMD (SQ counters, r05_az: 170 vector, 130 scalar — the bookkeeping of divergent branches —, 34 branch, 11 LDS, 3 global): what a
+// CU needs is waves to interleave, not lanes (five blocks per wave take as long as 64).
+// A launch may run AHEAD of the copies that bring its input (`ready`, below): its waves wait for their blocks to arrive.
 // When the 64 lanes of a wave have finished, the wave checks the CRC-32 of each of their blocks together: every lane takes 1/64 of a
-// block, the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses), one wave reduction per block.
+// block (16 bytes per load), the partial values are combined with x^(8 n) mod P (the identity crc32_combine uses).
 // A block is accepted exactly as the host decoder accepts it (pgzip.cpp, RawInflater::inflate): the final deflate block ends on
 // the block's last compressed byte, the output has the announced length, the CRC matches; any invalid code, distance or size
 // makes the block bad (status 1), a wrong CRC status 2.  Every loop consumes input or produces output and both are bounded by
 // the descriptor, so a lane leaves any input — random bytes included — after at most 8 x comp_len + a few iterations.
+// Measured (profiles/README.md, r05_ad ... r05_bk; BGZF level 1 of 16/12 records, ratio 0.50): 1e8 records (575 waves, TL) 0.045 s =
+// 53 GB/s of records; 3e8 (1724 waves at once) 0.0716 s = 100 GB/s = 4.2 G records/s; the host's 16 inflate threads: 9.6 GB/s.
+// On the way, at 1e8 records: bytes straight to global memory, counts in LDS 0.231 s; counts in registers, input one dword ahead, the
+// ring 0.124; the CRC pass 16 bytes per load (it was 25 of a wave's 134 ms) 0.109; literal runs batched 0.068; lengths tried likeliest
+// first 0.055; symbol orders in LDS for calls of one round 0.046.  The streams do not use the decoder: a ring slot holds a few hundred
+// blocks — a handful of waves for 45 ms.
 #include "kcommon.hpp"
 #include "kernels.h"
 
@@ -54,9 +52,7 @@ namespace {
 constexpr int kInfThreads = kWave;                           // one wave per workgroup: its LDS is the 64 lanes' tables
 constexpr u32 kDistSyms = 32;
 
-// per-wave tables, lane-interleaved.  The symbol orders live in GLOBAL memory (one InfTables per workgroup of the grid, in the caller's
-// scratch: they are read once per symbol, and kept in LDS — 24 KB per wave — they held a CU to three waves; a wave's step is a chain
-// of ~600 dependent instructions, so what a CU needs is waves to interleave); the ring and everything touched per byte stay in LDS.
+// Per-wave tables, lane-interleaved: in LDS behind InfLds (TL) or one per workgroup of the grid in the caller's scratch.
 struct InfTables {
   uint8_t sym_lo[288 * kWave];           // literal/length symbols in code order, low 8 bits: [k * 64 + lane]
   u32 sym_hi[9 * kWave];                 // bit k of the lane's 288 bits: symbol k of the order is >= 256

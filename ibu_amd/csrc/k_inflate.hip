@@ -426,7 +426,7 @@ struct LaneInflate {
 }  // namespace
 
 // TL: the lanes' symbol orders in LDS (47 KB per wave: three waves per CU — the form for inputs that fit one round of them, where the
-// symbol's round trip to L2 is a quarter of a wave's step) instead of global scratch (six waves per CU: the form for large inputs).
+// symbol's round trip to L2 is a quarter of a wave's step) instead of global scratch (eight waves per CU: the form for large inputs).
 template <bool TL>
 __global__ void __launch_bounds__(kInfThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))   // (two waves to a SIMD: 256 registers each — the scratch form sits right at that)
 ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* __restrict__ blocks, u32 nblocks, uint8_t* __restrict__ out_base,
@@ -547,7 +547,7 @@ ibu_k_inflate_blocks(const uint8_t* __restrict__ comp, const InflateBlockDesc* _
 // Always 64 blocks per wave: a wave's time does not shrink with fewer lanes (3678 blocks dealt five to a wave took 42 ms, 36 766 at 48
 // to a wave 46 ms: the step is a chain of dependent instructions, not divergence), and dense waves leave room for the next launch.
 static inline u32 inflate_bpw(const LaunchCfg&, size_t) { return kWave; }
-// one round of three waves per CU takes everything: the form with the symbol orders in LDS; else six waves per CU, tables in scratch
+// one round of three waves per CU takes everything: the form with the symbol orders in LDS; else eight waves per CU, tables in scratch
 static inline bool inflate_tables_in_lds(const LaunchCfg& cfg, size_t nblocks) { return (nblocks + kWave - 1) / kWave <= (size_t)cfg.cus * 3; }
 static inline u32 inflate_grid(const LaunchCfg& cfg, size_t nblocks) {
   const u32 bpw = inflate_bpw(cfg, nblocks);

@@ -561,7 +561,8 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
     d_first_bad = d_status + nrest;
     d_tables = reinterpret_cast<uint8_t*>(d_status) + status_room + 256;
     if (!ctx->h_inflate_marks) {
-      hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_inflate_marks), kInflateMarks * sizeof(uint64_t), hipHostMallocDefault);
+      // (coherent whatever HIP_HOST_COHERENT says: the device must see the host's stores while its kernel runs)
+      hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_inflate_marks), kInflateMarks * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent);
       if (he != hipSuccess) { ctx->h_inflate_marks = nullptr; return hip_fail(he, "hipHostMalloc"); }
     }
     d_ready = ctx->h_inflate_marks;                        // (pinned host memory: the device reads it over the link)

@@ -389,3 +389,71 @@ def test_load_bgzf_from_a_source_slower_than_the_waves_wait(ia, oracle, tmp_path
             assert "came later than the waves waited" in err, err
     finally:
         c.close()
+
+
+def _fuzz_data(rng):
+    """A byte string stitched from pieces of different character: random, runs, short periods, long-distance repeats, records."""
+    parts = []
+    for _ in range(int(rng.integers(1, 9))):
+        kind = int(rng.integers(0, 6))
+        n = int(rng.integers(1, 120_000))
+        if kind == 0:
+            parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        elif kind == 1:
+            parts.append(bytes([int(rng.integers(0, 256))]) * n)
+        elif kind == 2:
+            p = rng.integers(0, 256, int(rng.integers(2, 40)), dtype=np.uint8).tobytes()
+            parts.append((p * (n // len(p) + 1))[:n])
+        elif kind == 3:
+            p = rng.integers(0, 256, int(rng.integers(300, 30_000)), dtype=np.uint8).tobytes()
+            parts.append((p * (n // len(p) + 2))[:n])
+        elif kind == 4:
+            parts.append(bytes(rng.choice(np.array([65, 67, 71, 84, 10], np.uint8), n)))
+        else:
+            r = np.zeros(n // 24 + 1, dtype=[("b", "<u8"), ("u", "<u8"), ("i", "<u8")])
+            r["b"] = rng.integers(0, 1 << 32, len(r))
+            r["u"] = rng.integers(0, 1 << 24, len(r))
+            r["i"] = np.arange(len(r))
+            parts.append(r.tobytes()[:n])
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("IBU_FUZZ_SEEDS_INFLATE", "6"))))
+def test_inflate_fuzz(ia, ctx, seed):
+    """Seeded fuzz (IBU_FUZZ_SEEDS_INFLATE widens it): stitched data, any level / strategy / block size, then bits flipped in some blocks:
+    the device's bytes = zlib's, and the device refuses exactly the blocks zlib refuses (length, end of stream, CRC-32)."""
+    rng = np.random.default_rng(SEED * 1000 + seed)
+    data = _fuzz_data(rng)
+    level = int(rng.integers(0, 10))
+    strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 5))]
+    block = int(rng.choice([0xFF00, 0xF000, 30_000, 4093, 513, 97]))   # (bgzip stops at 0xFF00: an incompressible block still fits the 16-bit BSIZE)
+    if block < 1000:
+        data = data[:60_000]
+    comp = bytearray(_bgzf(data, block=block, level=level, strategy=strategy))
+    blocks, consumed, out_bytes, rc = ia.bgzf_scan(bytes(comp))
+    assert rc == 0 and out_bytes == len(data)
+    nb = len(blocks)
+    hurt = set()
+    for _ in range(int(rng.integers(0, 4))):                        # flipped bits in the deflate data of a few blocks
+        v = int(rng.integers(0, nb))
+        if blocks[v].comp_len:
+            comp[blocks[v].comp_offset + int(rng.integers(0, blocks[v].comp_len))] ^= 1 << int(rng.integers(0, 8))
+            hurt.add(v)
+    got, st, first, guards = _inflate_on_device(ia, ctx, bytes(comp), blocks, len(data))
+    assert guards
+    want_bad = []
+    for v in sorted(hurt):
+        b = blocks[v]
+        try:
+            d = zlib.decompressobj(-15)
+            o = d.decompress(bytes(comp[b.comp_offset:b.comp_offset + b.comp_len]))
+            ok = d.eof and not d.unused_data and len(o) == b.out_len and zlib.crc32(o) == b.crc32
+        except zlib.error:
+            ok = False
+        if not ok:
+            want_bad.append(v)
+    assert sorted(st.nonzero()[0].tolist()) == want_bad, (seed, level, strategy, block, st.nonzero()[0][:8], want_bad)
+    assert first == (want_bad[0] if want_bad else None)
+    for i, b in enumerate(blocks):
+        if i not in want_bad:
+            assert got[b.out_offset:b.out_offset + b.out_len] == data[b.out_offset:b.out_offset + b.out_len], (seed, i)

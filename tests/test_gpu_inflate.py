@@ -38,6 +38,9 @@ def _bgzf(data, block=0xFF00, level=1, strategy=zlib.Z_DEFAULT_STRATEGY, eof=Tru
         chunk = data[off:off + block]
         c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
         cd = c.compress(chunk) + c.flush()
+        if len(cd) + 25 > 0xFFFF:                                       # (what bgzip does with a block that grew: stored)
+            c = zlib.compressobj(0, zlib.DEFLATED, -15)
+            cd = c.compress(chunk) + c.flush()
         out += b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(cd) + 25)
         out += cd + struct.pack("<II", zlib.crc32(chunk), len(chunk))
     if eof:

@@ -559,13 +559,6 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
         t0 = time.perf_counter()
         bg_bytes = bgzf_parallel(path, bg, level=1, workers=max(2, min(16, usable_cores())))
         tc = time.perf_counter() - t0
-        r = ia.Reader.from_path(bg)
-        t0 = time.perf_counter()
-        _, st = r.process_device(ctxs[0], ia.PROC_DECODE, sink=(s_bc, s_umi, s_idx, n), ring=ring)
-        dt = time.perf_counter() - t0
-        r.close()
-        out["bgzf_reader_process_device_decode"] = rate(dt, st, bgzf_bytes=bg_bytes, compress_seconds=tc,
-                                                        input="BGZF blocks, level 1, inflated on the host cores (block-parallel)")
         dst = ctxs[0].alloc(24 * n)
         calls = []
         for rep in range(3):
@@ -588,9 +581,31 @@ def e2e_leg(ctx, ia, n, bc_len, umi_len, seed, tmpdir, torch=None):
         dst.free()
         if not ok:
             raise LegCheckFailed("e2e: BGZF load -> DECODE does not reproduce the records written")
+        # the Reader API on the same file (`Reader::from_path(bgzf)` + a device processor): by default the library reads an untouched
+        # BGZF file itself and inflates on the device (option "bgzf_device" = 1); = 0: the Reader's host inflate (block-parallel)
+        for opt, key, how in ((1, "bgzf_reader_process_device_decode", "BGZF blocks, level 1, read by the library and inflated ON THE DEVICE (the default for an untouched BGZF file)"),
+                              (0, "bgzf_reader_process_device_decode_host_inflate", "BGZF blocks, level 1, inflated on the host cores (block-parallel)")):
+            ctxs[0].set_option("bgzf_device", opt)
+            best = None
+            for rep in range(2 if opt else 1):
+                r = ia.Reader.from_path(bg)
+                t0 = time.perf_counter()
+                _, st = r.process_device(ctxs[0], ia.PROC_DECODE, sink=(s_bc, s_umi, s_idx, n), ring=ring)
+                dt = time.perf_counter() - t0
+                r.close()
+                best = dt if best is None or dt < best else best
+            back = ctxs[0].alloc(24 * n)
+            ctxs[0].encode_ascii(s_bc, s_umi, s_idx, n, bc_len, umi_len, back)
+            ctxs[0].codec_status()
+            ok = ctxs[0].reduce(back, n) == want
+            back.free()
+            if not ok:
+                raise LegCheckFailed("e2e: BGZF Reader -> DECODE does not reproduce the records written")
+            out[key] = rate(best, st, bgzf_bytes=bg_bytes, input=how, totals_equal_resident_copy=True)
+        ctxs[0].set_option("bgzf_device", 1)
         out["bgzf_load_to_device_then_decode"] = rate(dt_cols, None, totals_equal_resident_copy=True,
                                                       what="ibu_load_bgzf_to_device + ibu_decode_ascii: BGZF file -> ASCII columns on the device")
-        out["bgzf_load_to_device_device_inflate"] = rate(min(calls), st, calls_seconds=[round(c_, 4) for c_ in calls], bgzf_bytes=bg_bytes,
+        out["bgzf_load_to_device_device_inflate"] = rate(min(calls), None, calls_seconds=[round(c_, 4) for c_ in calls], bgzf_bytes=bg_bytes, compress_seconds=tc,
                                                          bytes_over_the_link=bg_bytes, totals_equal_resident_copy=True,
                                                          call="ibu_load_bgzf_to_device(ctx, path, ring, &header, &d_records, cap, &n, &stats): "
                                                               "one lane per BGZF block (k_inflate.hip)")

@@ -64,8 +64,12 @@ struct ibu_ctx {
   ibu::Ring ring;
   ibu::CodecRing cring;
   void* ring_lent = nullptr;       // the open ibu_stream_t that holds `ring` (its producer thread fills the slots): every other ring user is refused meanwhile
+  void* d_bgzf_range = nullptr;    // ibu_reader_process_device of a BGZF file: the records of the range being processed (grows only)
+  size_t bgzf_range_bytes = 0;
   void* d_inflate_stage = nullptr; // ibu_load_bgzf_to_device: the compressed file, the block descriptors and their status words on the device (grows only)
   size_t inflate_stage_bytes = 0;
+  size_t bgzf_range_bytes_opt = 0; // option "bgzf_range_bytes" (a test knob): compressed bytes per range of that path (0: 3.2 GB)
+  int bgzf_device = 1;             // option "bgzf_device": ibu_reader_process_device of a BGZF file reads the file itself and inflates on the device (1, default) or goes through the Reader's host inflate (0)
   uint32_t load_piece_delay_ms = 0; // option "load_piece_delay_ms" (a test knob): ibu_load_bgzf_*_to_device sleeps that long before every piece it copies — a slow disk
   size_t inflate_one_launch = 0;   // option "inflate_one_launch": files of more blocks than this get the launch that runs ahead of the copies (0: one round of the short form)
   uint64_t* h_inflate_marks = nullptr; // pinned: [0] = the compressed bytes whose copies the host has seen complete — what a launch that runs ahead of its input looks at

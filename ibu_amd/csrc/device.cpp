@@ -109,6 +109,7 @@ extern "C" void ibu_ctx_destroy(ibu_ctx_t* ctx) {
   for (hipStream_t q : ctx->inflate_streams)
     if (q) (void)hipStreamDestroy(q);
   if (ctx->d_inflate_stage) (void)hipFree(ctx->d_inflate_stage);
+  if (ctx->d_bgzf_range) (void)hipFree(ctx->d_bgzf_range);
   if (ctx->h_inflate_marks) (void)hipHostFree(ctx->h_inflate_marks);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -158,6 +159,16 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     ctx->inflate_one_launch = (size_t)value;
     return IBU_OK;
   }
+  if (strcmp(key, "bgzf_range_bytes") == 0) {            // a test knob: the ranges of ibu_reader_process_device's BGZF path
+    if (value < 0) return err_arg("bgzf_range_bytes must be >= 0");
+    ctx->bgzf_range_bytes_opt = (size_t)value;
+    return IBU_OK;
+  }
+  if (strcmp(key, "bgzf_device") == 0) {
+    if (value != 0 && value != 1) return err_arg("bgzf_device must be 0 or 1");
+    ctx->bgzf_device = (int)value;
+    return IBU_OK;
+  }
   if (strcmp(key, "load_piece_delay_ms") == 0) {         // a test knob: a slow source for the BGZF loads
     if (value < 0 || value > 10000) return err_arg("load_piece_delay_ms must be 0 .. 10000");
     ctx->load_piece_delay_ms = (uint32_t)value;
@@ -171,6 +182,9 @@ extern "C" int32_t ibu_ctx_set_option(ibu_ctx_t* ctx, const char* key, int64_t v
     if (ctx->d_inflate_stage) IBU_HIP(hipFree(ctx->d_inflate_stage));
     ctx->d_inflate_stage = nullptr;
     ctx->inflate_stage_bytes = 0;
+    if (ctx->d_bgzf_range) IBU_HIP(hipFree(ctx->d_bgzf_range));
+    ctx->d_bgzf_range = nullptr;
+    ctx->bgzf_range_bytes = 0;
     return IBU_OK;
   }
   if (strcmp(key, "sort_pull_streams") == 0) {

@@ -22,6 +22,7 @@
 #include <new>
 #include <thread>
 #include <utility>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -1034,6 +1035,7 @@ extern "C" void ibu_writer_close(ibu_writer_t* w) {  // Drop  writer.rs:519-523
 // ------------------------------------------------------------------------------------------
 struct ibu_reader {
   std::unique_ptr<Source> inner;
+  std::string bgzf_path;           // ibu_reader_open_path of a BGZF file: its path (the device processors may read the file themselves)
   bool compressed = false;
   std::vector<uint8_t> buffer;  // capacity DEFAULT_BUFFER_SIZE
   ibu_header_t header;
@@ -1129,7 +1131,24 @@ extern "C" int32_t ibu_reader_open_path(const char* path, ibu_reader_t** out) { 
   if (!path) return err_arg("path is NULL");
   int fd = ::open(path, O_RDONLY | O_CLOEXEC);
   if (fd < 0) return err_io(errno, path);
-  return reader_make_sniffed(std::unique_ptr<Source>(new FdSource(fd, true)), out);
+  const int32_t rc = reader_make_sniffed(std::unique_ptr<Source>(new FdSource(fd, true)), out);
+  if (rc == IBU_OK && dynamic_cast<BgzfSource*>((*out)->inner.get())) {
+    try { (*out)->bgzf_path = path; } catch (...) {}     // (no memory for the name: the reader works without it)
+  }
+  return rc;
+}
+// The path of a BGZF file behind a reader nothing has been read from yet beyond the header (else NULL): ibu_reader_process_device may then
+// load the file itself, the compressed bytes over the link and the blocks inflated on the device (stream.cpp).
+const char* ibu::reader_bgzf_path_if_untouched(const ibu_reader_t* r) {
+  if (!r || r->bgzf_path.empty() || r->eof || r->pos != r->cap || r->bytes_read != IBU_HEADER_SIZE) return nullptr;
+  return r->bgzf_path.c_str();
+}
+// ... and once it has: the reader stands at its end, as if every record had been read through it.
+void ibu::reader_set_drained(ibu_reader_t* r, uint64_t records) {
+  r->eof = true;
+  r->pos = r->cap = 0;
+  r->bytes_read = IBU_HEADER_SIZE + IBU_RECORD_SIZE * records;
+  r->inner.reset(new MemSource(nullptr, 0));             // (the inflate threads of the host path are not needed any more)
 }
 extern "C" int32_t ibu_reader_open_fd(int fd, ibu_reader_t** out) {  // reader.rs:389-396
   if (fd < 0) return err_arg("fd < 0");

@@ -17,6 +17,8 @@ int32_t open_plain_file(const char* path, int* fd_out, ibu_header_t* header, siz
 // r->bytes_read unchanged; a source error likewise leaves in *got_bytes the complete record bytes read in front of it.
 // *eof: the stream ended (possibly with *got_bytes > 0).
 int32_t reader_read_direct(ibu_reader_t* r, uint8_t* dst, size_t cap_bytes, size_t* got_bytes, bool* eof);
+const char* reader_bgzf_path_if_untouched(const ibu_reader_t* r);   // host_io.cpp
+void reader_set_drained(ibu_reader_t* r, uint64_t records);
 // num_cpus::get()
 size_t host_cores();
 // Threads for the inflate workers (BGZF blocks, pgzip chunks): the CPUs this process may run on, but at most twice its

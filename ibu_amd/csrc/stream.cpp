@@ -510,7 +510,7 @@ extern "C" int32_t ibu_load_bgzf_shard_to_device(ibu_ctx_t* ctx, const char* pat
       if (arc) return arc;
       owned = true;
     } else if (num > cap_records) {
-      return err_arg("device buffer too small for the shard");
+      return set_error(IBU_ERR_INVALID_ARG, num, cap_records, 0, "Invalid argument: device buffer too small for the shard (%zu records, room for %zu)", num, cap_records);
     }
     d_out = static_cast<uint8_t*>(*d_records);
     // the blocks wholly inside [lo, hi): the device's; what straddles an end (and the header's blocks): inflated here
@@ -1314,6 +1314,98 @@ extern "C" int32_t ibu_mmap_process_devices(const ibu_mmap_t* m, const int32_t* 
 // ------------------------------------------------------------------------------------------
 // streaming Reader (plain / gzip), device form
 // ------------------------------------------------------------------------------------------
+namespace {
+// A Reader over a BGZF FILE nothing has been read from: the processors need not pull it through the Reader's host inflate (0.4 G records/s
+// on 16 CPUs) — the file is loaded range by range with its compressed bytes crossing the link and its blocks inflated on the device
+// (ibu_load_bgzf_shard_to_device: ranges of about 6 GB of records, so that any file fits), and the processor runs over each range.
+// *handled = false: the file is not what that load takes (a foreign member, a cut, a length that is no whole number of records ...) —
+// nothing has been touched, and the Reader's own path delivers what it delivers for such a file, error and all.
+int32_t process_bgzf_file(ibu_ctx* ctx, const char* path, const ibu_ring_config_t* cfg, const ibu_header_t& want, DeviceProc& dp, int32_t proc, void* sink,
+                          ibu_stream_stats_t* stats, uint64_t* records, bool* handled) {
+  *handled = false;
+  struct stat sb;
+  if (stat(path, &sb) != 0) return IBU_OK;
+  // ranges of ~6.4 GB of records where the file compresses to half (BGZF of 16/12 records: 0.50) — every range costs its launch's
+  // waves' 45-75 ms once more, and a file that compresses better just gets larger ranges
+  const size_t K = (size_t)((double)sb.st_size / (ctx->bgzf_range_bytes_opt ? (double)ctx->bgzf_range_bytes_opt : 3.2e9)) + 1;
+  ibu_header_t h;
+  size_t n0 = 0;
+  uint64_t first = 0;
+  ibu_stream_stats_t st{};
+  const ibu_error_detail_t keep = tls_error();
+  // The ranges land in a buffer the CONTEXT keeps (it grows only; option "release_staging" frees it): allocating and freeing 2.4 GB
+  // around every call cost a call of 1e8 records 80 of its 155 ms.  First use, or a larger range than ever: the load allocates, and
+  // the context adopts what it allocated.
+  auto cap = [&] { return ctx->bgzf_range_bytes / IBU_RECORD_SIZE; };
+  int32_t rc = IBU_ERR_INVALID_ARG;
+  if (cap()) {
+    void* p = ctx->d_bgzf_range;
+    rc = ibu_load_bgzf_shard_to_device(ctx, path, cfg, 0, K, &h, &p, cap(), &n0, &first, &st);
+    if (rc == IBU_ERR_INVALID_ARG && tls_error().b == cap() && tls_error().a > cap()) {   // too small for this file's ranges
+      (void)hipFree(ctx->d_bgzf_range);
+      ctx->d_bgzf_range = nullptr;
+      ctx->bgzf_range_bytes = 0;
+    }
+  }
+  if (!cap()) {
+    const int probe = ctx->cfg.alloc_probe_tries;        // (no placement probing for it: the records only pass through)
+    ctx->cfg.alloc_probe_tries = 1;
+    void* p = nullptr;
+    rc = ibu_load_bgzf_shard_to_device(ctx, path, cfg, 0, K, &h, &p, 0, &n0, &first, &st);
+    ctx->cfg.alloc_probe_tries = probe;
+    if (rc == IBU_OK) { ctx->d_bgzf_range = p; ctx->bgzf_range_bytes = (n0 ? n0 : 1) * IBU_RECORD_SIZE; }
+  }
+  if (rc || memcmp(&h, &want, sizeof h) != 0) {          // not for this path: as if it had not been tried
+    tls_error() = keep;
+    return IBU_OK;
+  }
+  *handled = true;
+  auto done = [&](int32_t code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return code;
+  };
+  if (K > 1 && cap() < n0 + K) {                         // (a later range has at most K - 1 records more than the first)
+    void* big = nullptr;
+    hipError_t e = ctx_malloc(ctx, &big, (n0 + K) * IBU_RECORD_SIZE);
+    if (e == hipSuccess) e = hipMemcpy(big, ctx->d_bgzf_range, n0 * IBU_RECORD_SIZE, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { if (big) (void)hipFree(big); return done(hip_fail(e, "hipMalloc")); }
+    (void)hipFree(ctx->d_bgzf_range);
+    ctx->d_bgzf_range = big;
+    ctx->bgzf_range_bytes = (n0 + K) * IBU_RECORD_SIZE;
+  }
+  uint64_t total = 0;
+  if (proc == IBU_PROC_REDUCE) {
+    hipError_t e = hipMemsetAsync(ctx->d_acc, 0, kReduceAccBytes, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(e, "hipMemsetAsync"));
+  }
+  for (size_t i = 0; i < K; ++i) {
+    size_t n = n0;
+    if (i) {
+      void* p = ctx->d_bgzf_range;
+      rc = ibu_load_bgzf_shard_to_device(ctx, path, cfg, i, K, &h, &p, cap(), &n, &first, &st);
+      if (rc) return done(rc);
+    }
+    if (stats) { stats->bytes_h2d += st.bytes_h2d; stats->batches += st.batches; }
+    rc = dp.fits(n, (size_t)first);
+    if (rc) return done(rc);
+    if (n) {
+      rc = dp.launch(static_cast<const uint8_t*>(ctx->d_bgzf_range), n, (size_t)first);
+      if (rc) return done(rc);
+    }
+    total += n;
+    hipError_t e = hipStreamSynchronize(ctx->stream);      // (the next range is loaded over these records)
+    if (e != hipSuccess) return done(hip_fail(e, "hipStreamSynchronize"));
+  }
+  if (proc == IBU_PROC_REDUCE) {
+    rc = ibu_reduce_fetch(ctx, ctx->stream, static_cast<ibu_reduce_result_t*>(sink));
+    if (rc) return done(rc);
+  }
+  *records = total;
+  if (stats) { stats->records = total; stats->numa_node = st.numa_node; stats->ring_node = st.ring_node; }
+  return done(IBU_OK);
+}
+}  // namespace
+
 extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, const ibu_ring_config_t* cfg,
                                              int32_t proc, void* sink, ibu_stream_stats_t* stats) {
   if (!rd || !ctx) return err_arg("NULL argument");
@@ -1324,6 +1416,20 @@ extern "C" int32_t ibu_reader_process_device(ibu_reader_t* rd, ibu_ctx_t* ctx, c
   DeviceProc dp;
   int32_t rc = make_proc(ctx, proc, h, sink, &dp);   // argument errors before the producer thread exists
   if (rc) return rc;
+  if (const char* bp = ctx->bgzf_device ? reader_bgzf_path_if_untouched(rd) : nullptr) {
+    bool handled = false;
+    uint64_t records = 0;
+    IBU_HIP(hipSetDevice(ctx->device));
+    rc = process_bgzf_file(ctx, bp, cfg, h, dp, proc, sink, stats, &records, &handled);
+    if (handled) {
+      if (rc == IBU_OK) {
+        reader_set_drained(rd, records);
+        if (stats) stats->seconds_total = now_s() - t0;
+      }
+      return rc;
+    }
+    if (stats) memset(stats, 0, sizeof *stats);
+  }
   ibu_stream_t* s = nullptr;
   rc = ibu_stream_open_reader(rd, ctx, cfg, &s);
   return process_stream(s, rc, proc, sink, stats, t0);

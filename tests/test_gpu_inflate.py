@@ -460,3 +460,83 @@ def test_inflate_fuzz(ia, ctx, seed):
     for i, b in enumerate(blocks):
         if i not in want_bad:
             assert got[b.out_offset:b.out_offset + b.out_len] == data[b.out_offset:b.out_offset + b.out_len], (seed, i)
+
+
+def test_reader_process_device_of_a_bgzf_file_inflates_on_the_device(ia, oracle, tmp_path):
+    """`Reader::from_path(bgzf).process(...)` with the records on the device: the library reads the file itself, the compressed bytes cross
+    the link, the blocks inflate on the device (option "bgzf_device" = 1, the default) — same results as through the Reader's host inflate
+    (= 0); a file that load does not take (cut inside a record, a bad block) goes through the Reader's own path and fails as it fails there;
+    a reader something has been read from keeps to the host path."""
+    n = 300_007
+    recs = oracle.generate(SEED + 404, 0, n, 16, 12)
+    plain = struct.pack("<IIIIQ8s", 0x21554249, 2, 16, 12, 0, b"\0" * 8) + recs.tobytes()
+    good = _bgzf(plain, level=1)
+    p = tmp_path / "f.ibu.gz"
+    p.write_bytes(good)
+    want = oracle.reduce_records(recs)
+    bc, umi, idx = oracle.decode_records(recs, 16, 12)
+    ring = {"slots": 3, "slot_records": 60_000, "feeder_threads": 2}
+    c = ia.Context(0)
+    try:
+        for dev in (1, 0):
+            c.set_option("bgzf_device", dev)
+            r = ia.Reader.from_path(p)
+            res, st = r.process_device(c, ia.PROC_REDUCE, ring=ring)
+            assert res == want and st.records == n
+            assert (st.bytes_h2d == len(good)) == bool(dev), (dev, st.bytes_h2d, len(good))   # the compressed file / the records crossed the link
+            assert not r.read_batch()                                 # the reader stands at its end
+            r.close()
+            r = ia.Reader.from_path(p)
+            d_bc, d_umi, d_idx = c.alloc(n * 16), c.alloc(n * 12), c.alloc(n * 8)
+            r.process_device(c, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
+            assert (d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()) == (bc.tobytes(), umi.tobytes(), idx.tobytes())
+            r.close()
+            r = ia.Reader.from_path(p)                                # a sink that is too small: InvalidArg either way
+            with pytest.raises(ia.IbuError) as e:
+                r.process_device(c, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx, n - 1), ring=ring)
+            assert e.value.kind == "InvalidArg"
+            r.close()
+            for b in (d_bc, d_umi, d_idx):
+                b.free()
+        c.set_option("bgzf_device", 1)
+        for rng_bytes in (len(good) // 2 + 1, len(good) // 5, 40_000):   # the file in 2, 6 and ~90 ranges: rows land where they belong
+            c.set_option("bgzf_range_bytes", rng_bytes)
+            r = ia.Reader.from_path(p)
+            res, st = r.process_device(c, ia.PROC_REDUCE, ring=ring)
+            assert res == want and st.records == n and st.bytes_h2d <= len(good)
+            r.close()
+            r = ia.Reader.from_path(p)
+            d_bc, d_umi, d_idx = c.alloc(n * 16), c.alloc(n * 12), c.alloc(n * 8)
+            r.process_device(c, ia.PROC_DECODE, sink=(d_bc, d_umi, d_idx), ring=ring)
+            assert (d_bc.download().tobytes(), d_umi.download().tobytes(), d_idx.download().tobytes()) == (bc.tobytes(), umi.tobytes(), idx.tobytes())
+            r.close()
+            for b in (d_bc, d_umi, d_idx):
+                b.free()
+            c.set_option("release_staging", 1)                        # (the next round starts without the buffers of this one)
+        c.set_option("bgzf_range_bytes", 0)
+        r = ia.Reader.from_path(p)                                    # three records taken on the host first: the host path goes on from there
+        head = [next(r) for _ in range(3)]
+        res, st = r.process_device(c, ia.PROC_REDUCE, ring=ring)
+        assert res == oracle.reduce_records(recs[3:]) and st.bytes_h2d != len(good)
+        r.close()
+        kinds = {}
+        for name, data in (("cut", _bgzf(plain[:-5], level=1)), ("bad", None)):
+            if data is None:
+                blocks, _, _, _ = ia.bgzf_scan(good)
+                b = blocks[len(blocks) // 2]
+                data = bytearray(good)
+                struct.pack_into("<I", data, b.comp_offset + b.comp_len, b.crc32 ^ 2)
+                data = bytes(data)
+            q = tmp_path / (name + ".gz")
+            q.write_bytes(data)
+            for dev in (1, 0):
+                c.set_option("bgzf_device", dev)
+                r = ia.Reader.from_path(q)
+                with pytest.raises(ia.IbuError) as e:
+                    r.process_device(c, ia.PROC_REDUCE, ring=ring)
+                kinds[(name, dev)] = (e.value.kind, getattr(e.value, "pos", None))
+                r.close()
+        assert kinds[("cut", 1)] == kinds[("cut", 0)] and kinds[("cut", 0)][0] == "TruncatedRecord", kinds
+        assert kinds[("bad", 1)] == kinds[("bad", 0)] and kinds[("bad", 0)][0] == "Niffler", kinds
+    finally:
+        c.close()
